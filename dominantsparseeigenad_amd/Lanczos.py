@@ -1,0 +1,78 @@
+"""Lanczos tridiagonalisation and extreme Ritz pairs -- API of reference DominantSparseEigenAD/Lanczos.py.
+
+    Lanczos(A, k, device, *, sparse, dim)                     reference Lanczos.py:3-77
+    symeigLanczos(A, k, device, extreme, *, sparse, dim)      reference Lanczos.py:79-105
+
+Same names, argument meaning and return values.  On a CUDA (= MI355X / ROCm) device the loop runs in
+hand-written HIP kernels (csrc/dsea_kernels.hip) behind the C ABI of include/dsea.h:
+
+  * ``A`` a native operator (operators.TFIMOperator / CSROperator / Stencil3Operator): the whole k-step
+    loop, mat-vec included, is one library call with no host synchronisation;
+  * ``A`` any Python callable (``sparse=True``) or a dense tensor: the mat-vec is the caller's torch code,
+    every other vector operation of the loop is a library call.
+
+Keyword-only extensions (defaults reproduce the reference): ``q0`` -- start vector instead of the
+``torch.randn`` draw of Lanczos.py:52 (the unused second draw of Lanczos.py:59 is still consumed so the
+global RNG advances exactly as in the reference).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import engine
+from ._cpu_plumbing import lanczos_host
+
+
+def _resolve(A, device, sparse, dim):
+    if sparse:
+        n, dtype, amap = int(dim), torch.float64, A          # Lanczos.py:42-45 (fp64 forced)
+    else:
+        n, dtype = A.shape[0], A.dtype                         # Lanczos.py:46-48
+        amap = lambda v: torch.matmul(A, v)                    # noqa: E731
+    return n, dtype, amap
+
+
+def _lanczos_core(A, k, device, sparse, dim, q0):
+    device = torch.device(device)
+    n, dtype, amap = _resolve(A, device, sparse, dim)
+    if q0 is None:
+        q0 = torch.randn(n, dtype=dtype, device=device)        # Lanczos.py:52
+    torch.randn(n, dtype=dtype, device=device)                 # Lanczos.py:59 (value multiplies beta = 0)
+    if device.type == "cuda":
+        if dtype != torch.float64:
+            raise NotImplementedError("the HIP Lanczos kernels are fp64; got %s on %s" % (dtype, device))
+        native = engine.native_of(A) if sparse else None
+        if native is not None:
+            Q, ldq, alphas, betas = engine.lanczos(A, k, n, device, q0, native=native)
+        else:
+            Q, ldq, alphas, betas = engine.lanczos(A, k, n, device, q0, callable_A=amap)
+        return ("cuda", Q, ldq, n, alphas, betas)
+    Qk, alphas, betas = lanczos_host(amap, k, n, dtype, q0, device)
+    return ("cpu", Qk, None, n, alphas, betas)
+
+
+def Lanczos(A, k, device=torch.device("cpu"), *, sparse=False, dim=None, q0=None):
+    """Returns (Qk, T): Qk (n,k) with orthonormal columns, T the k x k tridiagonal (Lanczos.py:76-77).
+
+    On the GPU the basis is stored vector-contiguous, so ``Qk`` is the transposed view of a (k, ldq) buffer.
+    """
+    where, Q, ldq, n, alphas, betas = _lanczos_core(A, k, device, sparse, dim, q0)
+    Qk = Q[:, :n].T if where == "cuda" else Q
+    T = torch.diag(alphas) + torch.diag(betas, diagonal=1) + torch.diag(betas, diagonal=-1)
+    return Qk, T
+
+
+def symeigLanczos(A, k, device=torch.device("cpu"), extreme="both", *, sparse=False, dim=None, q0=None):
+    """Extreme eigenvalue(s)/eigenvector(s); outputs as in Lanczos.py:88-105 (all torch tensors)."""
+    if extreme not in ("both", "min", "max"):
+        raise ValueError("extreme must be 'both', 'min' or 'max'")
+    where, Q, ldq, n, alphas, betas = _lanczos_core(A, k, device, sparse, dim, q0)
+    pairs = engine.tridiag_extreme(alphas, betas, extreme)
+    out = []
+    for val, s in pairs:
+        if where == "cuda":
+            vec = engine.ritz_vector(Q, ldq, n, k, s, Q.device)
+        else:
+            vec = torch.matmul(Q, torch.from_numpy(s).to(Q.dtype))
+        out += [torch.tensor(val, dtype=alphas.dtype, device=alphas.device), vec]
+    return tuple(out)

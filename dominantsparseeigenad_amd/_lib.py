@@ -1,0 +1,97 @@
+"""ctypes binding of libdsea.so (C ABI declared in include/dsea.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C dominantsparseeigenad_amd/csrc``.
+There is no fallback: if the shared object is missing, ``load()`` raises and every GPU entry point of
+the package fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdsea.so")
+
+_lib = None
+
+CG_RR, CG_DAD, CG_RRNEW, CG_ALPHA, CG_BETA, CG_RESNORM, CG_DONE, CG_ITERS = range(8)
+CG_STATE_LEN = 8
+ERR_NOT_CONVERGED = -5
+
+
+class DseaError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); mirrors include/dsea.h one to one
+_SIGNATURES = {
+    "dsea_version": (c_int, []),
+    "dsea_error_string": (c_char_p, [c_int]),
+    "dsea_last_hip_error": (c_int, []),
+    "dsea_ws_bytes": (c_int, [c_int64, c_int, POINTER(c_size_t)]),
+    "dsea_ws_create": (c_int, [c_void_p, c_size_t, c_int64, c_int, POINTER(c_void_p)]),
+    "dsea_ws_destroy": (c_int, [c_void_p]),
+    "dsea_ws_set_rows_per_lane": (c_int, [c_void_p, c_int]),
+    "dsea_profile_begin": (c_int, [c_void_p, c_int]),
+    "dsea_profile_end": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_double)]),
+    "dsea_op_create_tfim": (c_int, [c_int, c_int, c_int64, c_void_p, c_double, c_double, POINTER(c_void_p)]),
+    "dsea_op_create_csr": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
+    "dsea_op_create_stencil3": (c_int, [c_int64, c_double, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
+    "dsea_op_destroy": (c_int, [c_void_p]),
+    "dsea_op_dim": (c_int, [c_void_p, POINTER(c_int64)]),
+    "dsea_spmv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dsea_dot": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "dsea_shift_dot": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "dsea_axpy": (c_int, [c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "dsea_nrm2sq": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "dsea_scale_store": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "dsea_lanczos_rdots": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p]),
+    "dsea_lanczos_axpy_norm": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p,
+                                       c_void_p, c_void_p]),
+    "dsea_ritz_combine": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "dsea_project_out": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "dsea_cg_init": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "dsea_cg_init_check": (c_int, [c_void_p, c_void_p, c_double, c_void_p]),
+    "dsea_cg_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "dsea_cg_check": (c_int, [c_void_p, c_void_p, c_double, c_void_p]),
+    "dsea_cg_direction": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "dsea_lanczos_run": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                 c_void_p]),
+    "dsea_cg_run": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int64,
+                            c_int, POINTER(c_int64), POINTER(c_double), c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def load():
+    """Return the ctypes handle of libdsea.so, loading it on first use.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DseaError(
+            "libdsea.so not found at %s -- the HIP extension is not built.  Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C dominantsparseeigenad_amd/csrc`.  There is no CPU fallback for CUDA tensors." % LIB_PATH
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status, what="dsea call", allow=()):
+    if status == 0 or status in allow:
+        return status
+    lib = load()
+    msg = lib.dsea_error_string(status).decode()
+    extra = ""
+    if status == -4:
+        extra = " (hipError %d)" % lib.dsea_last_hip_error()
+    raise DseaError("%s failed: %s%s" % (what, msg, extra))

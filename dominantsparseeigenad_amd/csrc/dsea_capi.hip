@@ -1,0 +1,457 @@
+// dsea_capi.hip -- the extern "C" boundary of libdsea.so (declared in include/dsea.h).
+// Host code only: argument checks, workspace carving, kernel sequencing.  No torch types.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+
+#include "dsea_internal.h"
+
+using namespace dsea;
+
+struct dsea_op_s {
+  OpDesc d;
+};
+struct dsea_ws_s {
+  Workspace w;
+};
+
+namespace {
+thread_local int g_last_hip = 0;
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline int check_launch() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    g_last_hip = (int)e;
+    return DSEA_ERR_HIP;
+  }
+  return DSEA_OK;
+}
+
+inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+struct WsLayout {
+  size_t partials_off, coef_off, scal_off, vec_off, total;
+  int64_t npad;
+};
+WsLayout ws_layout(int64_t n, int kmax) {
+  WsLayout L;
+  const int kk = kmax < 1 ? 1 : kmax;
+  L.npad = round_up(n < 1 ? 1 : n, 256);
+  size_t off = 0;
+  L.partials_off = off;
+  off += (size_t)DSEA_MAX_WAVE_TILES * (size_t)kk * sizeof(double);
+  L.coef_off = off;
+  off += (size_t)round_up(kk, 32) * sizeof(double);
+  L.scal_off = off;
+  off += (size_t)DSEA_SCALARS * sizeof(double);
+  off = (size_t)round_up((int64_t)off, 256);
+  L.vec_off = off;
+  off += 4 * (size_t)L.npad * sizeof(double);
+  L.total = off;
+  return L;
+}
+}  // namespace
+
+TileGeom Workspace::geom(int64_t n_rows) const {
+  TileGeom g;
+  int rpl = rpl_override;
+  if (rpl != 2 && rpl != 4 && rpl != 8 && rpl != 16) {
+    // automatic: enough wave tiles to fill 256 CUs several times over, at most DSEA_MAX_WAVE_TILES
+    if (n_rows <= (int64_t)64 * 2 * 4096) rpl = 2;
+    else if (n_rows <= (int64_t)64 * 4 * 4096) rpl = 4;
+    else rpl = 8;
+  }
+  g.rpl = rpl;
+  g.ntiles = (n_rows + 64 * rpl - 1) / (64 * rpl);
+  if (g.ntiles < 1) g.ntiles = 1;
+  g.nw = (int)(g.ntiles < DSEA_MAX_WAVE_TILES ? g.ntiles : DSEA_MAX_WAVE_TILES);
+  g.pstride = DSEA_MAX_WAVE_TILES;
+  return g;
+}
+
+extern "C" {
+
+int dsea_version(void) { return 100; }
+
+const char* dsea_error_string(int status) {
+  switch (status) {
+    case DSEA_OK: return "ok";
+    case DSEA_ERR_ARG: return "invalid argument";
+    case DSEA_ERR_ALIGN: return "pointer not 16-byte aligned or odd leading dimension";
+    case DSEA_ERR_WORKSPACE: return "workspace too small";
+    case DSEA_ERR_HIP: return "HIP runtime error";
+    case DSEA_ERR_NOT_CONVERGED: return "CG did not converge within maxiter";
+    case DSEA_ERR_UNSUPPORTED: return "unsupported configuration";
+    default: return "unknown status";
+  }
+}
+
+int dsea_last_hip_error(void) { return g_last_hip; }
+
+// ---------------------------------------------------------------------------- workspace
+int dsea_ws_bytes(int64_t n, int kmax, size_t* bytes) {
+  if (!bytes || n < 1 || kmax < 0) return DSEA_ERR_ARG;
+  *bytes = ws_layout(n, kmax).total;
+  return DSEA_OK;
+}
+
+int dsea_ws_create(void* device_buffer, size_t bytes, int64_t n, int kmax, dsea_ws_t* out) {
+  if (!device_buffer || !out || n < 1 || kmax < 0) return DSEA_ERR_ARG;
+  if (!aligned16(device_buffer)) return DSEA_ERR_ALIGN;
+  WsLayout L = ws_layout(n, kmax);
+  if (bytes < L.total) return DSEA_ERR_WORKSPACE;
+  dsea_ws_s* ws = new (std::nothrow) dsea_ws_s;
+  if (!ws) return DSEA_ERR_ARG;
+  char* base = static_cast<char*>(device_buffer);
+  ws->w.n = n;
+  ws->w.npad = L.npad;
+  ws->w.kmax = kmax;
+  ws->w.rpl_override = 0;
+  ws->w.prof = nullptr;
+  ws->w.partials = reinterpret_cast<double*>(base + L.partials_off);
+  ws->w.coef = reinterpret_cast<double*>(base + L.coef_off);
+  ws->w.scal = reinterpret_cast<double*>(base + L.scal_off);
+  for (int v = 0; v < 4; ++v)
+    ws->w.vec[v] = reinterpret_cast<double*>(base + L.vec_off) + (size_t)v * (size_t)L.npad;
+  *out = ws;
+  return DSEA_OK;
+}
+
+static void prof_free(Workspace& w) {
+  if (!w.prof) return;
+  for (int e = 0; e < w.prof->capacity; ++e) {
+    hipEventDestroy(w.prof->pairs[e].a);
+    hipEventDestroy(w.prof->pairs[e].b);
+  }
+  delete[] w.prof->pairs;
+  delete w.prof;
+  w.prof = nullptr;
+}
+
+int dsea_ws_destroy(dsea_ws_t ws) {
+  if (ws) prof_free(ws->w);
+  delete ws;
+  return DSEA_OK;
+}
+
+int dsea_profile_begin(dsea_ws_t ws, int max_records) {
+  if (!ws || max_records < 1) return DSEA_ERR_ARG;
+  prof_free(ws->w);
+  Profiler* p = new (std::nothrow) Profiler;
+  if (!p) return DSEA_ERR_ARG;
+  p->pairs = new (std::nothrow) EventPair[max_records];
+  p->capacity = max_records;
+  p->used = 0;
+  for (int e = 0; e < max_records; ++e) {
+    if (hipEventCreate(&p->pairs[e].a) != hipSuccess || hipEventCreate(&p->pairs[e].b) != hipSuccess) {
+      g_last_hip = (int)hipGetLastError();
+      return DSEA_ERR_HIP;
+    }
+  }
+  ws->w.prof = p;
+  return DSEA_OK;
+}
+
+int dsea_profile_end(dsea_ws_t ws, int64_t* launches, double* total_ms) {
+  if (!ws || !ws->w.prof || !launches || !total_ms) return DSEA_ERR_ARG;
+  Profiler* p = ws->w.prof;
+  for (int kd = 0; kd < PROF_KINDS; ++kd) {
+    launches[kd] = 0;
+    total_ms[kd] = 0.0;
+  }
+  for (int e = 0; e < p->used; ++e) {
+    if (hipEventSynchronize(p->pairs[e].b) != hipSuccess) return DSEA_ERR_HIP;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p->pairs[e].a, p->pairs[e].b) != hipSuccess) return DSEA_ERR_HIP;
+    launches[p->pairs[e].kind] += 1;
+    total_ms[p->pairs[e].kind] += (double)ms;
+  }
+  prof_free(ws->w);
+  return DSEA_OK;
+}
+
+int dsea_ws_set_rows_per_lane(dsea_ws_t ws, int rpl) {
+  if (!ws) return DSEA_ERR_ARG;
+  if (rpl != 0 && rpl != 2 && rpl != 4 && rpl != 8 && rpl != 16) return DSEA_ERR_ARG;
+  ws->w.rpl_override = rpl;
+  return DSEA_OK;
+}
+
+// ---------------------------------------------------------------------------- operators
+int dsea_op_create_tfim(int L, int L_local, int64_t row_offset, const double* g_dev, double g_const,
+                        double diag_scale, dsea_op_t* out) {
+  if (!out || L < 1 || L > 62 || L_local < 0 || L_local > L || row_offset < 0) return DSEA_ERR_ARG;
+  if (row_offset & (((int64_t)1 << L_local) - 1)) return DSEA_ERR_ARG;  // slab must be aligned
+  dsea_op_s* op = new (std::nothrow) dsea_op_s;
+  if (!op) return DSEA_ERR_ARG;
+  memset(&op->d, 0, sizeof(op->d));
+  op->d.kind = OP_TFIM;
+  op->d.n = (int64_t)1 << L_local;
+  op->d.tfim = TfimParams{L, L_local, row_offset, g_dev, g_const, diag_scale};
+  *out = op;
+  return DSEA_OK;
+}
+
+int dsea_op_create_csr(int64_t n, int64_t nnz, const int64_t* rowptr, const int32_t* colidx,
+                       const double* vals, dsea_op_t* out) {
+  if (!out || n < 1 || nnz < 0 || !rowptr || (nnz > 0 && (!colidx || !vals))) return DSEA_ERR_ARG;
+  dsea_op_s* op = new (std::nothrow) dsea_op_s;
+  if (!op) return DSEA_ERR_ARG;
+  memset(&op->d, 0, sizeof(op->d));
+  op->d.kind = OP_CSR;
+  op->d.n = n;
+  op->d.csr = CsrParams{n, nnz, rowptr, colidx, vals};
+  *out = op;
+  return DSEA_OK;
+}
+
+int dsea_op_create_stencil3(int64_t n, double coef, const double* V_dev, const double* halo_lo,
+                            const double* halo_hi, dsea_op_t* out) {
+  if (!out || n < 1 || !V_dev) return DSEA_ERR_ARG;
+  dsea_op_s* op = new (std::nothrow) dsea_op_s;
+  if (!op) return DSEA_ERR_ARG;
+  memset(&op->d, 0, sizeof(op->d));
+  op->d.kind = OP_STENCIL3;
+  op->d.n = n;
+  op->d.st3 = Stencil3Params{n, coef, V_dev, halo_lo, halo_hi};
+  *out = op;
+  return DSEA_OK;
+}
+
+int dsea_op_destroy(dsea_op_t op) {
+  delete op;
+  return DSEA_OK;
+}
+
+int dsea_op_dim(dsea_op_t op, int64_t* n) {
+  if (!op || !n) return DSEA_ERR_ARG;
+  *n = op->d.n;
+  return DSEA_OK;
+}
+
+int dsea_spmv(dsea_op_t op, dsea_ws_t ws, const double* x, double* y, const double* shift,
+              double* dot_out, const double* skip_flag, void* stream) {
+  if (!op || !x || !y || x == y) return DSEA_ERR_ARG;
+  if (dot_out && !ws) return DSEA_ERR_ARG;
+  if (!aligned16(x) || !aligned16(y)) return DSEA_ERR_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  double* P = dot_out ? ws->w.partials : nullptr;
+  int nb = launch_spmv(op->d, x, y, shift, skip_flag, P, st);
+  if (nb < 0) return DSEA_ERR_UNSUPPORTED;
+  if (dot_out) launch_finalize_slot(P, nb, dot_out, skip_flag, st);
+  return check_launch();
+}
+
+// ---------------------------------------------------------------------------- vector phases
+#define REQUIRE(cond, code) \
+  do {                      \
+    if (!(cond)) return (code); \
+  } while (0)
+
+int dsea_dot(dsea_ws_t ws, const double* x, const double* y, int64_t n, double* out, void* stream) {
+  REQUIRE(ws && x && y && out && n >= 1, DSEA_ERR_ARG);
+  REQUIRE(aligned16(x) && aligned16(y), DSEA_ERR_ALIGN);
+  launch_dot(x, y, n, ws->w.partials, out, static_cast<hipStream_t>(stream));
+  return check_launch();
+}
+
+int dsea_shift_dot(dsea_ws_t ws, const double* x, double* y, const double* shift, double* dot_out,
+                   const double* skip_flag, int64_t n, void* stream) {
+  REQUIRE(ws && x && y && dot_out && n >= 1, DSEA_ERR_ARG);
+  REQUIRE(aligned16(x) && aligned16(y), DSEA_ERR_ALIGN);
+  launch_shift_dot(x, y, shift, skip_flag, n, ws->w.partials, dot_out, static_cast<hipStream_t>(stream));
+  return check_launch();
+}
+
+int dsea_axpy(dsea_ws_t ws, double a_host, const double* a_dev, const double* x, double* y, int64_t n,
+              void* stream) {
+  (void)ws;
+  REQUIRE(x && y && n >= 1, DSEA_ERR_ARG);
+  REQUIRE(aligned16(x) && aligned16(y), DSEA_ERR_ALIGN);
+  launch_axpy(a_host, a_dev, x, y, n, static_cast<hipStream_t>(stream));
+  return check_launch();
+}
+
+int dsea_nrm2sq(dsea_ws_t ws, const double* x, int64_t n, double* nrm2_out, void* stream) {
+  return dsea_dot(ws, x, x, n, nrm2_out, stream);
+}
+
+int dsea_scale_store(dsea_ws_t ws, const double* r, const double* nrm2, double* q_out, double* beta_out,
+                     int64_t n, void* stream) {
+  (void)ws;
+  REQUIRE(r && nrm2 && q_out && n >= 1, DSEA_ERR_ARG);
+  REQUIRE(aligned16(r) && aligned16(q_out), DSEA_ERR_ALIGN);
+  launch_scale_store(r, nrm2, q_out, beta_out, n, static_cast<hipStream_t>(stream));
+  return check_launch();
+}
+
+int dsea_lanczos_rdots(dsea_ws_t ws, const double* Q, int64_t ldq, int64_t n, int i, const double* u,
+                       const double* alpha, const double* beta, double* r, double* c_out, void* stream) {
+  REQUIRE(ws && Q && u && alpha && r && c_out && n >= 1 && i >= 1 && ldq >= n, DSEA_ERR_ARG);
+  REQUIRE(i <= ws->w.kmax, DSEA_ERR_WORKSPACE);
+  REQUIRE(aligned16(Q) && aligned16(u) && aligned16(r) && (ldq % 2 == 0), DSEA_ERR_ALIGN);
+  TileGeom g = ws->w.geom(n);
+  launch_rdots(g, Q, ldq, n, i, u, alpha, beta, r, ws->w.partials, c_out, static_cast<hipStream_t>(stream));
+  return check_launch();
+}
+
+int dsea_lanczos_axpy_norm(dsea_ws_t ws, const double* Q, int64_t ldq, int64_t n, int i, const double* c,
+                           double* r, double* nrm2_out, void* stream) {
+  REQUIRE(ws && Q && c && r && nrm2_out && n >= 1 && i >= 1 && ldq >= n, DSEA_ERR_ARG);
+  REQUIRE(aligned16(Q) && aligned16(r) && (ldq % 2 == 0), DSEA_ERR_ALIGN);
+  TileGeom g = ws->w.geom(n);
+  launch_axpy_norm(g, Q, ldq, n, i, c, r, ws->w.partials, nrm2_out, static_cast<hipStream_t>(stream));
+  return check_launch();
+}
+
+int dsea_ritz_combine(dsea_ws_t ws, const double* Q, int64_t ldq, int64_t n, int k, const double* s,
+                      double* out, void* stream) {
+  REQUIRE(ws && Q && s && out && n >= 1 && k >= 1 && ldq >= n, DSEA_ERR_ARG);
+  REQUIRE(aligned16(Q) && aligned16(out) && (ldq % 2 == 0), DSEA_ERR_ALIGN);
+  TileGeom g = ws->w.geom(n);
+  launch_ritz(g, Q, ldq, n, k, s, out, static_cast<hipStream_t>(stream));
+  return check_launch();
+}
+
+int dsea_project_out(dsea_ws_t ws, const double* v, const double* a, double* out, double* a_dot_v,
+                     int64_t n, void* stream) {
+  REQUIRE(ws && v && a && out && n >= 1, DSEA_ERR_ARG);
+  REQUIRE(aligned16(v) && aligned16(a) && aligned16(out), DSEA_ERR_ALIGN);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  double* slot = a_dot_v ? a_dot_v : ws->w.scal + 8;
+  launch_dot(a, v, n, ws->w.partials, slot, st);
+  launch_project_apply(v, a, slot, out, n, st);
+  return check_launch();
+}
+
+// ---------------------------------------------------------------------------- CG phases
+int dsea_cg_init(dsea_ws_t ws, const double* b, const double* Ax0, double* r, double* d, double* state,
+                 int64_t n, void* stream) {
+  REQUIRE(ws && b && Ax0 && r && d && state && n >= 1, DSEA_ERR_ARG);
+  REQUIRE(aligned16(b) && aligned16(Ax0) && aligned16(r) && aligned16(d), DSEA_ERR_ALIGN);
+  launch_cg_init(b, Ax0, r, d, state, n, ws->w.partials, static_cast<hipStream_t>(stream));
+  return check_launch();
+}
+
+int dsea_cg_init_check(dsea_ws_t ws, double* state, double eps, void* stream) {
+  (void)ws;
+  REQUIRE(state, DSEA_ERR_ARG);
+  launch_cg_init_check(state, eps, static_cast<hipStream_t>(stream));
+  return check_launch();
+}
+
+int dsea_cg_update(dsea_ws_t ws, double* x, double* r, const double* d, const double* Ad, double* state,
+                   int64_t n, void* stream) {
+  REQUIRE(ws && x && r && d && Ad && state && n >= 1, DSEA_ERR_ARG);
+  REQUIRE(aligned16(x) && aligned16(r) && aligned16(d) && aligned16(Ad), DSEA_ERR_ALIGN);
+  launch_cg_update(x, r, d, Ad, state, n, ws->w.partials, static_cast<hipStream_t>(stream));
+  return check_launch();
+}
+
+int dsea_cg_check(dsea_ws_t ws, double* state, double eps, void* stream) {
+  (void)ws;
+  REQUIRE(state, DSEA_ERR_ARG);
+  launch_cg_check(state, eps, static_cast<hipStream_t>(stream));
+  return check_launch();
+}
+
+int dsea_cg_direction(dsea_ws_t ws, const double* r, double* d, const double* state, int64_t n,
+                      void* stream) {
+  (void)ws;
+  REQUIRE(r && d && state && n >= 1, DSEA_ERR_ARG);
+  REQUIRE(aligned16(r) && aligned16(d), DSEA_ERR_ALIGN);
+  launch_cg_direction(r, d, state, n, static_cast<hipStream_t>(stream));
+  return check_launch();
+}
+
+// ---------------------------------------------------------------------------- whole solvers
+int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double* Q, int64_t ldq,
+                     double* alphas, double* betas, void* stream) {
+  REQUIRE(op && ws && q0 && Q && alphas && betas && k >= 1, DSEA_ERR_ARG);
+  const int64_t n = op->d.n;
+  REQUIRE(ldq >= n && ws->w.n >= n, DSEA_ERR_ARG);
+  REQUIRE(k <= ws->w.kmax || k == 1, DSEA_ERR_WORKSPACE);
+  REQUIRE(aligned16(q0) && aligned16(Q) && (ldq % 2 == 0), DSEA_ERR_ALIGN);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Workspace& w = ws->w;
+  double* P = w.partials;
+  double* u = w.vec[0];
+  double* r = w.vec[1];
+  double* nrm2 = w.scal + 0;
+  TileGeom g = w.geom(n);
+
+  // q_0 = q0/||q0|| ; u = A q_0 ; alpha_0 = q_0.u          (Lanczos.py:52-57)
+  Profiler* prof = w.prof;
+  launch_dot(q0, q0, n, P, nrm2, st);
+  launch_scale_store(q0, nrm2, Q, nullptr, n, st);
+  int nb = launch_spmv(op->d, Q, u, nullptr, nullptr, P, st, prof ? prof->next(PROF_SPMV) : nullptr);
+  if (nb < 0) return DSEA_ERR_UNSUPPORTED;
+  launch_finalize1(P, nb, alphas, st);
+  for (int i = 1; i < k; ++i) {
+    const double* beta_prev = (i >= 2) ? betas + (i - 2) : nullptr;
+    launch_rdots(g, Q, ldq, n, i, u, alphas + (i - 1), beta_prev, r, P, w.coef, st,
+                 prof ? prof->next(PROF_RDOTS) : nullptr);
+    launch_axpy_norm(g, Q, ldq, n, i, w.coef, r, P, nrm2, st, prof ? prof->next(PROF_AXPY) : nullptr);
+    double* qi = Q + (int64_t)i * ldq;
+    launch_scale_store(r, nrm2, qi, betas + (i - 1), n, st);
+    nb = launch_spmv(op->d, qi, u, nullptr, nullptr, P, st, prof ? prof->next(PROF_SPMV) : nullptr);
+    launch_finalize1(P, nb, alphas + i, st);
+  }
+  return check_launch();
+}
+
+int dsea_cg_run(dsea_op_t op, dsea_ws_t ws, const double* shift, const double* b, double* x, double* state,
+                double eps, int64_t maxiter, int poll_every, int64_t* iters_out, double* resnorm_out,
+                void* stream) {
+  REQUIRE(op && ws && b && x && state && maxiter >= 0, DSEA_ERR_ARG);
+  const int64_t n = op->d.n;
+  REQUIRE(ws->w.n >= n, DSEA_ERR_ARG);
+  REQUIRE(aligned16(b) && aligned16(x), DSEA_ERR_ALIGN);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Workspace& w = ws->w;
+  double* P = w.partials;
+  double* r = w.vec[1];
+  double* d = w.vec[2];
+  double* Ad = w.vec[3];
+  const double* done = state + DSEA_CG_DONE;
+  if (poll_every <= 0) poll_every = 16;
+
+  // r = b - A'x0 ; early out ; d = r                            (CG.py:26-30)
+  int nb = launch_spmv(op->d, x, Ad, shift, nullptr, nullptr, st);
+  if (nb < 0) return DSEA_ERR_UNSUPPORTED;
+  launch_cg_init(b, Ad, r, d, state, n, P, st);
+  launch_cg_init_check(state, eps, st);
+
+  double host_state[DSEA_CG_STATE_LEN];
+  int64_t issued = 0;
+  bool finished = false;
+  while (!finished) {
+    const int64_t chunk = (maxiter - issued) < poll_every ? (maxiter - issued) : poll_every;
+    for (int64_t it = 0; it < chunk; ++it) {
+      nb = launch_spmv(op->d, d, Ad, shift, done, P, st);               // A'd and d.A'd  (CG.py:31/40)
+      launch_finalize_slot(P, nb, state + DSEA_CG_DAD, done, st);
+      launch_cg_update(x, r, d, Ad, state, n, P, st);                   // CG.py:33-34
+      launch_cg_check(state, eps, st);                                  // CG.py:35-38
+      launch_cg_direction(r, d, state, n, st);                          // CG.py:39
+    }
+    issued += chunk;
+    if (hipMemcpyAsync(host_state, state, sizeof(host_state), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+      g_last_hip = (int)hipGetLastError();
+      return DSEA_ERR_HIP;
+    }
+    finished = (host_state[DSEA_CG_DONE] != 0.0) || issued >= maxiter;
+  }
+  if (iters_out) *iters_out = (int64_t)host_state[DSEA_CG_ITERS];
+  if (resnorm_out) *resnorm_out = host_state[DSEA_CG_RESNORM];
+  int rc = check_launch();
+  if (rc != DSEA_OK) return rc;
+  return host_state[DSEA_CG_DONE] != 0.0 ? DSEA_OK : DSEA_ERR_NOT_CONVERGED;
+}
+
+}  // extern "C"

@@ -1,0 +1,110 @@
+// dsea_internal.h -- shared between dsea_kernels.hip (device code + launchers) and dsea_capi.hip (C ABI).
+#ifndef DSEA_INTERNAL_H
+#define DSEA_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dsea.h"
+
+#define DSEA_MAX_EW_BLOCKS 2048   /* grid cap of the grid-stride streaming kernels            */
+#define DSEA_MAX_WAVE_TILES 8192  /* cap on wave tiles (= partial sums per basis vector)      */
+#define DSEA_TFIM_TILE_LOG2 11    /* rows of x staged in LDS per block of the TFIM mat-vec    */
+#define DSEA_SCALARS 64
+
+namespace dsea {
+
+struct TfimParams {
+  int L, L_local;
+  int64_t row_offset;
+  const double* g_dev;
+  double g_const;
+  double diag_scale;
+};
+struct CsrParams {
+  int64_t n, nnz;
+  const int64_t* rowptr;
+  const int32_t* colidx;
+  const double* vals;
+};
+struct Stencil3Params {
+  int64_t n;
+  double coef;
+  const double* V;
+  const double* halo_lo;
+  const double* halo_hi;
+};
+enum OpKind { OP_TFIM = 1, OP_CSR = 2, OP_STENCIL3 = 3 };
+struct OpDesc {
+  OpKind kind;
+  int64_t n;
+  TfimParams tfim;
+  CsrParams csr;
+  Stencil3Params st3;
+};
+
+// how the rows of one vector are cut into wave tiles for the basis-streaming kernels
+struct TileGeom {
+  int rpl;         // rows per lane (2,4,8,16): a wave tile is 64*rpl rows
+  int nw;          // waves launched (<= DSEA_MAX_WAVE_TILES); wave w handles tiles w, w+nw, ...
+  int64_t ntiles;  // ceil(n / (64*rpl))
+  int pstride;     // stride between the partial rows of two basis vectors (>= nw)
+};
+
+// optional per-launch HIP-event timing of the dominant kernels (bench.py roofline); host objects only
+enum ProfKind { PROF_RDOTS = 0, PROF_AXPY = 1, PROF_SPMV = 2, PROF_KINDS = 3 };
+struct EventPair {
+  hipEvent_t a, b;
+  int kind;
+};
+struct Profiler {
+  EventPair* pairs;
+  int capacity, used;
+  EventPair* next(int kind) {
+    if (used >= capacity) return nullptr;
+    pairs[used].kind = kind;
+    return &pairs[used++];
+  }
+};
+
+struct Workspace {
+  int64_t n, npad;
+  int kmax;
+  int rpl_override;
+  double* partials;  // DSEA_MAX_WAVE_TILES * max(kmax,1) doubles (also >= DSEA_MAX_EW_BLOCKS)
+  double* coef;      // kmax doubles
+  double* scal;      // DSEA_SCALARS doubles
+  double* vec[4];    // four work vectors of npad doubles
+  Profiler* prof;    // null unless dsea_profile_begin was called
+  TileGeom geom(int64_t n_rows) const;
+};
+
+void launch_finalize1(const double* P, int count, double* out, hipStream_t st);
+void launch_finalize_slot(const double* P, int count, double* out, const double* skip, hipStream_t st);
+void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* u,
+                  const double* alpha, const double* beta, double* r, double* P, double* c_out,
+                  hipStream_t st, EventPair* ev = nullptr);
+void launch_axpy_norm(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* c,
+                      double* r, double* P, double* nrm2_out, hipStream_t st, EventPair* ev = nullptr);
+void launch_ritz(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int k, const double* s,
+                 double* out, hipStream_t st);
+void launch_dot(const double* x, const double* y, int64_t n, double* P, double* out, hipStream_t st);
+void launch_shift_dot(const double* x, double* y, const double* shift, const double* skip, int64_t n,
+                      double* P, double* out, hipStream_t st);
+void launch_axpy(double a_host, const double* a_dev, const double* x, double* y, int64_t n, hipStream_t st);
+void launch_scale_store(const double* r, const double* nrm2, double* q, double* beta_out, int64_t n,
+                        hipStream_t st);
+void launch_project_apply(const double* v, const double* a, const double* dot, double* out, int64_t n,
+                          hipStream_t st);
+void launch_cg_init(const double* b, const double* Ax0, double* r, double* d, double* state, int64_t n,
+                    double* P, hipStream_t st);
+void launch_cg_init_check(double* state, double eps, hipStream_t st);
+void launch_cg_update(double* x, double* r, const double* d, const double* Ad, double* state, int64_t n,
+                      double* P, hipStream_t st);
+void launch_cg_check(double* state, double eps, hipStream_t st);
+void launch_cg_direction(const double* r, double* d, const double* state, int64_t n, hipStream_t st);
+int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shift, const double* skip,
+                double* P, hipStream_t st, EventPair* ev = nullptr);
+
+}  // namespace dsea
+#endif

@@ -1,0 +1,740 @@
+// dsea_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the dominant-eigenpair hot path.
+//
+// Everything here is bandwidth-bound fp64 vector work (no MFMA): the Krylov basis is streamed
+// from HBM with 16-byte coalesced loads (one wave reads 1 KiB per instruction), partial sums are
+// reduced inside a wave with cross-lane shuffles, across waves through LDS, and across workgroups
+// by a deterministic second stage (no atomics: the reference is bitwise repeatable and so is this).
+//
+// Geometry of the basis-streaming kernels (the dominant pair, reference Lanczos.py:66):
+//   a wave owns a tile of 64*RPL consecutive rows and keeps its piece of r in registers
+//   (RPL doubles per lane, as RPL/2 double2); it then walks j = 0..i-1 over the basis vectors
+//   Q[j] (vector-contiguous, stride ldq) reading the same rows of each -- every byte of the basis
+//   is read exactly once per pass, r is read once and written once.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dsea_internal.h"
+
+namespace dsea {
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;  // butterfly: every lane holds the same, order-fixed total
+}
+
+// block of 256 threads = 4 waves; returns the total in thread 0 (fixed order w0+w1+w2+w3)
+__device__ __forceinline__ double block_sum(double v, double* sm4) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sm4[w] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0) t = ((sm4[0] + sm4[1]) + sm4[2]) + sm4[3];
+  return t;
+}
+
+template <bool GUARD>
+__device__ __forceinline__ double2 ld2(const double* __restrict__ p, int64_t row, int64_t n) {
+  if (!GUARD || row + 1 < n) return *reinterpret_cast<const double2*>(p + row);
+  double2 v = make_double2(0.0, 0.0);
+  if (row < n) v.x = p[row];
+  return v;
+}
+template <bool GUARD>
+__device__ __forceinline__ void st2(double* __restrict__ p, int64_t row, int64_t n, double2 v) {
+  if (!GUARD || row + 1 < n) {
+    *reinterpret_cast<double2*>(p + row) = v;
+  } else if (row < n) {
+    p[row] = v.x;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// stage-2 reductions (deterministic)
+// ------------------------------------------------------------------------------------------
+// out[0] = sum_{b<count} partials[b]
+__global__ __launch_bounds__(256) void k_finalize1(const double* __restrict__ partials, int count,
+                                                   double* __restrict__ out) {
+  __shared__ double sm4[4];
+  double acc = 0.0;
+  for (int b = threadIdx.x; b < count; b += 256) acc += partials[b];
+  double t = block_sum(acc, sm4);
+  if (threadIdx.x == 0) out[0] = t;
+}
+
+// c[j] = sum_{w<nw} P[j*pstride + w]   (one 64-thread block per j)
+__global__ __launch_bounds__(64) void k_finalize_multi(const double* __restrict__ P, int64_t pstride,
+                                                       int nw, double* __restrict__ c) {
+  const int j = blockIdx.x;
+  const double* row = P + (int64_t)j * pstride;
+  double acc = 0.0;
+  for (int w = threadIdx.x; w < nw; w += 64) acc += row[w];
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) c[j] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// Lanczos phase 1: r = u - alpha q1 - beta q2 ; partial c[j] = Q[j].r     (Lanczos.py:61,66)
+// ------------------------------------------------------------------------------------------
+template <int RPL, bool GUARD>
+__device__ __forceinline__ void rdots_tile(const double* __restrict__ Q, int64_t ldq, int i, int64_t n,
+                                           int64_t base, int lane, const double* __restrict__ u,
+                                           double a, double b, double* __restrict__ r,
+                                           double* __restrict__ P, int64_t pstride, int64_t widx,
+                                           bool accumulate) {
+  constexpr int NP = RPL / 2;
+  double2 rv[NP];
+  const double* __restrict__ q1 = Q + (int64_t)(i - 1) * ldq;
+  const double* __restrict__ q2 = (i >= 2) ? Q + (int64_t)(i - 2) * ldq : nullptr;
+#pragma unroll
+  for (int t = 0; t < NP; ++t) {
+    const int64_t row = base + t * 128 + lane * 2;
+    double2 uu = ld2<GUARD>(u, row, n);
+    double2 qa = ld2<GUARD>(q1, row, n);
+    double2 qb = make_double2(0.0, 0.0);
+    if (q2) qb = ld2<GUARD>(q2, row, n);
+    // (u - alpha*q) - beta*q' with each product rounded on its own, as the torch expression does
+    rv[t].x = __dsub_rn(__dsub_rn(uu.x, __dmul_rn(a, qa.x)), __dmul_rn(b, qb.x));
+    rv[t].y = __dsub_rn(__dsub_rn(uu.y, __dmul_rn(a, qa.y)), __dmul_rn(b, qb.y));
+    st2<GUARD>(r, row, n, rv[t]);
+  }
+  // four basis vectors per trip: 4*NP independent 16-byte loads in flight per lane, and one
+  // transposed butterfly (7 shuffles instead of 24) leaves the four totals in lanes 0/16/32/48.
+  int j = 0;
+  for (; j + 4 <= i; j += 4) {
+    const double* __restrict__ qj = Q + (int64_t)j * ldq;
+    double2 q[4][NP];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int t = 0; t < NP; ++t) q[v][t] = ld2<GUARD>(qj + (int64_t)v * ldq, base + t * 128 + lane * 2, n);
+    double acc[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      acc[v] = 0.0;
+#pragma unroll
+      for (int t = 0; t < NP; ++t) {
+        acc[v] = fma(q[v][t].x, rv[t].x, acc[v]);
+        acc[v] = fma(q[v][t].y, rv[t].y, acc[v]);
+      }
+    }
+    const bool hi32 = (lane & 32) != 0, hi16 = (lane & 16) != 0;
+    double a0 = hi32 ? acc[2] : acc[0], s0 = hi32 ? acc[0] : acc[2];
+    double a1 = hi32 ? acc[3] : acc[1], s1 = hi32 ? acc[1] : acc[3];
+    a0 += __shfl_xor(s0, 32, 64);
+    a1 += __shfl_xor(s1, 32, 64);
+    double bsum = hi16 ? a1 : a0, bs = hi16 ? a0 : a1;
+    bsum += __shfl_xor(bs, 16, 64);
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) bsum += __shfl_xor(bsum, m, 64);
+    if ((lane & 15) == 0) {
+      double* dst = P + (int64_t)(j + (lane >> 4)) * pstride + widx;
+      *dst = accumulate ? (*dst + bsum) : bsum;
+    }
+  }
+  for (; j < i; ++j) {
+    const double* __restrict__ qj = Q + (int64_t)j * ldq;
+    double acc = 0.0;
+#pragma unroll
+    for (int t = 0; t < NP; ++t) {
+      double2 q = ld2<GUARD>(qj, base + t * 128 + lane * 2, n);
+      acc = fma(q.x, rv[t].x, acc);
+      acc = fma(q.y, rv[t].y, acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      double* dst = P + (int64_t)j * pstride + widx;
+      *dst = accumulate ? (*dst + acc) : acc;
+    }
+  }
+}
+
+template <int RPL>
+__global__ __launch_bounds__(256) void k_rdots(const double* __restrict__ Q, int64_t ldq, int i,
+                                               int64_t n, const double* __restrict__ u,
+                                               const double* __restrict__ alpha,
+                                               const double* __restrict__ beta, double* __restrict__ r,
+                                               double* __restrict__ P, int64_t pstride, int nw,
+                                               int64_t ntiles) {
+  const int lane = threadIdx.x & 63;
+  const int64_t widx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (widx >= nw) return;
+  const double a = alpha[0];
+  const double b = beta ? beta[0] : 0.0;
+  constexpr int64_t TILE = 64 * RPL;
+  bool first = true;
+  for (int64_t tile = widx; tile < ntiles; tile += nw) {
+    const int64_t base = tile * TILE;
+    if (base + TILE <= n)
+      rdots_tile<RPL, false>(Q, ldq, i, n, base, lane, u, a, b, r, P, pstride, widx, !first);
+    else
+      rdots_tile<RPL, true>(Q, ldq, i, n, base, lane, u, a, b, r, P, pstride, widx, !first);
+    first = false;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Lanczos phase 2: r -= sum_j c[j] Q[j] ; partial ||r||^2          (Lanczos.py:66,69)
+// MODE 0: as above.  MODE 1 (Ritz vector, Lanczos.py:99): out = sum_j c[j] Q[j], no norm.
+// ------------------------------------------------------------------------------------------
+template <int RPL, bool GUARD, int MODE>
+__device__ __forceinline__ double axpy_tile(const double* __restrict__ Q, int64_t ldq, int i, int64_t n,
+                                            int64_t base, int lane, const double* __restrict__ c,
+                                            double* __restrict__ r) {
+  constexpr int NP = RPL / 2;
+  double2 w[NP];
+#pragma unroll
+  for (int t = 0; t < NP; ++t) w[t] = make_double2(0.0, 0.0);
+#pragma unroll 4
+  for (int j = 0; j < i; ++j) {
+    const double* __restrict__ qj = Q + (int64_t)j * ldq;
+    const double cj = c[j];
+#pragma unroll
+    for (int t = 0; t < NP; ++t) {
+      const int64_t row = base + t * 128 + lane * 2;
+      double2 q = ld2<GUARD>(qj, row, n);
+      w[t].x = fma(cj, q.x, w[t].x);
+      w[t].y = fma(cj, q.y, w[t].y);
+    }
+  }
+  double acc = 0.0;
+#pragma unroll
+  for (int t = 0; t < NP; ++t) {
+    const int64_t row = base + t * 128 + lane * 2;
+    if (MODE == 0) {
+      double2 rv = ld2<GUARD>(r, row, n);
+      rv.x -= w[t].x;
+      rv.y -= w[t].y;
+      st2<GUARD>(r, row, n, rv);
+      acc = fma(rv.x, rv.x, acc);
+      acc = fma(rv.y, rv.y, acc);
+    } else {
+      st2<GUARD>(r, row, n, w[t]);
+    }
+  }
+  return acc;
+}
+
+template <int RPL, int MODE>
+__global__ __launch_bounds__(256) void k_axpy_norm(const double* __restrict__ Q, int64_t ldq, int i,
+                                                   int64_t n, const double* __restrict__ c,
+                                                   double* __restrict__ r, double* __restrict__ P,
+                                                   int nw, int64_t ntiles) {
+  const int lane = threadIdx.x & 63;
+  const int64_t widx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (widx >= nw) return;
+  constexpr int64_t TILE = 64 * RPL;
+  double acc = 0.0;
+  for (int64_t tile = widx; tile < ntiles; tile += nw) {
+    const int64_t base = tile * TILE;
+    if (base + TILE <= n)
+      acc += axpy_tile<RPL, false, MODE>(Q, ldq, i, n, base, lane, c, r);
+    else
+      acc += axpy_tile<RPL, true, MODE>(Q, ldq, i, n, base, lane, c, r);
+  }
+  if (MODE == 0) {
+    acc = wave_sum(acc);
+    if (lane == 0) P[widx] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// streaming elementwise kernels with a fused reduction (grid-stride, double2)
+// ------------------------------------------------------------------------------------------
+enum { EW_DOT = 0, EW_NRM2, EW_SHIFT_DOT, EW_CG_INIT, EW_CG_UPDATE, EW_PROJECT_DOT };
+
+// Generic two-vector reduction kernels.  Each block writes one partial (P[blockIdx.x]).
+__global__ __launch_bounds__(256) void k_dot(const double* __restrict__ x, const double* __restrict__ y,
+                                             int64_t n, double* __restrict__ P) {
+  __shared__ double sm4[4];
+  double acc = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * 512;
+  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; row < n; row += stride) {
+    double2 a = ld2<true>(x, row, n), b = ld2<true>(y, row, n);
+    acc = fma(a.x, b.x, acc);
+    acc = fma(a.y, b.y, acc);
+  }
+  double t = block_sum(acc, sm4);
+  if (threadIdx.x == 0) P[blockIdx.x] = t;
+}
+
+// y -= shift*x ; partial x.y
+__global__ __launch_bounds__(256) void k_shift_dot(const double* __restrict__ x, double* __restrict__ y,
+                                                   const double* __restrict__ shift,
+                                                   const double* __restrict__ skip, int64_t n,
+                                                   double* __restrict__ P) {
+  __shared__ double sm4[4];
+  if (skip && skip[0] != 0.0) return;
+  const double s = shift ? shift[0] : 0.0;
+  double acc = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * 512;
+  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; row < n; row += stride) {
+    double2 a = ld2<true>(x, row, n), b = ld2<true>(y, row, n);
+    b.x = __dsub_rn(b.x, __dmul_rn(s, a.x));
+    b.y = __dsub_rn(b.y, __dmul_rn(s, a.y));
+    st2<true>(y, row, n, b);
+    acc = fma(a.x, b.x, acc);
+    acc = fma(a.y, b.y, acc);
+  }
+  double t = block_sum(acc, sm4);
+  if (threadIdx.x == 0) P[blockIdx.x] = t;
+}
+
+// y += (a_host * a_dev) x
+__global__ __launch_bounds__(256) void k_axpy(double a_host, const double* __restrict__ a_dev,
+                                              const double* __restrict__ x, double* __restrict__ y,
+                                              int64_t n) {
+  const double a = a_host * (a_dev ? a_dev[0] : 1.0);
+  const int64_t stride = (int64_t)gridDim.x * 512;
+  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; row < n; row += stride) {
+    double2 xv = ld2<true>(x, row, n), yv = ld2<true>(y, row, n);
+    yv.x = fma(a, xv.x, yv.x);
+    yv.y = fma(a, xv.y, yv.y);
+    st2<true>(y, row, n, yv);
+  }
+}
+
+// q = r / sqrt(nrm2) ; beta_out = sqrt(nrm2)
+__global__ __launch_bounds__(256) void k_scale_store(const double* __restrict__ r,
+                                                     const double* __restrict__ nrm2,
+                                                     double* __restrict__ q, double* __restrict__ beta_out,
+                                                     int64_t n) {
+  const double beta = sqrt(nrm2[0]);
+  if (beta_out && blockIdx.x == 0 && threadIdx.x == 0) beta_out[0] = beta;
+  const int64_t stride = (int64_t)gridDim.x * 512;
+  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; row < n; row += stride) {
+    double2 v = ld2<true>(r, row, n);
+    v.x = v.x / beta;
+    v.y = v.y / beta;
+    st2<true>(q, row, n, v);
+  }
+}
+
+// out = v - (adv) a, adv = *dot (already finalised)
+__global__ __launch_bounds__(256) void k_project_apply(const double* __restrict__ v,
+                                                       const double* __restrict__ a,
+                                                       const double* __restrict__ dot,
+                                                       double* __restrict__ out, int64_t n) {
+  const double d = dot[0];
+  const int64_t stride = (int64_t)gridDim.x * 512;
+  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; row < n; row += stride) {
+    double2 vv = ld2<true>(v, row, n), av = ld2<true>(a, row, n);
+    vv.x = __dsub_rn(vv.x, __dmul_rn(d, av.x));
+    vv.y = __dsub_rn(vv.y, __dmul_rn(d, av.y));
+    st2<true>(out, row, n, vv);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// CG kernels (CG.py:24-41)
+// ------------------------------------------------------------------------------------------
+// r = b - Ax0 ; d = r ; partial r.r
+__global__ __launch_bounds__(256) void k_cg_init(const double* __restrict__ b,
+                                                 const double* __restrict__ Ax0, double* __restrict__ r,
+                                                 double* __restrict__ d, int64_t n,
+                                                 double* __restrict__ P) {
+  __shared__ double sm4[4];
+  double acc = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * 512;
+  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; row < n; row += stride) {
+    double2 bv = ld2<true>(b, row, n), av = ld2<true>(Ax0, row, n);
+    bv.x -= av.x;
+    bv.y -= av.y;
+    st2<true>(r, row, n, bv);
+    st2<true>(d, row, n, bv);
+    acc = fma(bv.x, bv.x, acc);
+    acc = fma(bv.y, bv.y, acc);
+  }
+  double t = block_sum(acc, sm4);
+  if (threadIdx.x == 0) P[blockIdx.x] = t;
+}
+
+__global__ void k_cg_state_clear(double* __restrict__ state) {
+  if (threadIdx.x < DSEA_CG_STATE_LEN) state[threadIdx.x] = 0.0;
+}
+
+__global__ void k_cg_init_check(double* __restrict__ state, double eps) {
+  const double rn = sqrt(state[DSEA_CG_RR]);
+  state[DSEA_CG_RESNORM] = rn;
+  state[DSEA_CG_DONE] = (rn < eps) ? 1.0 : 0.0;
+  state[DSEA_CG_ITERS] = 0.0;
+}
+
+// x += alpha d ; r -= alpha Ad ; partial r.r          alpha = rr / dAd
+__global__ __launch_bounds__(256) void k_cg_update(double* __restrict__ x, double* __restrict__ r,
+                                                   const double* __restrict__ d,
+                                                   const double* __restrict__ Ad,
+                                                   const double* __restrict__ state, int64_t n,
+                                                   double* __restrict__ P) {
+  __shared__ double sm4[4];
+  if (state[DSEA_CG_DONE] != 0.0) return;
+  const double alpha = state[DSEA_CG_RR] / state[DSEA_CG_DAD];
+  double acc = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * 512;
+  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; row < n; row += stride) {
+    double2 xv = ld2<true>(x, row, n), rv = ld2<true>(r, row, n);
+    double2 dv = ld2<true>(d, row, n), av = ld2<true>(Ad, row, n);
+    xv.x = __dadd_rn(xv.x, __dmul_rn(alpha, dv.x));
+    xv.y = __dadd_rn(xv.y, __dmul_rn(alpha, dv.y));
+    rv.x = __dsub_rn(rv.x, __dmul_rn(alpha, av.x));
+    rv.y = __dsub_rn(rv.y, __dmul_rn(alpha, av.y));
+    st2<true>(x, row, n, xv);
+    st2<true>(r, row, n, rv);
+    acc = fma(rv.x, rv.x, acc);
+    acc = fma(rv.y, rv.y, acc);
+  }
+  double t = block_sum(acc, sm4);
+  if (threadIdx.x == 0) P[blockIdx.x] = t;
+}
+
+// stage 2 of the update's reduction; leaves the local sum in state[RRNEW] unless done
+__global__ __launch_bounds__(256) void k_cg_finalize_rrnew(const double* __restrict__ P, int count,
+                                                           double* __restrict__ state) {
+  __shared__ double sm4[4];
+  if (state[DSEA_CG_DONE] != 0.0) return;
+  double acc = 0.0;
+  for (int b = threadIdx.x; b < count; b += 256) acc += P[b];
+  double t = block_sum(acc, sm4);
+  if (threadIdx.x == 0) state[DSEA_CG_RRNEW] = t;
+}
+
+// same for d.Ad -> state[DAD]
+__global__ __launch_bounds__(256) void k_cg_finalize_slot(const double* __restrict__ P, int count,
+                                                          double* __restrict__ out,
+                                                          const double* __restrict__ skip) {
+  __shared__ double sm4[4];
+  if (skip && skip[0] != 0.0) return;
+  double acc = 0.0;
+  for (int b = threadIdx.x; b < count; b += 256) acc += P[b];
+  double t = block_sum(acc, sm4);
+  if (threadIdx.x == 0) out[0] = t;
+}
+
+__global__ void k_cg_check(double* __restrict__ state, double eps) {
+  if (state[DSEA_CG_DONE] != 0.0) return;
+  const double rr_new = state[DSEA_CG_RRNEW];
+  const double rn = sqrt(rr_new);
+  state[DSEA_CG_ITERS] += 1.0;
+  state[DSEA_CG_RESNORM] = rn;
+  if (rn < eps) {
+    state[DSEA_CG_DONE] = 1.0;
+  } else {
+    state[DSEA_CG_BETA] = rr_new / state[DSEA_CG_RR];
+    state[DSEA_CG_RR] = rr_new;
+  }
+}
+
+// d = r + beta d
+__global__ __launch_bounds__(256) void k_cg_direction(const double* __restrict__ r, double* __restrict__ d,
+                                                      const double* __restrict__ state, int64_t n) {
+  if (state[DSEA_CG_DONE] != 0.0) return;
+  const double beta = state[DSEA_CG_BETA];
+  const int64_t stride = (int64_t)gridDim.x * 512;
+  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; row < n; row += stride) {
+    double2 rv = ld2<true>(r, row, n), dv = ld2<true>(d, row, n);
+    dv.x = __dadd_rn(rv.x, __dmul_rn(beta, dv.x));
+    dv.y = __dadd_rn(rv.y, __dmul_rn(beta, dv.y));
+    st2<true>(d, row, n, dv);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// operators
+// ------------------------------------------------------------------------------------------
+// TFIM, matrix-free.  A block stages a tile of 2^T consecutive rows of x in LDS: flips of the low
+// T bits are LDS reads, flips of bits T..Lloc-1 are coalesced global reads of other tiles (served
+// by L2 / Infinity Cache: the whole vector is 8 MiB at L = 20).
+//   y[i] = dscale*d(gi)*x[i] - g * sum_j x[i^(1<<j)] - shift*x[i] ;   partial x.y
+template <int T>
+__global__ __launch_bounds__(256) void k_spmv_tfim(TfimParams p, const double* __restrict__ x,
+                                                   double* __restrict__ y,
+                                                   const double* __restrict__ shift,
+                                                   const double* __restrict__ skip,
+                                                   double* __restrict__ P) {
+  constexpr int TILE = 1 << T;
+  constexpr int PER = (TILE + 255) / 256;
+  __shared__ double tile[TILE];
+  __shared__ double sm4[4];
+  if (skip && skip[0] != 0.0) return;
+  const double g = p.g_dev ? p.g_dev[0] : p.g_const;
+  const double s = shift ? shift[0] : 0.0;
+  const int64_t base = (int64_t)blockIdx.x * TILE;
+#pragma unroll
+  for (int t = 0; t < PER; ++t) {
+    const int l = t * 256 + threadIdx.x;
+    if (l < TILE) tile[l] = x[base + l];
+  }
+  __syncthreads();
+  const uint64_t maskL = (p.L >= 64) ? ~0ull : ((1ull << p.L) - 1ull);
+  double acc = 0.0;
+#pragma unroll
+  for (int t = 0; t < PER; ++t) {
+    const int l = t * 256 + threadIdx.x;
+    if (l < TILE) {
+      const int64_t i = base + l;
+      double sum = 0.0;
+#pragma unroll
+      for (int j = 0; j < T; ++j) sum += tile[l ^ (1 << j)];
+      for (int j = T; j < p.L_local; ++j) sum += x[i ^ ((int64_t)1 << j)];
+      const double xi = tile[l];
+      const uint64_t gi = (uint64_t)(p.row_offset + i);
+      const uint64_t rot = ((gi << 1) | (gi >> (p.L - 1))) & maskL;
+      const int pop = __popcll(gi ^ rot);
+      const double diag = p.diag_scale * (double)(-(p.L - 2 * pop));
+      double v = __dsub_rn(__dmul_rn(xi, diag), __dmul_rn(g, sum));
+      if (shift) v = __dsub_rn(v, __dmul_rn(s, xi));
+      y[i] = v;
+      acc = fma(xi, v, acc);
+    }
+  }
+  if (P) {
+    double tot = block_sum(acc, sm4);
+    if (threadIdx.x == 0) P[blockIdx.x] = tot;
+  }
+}
+
+// CSR: G lanes cooperate on one row
+template <int G>
+__global__ __launch_bounds__(256) void k_spmv_csr(CsrParams p, const double* __restrict__ x,
+                                                  double* __restrict__ y,
+                                                  const double* __restrict__ shift,
+                                                  const double* __restrict__ skip,
+                                                  double* __restrict__ P) {
+  __shared__ double sm4[4];
+  if (skip && skip[0] != 0.0) return;
+  const double s = shift ? shift[0] : 0.0;
+  const int sub = threadIdx.x % G;
+  const int64_t rows_per_block = 256 / G;
+  double acc = 0.0;
+  for (int64_t row = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / G; row < p.n;
+       row += (int64_t)gridDim.x * rows_per_block) {
+    const int64_t lo = p.rowptr[row], hi = p.rowptr[row + 1];
+    double sum = 0.0;
+    for (int64_t e = lo + sub; e < hi; e += G) sum = fma(p.vals[e], x[p.colidx[e]], sum);
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
+    if (sub == 0) {
+      const double xi = x[row];
+      double v = sum;
+      if (shift) v = __dsub_rn(v, __dmul_rn(s, xi));
+      y[row] = v;
+      acc = fma(xi, v, acc);
+    }
+  }
+  if (P) {
+    double tot = block_sum(acc, sm4);
+    if (threadIdx.x == 0) P[blockIdx.x] = tot;
+  }
+}
+
+// 3-point stencil + diagonal (schrodinger1D.py:18-27)
+__global__ __launch_bounds__(256) void k_spmv_stencil3(Stencil3Params p, const double* __restrict__ x,
+                                                       double* __restrict__ y,
+                                                       const double* __restrict__ shift,
+                                                       const double* __restrict__ skip,
+                                                       double* __restrict__ P) {
+  __shared__ double sm4[4];
+  if (skip && skip[0] != 0.0) return;
+  const double s = shift ? shift[0] : 0.0;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * 256) {
+    const double xi = x[i];
+    const double up = (i + 1 < p.n) ? x[i + 1] : (p.halo_hi ? p.halo_hi[0] : 0.0);
+    const double dn = (i > 0) ? x[i - 1] : (p.halo_lo ? p.halo_lo[0] : 0.0);
+    const double lap = __dadd_rn(__dadd_rn(__dmul_rn(-2.0, xi), up), dn);
+    double v = __dadd_rn(__dmul_rn(p.coef, lap), __dmul_rn(p.V[i], xi));
+    if (shift) v = __dsub_rn(v, __dmul_rn(s, xi));
+    y[i] = v;
+    acc = fma(xi, v, acc);
+  }
+  if (P) {
+    double tot = block_sum(acc, sm4);
+    if (threadIdx.x == 0) P[blockIdx.x] = tot;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side launch wrappers (called from dsea_capi.hip)
+// ------------------------------------------------------------------------------------------
+static inline int ew_blocks(int64_t n) {
+  int64_t nb = (n + 2047) / 2048;  // 256 threads x double2 x 4 iterations
+  if (nb < 1) nb = 1;
+  if (nb > DSEA_MAX_EW_BLOCKS) nb = DSEA_MAX_EW_BLOCKS;
+  return (int)nb;
+}
+
+#define LAUNCH_RPL(KERNEL, rpl, grid, stream, ...)                                    \
+  do {                                                                                \
+    switch (rpl) {                                                                    \
+      case 2: hipLaunchKernelGGL((KERNEL<2>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break; \
+      case 4: hipLaunchKernelGGL((KERNEL<4>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break; \
+      case 8: hipLaunchKernelGGL((KERNEL<8>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break; \
+      default: hipLaunchKernelGGL((KERNEL<16>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break; \
+    }                                                                                 \
+  } while (0)
+
+void launch_finalize1(const double* P, int count, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_finalize1, dim3(1), dim3(256), 0, st, P, count, out);
+}
+
+void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* u,
+                  const double* alpha, const double* beta, double* r, double* P, double* c_out,
+                  hipStream_t st, EventPair* ev) {
+  const int grid = (g.nw + 3) / 4;
+  if (ev) hipEventRecord(ev->a, st);
+  LAUNCH_RPL(k_rdots, g.rpl, grid, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, g.nw,
+             g.ntiles);
+  if (ev) hipEventRecord(ev->b, st);
+  hipLaunchKernelGGL(k_finalize_multi, dim3(i), dim3(64), 0, st, (const double*)P, (int64_t)g.pstride,
+                     g.nw, c_out);
+}
+
+void launch_axpy_norm(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* c,
+                      double* r, double* P, double* nrm2_out, hipStream_t st, EventPair* ev) {
+  const int grid = (g.nw + 3) / 4;
+  if (ev) hipEventRecord(ev->a, st);
+  switch (g.rpl) {
+    case 2: hipLaunchKernelGGL((k_axpy_norm<2, 0>), dim3(grid), dim3(256), 0, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles); break;
+    case 4: hipLaunchKernelGGL((k_axpy_norm<4, 0>), dim3(grid), dim3(256), 0, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles); break;
+    case 8: hipLaunchKernelGGL((k_axpy_norm<8, 0>), dim3(grid), dim3(256), 0, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles); break;
+    default: hipLaunchKernelGGL((k_axpy_norm<16, 0>), dim3(grid), dim3(256), 0, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles); break;
+  }
+  if (ev) hipEventRecord(ev->b, st);
+  launch_finalize1(P, g.nw, nrm2_out, st);
+}
+
+void launch_ritz(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int k, const double* s,
+                 double* out, hipStream_t st) {
+  const int grid = (g.nw + 3) / 4;
+  double* nullP = nullptr;
+  switch (g.rpl) {
+    case 2: hipLaunchKernelGGL((k_axpy_norm<2, 1>), dim3(grid), dim3(256), 0, st, Q, ldq, k, n, s, out, nullP, g.nw, g.ntiles); break;
+    case 4: hipLaunchKernelGGL((k_axpy_norm<4, 1>), dim3(grid), dim3(256), 0, st, Q, ldq, k, n, s, out, nullP, g.nw, g.ntiles); break;
+    case 8: hipLaunchKernelGGL((k_axpy_norm<8, 1>), dim3(grid), dim3(256), 0, st, Q, ldq, k, n, s, out, nullP, g.nw, g.ntiles); break;
+    default: hipLaunchKernelGGL((k_axpy_norm<16, 1>), dim3(grid), dim3(256), 0, st, Q, ldq, k, n, s, out, nullP, g.nw, g.ntiles); break;
+  }
+}
+
+void launch_dot(const double* x, const double* y, int64_t n, double* P, double* out, hipStream_t st) {
+  const int nb = ew_blocks(n);
+  hipLaunchKernelGGL(k_dot, dim3(nb), dim3(256), 0, st, x, y, n, P);
+  launch_finalize1(P, nb, out, st);
+}
+
+void launch_shift_dot(const double* x, double* y, const double* shift, const double* skip, int64_t n,
+                      double* P, double* out, hipStream_t st) {
+  const int nb = ew_blocks(n);
+  hipLaunchKernelGGL(k_shift_dot, dim3(nb), dim3(256), 0, st, x, y, shift, skip, n, P);
+  hipLaunchKernelGGL(k_cg_finalize_slot, dim3(1), dim3(256), 0, st, (const double*)P, nb, out, skip);
+}
+
+void launch_axpy(double a_host, const double* a_dev, const double* x, double* y, int64_t n,
+                 hipStream_t st) {
+  hipLaunchKernelGGL(k_axpy, dim3(ew_blocks(n)), dim3(256), 0, st, a_host, a_dev, x, y, n);
+}
+
+void launch_scale_store(const double* r, const double* nrm2, double* q, double* beta_out, int64_t n,
+                        hipStream_t st) {
+  hipLaunchKernelGGL(k_scale_store, dim3(ew_blocks(n)), dim3(256), 0, st, r, nrm2, q, beta_out, n);
+}
+
+void launch_project_apply(const double* v, const double* a, const double* dot, double* out, int64_t n,
+                          hipStream_t st) {
+  hipLaunchKernelGGL(k_project_apply, dim3(ew_blocks(n)), dim3(256), 0, st, v, a, dot, out, n);
+}
+
+void launch_cg_init(const double* b, const double* Ax0, double* r, double* d, double* state, int64_t n,
+                    double* P, hipStream_t st) {
+  const int nb = ew_blocks(n);
+  hipLaunchKernelGGL(k_cg_state_clear, dim3(1), dim3(64), 0, st, state);
+  hipLaunchKernelGGL(k_cg_init, dim3(nb), dim3(256), 0, st, b, Ax0, r, d, n, P);
+  launch_finalize1(P, nb, state + DSEA_CG_RR, st);
+}
+
+void launch_cg_init_check(double* state, double eps, hipStream_t st) {
+  hipLaunchKernelGGL(k_cg_init_check, dim3(1), dim3(1), 0, st, state, eps);
+}
+
+void launch_cg_update(double* x, double* r, const double* d, const double* Ad, double* state, int64_t n,
+                      double* P, hipStream_t st) {
+  const int nb = ew_blocks(n);
+  hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(256), 0, st, x, r, d, Ad, (const double*)state, n, P);
+  hipLaunchKernelGGL(k_cg_finalize_rrnew, dim3(1), dim3(256), 0, st, (const double*)P, nb, state);
+}
+
+void launch_cg_check(double* state, double eps, hipStream_t st) {
+  hipLaunchKernelGGL(k_cg_check, dim3(1), dim3(1), 0, st, state, eps);
+}
+
+void launch_cg_direction(const double* r, double* d, const double* state, int64_t n, hipStream_t st) {
+  hipLaunchKernelGGL(k_cg_direction, dim3(ew_blocks(n)), dim3(256), 0, st, r, d, state, n);
+}
+
+// returns the number of partials written (0 when P == nullptr)
+static int launch_spmv_impl(const OpDesc& op, const double* x, double* y, const double* shift,
+                            const double* skip, double* P, hipStream_t st);
+
+int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shift, const double* skip,
+                double* P, hipStream_t st, EventPair* ev) {
+  if (ev) hipEventRecord(ev->a, st);
+  int nb = launch_spmv_impl(op, x, y, shift, skip, P, st);
+  if (ev) hipEventRecord(ev->b, st);
+  return nb;
+}
+
+static int launch_spmv_impl(const OpDesc& op, const double* x, double* y, const double* shift,
+                            const double* skip, double* P, hipStream_t st) {
+  switch (op.kind) {
+    case OP_TFIM: {
+      const TfimParams& p = op.tfim;
+      const int T = p.L_local < DSEA_TFIM_TILE_LOG2 ? p.L_local : DSEA_TFIM_TILE_LOG2;
+      const int64_t nb = ((int64_t)1 << p.L_local) >> T;
+#define TFIM_CASE(TT) \
+  case TT: hipLaunchKernelGGL((k_spmv_tfim<TT>), dim3((unsigned)nb), dim3(256), 0, st, p, x, y, shift, skip, P); break;
+      switch (T) {
+        TFIM_CASE(0) TFIM_CASE(1) TFIM_CASE(2) TFIM_CASE(3) TFIM_CASE(4) TFIM_CASE(5) TFIM_CASE(6)
+        TFIM_CASE(7) TFIM_CASE(8) TFIM_CASE(9) TFIM_CASE(10) TFIM_CASE(11)
+        default: return -1;
+      }
+#undef TFIM_CASE
+      return (int)nb;
+    }
+    case OP_CSR: {
+      const CsrParams& p = op.csr;
+      const double avg = p.n > 0 ? (double)p.nnz / (double)p.n : 1.0;
+      int G = 4;
+      while (G < 64 && G < avg) G *= 2;
+      const int64_t rows_per_block = 256 / G;
+      int64_t nb = (p.n + rows_per_block - 1) / rows_per_block;
+      if (nb > DSEA_MAX_EW_BLOCKS) nb = DSEA_MAX_EW_BLOCKS;
+      if (nb < 1) nb = 1;
+      switch (G) {
+        case 4: hipLaunchKernelGGL((k_spmv_csr<4>), dim3((unsigned)nb), dim3(256), 0, st, p, x, y, shift, skip, P); break;
+        case 8: hipLaunchKernelGGL((k_spmv_csr<8>), dim3((unsigned)nb), dim3(256), 0, st, p, x, y, shift, skip, P); break;
+        case 16: hipLaunchKernelGGL((k_spmv_csr<16>), dim3((unsigned)nb), dim3(256), 0, st, p, x, y, shift, skip, P); break;
+        case 32: hipLaunchKernelGGL((k_spmv_csr<32>), dim3((unsigned)nb), dim3(256), 0, st, p, x, y, shift, skip, P); break;
+        default: hipLaunchKernelGGL((k_spmv_csr<64>), dim3((unsigned)nb), dim3(256), 0, st, p, x, y, shift, skip, P); break;
+      }
+      return (int)nb;
+    }
+    case OP_STENCIL3: {
+      const Stencil3Params& p = op.st3;
+      int64_t nb = (p.n + 255) / 256;
+      if (nb > DSEA_MAX_EW_BLOCKS) nb = DSEA_MAX_EW_BLOCKS;
+      if (nb < 1) nb = 1;
+      hipLaunchKernelGGL(k_spmv_stencil3, dim3((unsigned)nb), dim3(256), 0, st, p, x, y, shift, skip, P);
+      return (int)nb;
+    }
+  }
+  return -1;
+}
+
+void launch_finalize_slot(const double* P, int count, double* out, const double* skip, hipStream_t st) {
+  hipLaunchKernelGGL(k_cg_finalize_slot, dim3(1), dim3(256), 0, st, P, count, out, skip);
+}
+
+}  // namespace dsea

@@ -1,0 +1,94 @@
+"""Dominant eigen primitives for general (non-symmetric) real matrices -- API of reference
+DominantSparseEigenAD/eig.py.
+
+    DominantEig.apply(A, k[, which])                                   reference eig.py:5-62
+    setDominantSparseEig(A, AT, Aadjoint_to_gadjoint)                  reference eig.py:64-152
+        -> module attribute ``DominantSparseEig``; ``.apply(g, k)``
+
+Scope note: in the reference the arithmetic of this path is not its
+own code but SciPy's ARPACK ``eigs`` and ``gmres`` on host NumPy arrays (eig.py:28-30,54-57), first order
+only.  It is outside the Lanczos/CG hot path this build accelerates, so the same third-party calls are
+kept (host pass-through, identical numerics); a device Arnoldi/GMRES is the "next" row f-1.
+"""
+from __future__ import annotations
+
+import inspect
+
+import numpy as np
+import torch
+from scipy.sparse import linalg as sla
+
+_GMRES_TOL = 1e-12
+_gmres_kw = "rtol" if "rtol" in inspect.signature(sla.gmres).parameters else "tol"
+
+
+def _gmres(op, rhs):
+    sol, _info = sla.gmres(op, rhs, atol=_GMRES_TOL, **{_gmres_kw: _GMRES_TOL})   # eig.py:54,57,140,144
+    return sol
+
+
+def _dominant_pair(A, AT, k, which):
+    """right / left eigenvectors of the wanted eigenvalue, normalised l.r = 1, r.r = 1 (eig.py:29-36)."""
+    wr, vr = sla.eigs(A, k=1, which=which, ncv=k)
+    wl, vl = sla.eigs(AT, k=1, which=which, ncv=k)
+    if not np.allclose(wr.imag, 0.0):
+        raise AssertionError("The desired eigenvalue of the matrix must be real")      # eig.py:31-32
+    lam = wr.real
+    r = vr[:, 0].real
+    l = vl[:, 0].real
+    l = l / np.dot(l, r)
+    return lam, l, r
+
+
+class DominantEig(torch.autograd.Function):
+    """(eigval (1,), left eigenvector, right eigenvector) of a real diagonalisable matrix tensor."""
+
+    @staticmethod
+    def forward(ctx, A, k, which="LM"):
+        M = A.detach().cpu().numpy()
+        lam, l, r = _dominant_pair(M, M.T, k, which)
+        ctx.M, ctx.lam, ctx.l, ctx.r = M, lam, l, r
+        return torch.from_numpy(lam), torch.from_numpy(l), torch.from_numpy(r)
+
+    @staticmethod
+    def backward(ctx, g_lam, g_l, g_r):
+        M, lam, l, r = ctx.M, ctx.lam, ctx.l, ctx.r
+        g_l, g_r = g_l.numpy(), g_r.numpy()
+        eye = np.eye(M.shape[0])
+        rhs = g_l - r * np.dot(l, g_l)                                           # eig.py:53
+        lam_l = _gmres(M - lam * eye, rhs)
+        rhs = g_r - l * np.dot(r, g_r)                                           # eig.py:56
+        lam_r = _gmres(M.T - lam * eye, rhs)
+        gA = g_lam.numpy() * l[:, None] * r - l[:, None] * lam_l - lam_r[:, None] * r   # eig.py:58-60
+        return torch.from_numpy(gA), None, None
+
+
+def _make_sparse_eig(A, AT, Aadjoint_to_gadjoint):
+    class DominantSparseEig(torch.autograd.Function):
+        """As DominantEig with A, A^T given as scipy LinearOperators; inputs (g, k) (eig.py:115-149)."""
+
+        @staticmethod
+        def forward(ctx, g, k):
+            lam, l, r = _dominant_pair(A, AT, k, "LM")
+            ctx.lam, ctx.l, ctx.r = lam, l, r
+            return torch.from_numpy(lam), torch.from_numpy(l), torch.from_numpy(r)
+
+        @staticmethod
+        def backward(ctx, g_lam, g_l, g_r):
+            lam, l, r = ctx.lam, ctx.l, ctx.r
+            g_lam, g_l, g_r = g_lam.numpy(), g_l.numpy(), g_r.numpy()
+            shifted = sla.LinearOperator(A.shape, matvec=lambda v: A.matvec(v) - lam * v)
+            lam_l = _gmres(shifted, g_l - r * np.dot(l, g_l))
+            shifted_T = sla.LinearOperator(AT.shape, matvec=lambda v: AT.matvec(v) - lam * v)
+            lam_r = _gmres(shifted_T, g_r - l * np.dot(r, g_r))
+            pieces = ((g_lam * l, r), (-l, lam_l), (-lam_r, r))                  # eig.py:145-147
+            return Aadjoint_to_gadjoint(pieces), None
+
+    return DominantSparseEig
+
+
+def setDominantSparseEig(A, AT, Aadjoint_to_gadjoint):
+    """Publish ``DominantSparseEig`` as a module attribute (reference protocol, eig.py:112,151)."""
+    global DominantSparseEig
+    DominantSparseEig = _make_sparse_eig(A, AT, Aadjoint_to_gadjoint)
+    return DominantSparseEig

@@ -1,0 +1,267 @@
+"""Device-side engine: torch tensors in, libdsea.so (HIP) calls out.
+
+PyTorch is used here for device memory, streams and nothing else: every arithmetic
+operation on an n-vector in the two hot loops goes through the C ABI of include/dsea.h.
+The engine never falls back to torch arithmetic; a missing library raises (``_lib.load``).
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import byref, c_double, c_int64, c_size_t, c_void_p
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+F64 = torch.float64
+
+
+def _stream(device):
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(None)
+
+
+def as_vector(t, n=None):
+    """contiguous, fp64, 16-byte aligned device vector (copies only when it has to)."""
+    if t.dtype != F64:
+        t = t.to(F64)
+    if not t.is_contiguous():
+        t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone()
+    if n is not None and t.numel() != n:
+        raise ValueError("expected a vector of %d elements, got %d" % (n, t.numel()))
+    return t
+
+
+class Workspace:
+    """Caller-owned scratch handed to the library (include/dsea.h: dsea_ws_*)."""
+
+    _cache = {}
+
+    def __init__(self, n, kmax, device):
+        self.lib = _lib.load()
+        self.n, self.kmax, self.device = int(n), int(kmax), torch.device(device)
+        nbytes = c_size_t()
+        check(self.lib.dsea_ws_bytes(self.n, self.kmax, byref(nbytes)), "dsea_ws_bytes")
+        self.buffer = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
+        handle = c_void_p()
+        check(self.lib.dsea_ws_create(_ptr(self.buffer), nbytes.value, self.n, self.kmax, byref(handle)),
+              "dsea_ws_create")
+        self.handle = handle
+        self.state = torch.zeros(_lib.CG_STATE_LEN, dtype=F64, device=self.device)
+        self.scal = torch.zeros(16, dtype=F64, device=self.device)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.dsea_ws_destroy(self.handle)
+        except Exception:
+            pass
+
+    @classmethod
+    def get(cls, n, kmax, device):
+        device = torch.device(device)
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        key = (int(n), str(device))
+        ws = cls._cache.get(key)
+        if ws is None or ws.kmax < kmax:
+            ws = cls(n, max(int(kmax), 8), device)
+            cls._cache[key] = ws
+        return ws
+
+    def set_rows_per_lane(self, rpl):
+        check(self.lib.dsea_ws_set_rows_per_lane(self.handle, int(rpl)), "dsea_ws_set_rows_per_lane")
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def native_of(A):
+    """The native operator behind ``A`` or None.  ``A`` may be the operator object itself or its bound
+    mat-vec method (``model.H``, the form the reference examples pass: examples/TFIM/E0.py:60)."""
+    if hasattr(A, "_native_methods"):
+        return A
+    owner = getattr(A, "__self__", None)
+    if owner is not None and hasattr(owner, "_native_methods") and getattr(A, "__name__", "") in owner._native_methods:
+        return owner
+    return None
+
+
+# --------------------------------------------------------------------------- Lanczos
+def lanczos(A, k, n, device, q0, native=None, callable_A=None):
+    """k-step Lanczos on the GPU (reference Lanczos.py:49-77).
+
+    native     : operator object exposing ``.handle`` -> whole loop in dsea_lanczos_run
+    callable_A : python callable v -> A v (torch tensors on ``device``) -> one C-ABI phase call per
+                 stage, the mat-vec itself is the user's code
+    Returns (Q (k, ldq) basis, ldq, alphas (k,), betas (k-1,)).
+    """
+    lib = _lib.load()
+    device = torch.device(device)
+    ws = Workspace.get(n, k, device)
+    st = _stream(device)
+    ldq = round_up(n, 32)
+    Q = torch.empty((k, ldq), dtype=F64, device=device)
+    alphas = torch.empty(k, dtype=F64, device=device)
+    betas = torch.empty(max(k - 1, 1), dtype=F64, device=device)
+    q0 = as_vector(q0, n)
+    if native is not None:
+        check(lib.dsea_lanczos_run(native.handle, ws.handle, int(k), _ptr(q0), _ptr(Q), ldq, _ptr(alphas),
+                                   _ptr(betas), st), "dsea_lanczos_run")
+        return Q, ldq, alphas, betas[: k - 1]
+
+    nrm2 = ws.scal[0:1]
+    r = torch.empty(n, dtype=F64, device=device)
+    c = torch.empty(max(k, 1), dtype=F64, device=device)
+    check(lib.dsea_nrm2sq(ws.handle, _ptr(q0), n, _ptr(nrm2), st), "dsea_nrm2sq")
+    check(lib.dsea_scale_store(ws.handle, _ptr(q0), _ptr(nrm2), _ptr(Q), None, n, st), "dsea_scale_store")
+    u = as_vector(callable_A(Q[0, :n]), n)
+    check(lib.dsea_dot(ws.handle, _ptr(Q), _ptr(u), n, _ptr(alphas), st), "dsea_dot")
+    esz = 8
+    for i in range(1, k):
+        a_ptr = c_void_p(alphas.data_ptr() + (i - 1) * esz)
+        b_ptr = c_void_p(betas.data_ptr() + (i - 2) * esz) if i >= 2 else c_void_p(None)
+        check(lib.dsea_lanczos_rdots(ws.handle, _ptr(Q), ldq, n, i, _ptr(u), a_ptr, b_ptr, _ptr(r), _ptr(c), st),
+              "dsea_lanczos_rdots")
+        check(lib.dsea_lanczos_axpy_norm(ws.handle, _ptr(Q), ldq, n, i, _ptr(c), _ptr(r), _ptr(nrm2), st),
+              "dsea_lanczos_axpy_norm")
+        qi = Q[i]
+        check(lib.dsea_scale_store(ws.handle, _ptr(r), _ptr(nrm2), _ptr(qi),
+                                   c_void_p(betas.data_ptr() + (i - 1) * esz), n, st), "dsea_scale_store")
+        u = as_vector(callable_A(qi[:n]), n)
+        check(lib.dsea_dot(ws.handle, _ptr(qi), _ptr(u), n, c_void_p(alphas.data_ptr() + i * esz), st), "dsea_dot")
+    return Q, ldq, alphas, betas[: k - 1]
+
+
+def tridiag_extreme(alphas, betas, which):
+    """Extreme eigenpair(s) of the k x k tridiagonal T (reference Lanczos.py:98: dense symeig of T).
+
+    T is tiny (k ~ 200): it is solved on the host with LAPACK through scipy (one 3 kB D2H copy,
+    which is also the only host sync of the forward pass).  Returns [(eigval, s (k,) numpy), ...].
+    """
+    from scipy.linalg import eigh_tridiagonal
+
+    d = alphas.detach().cpu().numpy()
+    e = betas.detach().cpu().numpy()
+    k = d.shape[0]
+    out = []
+    if k == 1:
+        return [(float(d[0]), np.ones(1))] * (2 if which == "both" else 1)
+    picks = {"min": [0], "max": [k - 1], "both": [0, k - 1]}[which]
+    for idx in picks:
+        w, v = eigh_tridiagonal(d, e, select="i", select_range=(idx, idx))
+        out.append((float(w[0]), np.ascontiguousarray(v[:, 0])))
+    return out
+
+
+def ritz_vector(Q, ldq, n, k, s_host, device):
+    lib = _lib.load()
+    ws = Workspace.get(n, k, device)
+    s = torch.from_numpy(np.asarray(s_host, dtype=np.float64)).to(device)
+    out = torch.empty(n, dtype=F64, device=device)
+    check(lib.dsea_ritz_combine(ws.handle, _ptr(Q), ldq, n, int(k), _ptr(s), _ptr(out), _stream(device)),
+          "dsea_ritz_combine")
+    return out
+
+
+# --------------------------------------------------------------------------- CG
+class CGInfo:
+    """iteration count / final residual norm of the last solve (diagnostics; reference prints nothing)."""
+    iters = 0
+    resnorm = float("nan")
+    converged = True
+
+
+last_cg = CGInfo()
+
+
+def cg(b, x0, *, native=None, callable_A=None, shift=None, eps=1e-7, maxiter=None, poll_every=8):
+    """Conjugate gradients on the GPU (reference CG.py:24-41) for (A - shift I) x = b.
+
+    ``shift`` is a 0-dim/1-element device tensor (the eigenvalue E0 of CG.py:120) or None.
+    Returns x (new tensor).  The loop state lives on the device; the host polls a flag.
+    """
+    lib = _lib.load()
+    device = b.device
+    n = b.numel()
+    b = as_vector(b, n)
+    x = as_vector(x0, n).clone()
+    cap = n if maxiter is None else int(maxiter)
+    ws = Workspace.get(n, 8, device)
+    st = _stream(device)
+    state = ws.state
+    shift_t = None
+    if shift is not None:
+        shift_t = shift.detach().reshape(-1)[:1].to(device=device, dtype=F64).contiguous()
+    if native is not None:
+        iters, res = c_int64(0), c_double(0.0)
+        rc = lib.dsea_cg_run(native.handle, ws.handle, _ptr(shift_t), _ptr(b), _ptr(x), _ptr(state), float(eps),
+                             cap, int(poll_every), byref(iters), byref(res), st)
+        check(rc, "dsea_cg_run", allow=(_lib.ERR_NOT_CONVERGED,))
+        last_cg.iters, last_cg.resnorm, last_cg.converged = iters.value, res.value, rc == 0
+        return x
+
+    r = torch.empty(n, dtype=F64, device=device)
+    d = torch.empty(n, dtype=F64, device=device)
+    done_ptr = c_void_p(state.data_ptr() + _lib.CG_DONE * 8)
+    dad_ptr = c_void_p(state.data_ptr() + _lib.CG_DAD * 8)
+    Ax = as_vector(callable_A(x), n)
+    if Ax.data_ptr() == x.data_ptr():
+        Ax = Ax.clone()
+    if shift_t is not None:
+        check(lib.dsea_shift_dot(ws.handle, _ptr(x), _ptr(Ax), _ptr(shift_t), _ptr(ws.scal[1:2]), None, n, st),
+              "dsea_shift_dot")
+    check(lib.dsea_cg_init(ws.handle, _ptr(b), _ptr(Ax), _ptr(r), _ptr(d), _ptr(state), n, st), "dsea_cg_init")
+    check(lib.dsea_cg_init_check(ws.handle, _ptr(state), float(eps), st), "dsea_cg_init_check")
+    issued = 0
+    host = state.cpu()
+    while host[_lib.CG_DONE].item() == 0.0 and issued < cap:
+        chunk = min(int(poll_every), cap - issued)
+        for _ in range(chunk):
+            Ad = as_vector(callable_A(d), n)
+            if Ad.data_ptr() == d.data_ptr():
+                Ad = Ad.clone()
+            check(lib.dsea_shift_dot(ws.handle, _ptr(d), _ptr(Ad), _ptr(shift_t), dad_ptr, done_ptr, n, st),
+                  "dsea_shift_dot")
+            check(lib.dsea_cg_update(ws.handle, _ptr(x), _ptr(r), _ptr(d), _ptr(Ad), _ptr(state), n, st),
+                  "dsea_cg_update")
+            check(lib.dsea_cg_check(ws.handle, _ptr(state), float(eps), st), "dsea_cg_check")
+            check(lib.dsea_cg_direction(ws.handle, _ptr(r), _ptr(d), _ptr(state), n, st), "dsea_cg_direction")
+        issued += chunk
+        host = state.cpu()
+    last_cg.iters = int(host[_lib.CG_ITERS].item())
+    last_cg.resnorm = float(host[_lib.CG_RESNORM].item())
+    last_cg.converged = host[_lib.CG_DONE].item() != 0.0
+    return x
+
+
+# --------------------------------------------------------------------------- small helpers
+def spmv(native, x, shift=None, out=None):
+    """y = A x (- shift x) through the native operator handle."""
+    lib = _lib.load()
+    n = native.n
+    x = as_vector(x, n)
+    y = out if out is not None else torch.empty(n, dtype=F64, device=x.device)
+    check(lib.dsea_spmv(native.handle, None, _ptr(x), _ptr(y), _ptr(shift), None, None, _stream(x.device)),
+          "dsea_spmv")
+    return y
+
+
+def project_out(v, a):
+    """v - (a.v) a on the device (reference CG.py:59,122; symeig.py:27,80)."""
+    lib = _lib.load()
+    n = v.numel()
+    v, a = as_vector(v, n), as_vector(a, n)
+    ws = Workspace.get(n, 8, v.device)
+    out = torch.empty(n, dtype=F64, device=v.device)
+    check(lib.dsea_project_out(ws.handle, _ptr(v), _ptr(a), _ptr(out), None, n, _stream(v.device)),
+          "dsea_project_out")
+    return out

@@ -1,0 +1,74 @@
+"""Dominant symmetric eigen primitives -- API of reference DominantSparseEigenAD/symeig.py.
+
+    DominantSymeig.apply(A, k[, device])                              reference symeig.py:4-31
+    setDominantSparseSymeig(A, Aadjoint_to_gadjoint)                  reference symeig.py:33-88
+        -> module attribute ``DominantSparseSymeig``; ``.apply(g, k, dim[, device])``
+
+forward  = Lanczos with full re-orthogonalisation (HIP on CUDA devices, see Lanczos.py)
+backward = projected CG solve of (A - lambda I) x = b (HIP on CUDA devices, see CG.py) followed by the
+           user's ``Aadjoint_to_gadjoint(v1, v2)`` hook; the backward is built from differentiable
+           pieces (torch glue + the re-entrant CG primitive) so second derivatives work as in the
+           reference (examples/TFIM/E0.py:63-64, chiF.py:49-52).
+"""
+from __future__ import annotations
+
+import torch
+
+from .Lanczos import symeigLanczos
+from . import CG as _CG
+
+
+class DominantSymeig(torch.autograd.Function):
+    """Smallest eigenvalue / eigenvector of a real symmetric matrix given as a torch.Tensor."""
+
+    @staticmethod
+    def forward(ctx, A, k, device=torch.device("cpu")):
+        device = A.device if A.is_cuda else torch.device(device)
+        eigval, eigvector = symeigLanczos(A.detach(), k, device=device, extreme="min")   # symeig.py:16
+        ctx.save_for_backward(A, eigval, eigvector)
+        ctx.device = device
+        return eigval, eigvector
+
+    @staticmethod
+    def backward(ctx, grad_eigval, grad_eigvector):
+        A, eigval, eigvector = ctx.saved_tensors
+        Aprime = A - eigval * torch.eye(A.shape[0], device=A.device, dtype=A.dtype)      # symeig.py:25
+        b = grad_eigvector - torch.matmul(eigvector, grad_eigvector) * eigvector         # symeig.py:27
+        lambda0 = _CG.CGSubspace.apply(Aprime, b, eigvector)                             # symeig.py:28
+        grad_A = (grad_eigval * eigvector - lambda0)[:, None] * eigvector                # symeig.py:29
+        return grad_A, None, None
+
+
+def _make_sparse_symeig(A, Aadjoint_to_gadjoint, cg_cls):
+    class DominantSparseSymeig(torch.autograd.Function):
+        """Smallest eigenpair of a matrix-free real symmetric operator depending on parameters g."""
+
+        @staticmethod
+        def forward(ctx, g, k, dim, device=torch.device("cpu")):
+            device = g.device if g.is_cuda else torch.device(device)
+            eigval, eigvector = symeigLanczos(A, k, device=device, extreme="min", sparse=True, dim=dim)
+            ctx.save_for_backward(g, eigval, eigvector)
+            return eigval, eigvector
+
+        @staticmethod
+        def backward(ctx, grad_eigval, grad_eigvector):
+            g, eigval, eigvector = ctx.saved_tensors
+            b = grad_eigvector - torch.matmul(eigvector, grad_eigvector) * eigvector     # symeig.py:80
+            lambda0 = cg_cls.apply(g, eigval, b, eigvector)                              # symeig.py:81
+            v1, v2 = grad_eigval * eigvector - lambda0, eigvector                        # symeig.py:82-83
+            grad_g = Aadjoint_to_gadjoint(v1, v2)                                        # symeig.py:84
+            return grad_g, None, None, None
+
+    return DominantSparseSymeig
+
+
+def setDominantSparseSymeig(A, Aadjoint_to_gadjoint):
+    """Publish ``DominantSparseSymeig`` as a module attribute (the reference's protocol, symeig.py:66,87).
+
+    ``A`` is the operator as a callable v -> A v -- either plain torch code or one of the native operators
+    of ``dominantsparseeigenad_amd.operators`` (then both loops run without any Python in them);
+    ``Aadjoint_to_gadjoint(v1, v2)`` maps the adjoint  A-bar = v1 v2^T  to the adjoint of g."""
+    global DominantSparseSymeig
+    cg_cls = _CG.setCGSubspaceSparse(A, Aadjoint_to_gadjoint)                            # symeig.py:67-69
+    DominantSparseSymeig = _make_sparse_symeig(A, Aadjoint_to_gadjoint, cg_cls)
+    return DominantSparseSymeig

@@ -1,0 +1,195 @@
+/*
+ * dsea.h -- C ABI of the MI355X-native dominant-eigenpair hot path (libdsea.so).
+ *
+ * The reference (buwantaiji/DominantSparseEigenAD) is pure Python on torch ops and
+ * has no FFI of its own; these entry points are the boundary a maintainer would
+ * bind (ctypes stub shown in INTEGRATION.md) to replace, op for op, the torch
+ * calls inside the two hot loops:
+ *
+ *      Lanczos tridiagonalisation      reference DominantSparseEigenAD/Lanczos.py:49-77
+ *      Ritz vector                     reference DominantSparseEigenAD/Lanczos.py:98-105
+ *      conjugate gradients             reference DominantSparseEigenAD/CG.py:24-41
+ *      projections b - (a.b) a         reference CG.py:59,67,122,132 ; symeig.py:27,80
+ *      user mat-vec A(v)               reference examples/TFIM/TFIM.py:91-98,
+ *                                      examples/schrodinger1D.py:18-27 (+ generic CSR)
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = ok, negative = DSEA_ERR_*; nothing throws;
+ *   - all data pointers are DEVICE pointers owned by the caller (PyTorch); the library
+ *     allocates no device memory.  The only library-owned objects are the small host-side
+ *     handles (dsea_op_t, dsea_ws_t) that carve / describe caller memory;
+ *   - vectors are fp64, contiguous, 16-byte aligned (DSEA_ERR_ALIGN otherwise);
+ *   - the Krylov basis is stored VECTOR-CONTIGUOUS: vector j starts at Q + j*ldq
+ *     (ldq >= n, ldq even).  The reference keeps it (n,k) row-major (Lanczos.py:49);
+ *     the host layer hands users the transposed view;
+ *   - `stream` is a hipStream_t passed as void*; every function is asynchronous on that
+ *     stream unless its comment says it synchronises;
+ *   - scalars that feed the next kernel (alpha, beta, CG state) stay on the device: they are
+ *     passed as device pointers so that no host round trip sits inside the loops.  In the
+ *     row-partitioned multi-GPU mode the caller all-reduces exactly those device scalars
+ *     between two phase calls (each phase leaves the LOCAL sum there).
+ *   - one workspace per stream; a workspace is not re-entrant; distinct workspaces are
+ *     independent.
+ */
+#ifndef DSEA_H
+#define DSEA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSEA_OK 0
+#define DSEA_ERR_ARG (-1)       /* null pointer / bad size / bad enum            */
+#define DSEA_ERR_ALIGN (-2)     /* pointer not 16-byte aligned or ldq odd        */
+#define DSEA_ERR_WORKSPACE (-3) /* workspace too small for (n, k)                */
+#define DSEA_ERR_HIP (-4)       /* a HIP runtime call failed (see dsea_last_hip_error) */
+#define DSEA_ERR_NOT_CONVERGED (-5) /* dsea_cg_run hit maxiter                   */
+#define DSEA_ERR_UNSUPPORTED (-6)
+
+typedef struct dsea_op_s *dsea_op_t; /* operator descriptor (host struct, device pointers inside) */
+typedef struct dsea_ws_s *dsea_ws_t; /* workspace descriptor                                     */
+
+int dsea_version(void);
+const char *dsea_error_string(int status);
+int dsea_last_hip_error(void);
+
+/* ------------------------------------------------------------------ workspace
+ * Scratch for partial sums, reorthogonalisation coefficients and four work vectors.
+ * dsea_ws_bytes tells the caller how much device memory to provide.                 */
+int dsea_ws_bytes(int64_t n, int kmax, size_t *bytes);
+int dsea_ws_create(void *device_buffer, size_t bytes, int64_t n, int kmax, dsea_ws_t *out);
+int dsea_ws_destroy(dsea_ws_t ws);
+/* tuning knob (0 = automatic): rows handled per lane in the basis-streaming kernels {2,4,8,16} */
+int dsea_ws_set_rows_per_lane(dsea_ws_t ws, int rpl);
+
+/* Per-launch timing of the dominant kernels with HIP events recorded on the launch stream
+ * (measurement aid for bench.py's roofline figure; not part of the numerical path).
+ * After dsea_profile_begin, dsea_lanczos_run brackets every launch of kind
+ *   0 = re-orthogonalisation dots kernel, 1 = re-orthogonalisation axpy kernel, 2 = operator mat-vec
+ * with an event pair; dsea_profile_end synchronises and returns launches[3], total_ms[3] (host). */
+int dsea_profile_begin(dsea_ws_t ws, int max_records);
+int dsea_profile_end(dsea_ws_t ws, int64_t *launches, double *total_ms);
+
+/* ------------------------------------------------------------------ operators
+ * An operator is y = A x on a slab of n_local rows.                                   */
+
+/* Transverse-field Ising chain, matrix-free (replaces the gather-table mat-vec of
+ * reference examples/TFIM/TFIM.py:39-51,91-98):
+ *     y[i] = diag_scale * d(gi) * x[i]  -  g * sum_{j < L_local} x[i ^ (1<<j)],
+ *     gi = row_offset + i,  d(gi) = -(L - 2*popcount(gi ^ rotl_L(gi,1))).
+ * g is read from the device pointer g_dev when it is non-null (the parameter tensor of the
+ * model, TFIM.py / E0.py:95-96), otherwise g_const is used.  diag_scale = 0, g_const = 1 gives
+ * dH/dg of TFIM.py:58-65.  Flips of bits >= L_local (row-partitioned runs) are the caller's
+ * exchange step.  n_local = 2^L_local.                                                        */
+int dsea_op_create_tfim(int L, int L_local, int64_t row_offset, const double *g_dev, double g_const,
+                        double diag_scale, dsea_op_t *out);
+
+/* CSR, caller-owned device arrays: rowptr int64 [n+1], colidx int32 [nnz], vals fp64 [nnz]. */
+int dsea_op_create_csr(int64_t n, int64_t nnz, const int64_t *rowptr, const int32_t *colidx,
+                       const double *vals, dsea_op_t *out);
+
+/* 3-point stencil + diagonal (reference examples/schrodinger1D.py:18-27):
+ *     y[i] = coef * ((-2 x[i] + x[i+1]) + x[i-1]) + V[i] * x[i],  x[-1] = *halo_lo, x[n] = *halo_hi
+ * (null halo pointer = 0, the Dirichlet padding of the reference).                            */
+int dsea_op_create_stencil3(int64_t n, double coef, const double *V_dev, const double *halo_lo,
+                            const double *halo_hi, dsea_op_t *out);
+
+int dsea_op_destroy(dsea_op_t op);
+int dsea_op_dim(dsea_op_t op, int64_t *n);
+
+/* y = A x - (*shift) x  (shift may be null);  if dot_out != null: *dot_out = x.y (local sum).
+ * If skip_flag != null and *skip_flag != 0 the call is a no-op on the device (converged CG). */
+int dsea_spmv(dsea_op_t op, dsea_ws_t ws, const double *x, double *y, const double *shift,
+              double *dot_out, const double *skip_flag, void *stream);
+
+/* ------------------------------------------------------------------ vector phases (Lanczos)
+ * Used one by one in the generic-callable and the multi-GPU modes, and composed by
+ * dsea_lanczos_run.                                                                       */
+
+/* out = x.y */
+int dsea_dot(dsea_ws_t ws, const double *x, const double *y, int64_t n, double *out, void *stream);
+
+/* y -= (*shift) * x ; *dot_out = x.y      (generic A: turns A(d) into (A - E0) d, CG.py:120)   */
+int dsea_shift_dot(dsea_ws_t ws, const double *x, double *y, const double *shift, double *dot_out,
+                   const double *skip_flag, int64_t n, void *stream);
+
+/* y += (a_host * (*a_dev)) * x   (a_dev may be null = 1)                                      */
+int dsea_axpy(dsea_ws_t ws, double a_host, const double *a_dev, const double *x, double *y,
+              int64_t n, void *stream);
+
+/* nrm2_out = ||x||^2 (local) */
+int dsea_nrm2sq(dsea_ws_t ws, const double *x, int64_t n, double *nrm2_out, void *stream);
+
+/* q_out = r / sqrt(*nrm2) ; if beta_out != null: *beta_out = sqrt(*nrm2)   (Lanczos.py:53,69-70,75) */
+int dsea_scale_store(dsea_ws_t ws, const double *r, const double *nrm2, double *q_out,
+                     double *beta_out, int64_t n, void *stream);
+
+/* Phase 1 of step i (1 <= i < k), Lanczos.py:61 and the first half of :66:
+ *     r = u - (*alpha) Q[i-1] - (*beta) Q[i-2]        (beta may be null: 0, the i = 1 case)
+ *     c[j] = Q[j] . r   for j < i                      (local sums)                           */
+int dsea_lanczos_rdots(dsea_ws_t ws, const double *Q, int64_t ldq, int64_t n, int i,
+                       const double *u, const double *alpha, const double *beta, double *r,
+                       double *c_out, void *stream);
+
+/* Phase 2, second half of Lanczos.py:66 and :69:  r -= sum_j c[j] Q[j] ; *nrm2_out = ||r||^2 (local) */
+int dsea_lanczos_axpy_norm(dsea_ws_t ws, const double *Q, int64_t ldq, int64_t n, int i,
+                           const double *c, double *r, double *nrm2_out, void *stream);
+
+/* out = sum_{j<k} s[j] Q[j]   (the one needed column of Qk @ eigvecs, Lanczos.py:99-105)      */
+int dsea_ritz_combine(dsea_ws_t ws, const double *Q, int64_t ldq, int64_t n, int k,
+                      const double *s, double *out, void *stream);
+
+/* out = v - (a.v) a   (CG.py:59,67,122,132 ; symeig.py:27,80); `a_dot_v` (nullable) receives a.v */
+int dsea_project_out(dsea_ws_t ws, const double *v, const double *a, double *out, double *a_dot_v,
+                     int64_t n, void *stream);
+
+/* ------------------------------------------------------------------ CG phases (CG.py:24-41)
+ * state = 8 device doubles: [0] rr  [1] dAd  [2] rr_new  [3] alpha  [4] beta  [5] resnorm
+ *                           [6] done (0/1)  [7] iterations                                   */
+#define DSEA_CG_RR 0
+#define DSEA_CG_DAD 1
+#define DSEA_CG_RRNEW 2
+#define DSEA_CG_ALPHA 3
+#define DSEA_CG_BETA 4
+#define DSEA_CG_RESNORM 5
+#define DSEA_CG_DONE 6
+#define DSEA_CG_ITERS 7
+#define DSEA_CG_STATE_LEN 8
+
+/* r = b - Ax0 ; d = r ; state[RR] = r.r (local) ; clears the rest of state               (CG.py:27,30) */
+int dsea_cg_init(dsea_ws_t ws, const double *b, const double *Ax0, double *r, double *d,
+                 double *state, int64_t n, void *stream);
+/* after the caller has made state[RR] global: done = sqrt(rr) < eps                       (CG.py:28-29) */
+int dsea_cg_init_check(dsea_ws_t ws, double *state, double eps, void *stream);
+/* alpha = rr/dAd ; x += alpha d ; r -= alpha Ad ; state[RRNEW] = r.r (local)              (CG.py:31,33-34) */
+int dsea_cg_update(dsea_ws_t ws, double *x, double *r, const double *d, const double *Ad,
+                   double *state, int64_t n, void *stream);
+/* after state[RRNEW] is global: iterations += 1 ; resnorm = sqrt(rr_new) ; done |= resnorm < eps ;
+ * beta = rr_new/rr ; rr = rr_new                                                          (CG.py:35-38) */
+int dsea_cg_check(dsea_ws_t ws, double *state, double eps, void *stream);
+/* d = r + beta d   (no-op when done)                                                       (CG.py:39) */
+int dsea_cg_direction(dsea_ws_t ws, const double *r, double *d, const double *state, int64_t n,
+                      void *stream);
+
+/* ------------------------------------------------------------------ whole solvers (native operator, one GPU)
+ * k-step Lanczos with full re-orthogonalisation, entirely on the stream, no host sync.
+ *   q0      : start vector (need not be normalised; Lanczos.py:52-53)
+ *   Q       : k x ldq basis (output), alphas[k], betas[max(k-1,1)] (outputs, device)            */
+int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double *q0, double *Q, int64_t ldq,
+                     double *alphas, double *betas, void *stream);
+
+/* CG on (A - (*shift) I) x = b from x (in: start vector, out: solution).  Stops when ||r|| < eps
+ * (absolute, CG.py:25) or after maxiter iterations.  The loop runs on the device; the host polls the
+ * device-side flag every `poll_every` iterations (0 = default).  SYNCHRONISES the stream before
+ * returning.  iters_out / resnorm_out are host pointers (nullable).  state = 8 device doubles.    */
+int dsea_cg_run(dsea_op_t op, dsea_ws_t ws, const double *shift, const double *b, double *x,
+                double *state, double eps, int64_t maxiter, int poll_every, int64_t *iters_out,
+                double *resnorm_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSEA_H */
