@@ -35,7 +35,7 @@ inline int check_launch() {
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
 struct WsLayout {
-  size_t partials_off, coef_off, scal_off, vec_off, total;
+  size_t partials_off, aux_off, coef_off, scal_off, vec_off, total;
   int64_t npad;
 };
 WsLayout ws_layout(int64_t n, int kmax) {
@@ -45,6 +45,8 @@ WsLayout ws_layout(int64_t n, int kmax) {
   size_t off = 0;
   L.partials_off = off;
   off += (size_t)DSEA_MAX_WAVE_TILES * (size_t)kk * sizeof(double);
+  L.aux_off = off;
+  off += (size_t)4 * DSEA_MAX_WAVE_TILES * sizeof(double);
   L.coef_off = off;
   off += (size_t)round_up(kk, 32) * sizeof(double);
   L.scal_off = off;
@@ -61,10 +63,14 @@ TileGeom Workspace::geom(int64_t n_rows) const {
   TileGeom g;
   int rpl = rpl_override;
   if (rpl != 2 && rpl != 4 && rpl != 8 && rpl != 16) {
-    // automatic: enough wave tiles to fill 256 CUs several times over, at most DSEA_MAX_WAVE_TILES
-    if (n_rows <= (int64_t)64 * 2 * 4096) rpl = 2;
-    else if (n_rows <= (int64_t)64 * 4 * 4096) rpl = 4;
-    else rpl = 8;
+    // automatic: about one wave per SIMD of the 256 CUs (1024 wave tiles), each with as many rows --
+    // i.e. as many independent 16-byte loads in flight and as long contiguous runs per basis vector --
+    // as registers allow.  Measured on MI355X at n = 2^20, i = 199 (tools/kbench.py): rpl 2/4/8/16 ->
+    // 5.2 / 5.5 / 5.8 / 6.2 TB/s for the axpy pass.
+    if (n_rows >= (int64_t)64 * 16 * 1024) rpl = 16;
+    else if (n_rows >= (int64_t)64 * 8 * 1024) rpl = 8;
+    else if (n_rows >= (int64_t)64 * 4 * 1024) rpl = 4;
+    else rpl = 2;
   }
   g.rpl = rpl;
   g.ntiles = (n_rows + 64 * rpl - 1) / (64 * rpl);
@@ -114,6 +120,7 @@ int dsea_ws_create(void* device_buffer, size_t bytes, int64_t n, int kmax, dsea_
   ws->w.rpl_override = 0;
   ws->w.prof = nullptr;
   ws->w.partials = reinterpret_cast<double*>(base + L.partials_off);
+  ws->w.aux = reinterpret_cast<double*>(base + L.aux_off);
   ws->w.coef = reinterpret_cast<double*>(base + L.coef_off);
   ws->w.scal = reinterpret_cast<double*>(base + L.scal_off);
   for (int v = 0; v < 4; ++v)
@@ -389,6 +396,25 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
   Profiler* prof = w.prof;
   launch_dot(q0, q0, n, P, nrm2, st);
   launch_scale_store(q0, nrm2, Q, nullptr, n, st);
+  if (op->d.kind == OP_TFIM) {
+    // Fused sequence, 4 launches per step and no stand-alone scalar reductions: the mat-vec leaves
+    // per-block partials of alpha (aP), the dots kernel sums them in its prologue; the axpy kernel leaves
+    // per-wave partials of ||r||^2 (nP), the fused scale + mat-vec kernel sums those.
+    double* aP = w.aux;
+    double* nP = w.aux + DSEA_MAX_WAVE_TILES;
+    int na = launch_spmv(op->d, Q, u, nullptr, nullptr, aP, st, prof ? prof->next(PROF_SPMV) : nullptr);
+    if (na < 0) return DSEA_ERR_UNSUPPORTED;
+    for (int i = 1; i < k; ++i) {
+      const double* beta_prev = (i >= 2) ? betas + (i - 2) : nullptr;
+      launch_rdots(g, Q, ldq, n, i, u, nullptr, beta_prev, r, P, w.coef, st,
+                   prof ? prof->next(PROF_RDOTS) : nullptr, aP, na, alphas + (i - 1));
+      launch_axpy_norm(g, Q, ldq, n, i, w.coef, r, nP, nullptr, st, prof ? prof->next(PROF_AXPY) : nullptr);
+      na = launch_tfim_fused(op->d, r, nP, g.nw, Q + (int64_t)i * ldq, u, betas + (i - 1), aP, st,
+                             prof ? prof->next(PROF_SPMV) : nullptr);
+    }
+    launch_finalize1(aP, na, alphas + (k - 1), st);
+    return check_launch();
+  }
   int nb = launch_spmv(op->d, Q, u, nullptr, nullptr, P, st, prof ? prof->next(PROF_SPMV) : nullptr);
   if (nb < 0) return DSEA_ERR_UNSUPPORTED;
   launch_finalize1(P, nb, alphas, st);
@@ -419,6 +445,8 @@ int dsea_cg_run(dsea_op_t op, dsea_ws_t ws, const double* shift, const double* b
   double* d = w.vec[2];
   double* Ad = w.vec[3];
   const double* done = state + DSEA_CG_DONE;
+  double* dP = w.aux;                            // partials of d.A'd (one per mat-vec block)
+  double* rP = w.aux + DSEA_MAX_WAVE_TILES;      // partials of r.r   (one per update block)
   if (poll_every <= 0) poll_every = 16;
 
   // r = b - A'x0 ; early out ; d = r                            (CG.py:26-30)
@@ -433,11 +461,10 @@ int dsea_cg_run(dsea_op_t op, dsea_ws_t ws, const double* shift, const double* b
   while (!finished) {
     const int64_t chunk = (maxiter - issued) < poll_every ? (maxiter - issued) : poll_every;
     for (int64_t it = 0; it < chunk; ++it) {
-      nb = launch_spmv(op->d, d, Ad, shift, done, P, st);               // A'd and d.A'd  (CG.py:31/40)
-      launch_finalize_slot(P, nb, state + DSEA_CG_DAD, done, st);
-      launch_cg_update(x, r, d, Ad, state, n, P, st);                   // CG.py:33-34
-      launch_cg_check(state, eps, st);                                  // CG.py:35-38
-      launch_cg_direction(r, d, state, n, st);                          // CG.py:39
+      const int parity = (int)((issued + it) & 1);
+      nb = launch_spmv(op->d, d, Ad, shift, done, dP, st);                              // A'd, d.A'd partials (CG.py:31/40)
+      const int nr = launch_cg_update_fused(x, r, d, Ad, state, parity, dP, nb, n, rP, st);  // CG.py:31,33-34
+      launch_cg_direction_fused(r, d, state, parity, rP, nr, eps, n, st);              // CG.py:35-39
     }
     issued += chunk;
     if (hipMemcpyAsync(host_state, state, sizeof(host_state), hipMemcpyDeviceToHost, st) != hipSuccess ||

@@ -72,6 +72,7 @@ struct Workspace {
   int kmax;
   int rpl_override;
   double* partials;  // DSEA_MAX_WAVE_TILES * max(kmax,1) doubles (also >= DSEA_MAX_EW_BLOCKS)
+  double* aux;       // 4 * DSEA_MAX_WAVE_TILES doubles: small partial buffers that must not alias `partials`
   double* coef;      // kmax doubles
   double* scal;      // DSEA_SCALARS doubles
   double* vec[4];    // four work vectors of npad doubles
@@ -83,7 +84,14 @@ void launch_finalize1(const double* P, int count, double* out, hipStream_t st);
 void launch_finalize_slot(const double* P, int count, double* out, const double* skip, hipStream_t st);
 void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* u,
                   const double* alpha, const double* beta, double* r, double* P, double* c_out,
-                  hipStream_t st, EventPair* ev = nullptr);
+                  hipStream_t st, EventPair* ev = nullptr, const double* aP = nullptr, int aCount = 0,
+                  double* a_store = nullptr);
+int launch_tfim_fused(const OpDesc& op, const double* r, const double* nP, int nCount, double* q_out, double* y,
+                      double* beta_store, double* P, hipStream_t st, EventPair* ev = nullptr);
+int launch_cg_update_fused(double* x, double* r, const double* d, const double* Ad, const double* state,
+                           int parity, const double* dP, int dCount, int64_t n, double* P, hipStream_t st);
+void launch_cg_direction_fused(const double* r, double* d, double* state, int parity, const double* rP,
+                               int rCount, double eps, int64_t n, hipStream_t st);
 void launch_axpy_norm(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* c,
                       double* r, double* P, double* nrm2_out, hipStream_t st, EventPair* ev = nullptr);
 void launch_ritz(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int k, const double* s,

@@ -66,15 +66,52 @@ __global__ __launch_bounds__(256) void k_finalize1(const double* __restrict__ pa
   if (threadIdx.x == 0) out[0] = t;
 }
 
-// c[j] = sum_{w<nw} P[j*pstride + w]   (one 64-thread block per j)
-__global__ __launch_bounds__(64) void k_finalize_multi(const double* __restrict__ P, int64_t pstride,
-                                                       int nw, double* __restrict__ c) {
+// c[j] = sum_{w<nw} P[j*pstride + w]   (one 256-thread block per j, 4 independent loads in flight per lane)
+__global__ __launch_bounds__(256) void k_finalize_multi(const double* __restrict__ P, int64_t pstride,
+                                                        int nw, double* __restrict__ c) {
+  __shared__ double sm4[4];
   const int j = blockIdx.x;
-  const double* row = P + (int64_t)j * pstride;
-  double acc = 0.0;
-  for (int w = threadIdx.x; w < nw; w += 64) acc += row[w];
-  acc = wave_sum(acc);
-  if (threadIdx.x == 0) c[j] = acc;
+  const double* __restrict__ row = P + (int64_t)j * pstride;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int w = threadIdx.x;
+  for (; w + 768 < nw; w += 1024) {
+    a0 += row[w];
+    a1 += row[w + 256];
+    a2 += row[w + 512];
+    a3 += row[w + 768];
+  }
+  for (; w < nw; w += 256) a0 += row[w];
+  double t = block_sum((a0 + a1) + (a2 + a3), sm4);
+  if (threadIdx.x == 0) c[j] = t;
+}
+
+// Consumers that fold the second reduction stage into their prologue: every wave / block sums the same
+// partials in the same order, so all of them obtain the bit-identical scalar without a separate launch.
+__device__ __forceinline__ double sum_partials_wave(const double* __restrict__ P, int count, int lane) {
+  double a0 = 0.0, a1 = 0.0;
+  int b = lane;
+  for (; b + 64 < count; b += 128) {
+    a0 += P[b];
+    a1 += P[b + 64];
+  }
+  if (b < count) a0 += P[b];
+  return wave_sum(a0 + a1);
+}
+__device__ __forceinline__ double sum_partials_block(const double* __restrict__ P, int count, double* sm5) {
+  double a0 = 0.0, a1 = 0.0;
+  int b = threadIdx.x;
+  for (; b + 256 < count; b += 512) {
+    a0 += P[b];
+    a1 += P[b + 256];
+  }
+  if (b < count) a0 += P[b];
+  double v = wave_sum(a0 + a1);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sm5[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) sm5[4] = ((sm5[0] + sm5[1]) + sm5[2]) + sm5[3];
+  __syncthreads();
+  return sm5[4];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -159,11 +196,19 @@ __global__ __launch_bounds__(256) void k_rdots(const double* __restrict__ Q, int
                                                const double* __restrict__ alpha,
                                                const double* __restrict__ beta, double* __restrict__ r,
                                                double* __restrict__ P, int64_t pstride, int nw,
-                                               int64_t ntiles) {
+                                               int64_t ntiles, const double* __restrict__ aP, int aCount,
+                                               double* __restrict__ a_store) {
   const int lane = threadIdx.x & 63;
   const int64_t widx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (widx >= nw) return;
-  const double a = alpha[0];
+  // alpha_{i-1}: either finalised already (phase API) or still as the mat-vec's per-block partials
+  double a;
+  if (aCount > 0) {
+    a = sum_partials_wave(aP, aCount, lane);
+    if (widx == 0 && lane == 0) a_store[0] = a;
+  } else {
+    a = alpha[0];
+  }
   const double b = beta ? beta[0] : 0.0;
   constexpr int64_t TILE = 64 * RPL;
   bool first = true;
@@ -497,6 +542,119 @@ __global__ __launch_bounds__(256) void k_spmv_tfim(TfimParams p, const double* _
   }
 }
 
+// Fused Lanczos tail for the TFIM operator (Lanczos.py:69-72,75 in one launch):
+//   beta = sqrt(sum of the ||r||^2 partials) ; q = r/beta -> Q[i] ; u = H q ; partial q.u
+// Neighbours inside the LDS tile use the scaled values; the out-of-tile neighbour sum is scaled once.
+template <int T>
+__global__ __launch_bounds__(256) void k_spmv_tfim_fused(TfimParams p, const double* __restrict__ r,
+                                                         const double* __restrict__ nP, int nCount,
+                                                         double* __restrict__ q_out, double* __restrict__ y,
+                                                         double* __restrict__ beta_store,
+                                                         double* __restrict__ P) {
+  constexpr int TILE = 1 << T;
+  constexpr int PER = (TILE + 255) / 256;
+  __shared__ double tile[TILE];
+  __shared__ double sm5[5];
+  const double beta = sqrt(sum_partials_block(nP, nCount, sm5));
+  if (blockIdx.x == 0 && threadIdx.x == 0) beta_store[0] = beta;
+  const double g = p.g_dev ? p.g_dev[0] : p.g_const;
+  const int64_t base = (int64_t)blockIdx.x * TILE;
+#pragma unroll
+  for (int t = 0; t < PER; ++t) {
+    const int l = t * 256 + threadIdx.x;
+    if (l < TILE) {
+      const double qv = r[base + l] / beta;
+      tile[l] = qv;
+      q_out[base + l] = qv;
+    }
+  }
+  __syncthreads();
+  const uint64_t maskL = (p.L >= 64) ? ~0ull : ((1ull << p.L) - 1ull);
+  double acc = 0.0;
+#pragma unroll
+  for (int t = 0; t < PER; ++t) {
+    const int l = t * 256 + threadIdx.x;
+    if (l < TILE) {
+      const int64_t i = base + l;
+      double sum = 0.0;
+#pragma unroll
+      for (int j = 0; j < T; ++j) sum += tile[l ^ (1 << j)];
+      double far = 0.0;
+      for (int j = T; j < p.L_local; ++j) far += r[i ^ ((int64_t)1 << j)];
+      sum += far / beta;
+      const double xi = tile[l];
+      const uint64_t gi = (uint64_t)(p.row_offset + i);
+      const uint64_t rot = ((gi << 1) | (gi >> (p.L - 1))) & maskL;
+      const int pop = __popcll(gi ^ rot);
+      const double diag = p.diag_scale * (double)(-(p.L - 2 * pop));
+      const double v = __dsub_rn(__dmul_rn(xi, diag), __dmul_rn(g, sum));
+      y[i] = v;
+      acc = fma(xi, v, acc);
+    }
+  }
+  double tot = block_sum(acc, sm5);
+  if (threadIdx.x == 0) P[blockIdx.x] = tot;
+}
+
+// CG with the scalar stages folded into the consumers (3 launches per iteration: mat-vec, update,
+// direction).  rr lives in two ping-pong slots of state: cur = parity ? RRNEW : RR.
+__global__ __launch_bounds__(256) void k_cg_update_fused(double* __restrict__ x, double* __restrict__ r,
+                                                         const double* __restrict__ d,
+                                                         const double* __restrict__ Ad,
+                                                         const double* __restrict__ state, int parity,
+                                                         const double* __restrict__ dP, int dCount,
+                                                         int64_t n, double* __restrict__ P) {
+  __shared__ double sm5[5];
+  if (state[DSEA_CG_DONE] != 0.0) return;
+  const double dAd = sum_partials_block(dP, dCount, sm5);
+  const double alpha = state[parity ? DSEA_CG_RRNEW : DSEA_CG_RR] / dAd;
+  double acc = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * 512;
+  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; row < n; row += stride) {
+    double2 xv = ld2<true>(x, row, n), rv = ld2<true>(r, row, n);
+    double2 dv = ld2<true>(d, row, n), av = ld2<true>(Ad, row, n);
+    xv.x = __dadd_rn(xv.x, __dmul_rn(alpha, dv.x));
+    xv.y = __dadd_rn(xv.y, __dmul_rn(alpha, dv.y));
+    rv.x = __dsub_rn(rv.x, __dmul_rn(alpha, av.x));
+    rv.y = __dsub_rn(rv.y, __dmul_rn(alpha, av.y));
+    st2<true>(x, row, n, xv);
+    st2<true>(r, row, n, rv);
+    acc = fma(rv.x, rv.x, acc);
+    acc = fma(rv.y, rv.y, acc);
+  }
+  __syncthreads();
+  double t = block_sum(acc, sm5);
+  if (threadIdx.x == 0) P[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void k_cg_direction_fused(const double* __restrict__ r,
+                                                            double* __restrict__ d,
+                                                            double* __restrict__ state, int parity,
+                                                            const double* __restrict__ rP, int rCount,
+                                                            double eps, int64_t n) {
+  __shared__ double sm5[5];
+  if (state[DSEA_CG_DONE] != 0.0) return;
+  const double rr_new = sum_partials_block(rP, rCount, sm5);
+  const double rr = state[parity ? DSEA_CG_RRNEW : DSEA_CG_RR];
+  const double rn = sqrt(rr_new);
+  const bool conv = rn < eps;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    state[DSEA_CG_ITERS] += 1.0;
+    state[DSEA_CG_RESNORM] = rn;
+    if (conv) state[DSEA_CG_DONE] = 1.0;
+    else state[parity ? DSEA_CG_RR : DSEA_CG_RRNEW] = rr_new;
+  }
+  if (conv) return;
+  const double beta = rr_new / rr;
+  const int64_t stride = (int64_t)gridDim.x * 512;
+  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; row < n; row += stride) {
+    double2 rv = ld2<true>(r, row, n), dv = ld2<true>(d, row, n);
+    dv.x = __dadd_rn(rv.x, __dmul_rn(beta, dv.x));
+    dv.y = __dadd_rn(rv.y, __dmul_rn(beta, dv.y));
+    st2<true>(d, row, n, dv);
+  }
+}
+
 // CSR: G lanes cooperate on one row
 template <int G>
 __global__ __launch_bounds__(256) void k_spmv_csr(CsrParams p, const double* __restrict__ x,
@@ -583,28 +741,28 @@ void launch_finalize1(const double* P, int count, double* out, hipStream_t st) {
 
 void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* u,
                   const double* alpha, const double* beta, double* r, double* P, double* c_out,
-                  hipStream_t st, EventPair* ev) {
+                  hipStream_t st, EventPair* ev, const double* aP, int aCount, double* a_store) {
   const int grid = (g.nw + 3) / 4;
-  if (ev) hipEventRecord(ev->a, st);
+  if (ev) (void)hipEventRecord(ev->a, st);
   LAUNCH_RPL(k_rdots, g.rpl, grid, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, g.nw,
-             g.ntiles);
-  if (ev) hipEventRecord(ev->b, st);
-  hipLaunchKernelGGL(k_finalize_multi, dim3(i), dim3(64), 0, st, (const double*)P, (int64_t)g.pstride,
+             g.ntiles, aP, aCount, a_store);
+  if (ev) (void)hipEventRecord(ev->b, st);
+  hipLaunchKernelGGL(k_finalize_multi, dim3(i), dim3(256), 0, st, (const double*)P, (int64_t)g.pstride,
                      g.nw, c_out);
 }
 
 void launch_axpy_norm(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* c,
                       double* r, double* P, double* nrm2_out, hipStream_t st, EventPair* ev) {
   const int grid = (g.nw + 3) / 4;
-  if (ev) hipEventRecord(ev->a, st);
+  if (ev) (void)hipEventRecord(ev->a, st);
   switch (g.rpl) {
     case 2: hipLaunchKernelGGL((k_axpy_norm<2, 0>), dim3(grid), dim3(256), 0, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles); break;
     case 4: hipLaunchKernelGGL((k_axpy_norm<4, 0>), dim3(grid), dim3(256), 0, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles); break;
     case 8: hipLaunchKernelGGL((k_axpy_norm<8, 0>), dim3(grid), dim3(256), 0, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles); break;
     default: hipLaunchKernelGGL((k_axpy_norm<16, 0>), dim3(grid), dim3(256), 0, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles); break;
   }
-  if (ev) hipEventRecord(ev->b, st);
-  launch_finalize1(P, g.nw, nrm2_out, st);
+  if (ev) (void)hipEventRecord(ev->b, st);
+  if (nrm2_out) launch_finalize1(P, g.nw, nrm2_out, st);  // null: the consumer sums the g.nw partials itself
 }
 
 void launch_ritz(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int k, const double* s,
@@ -680,9 +838,9 @@ static int launch_spmv_impl(const OpDesc& op, const double* x, double* y, const 
 
 int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shift, const double* skip,
                 double* P, hipStream_t st, EventPair* ev) {
-  if (ev) hipEventRecord(ev->a, st);
+  if (ev) (void)hipEventRecord(ev->a, st);
   int nb = launch_spmv_impl(op, x, y, shift, skip, P, st);
-  if (ev) hipEventRecord(ev->b, st);
+  if (ev) (void)hipEventRecord(ev->b, st);
   return nb;
 }
 
@@ -731,6 +889,37 @@ static int launch_spmv_impl(const OpDesc& op, const double* x, double* y, const 
     }
   }
   return -1;
+}
+
+int launch_tfim_fused(const OpDesc& op, const double* r, const double* nP, int nCount, double* q_out, double* y,
+                      double* beta_store, double* P, hipStream_t st, EventPair* ev) {
+  const TfimParams& p = op.tfim;
+  const int T = p.L_local < DSEA_TFIM_TILE_LOG2 ? p.L_local : DSEA_TFIM_TILE_LOG2;
+  const int64_t nb = ((int64_t)1 << p.L_local) >> T;
+  if (ev) (void)hipEventRecord(ev->a, st);
+#define TFIM_FCASE(TT) \
+  case TT: hipLaunchKernelGGL((k_spmv_tfim_fused<TT>), dim3((unsigned)nb), dim3(256), 0, st, p, r, nP, nCount, q_out, y, beta_store, P); break;
+  switch (T) {
+    TFIM_FCASE(0) TFIM_FCASE(1) TFIM_FCASE(2) TFIM_FCASE(3) TFIM_FCASE(4) TFIM_FCASE(5) TFIM_FCASE(6)
+    TFIM_FCASE(7) TFIM_FCASE(8) TFIM_FCASE(9) TFIM_FCASE(10) TFIM_FCASE(11)
+    default: return -1;
+  }
+#undef TFIM_FCASE
+  if (ev) (void)hipEventRecord(ev->b, st);
+  return (int)nb;
+}
+
+int launch_cg_update_fused(double* x, double* r, const double* d, const double* Ad, const double* state,
+                           int parity, const double* dP, int dCount, int64_t n, double* P, hipStream_t st) {
+  const int nb = ew_blocks(n);
+  hipLaunchKernelGGL(k_cg_update_fused, dim3(nb), dim3(256), 0, st, x, r, d, Ad, state, parity, dP, dCount, n, P);
+  return nb;
+}
+
+void launch_cg_direction_fused(const double* r, double* d, double* state, int parity, const double* rP,
+                               int rCount, double eps, int64_t n, hipStream_t st) {
+  hipLaunchKernelGGL(k_cg_direction_fused, dim3(ew_blocks(n)), dim3(256), 0, st, r, d, state, parity, rP, rCount,
+                     eps, n);
 }
 
 void launch_finalize_slot(const double* P, int count, double* out, const double* skip, hipStream_t st) {
