@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--cpu-cg-cap", type=int, default=30)
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--rpl", type=int, default=0)
+    ap.add_argument("--force-partitioned", action="store_true",
+                    help="run the row-partitioned driver even with one rank (measures its host overhead)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,7 +146,8 @@ def main():
     draws = [slab(SEED + 10 + c) for c in range(3)]  # q0, unused second draw, CG start vector
     tvec = slab(SEED + 1)
 
-    if world == 1:
+    partitioned_path = world > 1 or args.force_partitioned
+    if not partitioned_path:
         import dominantsparseeigenad_amd.symeig as symeig
         from dominantsparseeigenad_amd.operators import TFIMOperator
         tvec = tvec / tvec.norm()
@@ -165,7 +168,11 @@ def main():
     else:
         import torch.distributed as dist
         from dominantsparseeigenad_amd import partitioned
-        dist.init_process_group("nccl", device_id=dev)
+        if not dist.is_initialized():
+            if world == 1:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         nrm = tvec.dot(tvec).reshape(1)
         dist.all_reduce(nrm)
         tvec = tvec / nrm.sqrt()
@@ -187,7 +194,7 @@ def main():
     for _ in range(args.warmup):
         E0, gl = step()
     barrier()
-    use_events = (world == 1) and not args.no_kernel_events
+    use_events = (not partitioned_path) and not args.no_kernel_events
     if use_events:
         _lib.check(lib.dsea_profile_begin(ws.handle, 3 * k * args.steps + 8), "dsea_profile_begin")
     t0 = time.perf_counter()
@@ -200,7 +207,7 @@ def main():
     if use_events:
         _lib.check(lib.dsea_profile_end(ws.handle, launches, total_ms), "dsea_profile_end")
     m = engine.last_cg.iters
-    if world > 1:
+    if partitioned_path:
         import torch.distributed as dist
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -248,7 +255,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(L, args.cpu_k, args.cpu_cg_cap)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if partitioned_path:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -1,0 +1,104 @@
+"""TEST DOUBLE (lives under tests/, never imported by the package): a torch-CPU stand-in for
+``partitioned.HipBackend`` with the same phase semantics as include/dsea.h, used to exercise the
+partition / exchange / all-reduce logic of ``PartitionedTFIM`` with gloo on machines without GPUs."""
+import torch
+
+F64 = torch.float64
+RR, DAD, RRNEW, ALPHA, BETA, RESNORM, DONE, ITERS = range(8)
+
+
+class CpuBackend:
+    def __init__(self, L, L_local, row_offset, g):
+        self.L, self.Lloc, self.off, self.g = L, L_local, row_offset, g
+        self.device = torch.device("cpu")
+        self.n = 1 << L_local
+        idx = torch.arange(self.n, dtype=torch.int64)
+        gi = idx + row_offset
+        rot = ((gi << 1) | (gi >> (L - 1))) & ((1 << L) - 1)
+        x = gi ^ rot
+        pop = torch.zeros_like(x)
+        for b in range(L):
+            pop += (x >> b) & 1
+        self.diag = (-(L - 2 * pop)).to(F64)
+        self.idx = idx
+
+    def empty(self, *shape):
+        return torch.zeros(*shape, dtype=F64)
+
+    zeros = empty
+
+    def tfim_local(self, x, y, which="H"):
+        s = torch.zeros(self.n, dtype=F64)
+        for j in range(self.Lloc):
+            s += x[self.idx ^ (1 << j)]
+        if which == "H":
+            y.copy_(x * self.diag - self.g.detach() * s)
+        else:
+            y.copy_(-s)
+
+    def axpy(self, a_host, a_dev, x, y):
+        a = a_host * (a_dev.reshape(-1)[0] if a_dev is not None else 1.0)
+        y.add_(a * x)
+
+    def dot(self, x, y, out):
+        out[0] = torch.dot(x, y)
+
+    def scale_store(self, r, nrm2, q_out, beta_out):
+        beta = nrm2[0].sqrt()
+        q_out[: r.numel()] = r / beta
+        if beta_out is not None:
+            beta_out[0] = beta
+
+    def rdots(self, Q, ldq, n, i, u, alpha, beta, r, c):
+        r.copy_(u - alpha[0] * Q[i - 1, :n] - (beta[0] * Q[i - 2, :n] if beta is not None else 0.0))
+        c[:i] = Q[:i, :n] @ r
+
+    def axpy_norm(self, Q, ldq, n, i, c, r, nrm2):
+        r.sub_(Q[:i, :n].T @ c[:i])
+        nrm2[0] = torch.dot(r, r)
+
+    def ritz(self, Q, ldq, n, k, s, out):
+        out.copy_(Q[:k, :n].T @ s)
+
+    def shift_dot(self, x, y, shift, out, skip):
+        if skip is not None and skip[0] != 0:
+            return
+        if shift is not None:
+            y.sub_(shift[0] * x)
+        out[0] = torch.dot(x, y)
+
+    def cg_init(self, b, Ax0, r, d, state):
+        state.zero_()
+        r.copy_(b - Ax0)
+        d.copy_(r)
+        state[RR] = torch.dot(r, r)
+
+    def cg_init_check(self, state, eps):
+        rn = state[RR].sqrt()
+        state[RESNORM] = rn
+        state[DONE] = 1.0 if rn < eps else 0.0
+
+    def cg_update(self, x, r, d, Ad, state):
+        if state[DONE] != 0:
+            return
+        a = state[RR] / state[DAD]
+        x.add_(a * d)
+        r.sub_(a * Ad)
+        state[RRNEW] = torch.dot(r, r)
+
+    def cg_check(self, state, eps):
+        if state[DONE] != 0:
+            return
+        rn = state[RRNEW].sqrt()
+        state[ITERS] += 1
+        state[RESNORM] = rn
+        if rn < eps:
+            state[DONE] = 1.0
+        else:
+            state[BETA] = state[RRNEW] / state[RR]
+            state[RR] = state[RRNEW].clone()
+
+    def cg_direction(self, r, d, state):
+        if state[DONE] != 0:
+            return
+        d.copy_(r + state[BETA] * d)
