@@ -44,11 +44,11 @@ WsLayout ws_layout(int64_t n, int kmax) {
   L.npad = round_up(n < 1 ? 1 : n, 256);
   size_t off = 0;
   L.partials_off = off;
-  off += (size_t)DSEA_MAX_WAVE_TILES * (size_t)kk * sizeof(double);
+  off += (size_t)DSEA_MAX_WAVE_TILES * (size_t)(kk + 1) * sizeof(double);  // +1 row: ||r||^2 pseudo-vector
   L.aux_off = off;
   off += (size_t)4 * DSEA_MAX_WAVE_TILES * sizeof(double);
   L.coef_off = off;
-  off += (size_t)round_up(kk, 32) * sizeof(double);
+  off += (size_t)round_up(kk + 2, 32) * sizeof(double);
   L.scal_off = off;
   off += (size_t)DSEA_SCALARS * sizeof(double);
   off = (size_t)round_up((int64_t)off, 256);
@@ -119,6 +119,10 @@ int dsea_ws_create(void* device_buffer, size_t bytes, int64_t n, int kmax, dsea_
   ws->w.kmax = kmax;
   ws->w.rpl_override = 0;
   ws->w.prof = nullptr;
+  ws->w.shadow = nullptr;
+  ws->w.shadow_ld = 0;
+  ws->w.shadow_rows = 0;
+  ws->w.lp_tau = 1e-12;
   ws->w.partials = reinterpret_cast<double*>(base + L.partials_off);
   ws->w.aux = reinterpret_cast<double*>(base + L.aux_off);
   ws->w.coef = reinterpret_cast<double*>(base + L.coef_off);
@@ -179,6 +183,37 @@ int dsea_profile_end(dsea_ws_t ws, int64_t* launches, double* total_ms) {
     total_ms[p->pairs[e].kind] += (double)ms;
   }
   prof_free(ws->w);
+  return DSEA_OK;
+}
+
+int dsea_ws_set_shadow(dsea_ws_t ws, void* shadow_bf16, int64_t ld, int rows, double tau) {
+  if (!ws) return DSEA_ERR_ARG;
+  if (!shadow_bf16) {
+    ws->w.shadow = nullptr;
+    ws->w.shadow_ld = 0;
+    ws->w.shadow_rows = 0;
+    return DSEA_OK;
+  }
+  if (rows < 1 || ld < 8 || tau < 0.0) return DSEA_ERR_ARG;
+  if (!aligned16(shadow_bf16) || (ld % 8) != 0) return DSEA_ERR_ALIGN;
+  ws->w.shadow = static_cast<uint16_t*>(shadow_bf16);
+  ws->w.shadow_ld = ld;
+  ws->w.shadow_rows = rows;
+  ws->w.lp_tau = tau;
+  return DSEA_OK;
+}
+
+int dsea_lanczos_lp_stats(dsea_ws_t ws, int64_t* lp_steps, int64_t* fp64_steps, void* stream) {
+  if (!ws || !lp_steps || !fp64_steps) return DSEA_ERR_ARG;
+  double h[2] = {0.0, 0.0};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemcpyAsync(h, ws->w.scal + 16, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess) {
+    g_last_hip = (int)hipGetLastError();
+    return DSEA_ERR_HIP;
+  }
+  *lp_steps = (int64_t)h[0];
+  *fp64_steps = (int64_t)h[1];
   return DSEA_OK;
 }
 
@@ -394,8 +429,18 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
 
   // q_0 = q0/||q0|| ; u = A q_0 ; alpha_0 = q_0.u          (Lanczos.py:52-57)
   Profiler* prof = w.prof;
+  // optional bf16 shadow of the basis for the correction pass (see k_axpy_norm_lp)
+  uint16_t* Qs = nullptr;
+  int64_t lds = 0;
+  if (w.shadow && w.shadow_rows >= k && w.shadow_ld >= n) {
+    Qs = w.shadow;
+    lds = w.shadow_ld;
+  }
+  double* lp_count = w.scal + 16;
+  if (hipMemsetAsync(lp_count, 0, 2 * sizeof(double), st) != hipSuccess) return DSEA_ERR_HIP;
+  const int rps = n >= 512 * 2 * 512 ? 2 : 1;
   launch_dot(q0, q0, n, P, nrm2, st);
-  launch_scale_store(q0, nrm2, Q, nullptr, n, st);
+  launch_scale_store(q0, nrm2, Q, nullptr, n, st, Qs);
   if (op->d.kind == OP_TFIM) {
     // Fused sequence, 4 launches per step and no stand-alone scalar reductions: the mat-vec leaves
     // per-block partials of alpha (aP), the dots kernel sums them in its prologue; the axpy kernel leaves
@@ -407,10 +452,15 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
     for (int i = 1; i < k; ++i) {
       const double* beta_prev = (i >= 2) ? betas + (i - 2) : nullptr;
       launch_rdots(g, Q, ldq, n, i, u, nullptr, beta_prev, r, P, w.coef, st,
-                   prof ? prof->next(PROF_RDOTS) : nullptr, aP, na, alphas + (i - 1));
-      launch_axpy_norm(g, Q, ldq, n, i, w.coef, r, nP, nullptr, st, prof ? prof->next(PROF_AXPY) : nullptr);
-      na = launch_tfim_fused(op->d, r, nP, g.nw, Q + (int64_t)i * ldq, u, betas + (i - 1), aP, st,
-                             prof ? prof->next(PROF_SPMV) : nullptr);
+                   prof ? prof->next(PROF_RDOTS) : nullptr, aP, na, alphas + (i - 1), Qs != nullptr);
+      int nn = g.nw;
+      if (Qs)
+        nn = launch_axpy_norm_lp(n, rps, Q, ldq, Qs, lds, i, w.coef, w.lp_tau, r, nP, lp_count, st,
+                                 prof ? prof->next(PROF_AXPY) : nullptr);
+      else
+        launch_axpy_norm(g, Q, ldq, n, i, w.coef, r, nP, nullptr, st, prof ? prof->next(PROF_AXPY) : nullptr);
+      na = launch_tfim_fused(op->d, r, nP, nn, Q + (int64_t)i * ldq, u, betas + (i - 1), aP, st,
+                             prof ? prof->next(PROF_SPMV) : nullptr, Qs ? Qs + (int64_t)i * lds : nullptr);
     }
     launch_finalize1(aP, na, alphas + (k - 1), st);
     return check_launch();
@@ -421,10 +471,17 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
   for (int i = 1; i < k; ++i) {
     const double* beta_prev = (i >= 2) ? betas + (i - 2) : nullptr;
     launch_rdots(g, Q, ldq, n, i, u, alphas + (i - 1), beta_prev, r, P, w.coef, st,
-                 prof ? prof->next(PROF_RDOTS) : nullptr);
-    launch_axpy_norm(g, Q, ldq, n, i, w.coef, r, P, nrm2, st, prof ? prof->next(PROF_AXPY) : nullptr);
+                 prof ? prof->next(PROF_RDOTS) : nullptr, nullptr, 0, nullptr, Qs != nullptr);
+    if (Qs) {
+      double* nP = w.aux + DSEA_MAX_WAVE_TILES;
+      int nn = launch_axpy_norm_lp(n, rps, Q, ldq, Qs, lds, i, w.coef, w.lp_tau, r, nP, lp_count, st,
+                                   prof ? prof->next(PROF_AXPY) : nullptr);
+      launch_finalize1(nP, nn, nrm2, st);
+    } else {
+      launch_axpy_norm(g, Q, ldq, n, i, w.coef, r, P, nrm2, st, prof ? prof->next(PROF_AXPY) : nullptr);
+    }
     double* qi = Q + (int64_t)i * ldq;
-    launch_scale_store(r, nrm2, qi, betas + (i - 1), n, st);
+    launch_scale_store(r, nrm2, qi, betas + (i - 1), n, st, Qs ? Qs + (int64_t)i * lds : nullptr);
     nb = launch_spmv(op->d, qi, u, nullptr, nullptr, P, st, prof ? prof->next(PROF_SPMV) : nullptr);
     launch_finalize1(P, nb, alphas + i, st);
   }

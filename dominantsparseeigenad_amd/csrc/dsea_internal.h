@@ -77,6 +77,10 @@ struct Workspace {
   double* scal;      // DSEA_SCALARS doubles
   double* vec[4];    // four work vectors of npad doubles
   Profiler* prof;    // null unless dsea_profile_begin was called
+  uint16_t* shadow;  // caller-owned bf16 shadow of the basis (k rows x shadow_ld), or null
+  int64_t shadow_ld;
+  int shadow_rows;
+  double lp_tau;     // low-precision pass allowed while max|c_j| <= lp_tau * ||r||
   TileGeom geom(int64_t n_rows) const;
 };
 
@@ -85,9 +89,13 @@ void launch_finalize_slot(const double* P, int count, double* out, const double*
 void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* u,
                   const double* alpha, const double* beta, double* r, double* P, double* c_out,
                   hipStream_t st, EventPair* ev = nullptr, const double* aP = nullptr, int aCount = 0,
-                  double* a_store = nullptr);
+                  double* a_store = nullptr, bool want_rr = false);
+int launch_axpy_norm_lp(int64_t n, int rps, const double* Q, int64_t ldq, const uint16_t* Qs, int64_t lds, int i,
+                        const double* c, double tau, double* r, double* P, double* lp_count, hipStream_t st,
+                        EventPair* ev = nullptr);
 int launch_tfim_fused(const OpDesc& op, const double* r, const double* nP, int nCount, double* q_out, double* y,
-                      double* beta_store, double* P, hipStream_t st, EventPair* ev = nullptr);
+                      double* beta_store, double* P, hipStream_t st, EventPair* ev = nullptr,
+                      uint16_t* qs_out = nullptr);
 int launch_cg_update_fused(double* x, double* r, const double* d, const double* Ad, const double* state,
                            int parity, const double* dP, int dCount, int64_t n, double* P, hipStream_t st);
 void launch_cg_direction_fused(const double* r, double* d, double* state, int parity, const double* rP,
@@ -101,7 +109,7 @@ void launch_shift_dot(const double* x, double* y, const double* shift, const dou
                       double* P, double* out, hipStream_t st);
 void launch_axpy(double a_host, const double* a_dev, const double* x, double* y, int64_t n, hipStream_t st);
 void launch_scale_store(const double* r, const double* nrm2, double* q, double* beta_out, int64_t n,
-                        hipStream_t st);
+                        hipStream_t st, uint16_t* qs = nullptr);
 void launch_project_apply(const double* v, const double* a, const double* dot, double* out, int64_t n,
                           hipStream_t st);
 void launch_cg_init(const double* b, const double* Ax0, double* r, double* d, double* state, int64_t n,

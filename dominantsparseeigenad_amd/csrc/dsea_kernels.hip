@@ -53,6 +53,23 @@ __device__ __forceinline__ void st2(double* __restrict__ p, int64_t row, int64_t
   }
 }
 
+// bf16 shadow of the basis (storage only, see k_axpy_norm_lp): fp64 -> bf16 round-to-nearest-even
+__device__ __forceinline__ uint16_t f64_to_bf16(double v) {
+  const uint32_t u = __float_as_uint((float)v);
+  return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ double bf16lo_to_f64(uint32_t packed) { return (double)__uint_as_float(packed << 16); }
+__device__ __forceinline__ double bf16hi_to_f64(uint32_t packed) {
+  return (double)__uint_as_float(packed & 0xFFFF0000u);
+}
+__device__ __forceinline__ void st_bf16x2(uint16_t* __restrict__ p, int64_t row, int64_t n, double2 v) {
+  if (row + 1 < n) {
+    *reinterpret_cast<uint32_t*>(p + row) = (uint32_t)f64_to_bf16(v.x) | ((uint32_t)f64_to_bf16(v.y) << 16);
+  } else if (row < n) {
+    p[row] = f64_to_bf16(v.x);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // stage-2 reductions (deterministic)
 // ------------------------------------------------------------------------------------------
@@ -122,7 +139,7 @@ __device__ __forceinline__ void rdots_tile(const double* __restrict__ Q, int64_t
                                            int64_t base, int lane, const double* __restrict__ u,
                                            double a, double b, double* __restrict__ r,
                                            double* __restrict__ P, int64_t pstride, int64_t widx,
-                                           bool accumulate) {
+                                           bool accumulate, bool want_rr) {
   constexpr int NP = RPL / 2;
   double2 rv[NP];
   const double* __restrict__ q1 = Q + (int64_t)(i - 1) * ldq;
@@ -138,6 +155,19 @@ __device__ __forceinline__ void rdots_tile(const double* __restrict__ Q, int64_t
     rv[t].x = __dsub_rn(__dsub_rn(uu.x, __dmul_rn(a, qa.x)), __dmul_rn(b, qb.x));
     rv[t].y = __dsub_rn(__dsub_rn(uu.y, __dmul_rn(a, qa.y)), __dmul_rn(b, qb.y));
     st2<GUARD>(r, row, n, rv[t]);
+  }
+  if (want_rr) {  // ||r||^2 before the correction, as pseudo-vector i (scale for the low-precision test)
+    double acc = 0.0;
+#pragma unroll
+    for (int t = 0; t < NP; ++t) {
+      acc = fma(rv[t].x, rv[t].x, acc);
+      acc = fma(rv[t].y, rv[t].y, acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      double* dst = P + (int64_t)i * pstride + widx;
+      *dst = accumulate ? (*dst + acc) : acc;
+    }
   }
   // four basis vectors per trip: 4*NP independent 16-byte loads in flight per lane, and one
   // transposed butterfly (7 shuffles instead of 24) leaves the four totals in lanes 0/16/32/48.
@@ -197,7 +227,7 @@ __global__ __launch_bounds__(256) void k_rdots(const double* __restrict__ Q, int
                                                const double* __restrict__ beta, double* __restrict__ r,
                                                double* __restrict__ P, int64_t pstride, int nw,
                                                int64_t ntiles, const double* __restrict__ aP, int aCount,
-                                               double* __restrict__ a_store) {
+                                               double* __restrict__ a_store, int want_rr) {
   const int lane = threadIdx.x & 63;
   const int64_t widx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (widx >= nw) return;
@@ -215,9 +245,9 @@ __global__ __launch_bounds__(256) void k_rdots(const double* __restrict__ Q, int
   for (int64_t tile = widx; tile < ntiles; tile += nw) {
     const int64_t base = tile * TILE;
     if (base + TILE <= n)
-      rdots_tile<RPL, false>(Q, ldq, i, n, base, lane, u, a, b, r, P, pstride, widx, !first);
+      rdots_tile<RPL, false>(Q, ldq, i, n, base, lane, u, a, b, r, P, pstride, widx, !first, want_rr != 0);
     else
-      rdots_tile<RPL, true>(Q, ldq, i, n, base, lane, u, a, b, r, P, pstride, widx, !first);
+      rdots_tile<RPL, true>(Q, ldq, i, n, base, lane, u, a, b, r, P, pstride, widx, !first, want_rr != 0);
     first = false;
   }
 }
@@ -234,8 +264,12 @@ __device__ __forceinline__ double axpy_tile(const double* __restrict__ Q, int64_
   double2 w[NP];
 #pragma unroll
   for (int t = 0; t < NP; ++t) w[t] = make_double2(0.0, 0.0);
+  // Descending j: the dots pass (ascending) has just streamed Q[0..i-1], so the most recently read
+  // vectors are the ones still resident in the 256 MiB Infinity Cache; walking back over them first
+  // turns the tail of pass 1 into hits of pass 2 (and leaves Q[0..] resident for the next dots pass).
 #pragma unroll 4
-  for (int j = 0; j < i; ++j) {
+  for (int jj = 0; jj < i; ++jj) {
+    const int j = i - 1 - jj;
     const double* __restrict__ qj = Q + (int64_t)j * ldq;
     const double cj = c[j];
 #pragma unroll
@@ -285,6 +319,124 @@ __global__ __launch_bounds__(256) void k_axpy_norm(const double* __restrict__ Q,
     acc = wave_sum(acc);
     if (lane == 0) P[widx] = acc;
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Lanczos phase 2 reading a bf16 SHADOW of the basis (storage precision only; all arithmetic is fp64).
+//
+// Why this is exact to working precision: with full re-orthogonalisation every step the coefficients
+// c_j = q_j . r are pure rounding residue, max_j |c_j| ~ 1e-16..1e-15 ||r|| (measured on every golden
+// case, also at k = n), so the correction  sum_j c_j q_j  sits at the last bit of r.  Reading q_j with a
+// relative error of 2^-9 perturbs r by <= 2^-9 max|c_j| ~ 1e-18 ||r||, far below the fp64 rounding of the
+// subtraction itself; the next step's dots (always from the fp64 basis) re-measure orthogonality exactly.
+// The kernel checks the premise on the device: if max_j |c_j| > tau ||r|| it takes the fp64 basis instead.
+// The pass then moves 2 bytes per basis element instead of 8.
+//
+// Geometry: a lane owns RPS groups of 8 consecutive rows (one 16-byte shadow load each); a wave tile is
+// 512*RPS rows.  j runs downwards (most recently streamed vectors first).
+template <int RPS, bool GUARD>
+__device__ __forceinline__ double axpy_lp_tile(const double* __restrict__ Q, int64_t ldq,
+                                               const uint16_t* __restrict__ Qs, int64_t lds, int i,
+                                               int64_t n, int64_t base, int lane,
+                                               const double* __restrict__ c, bool use_lp,
+                                               double* __restrict__ r) {
+  double w[RPS][8];
+#pragma unroll
+  for (int s = 0; s < RPS; ++s)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) w[s][e] = 0.0;
+  if (use_lp) {
+#pragma unroll 4
+    for (int jj = 0; jj < i; ++jj) {
+      const int j = i - 1 - jj;
+      const uint16_t* __restrict__ qj = Qs + (int64_t)j * lds;
+      const double cj = c[j];
+#pragma unroll
+      for (int s = 0; s < RPS; ++s) {
+        const int64_t row = base + s * 512 + lane * 8;
+        uint4 h;
+        if (!GUARD || row + 8 <= n) {
+          h = *reinterpret_cast<const uint4*>(qj + row);
+        } else {
+          uint32_t t[4] = {0u, 0u, 0u, 0u};
+          for (int e = 0; e < 8; ++e)
+            if (row + e < n) t[e >> 1] |= (uint32_t)qj[row + e] << ((e & 1) * 16);
+          h = make_uint4(t[0], t[1], t[2], t[3]);
+        }
+        w[s][0] = fma(cj, bf16lo_to_f64(h.x), w[s][0]);
+        w[s][1] = fma(cj, bf16hi_to_f64(h.x), w[s][1]);
+        w[s][2] = fma(cj, bf16lo_to_f64(h.y), w[s][2]);
+        w[s][3] = fma(cj, bf16hi_to_f64(h.y), w[s][3]);
+        w[s][4] = fma(cj, bf16lo_to_f64(h.z), w[s][4]);
+        w[s][5] = fma(cj, bf16hi_to_f64(h.z), w[s][5]);
+        w[s][6] = fma(cj, bf16lo_to_f64(h.w), w[s][6]);
+        w[s][7] = fma(cj, bf16hi_to_f64(h.w), w[s][7]);
+      }
+    }
+  } else {
+    for (int jj = 0; jj < i; ++jj) {
+      const int j = i - 1 - jj;
+      const double* __restrict__ qj = Q + (int64_t)j * ldq;
+      const double cj = c[j];
+#pragma unroll
+      for (int s = 0; s < RPS; ++s) {
+        const int64_t row = base + s * 512 + lane * 8;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          double2 q = ld2<GUARD>(qj, row + 2 * t, n);
+          w[s][2 * t] = fma(cj, q.x, w[s][2 * t]);
+          w[s][2 * t + 1] = fma(cj, q.y, w[s][2 * t + 1]);
+        }
+      }
+    }
+  }
+  double acc = 0.0;
+#pragma unroll
+  for (int s = 0; s < RPS; ++s) {
+    const int64_t row = base + s * 512 + lane * 8;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      double2 rv = ld2<GUARD>(r, row + 2 * t, n);
+      rv.x -= w[s][2 * t];
+      rv.y -= w[s][2 * t + 1];
+      st2<GUARD>(r, row + 2 * t, n, rv);
+      acc = fma(rv.x, rv.x, acc);
+      acc = fma(rv.y, rv.y, acc);
+    }
+  }
+  return acc;
+}
+
+template <int RPS>
+__global__ __launch_bounds__(256) void k_axpy_norm_lp(const double* __restrict__ Q, int64_t ldq,
+                                                      const uint16_t* __restrict__ Qs, int64_t lds, int i,
+                                                      int64_t n, const double* __restrict__ c, double tau2,
+                                                      double* __restrict__ r, double* __restrict__ P, int nw,
+                                                      int64_t ntiles, double* __restrict__ lp_count) {
+  const int lane = threadIdx.x & 63;
+  const int64_t widx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (widx >= nw) return;
+  // premise check, identical in every wave: max_j c_j^2 <= tau^2 ||r||^2   (c[i] = ||r||^2 from the dots pass)
+  double m = 0.0;
+  for (int b = lane; b < i; b += 64) {
+    const double v = c[b];
+    m = fmax(m, v * v);
+  }
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) m = fmax(m, __shfl_xor(m, s, 64));
+  const bool use_lp = m <= tau2 * c[i];
+  if (widx == 0 && lane == 0 && lp_count) lp_count[use_lp ? 0 : 1] += 1.0;
+  constexpr int64_t TILE = 512 * RPS;
+  double acc = 0.0;
+  for (int64_t tile = widx; tile < ntiles; tile += nw) {
+    const int64_t base = tile * TILE;
+    if (base + TILE <= n)
+      acc += axpy_lp_tile<RPS, false>(Q, ldq, Qs, lds, i, n, base, lane, c, use_lp, r);
+    else
+      acc += axpy_lp_tile<RPS, true>(Q, ldq, Qs, lds, i, n, base, lane, c, use_lp, r);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) P[widx] = acc;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -347,7 +499,7 @@ __global__ __launch_bounds__(256) void k_axpy(double a_host, const double* __res
 __global__ __launch_bounds__(256) void k_scale_store(const double* __restrict__ r,
                                                      const double* __restrict__ nrm2,
                                                      double* __restrict__ q, double* __restrict__ beta_out,
-                                                     int64_t n) {
+                                                     int64_t n, uint16_t* __restrict__ qs) {
   const double beta = sqrt(nrm2[0]);
   if (beta_out && blockIdx.x == 0 && threadIdx.x == 0) beta_out[0] = beta;
   const int64_t stride = (int64_t)gridDim.x * 512;
@@ -356,6 +508,7 @@ __global__ __launch_bounds__(256) void k_scale_store(const double* __restrict__ 
     v.x = v.x / beta;
     v.y = v.y / beta;
     st2<true>(q, row, n, v);
+    if (qs) st_bf16x2(qs, row, n, v);
   }
 }
 
@@ -550,7 +703,7 @@ __global__ __launch_bounds__(256) void k_spmv_tfim_fused(TfimParams p, const dou
                                                          const double* __restrict__ nP, int nCount,
                                                          double* __restrict__ q_out, double* __restrict__ y,
                                                          double* __restrict__ beta_store,
-                                                         double* __restrict__ P) {
+                                                         double* __restrict__ P, uint16_t* __restrict__ qs_out) {
   constexpr int TILE = 1 << T;
   constexpr int PER = (TILE + 255) / 256;
   __shared__ double tile[TILE];
@@ -566,6 +719,7 @@ __global__ __launch_bounds__(256) void k_spmv_tfim_fused(TfimParams p, const dou
       const double qv = r[base + l] / beta;
       tile[l] = qv;
       q_out[base + l] = qv;
+      if (qs_out) qs_out[base + l] = f64_to_bf16(qv);
     }
   }
   __syncthreads();
@@ -741,14 +895,15 @@ void launch_finalize1(const double* P, int count, double* out, hipStream_t st) {
 
 void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* u,
                   const double* alpha, const double* beta, double* r, double* P, double* c_out,
-                  hipStream_t st, EventPair* ev, const double* aP, int aCount, double* a_store) {
+                  hipStream_t st, EventPair* ev, const double* aP, int aCount, double* a_store, bool want_rr) {
   const int grid = (g.nw + 3) / 4;
   if (ev) (void)hipEventRecord(ev->a, st);
   LAUNCH_RPL(k_rdots, g.rpl, grid, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, g.nw,
-             g.ntiles, aP, aCount, a_store);
+             g.ntiles, aP, aCount, a_store, want_rr ? 1 : 0);
   if (ev) (void)hipEventRecord(ev->b, st);
-  hipLaunchKernelGGL(k_finalize_multi, dim3(i), dim3(256), 0, st, (const double*)P, (int64_t)g.pstride,
-                     g.nw, c_out);
+  // want_rr: one more row of partials (||r||^2) -> c_out[i]
+  hipLaunchKernelGGL(k_finalize_multi, dim3(want_rr ? i + 1 : i), dim3(256), 0, st, (const double*)P,
+                     (int64_t)g.pstride, g.nw, c_out);
 }
 
 void launch_axpy_norm(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* c,
@@ -763,6 +918,24 @@ void launch_axpy_norm(const TileGeom& g, const double* Q, int64_t ldq, int64_t n
   }
   if (ev) (void)hipEventRecord(ev->b, st);
   if (nrm2_out) launch_finalize1(P, g.nw, nrm2_out, st);  // null: the consumer sums the g.nw partials itself
+}
+
+// returns the number of partials written
+int launch_axpy_norm_lp(int64_t n, int rps, const double* Q, int64_t ldq, const uint16_t* Qs, int64_t lds, int i,
+                        const double* c, double tau, double* r, double* P, double* lp_count, hipStream_t st,
+                        EventPair* ev) {
+  const int64_t tile = 512 * (int64_t)rps;
+  int64_t ntiles = (n + tile - 1) / tile;
+  if (ntiles < 1) ntiles = 1;
+  const int nw = (int)(ntiles < DSEA_MAX_WAVE_TILES ? ntiles : DSEA_MAX_WAVE_TILES);
+  const int grid = (nw + 3) / 4;
+  if (ev) (void)hipEventRecord(ev->a, st);
+  if (rps == 1)
+    hipLaunchKernelGGL((k_axpy_norm_lp<1>), dim3(grid), dim3(256), 0, st, Q, ldq, Qs, lds, i, n, c, tau * tau, r, P, nw, ntiles, lp_count);
+  else
+    hipLaunchKernelGGL((k_axpy_norm_lp<2>), dim3(grid), dim3(256), 0, st, Q, ldq, Qs, lds, i, n, c, tau * tau, r, P, nw, ntiles, lp_count);
+  if (ev) (void)hipEventRecord(ev->b, st);
+  return nw;
 }
 
 void launch_ritz(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int k, const double* s,
@@ -796,8 +969,8 @@ void launch_axpy(double a_host, const double* a_dev, const double* x, double* y,
 }
 
 void launch_scale_store(const double* r, const double* nrm2, double* q, double* beta_out, int64_t n,
-                        hipStream_t st) {
-  hipLaunchKernelGGL(k_scale_store, dim3(ew_blocks(n)), dim3(256), 0, st, r, nrm2, q, beta_out, n);
+                        hipStream_t st, uint16_t* qs) {
+  hipLaunchKernelGGL(k_scale_store, dim3(ew_blocks(n)), dim3(256), 0, st, r, nrm2, q, beta_out, n, qs);
 }
 
 void launch_project_apply(const double* v, const double* a, const double* dot, double* out, int64_t n,
@@ -892,13 +1065,13 @@ static int launch_spmv_impl(const OpDesc& op, const double* x, double* y, const 
 }
 
 int launch_tfim_fused(const OpDesc& op, const double* r, const double* nP, int nCount, double* q_out, double* y,
-                      double* beta_store, double* P, hipStream_t st, EventPair* ev) {
+                      double* beta_store, double* P, hipStream_t st, EventPair* ev, uint16_t* qs_out) {
   const TfimParams& p = op.tfim;
   const int T = p.L_local < DSEA_TFIM_TILE_LOG2 ? p.L_local : DSEA_TFIM_TILE_LOG2;
   const int64_t nb = ((int64_t)1 << p.L_local) >> T;
   if (ev) (void)hipEventRecord(ev->a, st);
 #define TFIM_FCASE(TT) \
-  case TT: hipLaunchKernelGGL((k_spmv_tfim_fused<TT>), dim3((unsigned)nb), dim3(256), 0, st, p, r, nP, nCount, q_out, y, beta_store, P); break;
+  case TT: hipLaunchKernelGGL((k_spmv_tfim_fused<TT>), dim3((unsigned)nb), dim3(256), 0, st, p, r, nP, nCount, q_out, y, beta_store, P, qs_out); break;
   switch (T) {
     TFIM_FCASE(0) TFIM_FCASE(1) TFIM_FCASE(2) TFIM_FCASE(3) TFIM_FCASE(4) TFIM_FCASE(5) TFIM_FCASE(6)
     TFIM_FCASE(7) TFIM_FCASE(8) TFIM_FCASE(9) TFIM_FCASE(10) TFIM_FCASE(11)

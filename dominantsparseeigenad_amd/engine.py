@@ -17,6 +17,12 @@ from ._lib import check
 
 F64 = torch.float64
 
+# bf16 shadow of the basis for the correction pass of the native Lanczos loop (include/dsea.h,
+# dsea_ws_set_shadow).  SHADOW_TAU is the device-side premise bound max|c_j| <= tau ||r||.
+USE_SHADOW = True
+SHADOW_TAU = 1e-12
+last_lp_steps = (0, 0)
+
 
 def _stream(device):
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
@@ -114,8 +120,16 @@ def lanczos(A, k, n, device, q0, native=None, callable_A=None):
     betas = torch.empty(max(k - 1, 1), dtype=F64, device=device)
     q0 = as_vector(q0, n)
     if native is not None:
-        check(lib.dsea_lanczos_run(native.handle, ws.handle, int(k), _ptr(q0), _ptr(Q), ldq, _ptr(alphas),
-                                   _ptr(betas), st), "dsea_lanczos_run")
+        shadow = None
+        if USE_SHADOW and k > 1:
+            shadow = torch.empty((k, ldq), dtype=torch.bfloat16, device=device)
+            check(lib.dsea_ws_set_shadow(ws.handle, _ptr(shadow), ldq, int(k), float(SHADOW_TAU)), "dsea_ws_set_shadow")
+        try:
+            check(lib.dsea_lanczos_run(native.handle, ws.handle, int(k), _ptr(q0), _ptr(Q), ldq, _ptr(alphas),
+                                       _ptr(betas), st), "dsea_lanczos_run")
+        finally:
+            if shadow is not None:
+                check(lib.dsea_ws_set_shadow(ws.handle, None, 0, 0, 0.0), "dsea_ws_set_shadow")
         return Q, ldq, alphas, betas[: k - 1]
 
     nrm2 = ws.scal[0:1]
@@ -139,6 +153,15 @@ def lanczos(A, k, n, device, q0, native=None, callable_A=None):
         u = as_vector(callable_A(qi[:n]), n)
         check(lib.dsea_dot(ws.handle, _ptr(qi), _ptr(u), n, c_void_p(alphas.data_ptr() + i * esz), st), "dsea_dot")
     return Q, ldq, alphas, betas[: k - 1]
+
+
+def lanczos_lp_stats(n, device):
+    """(steps that streamed the bf16 shadow, steps that fell back to the fp64 basis) of the last native run"""
+    lib = _lib.load()
+    ws = Workspace.get(n, 8, device)
+    a, b = c_int64(0), c_int64(0)
+    check(lib.dsea_lanczos_lp_stats(ws.handle, byref(a), byref(b), _stream(torch.device(device))), "dsea_lanczos_lp_stats")
+    return a.value, b.value
 
 
 def tridiag_extreme(alphas, betas, which):

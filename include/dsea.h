@@ -65,6 +65,17 @@ int dsea_ws_destroy(dsea_ws_t ws);
 /* tuning knob (0 = automatic): rows handled per lane in the basis-streaming kernels {2,4,8,16} */
 int dsea_ws_set_rows_per_lane(dsea_ws_t ws, int rpl);
 
+/* Optional bf16 SHADOW of the Krylov basis (caller-owned, `rows` x `ld` uint16, ld % 8 == 0, 16-byte
+ * aligned; null = off).  When registered, dsea_lanczos_run also stores every new basis vector rounded to
+ * bf16 and the correction pass  r -= sum_j c_j q_j  (second half of Lanczos.py:66) streams the shadow
+ * (2 bytes/element) instead of the fp64 basis.  Arithmetic stays fp64 and the dots pass always reads the
+ * fp64 basis.  This is exact to working precision because with full re-orthogonalisation
+ * max|c_j| ~ 1e-16..1e-15 ||r|| (the correction lives in the last bit of r); the kernel verifies
+ * max|c_j| <= tau ||r|| on the device each step and otherwise reads the fp64 basis.
+ * dsea_lanczos_lp_stats (synchronises) reports how many steps of the last run took each path.       */
+int dsea_ws_set_shadow(dsea_ws_t ws, void *shadow_bf16, int64_t ld, int rows, double tau);
+int dsea_lanczos_lp_stats(dsea_ws_t ws, int64_t *lp_steps, int64_t *fp64_steps, void *stream);
+
 /* Per-launch timing of the dominant kernels with HIP events recorded on the launch stream
  * (measurement aid for bench.py's roofline figure; not part of the numerical path).
  * After dsea_profile_begin, dsea_lanczos_run brackets every launch of kind

@@ -356,3 +356,43 @@ def test_adjoint_tight_eps_headline_size(monkeypatch):
     (dE_an,) = torch.autograd.grad(E_an, gt)
     assert abs(E.item() - E_an.item()) < 1e-12 * abs(E_an.item())
     assert abs(dE.item() - dE_an.item()) < TOL * abs(dE_an.item()), (dE.item(), dE_an.item())
+
+
+# ------------------------------------------------------------------ bf16 shadow of the basis (correction pass)
+def test_shadow_basis_pass_is_exact_to_working_precision(monkeypatch):
+    """The correction pass may stream a bf16 shadow of the basis (include/dsea.h, dsea_ws_set_shadow).
+    Compared with the all-fp64 run: the well-conditioned outputs -- extreme Ritz pair, the leading part of
+    the tridiagonal, orthonormality of the basis -- agree to rounding level; every step takes the shadow path
+    on a healthy run; tau = 0 forces the in-kernel fp64 fallback on every step.  (Late Lanczos coefficients
+    are ill-conditioned functions of the data -- any two rounding-different fp64 runs disagree there too --
+    so they are not compared.)"""
+    L, k = 14, 120
+    n = 1 << L
+    g = torch.tensor([1.0], dtype=F64, device=dev())
+    op = TFIMOperator(L, dev(), g=g)
+    q0 = torch.from_numpy(normal_vector(n, 9100)).to(dev())
+    runs = {}
+    for name, use, tau in (("fp64", False, 1e-12), ("shadow", True, 1e-12), ("fallback", True, 0.0)):
+        monkeypatch.setattr(engine, "USE_SHADOW", use)
+        monkeypatch.setattr(engine, "SHADOW_TAU", tau)
+        Qk, T = Lanczos(op, k, dev(), sparse=True, dim=n, q0=q0)
+        stats = engine.lanczos_lp_stats(n, dev()) if use else (0, 0)
+        lo, vlo, hi, vhi = symeigLanczos(op, k, dev(), sparse=True, dim=n, q0=q0)
+        runs[name] = (torch.diagonal(T).cpu(), torch.diagonal(T, 1).cpu(), Qk.cpu().clone(), stats,
+                      lo.item(), vlo.cpu(), hi.item(), vhi.cpu())
+    a0, b0, Q0, _, lo0, vlo0, hi0, vhi0 = runs["fp64"]
+    scale = float(a0.abs().max())
+    for name in ("shadow", "fallback"):
+        a, b, Q, stats, lo, vlo, hi, vhi = runs[name]
+        assert float((a[:30] - a0[:30]).abs().max()) <= 1e-12 * scale, name
+        assert float((b[:30] - b0[:30]).abs().max()) <= 1e-12 * scale, name
+        assert float((Q[:, :24] - Q0[:, :24]).abs().max()) <= 1e-12, name
+        G = Q.T @ Q
+        assert float((G - torch.eye(k, dtype=F64)).abs().max()) < 1e-13, name
+        assert abs(lo - lo0) <= 1e-13 * abs(lo0) and abs(hi - hi0) <= 1e-13 * abs(hi0), name
+        assert signed_close(vlo, vlo0, 1e-12)[0] and signed_close(vhi, vhi0, 1e-11)[0], name
+    G0 = Q0.T @ Q0
+    print("orthonormality fp64 %.2e shadow %.2e" % (float((G0 - torch.eye(k, dtype=F64)).abs().max()),
+          float((runs["shadow"][2].T @ runs["shadow"][2] - torch.eye(k, dtype=F64)).abs().max())))
+    assert runs["shadow"][3] == (k - 1, 0)
+    assert runs["fallback"][3] == (0, k - 1)
