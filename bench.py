@@ -108,8 +108,8 @@ def main():
     ap.add_argument("--L-local", type=int, default=20, help="log2 rows per GPU")
     ap.add_argument("--k", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-k", type=int, default=40)
-    ap.add_argument("--cpu-cg-cap", type=int, default=30)
+    ap.add_argument("--cpu-k", type=int, default=64)
+    ap.add_argument("--cpu-cg-cap", type=int, default=60)
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--rpl", type=int, default=0)
     ap.add_argument("--force-partitioned", action="store_true",

@@ -11,6 +11,7 @@
 //   Q[j] (vector-contiguous, stride ldq) reading the same rows of each -- every byte of the basis
 //   is read exactly once per pass, r is read once and written once.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "dsea_internal.h"
@@ -879,13 +880,23 @@ static inline int ew_blocks(int64_t n) {
   return (int)nb;
 }
 
-#define LAUNCH_RPL(KERNEL, rpl, grid, stream, ...)                                    \
+// Launch, optionally with a start/stop event pair attached to the dispatch itself (hipExtLaunchKernelGGL):
+// the events then carry the kernel's own begin/end timestamps, i.e. the same duration a profiler reports.
+#define KLAUNCH(ev, KERNEL, grid, block, stream, ...)                                              \
+  do {                                                                                             \
+    if (ev)                                                                                        \
+      hipExtLaunchKernelGGL(KERNEL, dim3(grid), dim3(block), 0, stream, (ev)->a, (ev)->b, 0, __VA_ARGS__); \
+    else                                                                                           \
+      hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(block), 0, stream, __VA_ARGS__);                 \
+  } while (0)
+
+#define LAUNCH_RPL(ev, KERNEL, rpl, grid, stream, ...)                                \
   do {                                                                                \
     switch (rpl) {                                                                    \
-      case 2: hipLaunchKernelGGL((KERNEL<2>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break; \
-      case 4: hipLaunchKernelGGL((KERNEL<4>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break; \
-      case 8: hipLaunchKernelGGL((KERNEL<8>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break; \
-      default: hipLaunchKernelGGL((KERNEL<16>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__); break; \
+      case 2: KLAUNCH(ev, (KERNEL<2>), grid, 256, stream, __VA_ARGS__); break;        \
+      case 4: KLAUNCH(ev, (KERNEL<4>), grid, 256, stream, __VA_ARGS__); break;        \
+      case 8: KLAUNCH(ev, (KERNEL<8>), grid, 256, stream, __VA_ARGS__); break;        \
+      default: KLAUNCH(ev, (KERNEL<16>), grid, 256, stream, __VA_ARGS__); break;      \
     }                                                                                 \
   } while (0)
 
@@ -897,10 +908,8 @@ void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, in
                   const double* alpha, const double* beta, double* r, double* P, double* c_out,
                   hipStream_t st, EventPair* ev, const double* aP, int aCount, double* a_store, bool want_rr) {
   const int grid = (g.nw + 3) / 4;
-  if (ev) (void)hipEventRecord(ev->a, st);
-  LAUNCH_RPL(k_rdots, g.rpl, grid, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, g.nw,
+  LAUNCH_RPL(ev, k_rdots, g.rpl, grid, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, g.nw,
              g.ntiles, aP, aCount, a_store, want_rr ? 1 : 0);
-  if (ev) (void)hipEventRecord(ev->b, st);
   // want_rr: one more row of partials (||r||^2) -> c_out[i]
   hipLaunchKernelGGL(k_finalize_multi, dim3(want_rr ? i + 1 : i), dim3(256), 0, st, (const double*)P,
                      (int64_t)g.pstride, g.nw, c_out);
@@ -909,14 +918,12 @@ void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, in
 void launch_axpy_norm(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* c,
                       double* r, double* P, double* nrm2_out, hipStream_t st, EventPair* ev) {
   const int grid = (g.nw + 3) / 4;
-  if (ev) (void)hipEventRecord(ev->a, st);
   switch (g.rpl) {
-    case 2: hipLaunchKernelGGL((k_axpy_norm<2, 0>), dim3(grid), dim3(256), 0, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles); break;
-    case 4: hipLaunchKernelGGL((k_axpy_norm<4, 0>), dim3(grid), dim3(256), 0, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles); break;
-    case 8: hipLaunchKernelGGL((k_axpy_norm<8, 0>), dim3(grid), dim3(256), 0, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles); break;
-    default: hipLaunchKernelGGL((k_axpy_norm<16, 0>), dim3(grid), dim3(256), 0, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles); break;
+    case 2: KLAUNCH(ev, (k_axpy_norm<2, 0>), grid, 256, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles); break;
+    case 4: KLAUNCH(ev, (k_axpy_norm<4, 0>), grid, 256, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles); break;
+    case 8: KLAUNCH(ev, (k_axpy_norm<8, 0>), grid, 256, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles); break;
+    default: KLAUNCH(ev, (k_axpy_norm<16, 0>), grid, 256, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles); break;
   }
-  if (ev) (void)hipEventRecord(ev->b, st);
   if (nrm2_out) launch_finalize1(P, g.nw, nrm2_out, st);  // null: the consumer sums the g.nw partials itself
 }
 
@@ -929,12 +936,11 @@ int launch_axpy_norm_lp(int64_t n, int rps, const double* Q, int64_t ldq, const 
   if (ntiles < 1) ntiles = 1;
   const int nw = (int)(ntiles < DSEA_MAX_WAVE_TILES ? ntiles : DSEA_MAX_WAVE_TILES);
   const int grid = (nw + 3) / 4;
-  if (ev) (void)hipEventRecord(ev->a, st);
+  const double tau2 = tau * tau;
   if (rps == 1)
-    hipLaunchKernelGGL((k_axpy_norm_lp<1>), dim3(grid), dim3(256), 0, st, Q, ldq, Qs, lds, i, n, c, tau * tau, r, P, nw, ntiles, lp_count);
+    KLAUNCH(ev, (k_axpy_norm_lp<1>), grid, 256, st, Q, ldq, Qs, lds, i, n, c, tau2, r, P, nw, ntiles, lp_count);
   else
-    hipLaunchKernelGGL((k_axpy_norm_lp<2>), dim3(grid), dim3(256), 0, st, Q, ldq, Qs, lds, i, n, c, tau * tau, r, P, nw, ntiles, lp_count);
-  if (ev) (void)hipEventRecord(ev->b, st);
+    KLAUNCH(ev, (k_axpy_norm_lp<2>), grid, 256, st, Q, ldq, Qs, lds, i, n, c, tau2, r, P, nw, ntiles, lp_count);
   return nw;
 }
 
@@ -1006,26 +1012,15 @@ void launch_cg_direction(const double* r, double* d, const double* state, int64_
 }
 
 // returns the number of partials written (0 when P == nullptr)
-static int launch_spmv_impl(const OpDesc& op, const double* x, double* y, const double* shift,
-                            const double* skip, double* P, hipStream_t st);
-
 int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shift, const double* skip,
                 double* P, hipStream_t st, EventPair* ev) {
-  if (ev) (void)hipEventRecord(ev->a, st);
-  int nb = launch_spmv_impl(op, x, y, shift, skip, P, st);
-  if (ev) (void)hipEventRecord(ev->b, st);
-  return nb;
-}
-
-static int launch_spmv_impl(const OpDesc& op, const double* x, double* y, const double* shift,
-                            const double* skip, double* P, hipStream_t st) {
   switch (op.kind) {
     case OP_TFIM: {
       const TfimParams& p = op.tfim;
       const int T = p.L_local < DSEA_TFIM_TILE_LOG2 ? p.L_local : DSEA_TFIM_TILE_LOG2;
       const int64_t nb = ((int64_t)1 << p.L_local) >> T;
 #define TFIM_CASE(TT) \
-  case TT: hipLaunchKernelGGL((k_spmv_tfim<TT>), dim3((unsigned)nb), dim3(256), 0, st, p, x, y, shift, skip, P); break;
+  case TT: KLAUNCH(ev, (k_spmv_tfim<TT>), (unsigned)nb, 256, st, p, x, y, shift, skip, P); break;
       switch (T) {
         TFIM_CASE(0) TFIM_CASE(1) TFIM_CASE(2) TFIM_CASE(3) TFIM_CASE(4) TFIM_CASE(5) TFIM_CASE(6)
         TFIM_CASE(7) TFIM_CASE(8) TFIM_CASE(9) TFIM_CASE(10) TFIM_CASE(11)
@@ -1044,11 +1039,11 @@ static int launch_spmv_impl(const OpDesc& op, const double* x, double* y, const 
       if (nb > DSEA_MAX_EW_BLOCKS) nb = DSEA_MAX_EW_BLOCKS;
       if (nb < 1) nb = 1;
       switch (G) {
-        case 4: hipLaunchKernelGGL((k_spmv_csr<4>), dim3((unsigned)nb), dim3(256), 0, st, p, x, y, shift, skip, P); break;
-        case 8: hipLaunchKernelGGL((k_spmv_csr<8>), dim3((unsigned)nb), dim3(256), 0, st, p, x, y, shift, skip, P); break;
-        case 16: hipLaunchKernelGGL((k_spmv_csr<16>), dim3((unsigned)nb), dim3(256), 0, st, p, x, y, shift, skip, P); break;
-        case 32: hipLaunchKernelGGL((k_spmv_csr<32>), dim3((unsigned)nb), dim3(256), 0, st, p, x, y, shift, skip, P); break;
-        default: hipLaunchKernelGGL((k_spmv_csr<64>), dim3((unsigned)nb), dim3(256), 0, st, p, x, y, shift, skip, P); break;
+        case 4: KLAUNCH(ev, (k_spmv_csr<4>), (unsigned)nb, 256, st, p, x, y, shift, skip, P); break;
+        case 8: KLAUNCH(ev, (k_spmv_csr<8>), (unsigned)nb, 256, st, p, x, y, shift, skip, P); break;
+        case 16: KLAUNCH(ev, (k_spmv_csr<16>), (unsigned)nb, 256, st, p, x, y, shift, skip, P); break;
+        case 32: KLAUNCH(ev, (k_spmv_csr<32>), (unsigned)nb, 256, st, p, x, y, shift, skip, P); break;
+        default: KLAUNCH(ev, (k_spmv_csr<64>), (unsigned)nb, 256, st, p, x, y, shift, skip, P); break;
       }
       return (int)nb;
     }
@@ -1057,7 +1052,7 @@ static int launch_spmv_impl(const OpDesc& op, const double* x, double* y, const 
       int64_t nb = (p.n + 255) / 256;
       if (nb > DSEA_MAX_EW_BLOCKS) nb = DSEA_MAX_EW_BLOCKS;
       if (nb < 1) nb = 1;
-      hipLaunchKernelGGL(k_spmv_stencil3, dim3((unsigned)nb), dim3(256), 0, st, p, x, y, shift, skip, P);
+      KLAUNCH(ev, k_spmv_stencil3, (unsigned)nb, 256, st, p, x, y, shift, skip, P);
       return (int)nb;
     }
   }
@@ -1069,16 +1064,14 @@ int launch_tfim_fused(const OpDesc& op, const double* r, const double* nP, int n
   const TfimParams& p = op.tfim;
   const int T = p.L_local < DSEA_TFIM_TILE_LOG2 ? p.L_local : DSEA_TFIM_TILE_LOG2;
   const int64_t nb = ((int64_t)1 << p.L_local) >> T;
-  if (ev) (void)hipEventRecord(ev->a, st);
 #define TFIM_FCASE(TT) \
-  case TT: hipLaunchKernelGGL((k_spmv_tfim_fused<TT>), dim3((unsigned)nb), dim3(256), 0, st, p, r, nP, nCount, q_out, y, beta_store, P, qs_out); break;
+  case TT: KLAUNCH(ev, (k_spmv_tfim_fused<TT>), (unsigned)nb, 256, st, p, r, nP, nCount, q_out, y, beta_store, P, qs_out); break;
   switch (T) {
     TFIM_FCASE(0) TFIM_FCASE(1) TFIM_FCASE(2) TFIM_FCASE(3) TFIM_FCASE(4) TFIM_FCASE(5) TFIM_FCASE(6)
     TFIM_FCASE(7) TFIM_FCASE(8) TFIM_FCASE(9) TFIM_FCASE(10) TFIM_FCASE(11)
     default: return -1;
   }
 #undef TFIM_FCASE
-  if (ev) (void)hipEventRecord(ev->b, st);
   return (int)nb;
 }
 

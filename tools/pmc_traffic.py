@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs as MI355X_MICROARCH.md
+prescribes) into HBM bytes per launch of each dsea kernel and write profiles/pmc_traffic.json.
+
+Units / corrections (MI355X_MICROARCH.md, section HBM):
+  * FETCH_SIZE, WRITE_SIZE are in KiB  -> x 1024;
+  * on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read -> x 2
+    (all dsea kernels read with 16-byte-per-lane coalesced loads); WRITE_SIZE is used uncorrected.
+   python tools/pmc_traffic.py gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv
+"""
+import csv, json, os, sys, collections
+
+def per_kernel(path, counter):
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            name = row["Kernel_Name"]
+            short = name.split("(")[0].replace("void ", "").replace("dsea::", "")
+            short = short.split("<")[0]
+            acc[short][0] += 1
+            acc[short][1] += float(row["Counter_Value"])
+    return acc
+
+fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+write = per_kernel(sys.argv[2], "WRITE_SIZE")
+out = {"_method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
+                  "`bench.py --steps 1 --warmup 1`; bytes = FETCH_SIZE[KiB]*1024*2 (gfx950 wide-read correction) "
+                  "+ WRITE_SIZE[KiB]*1024; averaged over all launches of the kernel (i = 1..k-1)"}
+for name in sorted(fetch):
+    if not name.startswith("k_"):
+        continue
+    n, fs = fetch[name]
+    nw, wsz = write.get(name, [0, 0.0])
+    rd = fs / n * 1024 * 2
+    wr = (wsz / nw * 1024) if nw else 0.0
+    out[name] = {"launches": n, "fetch_bytes_per_launch": rd, "write_bytes_per_launch": wr,
+                 "hbm_bytes_per_launch": rd + wr}
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+with open(os.path.join(root, "profiles", "pmc_traffic.json"), "w") as f:
+    json.dump(out, f, indent=1)
+for k, v in out.items():
+    if k != "_method":
+        print("%-24s launches %5d  read %10.1f MB  write %8.1f MB  total %10.1f MB" % (
+            k, v["launches"], v["fetch_bytes_per_launch"] / 1e6, v["write_bytes_per_launch"] / 1e6, v["hbm_bytes_per_launch"] / 1e6))
