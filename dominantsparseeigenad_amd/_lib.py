@@ -29,6 +29,7 @@ _SIGNATURES = {
     "dsea_version": (c_int, []),
     "dsea_error_string": (c_char_p, [c_int]),
     "dsea_last_hip_error": (c_int, []),
+    "dsea_set_tuning": (c_int, [c_int, c_int]),
     "dsea_ws_bytes": (c_int, [c_int64, c_int, POINTER(c_size_t)]),
     "dsea_ws_create": (c_int, [c_void_p, c_size_t, c_int64, c_int, POINTER(c_void_p)]),
     "dsea_ws_destroy": (c_int, [c_void_p]),

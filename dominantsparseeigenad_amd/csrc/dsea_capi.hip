@@ -99,6 +99,13 @@ const char* dsea_error_string(int status) {
 
 int dsea_last_hip_error(void) { return g_last_hip; }
 
+int dsea_set_tuning(int key, int value) {
+  switch (key) {
+    case DSEA_TUNE_TFIM_TILE_LOG2: set_tfim_tile_log2(value); return DSEA_OK;
+    default: return DSEA_ERR_ARG;
+  }
+}
+
 // ---------------------------------------------------------------------------- workspace
 int dsea_ws_bytes(int64_t n, int kmax, size_t* bytes) {
   if (!bytes || n < 1 || kmax < 0) return DSEA_ERR_ARG;
@@ -441,7 +448,7 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
   const int rps = n >= 512 * 2 * 512 ? 2 : 1;
   launch_dot(q0, q0, n, P, nrm2, st);
   launch_scale_store(q0, nrm2, Q, nullptr, n, st, Qs);
-  if (op->d.kind == OP_TFIM) {
+  if (op->d.kind == OP_TFIM && op->d.tfim.L_local >= 1) {
     // Fused sequence, 4 launches per step and no stand-alone scalar reductions: the mat-vec leaves
     // per-block partials of alpha (aP), the dots kernel sums them in its prologue; the axpy kernel leaves
     // per-wave partials of ||r||^2 (nP), the fused scale + mat-vec kernel sums those.

@@ -84,6 +84,7 @@ struct Workspace {
   TileGeom geom(int64_t n_rows) const;
 };
 
+void set_tfim_tile_log2(int t);
 void launch_finalize1(const double* P, int count, double* out, hipStream_t st);
 void launch_finalize_slot(const double* P, int count, double* out, const double* skip, hipStream_t st);
 void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* u,

@@ -648,107 +648,146 @@ __global__ __launch_bounds__(256) void k_cg_direction(const double* __restrict__
 // T bits are LDS reads, flips of bits T..Lloc-1 are coalesced global reads of other tiles (served
 // by L2 / Infinity Cache: the whole vector is 8 MiB at L = 20).
 //   y[i] = dscale*d(gi)*x[i] - g * sum_j x[i^(1<<j)] - shift*x[i] ;   partial x.y
-template <int T>
+// A thread owns PAIR consecutive-row pairs (16-byte LDS and global accesses); the out-of-tile loads of
+// all its pairs are issued four bits at a time before any of them is consumed.
+//
+// FUSED (Lanczos tail, Lanczos.py:69-72,75 in one launch): the input is the un-normalised r,
+//   beta = sqrt(sum of the ||r||^2 partials) ; q = r/beta -> Q[i] (+ bf16 shadow) ; u = H q ; partial q.u
+// in-tile neighbours use the scaled values, the out-of-tile neighbour sum is scaled once (linearity).
+struct TfimFusedArgs {
+  const double* nP;      // partials of ||r||^2
+  int nCount;
+  double* q_out;         // Q[i]
+  uint16_t* qs_out;      // bf16 shadow row or null
+  double* beta_store;    // betas[i-1]
+};
+
+__device__ __forceinline__ double tfim_diag(const TfimParams& p, int64_t i, uint64_t maskL) {
+  const uint64_t gi = (uint64_t)(p.row_offset + i);
+  const uint64_t rot = ((gi << 1) | (gi >> (p.L - 1))) & maskL;
+  const int pop = __popcll(gi ^ rot);
+  return p.diag_scale * (double)(-(p.L - 2 * pop));
+}
+
+template <int T, bool FUSED>
 __global__ __launch_bounds__(256) void k_spmv_tfim(TfimParams p, const double* __restrict__ x,
                                                    double* __restrict__ y,
                                                    const double* __restrict__ shift,
                                                    const double* __restrict__ skip,
-                                                   double* __restrict__ P) {
+                                                   double* __restrict__ P, TfimFusedArgs fa) {
   constexpr int TILE = 1 << T;
-  constexpr int PER = (TILE + 255) / 256;
-  __shared__ double tile[TILE];
-  __shared__ double sm4[4];
-  if (skip && skip[0] != 0.0) return;
+  constexpr int NPAIR = TILE / 2;                       // T >= 1
+  constexpr int PER = (NPAIR + 255) / 256;              // pairs per thread
+  __shared__ double2 tile2[NPAIR];
+  __shared__ double sm5[5];
+  if (!FUSED && skip && skip[0] != 0.0) return;
+  double beta = 1.0;
+  if (FUSED) {
+    beta = sqrt(sum_partials_block(fa.nP, fa.nCount, sm5));
+    if (blockIdx.x == 0 && threadIdx.x == 0) fa.beta_store[0] = beta;
+  }
   const double g = p.g_dev ? p.g_dev[0] : p.g_const;
   const double s = shift ? shift[0] : 0.0;
   const int64_t base = (int64_t)blockIdx.x * TILE;
 #pragma unroll
   for (int t = 0; t < PER; ++t) {
-    const int l = t * 256 + threadIdx.x;
-    if (l < TILE) tile[l] = x[base + l];
+    const int lp = t * 256 + threadIdx.x;
+    if (lp < NPAIR) {
+      double2 v = *reinterpret_cast<const double2*>(x + base + 2 * lp);
+      if (FUSED) {
+        v.x = v.x / beta;
+        v.y = v.y / beta;
+        *reinterpret_cast<double2*>(fa.q_out + base + 2 * lp) = v;
+        if (fa.qs_out)
+          *reinterpret_cast<uint32_t*>(fa.qs_out + base + 2 * lp) =
+              (uint32_t)f64_to_bf16(v.x) | ((uint32_t)f64_to_bf16(v.y) << 16);
+      }
+      tile2[lp] = v;
+    }
   }
   __syncthreads();
   const uint64_t maskL = (p.L >= 64) ? ~0ull : ((1ull << p.L) - 1ull);
+  // out-of-tile neighbours: all pairs of this thread, four bits per trip, loads first
+  double2 far[PER];
+#pragma unroll
+  for (int t = 0; t < PER; ++t) far[t] = make_double2(0.0, 0.0);
+  int j = T;
+  for (; j + 4 <= p.L_local; j += 4) {
+    double2 nb[PER][4];
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+      const int lp = t * 256 + threadIdx.x;
+      const int64_t i0 = base + 2 * (int64_t)(lp < NPAIR ? lp : 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        nb[t][e] = *reinterpret_cast<const double2*>(x + (i0 ^ ((int64_t)1 << (j + e))));
+    }
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+      far[t].x += (nb[t][0].x + nb[t][1].x) + (nb[t][2].x + nb[t][3].x);
+      far[t].y += (nb[t][0].y + nb[t][1].y) + (nb[t][2].y + nb[t][3].y);
+    }
+  }
+  for (; j < p.L_local; ++j) {
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+      const int lp = t * 256 + threadIdx.x;
+      const int64_t i0 = base + 2 * (int64_t)(lp < NPAIR ? lp : 0);
+      const double2 nbv = *reinterpret_cast<const double2*>(x + (i0 ^ ((int64_t)1 << j)));
+      far[t].x += nbv.x;
+      far[t].y += nbv.y;
+    }
+  }
   double acc = 0.0;
 #pragma unroll
   for (int t = 0; t < PER; ++t) {
-    const int l = t * 256 + threadIdx.x;
-    if (l < TILE) {
-      const int64_t i = base + l;
-      double sum = 0.0;
+    const int lp = t * 256 + threadIdx.x;
+    if (lp < NPAIR) {
+      const int64_t i0 = base + 2 * (int64_t)lp;
+      const double2 xv = tile2[lp];
+      double2 sum = make_double2(xv.y, xv.x);  // bit 0: the other element of the pair
 #pragma unroll
-      for (int j = 0; j < T; ++j) sum += tile[l ^ (1 << j)];
-      for (int j = T; j < p.L_local; ++j) sum += x[i ^ ((int64_t)1 << j)];
-      const double xi = tile[l];
-      const uint64_t gi = (uint64_t)(p.row_offset + i);
-      const uint64_t rot = ((gi << 1) | (gi >> (p.L - 1))) & maskL;
-      const int pop = __popcll(gi ^ rot);
-      const double diag = p.diag_scale * (double)(-(p.L - 2 * pop));
-      double v = __dsub_rn(__dmul_rn(xi, diag), __dmul_rn(g, sum));
-      if (shift) v = __dsub_rn(v, __dmul_rn(s, xi));
-      y[i] = v;
-      acc = fma(xi, v, acc);
+      for (int jb = 1; jb < T; ++jb) {
+        const double2 nbv = tile2[lp ^ (1 << (jb - 1))];
+        sum.x += nbv.x;
+        sum.y += nbv.y;
+      }
+      if (FUSED) {
+        sum.x += far[t].x / beta;
+        sum.y += far[t].y / beta;
+      } else {
+        sum.x += far[t].x;
+        sum.y += far[t].y;
+      }
+      double2 v;
+      v.x = __dsub_rn(__dmul_rn(xv.x, tfim_diag(p, i0, maskL)), __dmul_rn(g, sum.x));
+      v.y = __dsub_rn(__dmul_rn(xv.y, tfim_diag(p, i0 + 1, maskL)), __dmul_rn(g, sum.y));
+      if (!FUSED && shift) {
+        v.x = __dsub_rn(v.x, __dmul_rn(s, xv.x));
+        v.y = __dsub_rn(v.y, __dmul_rn(s, xv.y));
+      }
+      *reinterpret_cast<double2*>(y + i0) = v;
+      acc = fma(xv.x, v.x, acc);
+      acc = fma(xv.y, v.y, acc);
     }
   }
   if (P) {
-    double tot = block_sum(acc, sm4);
+    double tot = block_sum(acc, sm5);
     if (threadIdx.x == 0) P[blockIdx.x] = tot;
   }
 }
 
-// Fused Lanczos tail for the TFIM operator (Lanczos.py:69-72,75 in one launch):
-//   beta = sqrt(sum of the ||r||^2 partials) ; q = r/beta -> Q[i] ; u = H q ; partial q.u
-// Neighbours inside the LDS tile use the scaled values; the out-of-tile neighbour sum is scaled once.
-template <int T>
-__global__ __launch_bounds__(256) void k_spmv_tfim_fused(TfimParams p, const double* __restrict__ r,
-                                                         const double* __restrict__ nP, int nCount,
-                                                         double* __restrict__ q_out, double* __restrict__ y,
-                                                         double* __restrict__ beta_store,
-                                                         double* __restrict__ P, uint16_t* __restrict__ qs_out) {
-  constexpr int TILE = 1 << T;
-  constexpr int PER = (TILE + 255) / 256;
-  __shared__ double tile[TILE];
-  __shared__ double sm5[5];
-  const double beta = sqrt(sum_partials_block(nP, nCount, sm5));
-  if (blockIdx.x == 0 && threadIdx.x == 0) beta_store[0] = beta;
-  const double g = p.g_dev ? p.g_dev[0] : p.g_const;
-  const int64_t base = (int64_t)blockIdx.x * TILE;
-#pragma unroll
-  for (int t = 0; t < PER; ++t) {
-    const int l = t * 256 + threadIdx.x;
-    if (l < TILE) {
-      const double qv = r[base + l] / beta;
-      tile[l] = qv;
-      q_out[base + l] = qv;
-      if (qs_out) qs_out[base + l] = f64_to_bf16(qv);
-    }
-  }
-  __syncthreads();
+// n = 1 (L_local = 0): a single row, no neighbours inside the slab
+__global__ void k_spmv_tfim_single(TfimParams p, const double* __restrict__ x, double* __restrict__ y,
+                                   const double* __restrict__ shift, const double* __restrict__ skip,
+                                   double* __restrict__ P) {
+  if (skip && skip[0] != 0.0) return;
   const uint64_t maskL = (p.L >= 64) ? ~0ull : ((1ull << p.L) - 1ull);
-  double acc = 0.0;
-#pragma unroll
-  for (int t = 0; t < PER; ++t) {
-    const int l = t * 256 + threadIdx.x;
-    if (l < TILE) {
-      const int64_t i = base + l;
-      double sum = 0.0;
-#pragma unroll
-      for (int j = 0; j < T; ++j) sum += tile[l ^ (1 << j)];
-      double far = 0.0;
-      for (int j = T; j < p.L_local; ++j) far += r[i ^ ((int64_t)1 << j)];
-      sum += far / beta;
-      const double xi = tile[l];
-      const uint64_t gi = (uint64_t)(p.row_offset + i);
-      const uint64_t rot = ((gi << 1) | (gi >> (p.L - 1))) & maskL;
-      const int pop = __popcll(gi ^ rot);
-      const double diag = p.diag_scale * (double)(-(p.L - 2 * pop));
-      const double v = __dsub_rn(__dmul_rn(xi, diag), __dmul_rn(g, sum));
-      y[i] = v;
-      acc = fma(xi, v, acc);
-    }
-  }
-  double tot = block_sum(acc, sm5);
-  if (threadIdx.x == 0) P[blockIdx.x] = tot;
+  const double xi = x[0];
+  double v = __dmul_rn(xi, tfim_diag(p, 0, maskL));
+  if (shift) v = __dsub_rn(v, __dmul_rn(shift[0], xi));
+  y[0] = v;
+  if (P) P[0] = xi * v;
 }
 
 // CG with the scalar stages folded into the consumers (3 launches per iteration: mat-vec, update,
@@ -873,6 +912,11 @@ __global__ __launch_bounds__(256) void k_spmv_stencil3(Stencil3Params p, const d
 // ------------------------------------------------------------------------------------------
 // host-side launch wrappers (called from dsea_capi.hip)
 // ------------------------------------------------------------------------------------------
+static int g_tfim_tile_log2 = DSEA_TFIM_TILE_LOG2;
+void set_tfim_tile_log2(int t) {
+  if (t >= 6 && t <= 12) g_tfim_tile_log2 = t;
+}
+
 static inline int ew_blocks(int64_t n) {
   int64_t nb = (n + 2047) / 2048;  // 256 threads x double2 x 4 iterations
   if (nb < 1) nb = 1;
@@ -1017,13 +1061,18 @@ int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shif
   switch (op.kind) {
     case OP_TFIM: {
       const TfimParams& p = op.tfim;
-      const int T = p.L_local < DSEA_TFIM_TILE_LOG2 ? p.L_local : DSEA_TFIM_TILE_LOG2;
+      if (p.L_local == 0) {
+        KLAUNCH(ev, k_spmv_tfim_single, 1, 1, st, p, x, y, shift, skip, P);
+        return 1;
+      }
+      const int T = p.L_local < g_tfim_tile_log2 ? p.L_local : g_tfim_tile_log2;
       const int64_t nb = ((int64_t)1 << p.L_local) >> T;
+      TfimFusedArgs fa = {nullptr, 0, nullptr, nullptr, nullptr};
 #define TFIM_CASE(TT) \
-  case TT: KLAUNCH(ev, (k_spmv_tfim<TT>), (unsigned)nb, 256, st, p, x, y, shift, skip, P); break;
+  case TT: KLAUNCH(ev, (k_spmv_tfim<TT, false>), (unsigned)nb, 256, st, p, x, y, shift, skip, P, fa); break;
       switch (T) {
-        TFIM_CASE(0) TFIM_CASE(1) TFIM_CASE(2) TFIM_CASE(3) TFIM_CASE(4) TFIM_CASE(5) TFIM_CASE(6)
-        TFIM_CASE(7) TFIM_CASE(8) TFIM_CASE(9) TFIM_CASE(10) TFIM_CASE(11)
+        TFIM_CASE(1) TFIM_CASE(2) TFIM_CASE(3) TFIM_CASE(4) TFIM_CASE(5) TFIM_CASE(6)
+        TFIM_CASE(7) TFIM_CASE(8) TFIM_CASE(9) TFIM_CASE(10) TFIM_CASE(11) TFIM_CASE(12)
         default: return -1;
       }
 #undef TFIM_CASE
@@ -1062,13 +1111,16 @@ int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shif
 int launch_tfim_fused(const OpDesc& op, const double* r, const double* nP, int nCount, double* q_out, double* y,
                       double* beta_store, double* P, hipStream_t st, EventPair* ev, uint16_t* qs_out) {
   const TfimParams& p = op.tfim;
-  const int T = p.L_local < DSEA_TFIM_TILE_LOG2 ? p.L_local : DSEA_TFIM_TILE_LOG2;
+  if (p.L_local == 0) return -1;  // callers use the unfused sequence for a 1-row slab
+  const int T = p.L_local < g_tfim_tile_log2 ? p.L_local : g_tfim_tile_log2;
   const int64_t nb = ((int64_t)1 << p.L_local) >> T;
+  TfimFusedArgs fa = {nP, nCount, q_out, qs_out, beta_store};
+  const double* nullc = nullptr;
 #define TFIM_FCASE(TT) \
-  case TT: KLAUNCH(ev, (k_spmv_tfim_fused<TT>), (unsigned)nb, 256, st, p, r, nP, nCount, q_out, y, beta_store, P, qs_out); break;
+  case TT: KLAUNCH(ev, (k_spmv_tfim<TT, true>), (unsigned)nb, 256, st, p, r, y, nullc, nullc, P, fa); break;
   switch (T) {
-    TFIM_FCASE(0) TFIM_FCASE(1) TFIM_FCASE(2) TFIM_FCASE(3) TFIM_FCASE(4) TFIM_FCASE(5) TFIM_FCASE(6)
-    TFIM_FCASE(7) TFIM_FCASE(8) TFIM_FCASE(9) TFIM_FCASE(10) TFIM_FCASE(11)
+    TFIM_FCASE(1) TFIM_FCASE(2) TFIM_FCASE(3) TFIM_FCASE(4) TFIM_FCASE(5) TFIM_FCASE(6)
+    TFIM_FCASE(7) TFIM_FCASE(8) TFIM_FCASE(9) TFIM_FCASE(10) TFIM_FCASE(11) TFIM_FCASE(12)
     default: return -1;
   }
 #undef TFIM_FCASE

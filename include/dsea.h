@@ -55,6 +55,10 @@ typedef struct dsea_ws_s *dsea_ws_t; /* workspace descriptor                    
 int dsea_version(void);
 const char *dsea_error_string(int status);
 int dsea_last_hip_error(void);
+/* process-wide tuning knobs (measurement aid): key DSEA_TUNE_TFIM_TILE_LOG2 = log2 rows of x staged in LDS per
+ * block of the TFIM mat-vec (6..12, default 11)                                                          */
+#define DSEA_TUNE_TFIM_TILE_LOG2 1
+int dsea_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------ workspace
  * Scratch for partial sums, reorthogonalisation coefficients and four work vectors.
