@@ -11,7 +11,7 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdsea.so")
+LIB_PATH = os.environ.get("DSEA_LIB", os.path.join(_HERE, "csrc", "libdsea.so"))
 
 _lib = None
 
