@@ -60,6 +60,14 @@ _SIGNATURES = {
     "dsea_cg_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "dsea_cg_check": (c_int, [c_void_p, c_void_p, c_double, c_void_p]),
     "dsea_cg_direction": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "dsea_plz_dots": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_void_p]),
+    "dsea_plz_correct_matvec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p]),
+    "dsea_axpy_multi_dot": (c_int, [c_void_p, c_double, c_void_p, POINTER(c_void_p), c_int, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "dsea_plz_finish": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                c_void_p, c_int64, c_void_p]),
     "dsea_lanczos_run": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                  c_void_p]),
     "dsea_cg_run": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int64,

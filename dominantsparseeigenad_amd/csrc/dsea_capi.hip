@@ -418,6 +418,69 @@ int dsea_cg_direction(dsea_ws_t ws, const double* r, double* d, const double* st
   return check_launch();
 }
 
+// ---------------------------------------------------------------------------- row-partitioned macro phases
+int dsea_axpy_multi_dot(dsea_ws_t ws, double a_host, const double* a_dev, const double* const* xs, int count,
+                        const double* shift, const double* skip_flag, const double* x, double* y, int64_t n,
+                        double* dot_out, void* stream) {
+  REQUIRE(ws && x && y && dot_out && n >= 1 && count >= 0 && count <= 6 && (count == 0 || xs), DSEA_ERR_ARG);
+  REQUIRE(aligned16(x) && aligned16(y), DSEA_ERR_ALIGN);
+  for (int b = 0; b < count; ++b) {
+    REQUIRE(xs[b] != nullptr, DSEA_ERR_ARG);
+    REQUIRE(aligned16(xs[b]), DSEA_ERR_ALIGN);
+  }
+  launch_axpy_multi_dot(a_host, a_dev, xs, count, shift, skip_flag, x, y, n, ws->w.aux + 2 * DSEA_MAX_WAVE_TILES,
+                        dot_out, static_cast<hipStream_t>(stream));
+  return check_launch();
+}
+
+int dsea_plz_dots(dsea_ws_t ws, const double* Q, int64_t ldq, int64_t n, int i, const double* u,
+                  const double* alpha, const double* beta, double* r, double* c_out, void* stream) {
+  REQUIRE(ws && Q && u && alpha && r && c_out && n >= 1 && i >= 1 && ldq >= n, DSEA_ERR_ARG);
+  REQUIRE(i <= ws->w.kmax, DSEA_ERR_WORKSPACE);
+  REQUIRE(aligned16(Q) && aligned16(u) && aligned16(r) && (ldq % 2 == 0), DSEA_ERR_ALIGN);
+  TileGeom g = ws->w.geom(n);
+  launch_rdots(g, Q, ldq, n, i, u, alpha, beta, r, ws->w.partials, c_out, static_cast<hipStream_t>(stream),
+               nullptr, nullptr, 0, nullptr, true);
+  return check_launch();
+}
+
+int dsea_plz_correct_matvec(dsea_op_t op, dsea_ws_t ws, const double* Q, int64_t ldq, int row, const double* c,
+                            double* r, double* y, double* pair_out, void* stream) {
+  REQUIRE(op && ws && r && y && pair_out && row >= 0 && r != y, DSEA_ERR_ARG);
+  const int64_t n = op->d.n;
+  REQUIRE(aligned16(r) && aligned16(y), DSEA_ERR_ALIGN);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Workspace& w = ws->w;
+  double* nP = w.aux + DSEA_MAX_WAVE_TILES;
+  if (row >= 1) {
+    REQUIRE(Q && c && ldq >= n && (ldq % 2 == 0) && aligned16(Q), DSEA_ERR_ARG);
+    if (w.shadow && w.shadow_rows > row && w.shadow_ld >= n) {
+      const int rps = n >= 512 * 2 * 512 ? 2 : 1;
+      int nn = launch_axpy_norm_lp(n, rps, Q, ldq, w.shadow, w.shadow_ld, row, c, w.lp_tau, r, nP, w.scal + 16, st);
+      launch_finalize1(nP, nn, pair_out, st);
+    } else {
+      TileGeom g = w.geom(n);
+      launch_axpy_norm(g, Q, ldq, n, row, c, r, w.partials, pair_out, st);
+    }
+  } else {
+    launch_dot(r, r, n, w.partials, pair_out, st);
+  }
+  int nb = launch_spmv(op->d, r, y, nullptr, nullptr, nullptr, st);
+  if (nb < 0) return DSEA_ERR_UNSUPPORTED;
+  return check_launch();
+}
+
+int dsea_plz_finish(dsea_ws_t ws, const double* r, const double* y, const double* pair, double* q_out, int row,
+                    double* u_out, double* alpha_out, double* beta_out, int64_t n, void* stream) {
+  REQUIRE(ws && r && y && pair && q_out && u_out && alpha_out && n >= 1 && row >= 0, DSEA_ERR_ARG);
+  REQUIRE(aligned16(r) && aligned16(y) && aligned16(q_out) && aligned16(u_out), DSEA_ERR_ALIGN);
+  Workspace& w = ws->w;
+  uint16_t* qs = nullptr;
+  if (w.shadow && w.shadow_rows > row && w.shadow_ld >= n) qs = w.shadow + (int64_t)row * w.shadow_ld;
+  launch_plz_finish(r, y, pair, q_out, qs, u_out, alpha_out, beta_out, n, static_cast<hipStream_t>(stream));
+  return check_launch();
+}
+
 // ---------------------------------------------------------------------------- whole solvers
 int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double* Q, int64_t ldq,
                      double* alphas, double* betas, void* stream) {

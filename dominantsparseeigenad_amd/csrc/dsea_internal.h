@@ -120,6 +120,11 @@ void launch_cg_update(double* x, double* r, const double* d, const double* Ad, d
                       double* P, hipStream_t st);
 void launch_cg_check(double* state, double eps, hipStream_t st);
 void launch_cg_direction(const double* r, double* d, const double* state, int64_t n, hipStream_t st);
+void launch_axpy_multi_dot(double a_host, const double* a_dev, const double* const* xs, int count,
+                           const double* shift, const double* skip, const double* x, double* y, int64_t n,
+                           double* P, double* dot_out, hipStream_t st);
+void launch_plz_finish(const double* r, const double* y, const double* pair, double* q, uint16_t* qs, double* u,
+                       double* alpha_out, double* beta_out, int64_t n, hipStream_t st);
 int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shift, const double* skip,
                 double* P, hipStream_t st, EventPair* ev = nullptr);
 

@@ -556,6 +556,77 @@ __global__ __launch_bounds__(256) void k_project_apply(const double* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// row-partitioned mode: remote part of the mat-vec and the normalising tail of a Lanczos step
+// ------------------------------------------------------------------------------------------
+struct MultiSrc {
+  const double* p[6];
+  int count;
+};
+
+// y += a * (xs[0] + ... + xs[count-1]) - shift * x ; partial x.y
+// (TFIM top-bit flips: a = -g, xs = the partner slabs; shift = E0 in the adjoint solve, CG.py:120)
+__global__ __launch_bounds__(256) void k_axpy_multi_dot(double a_host, const double* __restrict__ a_dev,
+                                                        MultiSrc xs, const double* __restrict__ shift,
+                                                        const double* __restrict__ skip,
+                                                        const double* __restrict__ x, double* __restrict__ y,
+                                                        int64_t n, double* __restrict__ P) {
+  __shared__ double sm4[4];
+  if (skip && skip[0] != 0.0) return;
+  const double a = a_host * (a_dev ? a_dev[0] : 1.0);
+  const double s = shift ? shift[0] : 0.0;
+  double acc = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * 512;
+  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; row < n; row += stride) {
+    double2 yv = ld2<true>(y, row, n), xv = ld2<true>(x, row, n);
+    double2 sum = make_double2(0.0, 0.0);
+    for (int b = 0; b < xs.count; ++b) {
+      double2 t = ld2<true>(xs.p[b], row, n);
+      sum.x += t.x;
+      sum.y += t.y;
+    }
+    if (xs.count > 0) {
+      yv.x = __dadd_rn(yv.x, __dmul_rn(a, sum.x));
+      yv.y = __dadd_rn(yv.y, __dmul_rn(a, sum.y));
+    }
+    if (shift) {
+      yv.x = __dsub_rn(yv.x, __dmul_rn(s, xv.x));
+      yv.y = __dsub_rn(yv.y, __dmul_rn(s, xv.y));
+    }
+    if (xs.count > 0 || shift) st2<true>(y, row, n, yv);
+    acc = fma(xv.x, yv.x, acc);
+    acc = fma(xv.y, yv.y, acc);
+  }
+  double t = block_sum(acc, sm4);
+  if (threadIdx.x == 0) P[blockIdx.x] = t;
+}
+
+// pair = [||r||^2, r.Ar] (global).  beta = sqrt(pair[0]) ; q = r/beta (+ bf16 shadow) ; u = y/beta ;
+// alpha = pair[1]/pair[0]  (= q.Aq by linearity of the mat-vec; Lanczos.py:69-75)
+__global__ __launch_bounds__(256) void k_plz_finish(const double* __restrict__ r, const double* __restrict__ y,
+                                                    const double* __restrict__ pair, double* __restrict__ q,
+                                                    uint16_t* __restrict__ qs, double* __restrict__ u,
+                                                    double* __restrict__ alpha_out,
+                                                    double* __restrict__ beta_out, int64_t n) {
+  const double nrm2 = pair[0];
+  const double beta = sqrt(nrm2);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    alpha_out[0] = pair[1] / nrm2;
+    if (beta_out) beta_out[0] = beta;
+  }
+  const int64_t stride = (int64_t)gridDim.x * 512;
+  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; row < n; row += stride) {
+    double2 rv = ld2<true>(r, row, n), yv = ld2<true>(y, row, n);
+    rv.x = rv.x / beta;
+    rv.y = rv.y / beta;
+    yv.x = yv.x / beta;
+    yv.y = yv.y / beta;
+    st2<true>(q, row, n, rv);
+    if (qs) st_bf16x2(qs, row, n, rv);
+    st2<true>(u, row, n, yv);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // CG kernels (CG.py:24-41)
 // ------------------------------------------------------------------------------------------
 // r = b - Ax0 ; d = r ; partial r.r
@@ -1165,6 +1236,23 @@ void launch_cg_direction_fused(const double* r, double* d, double* state, int pa
                                int rCount, double eps, int64_t n, hipStream_t st) {
   hipLaunchKernelGGL(k_cg_direction_fused, dim3(ew_blocks(n)), dim3(256), 0, st, r, d, state, parity, rP, rCount,
                      eps, n);
+}
+
+void launch_axpy_multi_dot(double a_host, const double* a_dev, const double* const* xs, int count,
+                           const double* shift, const double* skip, const double* x, double* y, int64_t n,
+                           double* P, double* dot_out, hipStream_t st) {
+  MultiSrc ms;
+  ms.count = count;
+  for (int b = 0; b < 6; ++b) ms.p[b] = b < count ? xs[b] : nullptr;
+  const int nb = ew_blocks(n);
+  hipLaunchKernelGGL(k_axpy_multi_dot, dim3(nb), dim3(256), 0, st, a_host, a_dev, ms, shift, skip, x, y, n, P);
+  hipLaunchKernelGGL(k_cg_finalize_slot, dim3(1), dim3(256), 0, st, (const double*)P, nb, dot_out, skip);
+}
+
+void launch_plz_finish(const double* r, const double* y, const double* pair, double* q, uint16_t* qs, double* u,
+                       double* alpha_out, double* beta_out, int64_t n, hipStream_t st) {
+  hipLaunchKernelGGL(k_plz_finish, dim3(ew_blocks(n)), dim3(256), 0, st, r, y, pair, q, qs, u, alpha_out,
+                     beta_out, n);
 }
 
 void launch_finalize_slot(const double* P, int count, double* out, const double* skip, hipStream_t st) {

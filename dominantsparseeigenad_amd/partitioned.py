@@ -92,6 +92,36 @@ class HipBackend:
         self._ck(self.lib.dsea_ritz_combine(self.ws.handle, self._p(Q), ldq, n, k, self._p(s), self._p(out),
                                             self._st()), "dsea_ritz_combine")
 
+    # -- macro phases of the partitioned Lanczos step (include/dsea.h "row-partitioned macro phases")
+    def set_shadow(self, k, ldq):
+        self._shadow = torch.empty((k, ldq), dtype=torch.bfloat16, device=self.device)
+        self._ck(self.lib.dsea_ws_set_shadow(self.ws.handle, self._p(self._shadow), ldq, int(k),
+                                             float(self.engine.SHADOW_TAU)), "dsea_ws_set_shadow")
+
+    def clear_shadow(self):
+        self._ck(self.lib.dsea_ws_set_shadow(self.ws.handle, None, 0, 0, 0.0), "dsea_ws_set_shadow")
+        self._shadow = None
+
+    def plz_dots(self, Q, ldq, n, i, u, alpha, beta, r, c):
+        self._ck(self.lib.dsea_plz_dots(self.ws.handle, self._p(Q), ldq, n, i, self._p(u), self._p(alpha),
+                                        self._p(beta), self._p(r), self._p(c), self._st()), "dsea_plz_dots")
+
+    def plz_correct_matvec(self, Q, ldq, row, c, r, y, pair):
+        self._ck(self.lib.dsea_plz_correct_matvec(self.op.handle, self.ws.handle, self._p(Q), ldq, int(row),
+                                                  self._p(c), self._p(r), self._p(y), self._p(pair), self._st()),
+                 "dsea_plz_correct_matvec")
+
+    def axpy_multi_dot(self, a_host, a_dev, xs, shift, skip, x, y, out):
+        arr = (c_void_p * max(len(xs), 1))(*[t.data_ptr() for t in xs])
+        self._ck(self.lib.dsea_axpy_multi_dot(self.ws.handle, float(a_host), self._p(a_dev), arr, len(xs),
+                                              self._p(shift), self._p(skip), self._p(x), self._p(y), x.numel(),
+                                              self._p(out), self._st()), "dsea_axpy_multi_dot")
+
+    def plz_finish(self, r, y, pair, q_out, row, u_out, alpha_out, beta_out):
+        self._ck(self.lib.dsea_plz_finish(self.ws.handle, self._p(r), self._p(y), self._p(pair), self._p(q_out),
+                                          int(row), self._p(u_out), self._p(alpha_out), self._p(beta_out),
+                                          r.numel(), self._st()), "dsea_plz_finish")
+
     def shift_dot(self, x, y, shift, out, skip):
         self._ck(self.lib.dsea_shift_dot(self.ws.handle, self._p(x), self._p(y), self._p(shift), self._p(out),
                                          self._p(skip), x.numel(), self._st()), "dsea_shift_dot")
@@ -167,6 +197,7 @@ class PartitionedTFIM:
         self.be = backend if backend is not None else HipBackend(self.L, self.Lloc, self.row_offset, g, self.device)
         self.eps = float(eps)
         self.poll_every = int(poll_every)
+        self.use_shadow = True
         self.last_cg_iters = 0
         self.last_cg_resnorm = float("nan")
         self._recv = [self.be.empty(self.nloc) for _ in range(self.p)]
@@ -193,32 +224,45 @@ class PartitionedTFIM:
             else:
                 self.be.axpy(-1.0, None, buf, y)                 # dH/dg: y -= x_partner (TFIM.py:64)
 
+    def matvec_shift_dot(self, x, y, shift, out, skip):
+        """y = (H - shift) x with the remote part, the shift and the local x.y in ONE kernel after the exchange"""
+        self.be.tfim_local(x, y, "H")
+        recv = self._exchange(x)
+        self.be.axpy_multi_dot(-1.0, self.g.detach(), recv, shift, skip, x, y, out)
+
     def global_dot(self, x, y, out):
         self.be.dot(x, y, out)
         self._allreduce(out)
 
     # ---------------------------------------------------------------- forward: Lanczos (Lanczos.py:49-105)
     def forward(self, k, q0_slab):
+        """Per step: [dots] -> all-reduce(c, ||r||^2) -> [correction + local mat-vec] -> slab exchange ->
+        [remote part + r.Ar] -> all-reduce(||r||^2, r.Ar) -> [normalise, store].  The mat-vec acts on the
+        un-normalised r (linearity), which is what lets the two scalar reductions travel together."""
         be, n = self.be, self.nloc
         if hasattr(be, "reserve"):
             be.reserve(k)
         ldq = (n + 31) // 32 * 32
         Q = be.empty(k, ldq)
         alphas, betas = be.zeros(k), be.zeros(max(k - 1, 1))
-        c, nrm2 = be.zeros(max(k, 1)), be.zeros(1)
-        r, u = be.empty(n), be.empty(n)
-        self.global_dot(q0_slab, q0_slab, nrm2)
-        be.scale_store(q0_slab, nrm2, Q[0], None)
-        self.matvec(Q[0, :n], u)
-        self.global_dot(Q[0, :n], u, alphas[0:1])
-        for i in range(1, k):
-            be.rdots(Q, ldq, n, i, u, alphas[i - 1:i], betas[i - 2:i - 1] if i >= 2 else None, r, c)
-            self._allreduce(c[:i])
-            be.axpy_norm(Q, ldq, n, i, c, r, nrm2)
-            self._allreduce(nrm2)
-            be.scale_store(r, nrm2, Q[i], betas[i - 1:i])
-            self.matvec(Q[i, :n], u)
-            self.global_dot(Q[i, :n], u, alphas[i:i + 1])
+        c, pair = be.zeros(k + 2), be.zeros(2)
+        r, u, y = q0_slab.clone(), be.empty(n), be.empty(n)
+        use_shadow = self.use_shadow and k > 1 and hasattr(be, "set_shadow")
+        if use_shadow:
+            be.set_shadow(k, ldq)
+        try:
+            for i in range(k):
+                if i >= 1:
+                    be.plz_dots(Q, ldq, n, i, u, alphas[i - 1:i], betas[i - 2:i - 1] if i >= 2 else None, r, c)
+                    self._allreduce(c[:i + 1])
+                be.plz_correct_matvec(Q, ldq, i, c, r, y, pair)
+                recv = self._exchange(r)
+                be.axpy_multi_dot(-1.0, self.g.detach(), recv, None, None, r, y, pair[1:2])
+                self._allreduce(pair)
+                be.plz_finish(r, y, pair, Q[i], i, u, alphas[i:i + 1], betas[i - 1:i] if i >= 1 else None)
+        finally:
+            if use_shadow:
+                be.clear_shadow()
         # Ritz pair: T is replicated (identical scalars on all ranks), solved on the host (Lanczos.py:98)
         from scipy.linalg import eigh_tridiagonal
         d, e = alphas.cpu().numpy(), betas[:k - 1].cpu().numpy()
@@ -244,8 +288,7 @@ class PartitionedTFIM:
         r, d, Ad = be.empty(n), be.empty(n), be.empty(n)
         x = x0
         shift = E0.reshape(1)
-        self.matvec(x, Ad)
-        be.shift_dot(x, Ad, shift, state[CG_DAD:CG_DAD + 1], None)
+        self.matvec_shift_dot(x, Ad, shift, state[CG_DAD:CG_DAD + 1], None)
         be.cg_init(b, Ad, r, d, state)
         self._allreduce(state[CG_RR:CG_RR + 1])
         be.cg_init_check(state, self.eps)
@@ -254,8 +297,7 @@ class PartitionedTFIM:
         host = state.cpu()
         while host[CG_DONE].item() == 0.0 and issued < cap:
             for _ in range(min(self.poll_every, cap - issued)):
-                self.matvec(d, Ad)
-                be.shift_dot(d, Ad, shift, state[CG_DAD:CG_DAD + 1], done)
+                self.matvec_shift_dot(d, Ad, shift, state[CG_DAD:CG_DAD + 1], done)
                 self._allreduce(state[CG_DAD:CG_DAD + 1])
                 be.cg_update(x, r, d, Ad, state)
                 self._allreduce(state[CG_RRNEW:CG_RRNEW + 1])

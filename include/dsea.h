@@ -189,6 +189,32 @@ int dsea_cg_check(dsea_ws_t ws, double *state, double eps, void *stream);
 int dsea_cg_direction(dsea_ws_t ws, const double *r, double *d, const double *state, int64_t n,
                       void *stream);
 
+/* ------------------------------------------------------------------ row-partitioned macro phases
+ * One Lanczos step of the row-partitioned mode (no reference counterpart) is
+ *     dsea_plz_dots            -> caller all-reduces c[0..i]   (i coefficients + ||r||^2)
+ *     dsea_plz_correct_matvec  -> caller exchanges r with the partner slabs
+ *     dsea_axpy_multi_dot      -> caller all-reduces pair[0..1] = (||r||^2, r.Ar)
+ *     dsea_plz_finish
+ * i.e. two latency-bound all-reduces and one slab exchange per step.  The mat-vec is applied to the
+ * un-normalised r (linearity): beta = sqrt(pair[0]), alpha = pair[1]/pair[0], q = r/beta, u = (A r)/beta.   */
+
+/* r = u - (*alpha) Q[i-1] - (*beta) Q[i-2] ; c_out[j] = Q[j].r (j < i) ; c_out[i] = r.r   (local sums)   */
+int dsea_plz_dots(dsea_ws_t ws, const double *Q, int64_t ldq, int64_t n, int i, const double *u,
+                  const double *alpha, const double *beta, double *r, double *c_out, void *stream);
+/* row >= 1: r -= sum_{j<row} c[j] Q[j] (bf16 shadow if registered and the premise holds) ; pair_out[0] = ||r||^2
+ * (local).  row == 0: only pair_out[0] = r.r.  Then y = A_local r (slab-local part of the mat-vec).       */
+int dsea_plz_correct_matvec(dsea_op_t op, dsea_ws_t ws, const double *Q, int64_t ldq, int row,
+                            const double *c, double *r, double *y, double *pair_out, void *stream);
+/* y += a_host*(*a_dev) * (xs[0] + ... + xs[count-1]) - (*shift) x ; *dot_out = x.y (local).  count <= 6,
+ * a_dev / shift / skip_flag nullable.  (remote part of the TFIM mat-vec: a = -g, xs = partner slabs)       */
+int dsea_axpy_multi_dot(dsea_ws_t ws, double a_host, const double *a_dev, const double *const *xs, int count,
+                        const double *shift, const double *skip_flag, const double *x, double *y, int64_t n,
+                        double *dot_out, void *stream);
+/* pair = global (||r||^2, r.Ar): q_out = r/beta (row `row` of the basis; also its bf16 shadow row if registered),
+ * u_out = y/beta, *alpha_out = pair[1]/pair[0], *beta_out = beta (nullable)                               */
+int dsea_plz_finish(dsea_ws_t ws, const double *r, const double *y, const double *pair, double *q_out, int row,
+                    double *u_out, double *alpha_out, double *beta_out, int64_t n, void *stream);
+
 /* ------------------------------------------------------------------ whole solvers (native operator, one GPU)
  * k-step Lanczos with full re-orthogonalisation, entirely on the stream, no host sync.
  *   q0      : start vector (need not be normalised; Lanczos.py:52-53)

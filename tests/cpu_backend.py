@@ -60,6 +60,36 @@ class CpuBackend:
     def ritz(self, Q, ldq, n, k, s, out):
         out.copy_(Q[:k, :n].T @ s)
 
+    # macro phases (same semantics as include/dsea.h "row-partitioned macro phases"; no shadow here)
+    def plz_dots(self, Q, ldq, n, i, u, alpha, beta, r, c):
+        self.rdots(Q, ldq, n, i, u, alpha, beta, r, c)
+        c[i] = torch.dot(r, r)
+
+    def plz_correct_matvec(self, Q, ldq, row, c, r, y, pair):
+        n = r.numel()
+        if row >= 1:
+            r.sub_(Q[:row, :n].T @ c[:row])
+        pair[0] = torch.dot(r, r)
+        self.tfim_local(r, y, "H")
+
+    def axpy_multi_dot(self, a_host, a_dev, xs, shift, skip, x, y, out):
+        if skip is not None and skip[0] != 0:
+            return
+        a = a_host * (a_dev.reshape(-1)[0] if a_dev is not None else 1.0)
+        for t in xs:
+            y.add_(a * t)
+        if shift is not None:
+            y.sub_(shift[0] * x)
+        out[0] = torch.dot(x, y)
+
+    def plz_finish(self, r, y, pair, q_out, row, u_out, alpha_out, beta_out):
+        beta = pair[0].sqrt()
+        q_out[: r.numel()] = r / beta
+        u_out.copy_(y / beta)
+        alpha_out[0] = pair[1] / pair[0]
+        if beta_out is not None:
+            beta_out[0] = beta
+
     def shift_dot(self, x, y, shift, out, skip):
         if skip is not None and skip[0] != 0:
             return
