@@ -37,6 +37,12 @@ def algorithmic_bytes(n, k, m):
     return 8.0 * n * (k * k + 12 * k + 11 * m + 17)
 
 
+def analytic_E0_per_site(L, g):
+    """closed form of reference examples/TFIM/E0.py:15-18 (sanity value printed next to the measured one)"""
+    ks = np.linspace(-(L - 1) / 2, (L - 1) / 2, num=L) / L * 2 * np.pi
+    return float(-0.5 * (2 * np.sqrt(g * g - 2 * g * np.cos(ks) + 1)).sum() / L)
+
+
 def reorth_bytes_per_launch(n, k):
     """average algorithmic bytes of one launch of each reorth kernel over steps i = 1..k-1:
     dots kernel: 3-term (read u,q,q' + write r = 4) + (i+1)-1 basis reads -> (i + 4) vectors... we use the
@@ -236,7 +242,8 @@ def main():
                                    "loss=E0+psi.t" % (L, L, nloc, k),
                        "cg_iterations": int(m), "algorithmic_bytes_per_step": total_bytes,
                        "frac_of_hbm_peak_whole_step": round(value / (HBM_PEAK_GBS * world), 4),
-                       "E0_per_site": E0.item() / L, "dloss_dg": float(gl.reshape(-1)[0].item())},
+                       "E0_per_site": E0.item() / L, "E0_per_site_closed_form": analytic_E0_per_site(L, 1.0),
+                       "dloss_dg": float(gl.reshape(-1)[0].item())},
         }
         if use_events and launches[0] > 0:
             dots_b, axpy_b = reorth_bytes_per_launch(nloc, k)

@@ -10,6 +10,7 @@
 #define DSEA_MAX_EW_BLOCKS 2048   /* grid cap of the grid-stride streaming kernels            */
 #define DSEA_MAX_WAVE_TILES 8192  /* cap on wave tiles (= partial sums per basis vector)      */
 #define DSEA_TFIM_TILE_LOG2 11    /* rows of x staged in LDS per block of the TFIM mat-vec    */
+#define DSEA_MAX_TFIM_BLOCKS 4096 /* grid cap of the TFIM mat-vec (<= DSEA_MAX_WAVE_TILES partial slots)   */
 #define DSEA_SCALARS 64
 
 namespace dsea {

@@ -786,90 +786,96 @@ __global__ __launch_bounds__(256) void k_spmv_tfim(TfimParams p, const double* _
   }
   const double g = p.g_dev ? p.g_dev[0] : p.g_const;
   const double s = shift ? shift[0] : 0.0;
-  const int64_t base = (int64_t)blockIdx.x * TILE;
-#pragma unroll
-  for (int t = 0; t < PER; ++t) {
-    const int lp = t * 256 + threadIdx.x;
-    if (lp < NPAIR) {
-      double2 v = *reinterpret_cast<const double2*>(x + base + 2 * lp);
-      if (FUSED) {
-        v.x = v.x / beta;
-        v.y = v.y / beta;
-        *reinterpret_cast<double2*>(fa.q_out + base + 2 * lp) = v;
-        if (fa.qs_out)
-          *reinterpret_cast<uint32_t*>(fa.qs_out + base + 2 * lp) =
-              (uint32_t)f64_to_bf16(v.x) | ((uint32_t)f64_to_bf16(v.y) << 16);
-      }
-      tile2[lp] = v;
-    }
-  }
-  __syncthreads();
   const uint64_t maskL = (p.L >= 64) ? ~0ull : ((1ull << p.L) - 1ull);
-  // out-of-tile neighbours: all pairs of this thread, four bits per trip, loads first
-  double2 far[PER];
-#pragma unroll
-  for (int t = 0; t < PER; ++t) far[t] = make_double2(0.0, 0.0);
-  int j = T;
-  for (; j + 4 <= p.L_local; j += 4) {
-    double2 nb[PER][4];
-#pragma unroll
-    for (int t = 0; t < PER; ++t) {
-      const int lp = t * 256 + threadIdx.x;
-      const int64_t i0 = base + 2 * (int64_t)(lp < NPAIR ? lp : 0);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        nb[t][e] = *reinterpret_cast<const double2*>(x + (i0 ^ ((int64_t)1 << (j + e))));
-    }
-#pragma unroll
-    for (int t = 0; t < PER; ++t) {
-      far[t].x += (nb[t][0].x + nb[t][1].x) + (nb[t][2].x + nb[t][3].x);
-      far[t].y += (nb[t][0].y + nb[t][1].y) + (nb[t][2].y + nb[t][3].y);
-    }
-  }
-  for (; j < p.L_local; ++j) {
-#pragma unroll
-    for (int t = 0; t < PER; ++t) {
-      const int lp = t * 256 + threadIdx.x;
-      const int64_t i0 = base + 2 * (int64_t)(lp < NPAIR ? lp : 0);
-      const double2 nbv = *reinterpret_cast<const double2*>(x + (i0 ^ ((int64_t)1 << j)));
-      far[t].x += nbv.x;
-      far[t].y += nbv.y;
-    }
-  }
+  const int64_t ntiles = ((int64_t)1 << p.L_local) >> T;
   double acc = 0.0;
+  // a block walks tiles blockIdx.x, +gridDim.x, ... (the grid is capped so that the per-block partials fit)
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t base = tile * TILE;
+    __syncthreads();  // previous tile's LDS reads are done
 #pragma unroll
-  for (int t = 0; t < PER; ++t) {
-    const int lp = t * 256 + threadIdx.x;
-    if (lp < NPAIR) {
-      const int64_t i0 = base + 2 * (int64_t)lp;
-      const double2 xv = tile2[lp];
-      double2 sum = make_double2(xv.y, xv.x);  // bit 0: the other element of the pair
+    for (int t = 0; t < PER; ++t) {
+      const int lp = t * 256 + threadIdx.x;
+      if (lp < NPAIR) {
+        double2 v = *reinterpret_cast<const double2*>(x + base + 2 * lp);
+        if (FUSED) {
+          v.x = v.x / beta;
+          v.y = v.y / beta;
+          *reinterpret_cast<double2*>(fa.q_out + base + 2 * lp) = v;
+          if (fa.qs_out)
+            *reinterpret_cast<uint32_t*>(fa.qs_out + base + 2 * lp) =
+                (uint32_t)f64_to_bf16(v.x) | ((uint32_t)f64_to_bf16(v.y) << 16);
+        }
+        tile2[lp] = v;
+      }
+    }
+    __syncthreads();
+    // out-of-tile neighbours: all pairs of this thread, four bits per trip, loads first
+    double2 far[PER];
 #pragma unroll
-      for (int jb = 1; jb < T; ++jb) {
-        const double2 nbv = tile2[lp ^ (1 << (jb - 1))];
-        sum.x += nbv.x;
-        sum.y += nbv.y;
+    for (int t = 0; t < PER; ++t) far[t] = make_double2(0.0, 0.0);
+    int j = T;
+    for (; j + 4 <= p.L_local; j += 4) {
+      double2 nb[PER][4];
+#pragma unroll
+      for (int t = 0; t < PER; ++t) {
+        const int lp = t * 256 + threadIdx.x;
+        const int64_t i0 = base + 2 * (int64_t)(lp < NPAIR ? lp : 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          nb[t][e] = *reinterpret_cast<const double2*>(x + (i0 ^ ((int64_t)1 << (j + e))));
       }
-      if (FUSED) {
-        sum.x += far[t].x / beta;
-        sum.y += far[t].y / beta;
-      } else {
-        sum.x += far[t].x;
-        sum.y += far[t].y;
+#pragma unroll
+      for (int t = 0; t < PER; ++t) {
+        far[t].x += (nb[t][0].x + nb[t][1].x) + (nb[t][2].x + nb[t][3].x);
+        far[t].y += (nb[t][0].y + nb[t][1].y) + (nb[t][2].y + nb[t][3].y);
       }
-      double2 v;
-      v.x = __dsub_rn(__dmul_rn(xv.x, tfim_diag(p, i0, maskL)), __dmul_rn(g, sum.x));
-      v.y = __dsub_rn(__dmul_rn(xv.y, tfim_diag(p, i0 + 1, maskL)), __dmul_rn(g, sum.y));
-      if (!FUSED && shift) {
-        v.x = __dsub_rn(v.x, __dmul_rn(s, xv.x));
-        v.y = __dsub_rn(v.y, __dmul_rn(s, xv.y));
+    }
+    for (; j < p.L_local; ++j) {
+#pragma unroll
+      for (int t = 0; t < PER; ++t) {
+        const int lp = t * 256 + threadIdx.x;
+        const int64_t i0 = base + 2 * (int64_t)(lp < NPAIR ? lp : 0);
+        const double2 nbv = *reinterpret_cast<const double2*>(x + (i0 ^ ((int64_t)1 << j)));
+        far[t].x += nbv.x;
+        far[t].y += nbv.y;
       }
-      *reinterpret_cast<double2*>(y + i0) = v;
-      acc = fma(xv.x, v.x, acc);
-      acc = fma(xv.y, v.y, acc);
+    }
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+      const int lp = t * 256 + threadIdx.x;
+      if (lp < NPAIR) {
+        const int64_t i0 = base + 2 * (int64_t)lp;
+        const double2 xv = tile2[lp];
+        double2 sum = make_double2(xv.y, xv.x);  // bit 0: the other element of the pair
+#pragma unroll
+        for (int jb = 1; jb < T; ++jb) {
+          const double2 nbv = tile2[lp ^ (1 << (jb - 1))];
+          sum.x += nbv.x;
+          sum.y += nbv.y;
+        }
+        if (FUSED) {
+          sum.x += far[t].x / beta;
+          sum.y += far[t].y / beta;
+        } else {
+          sum.x += far[t].x;
+          sum.y += far[t].y;
+        }
+        double2 v;
+        v.x = __dsub_rn(__dmul_rn(xv.x, tfim_diag(p, i0, maskL)), __dmul_rn(g, sum.x));
+        v.y = __dsub_rn(__dmul_rn(xv.y, tfim_diag(p, i0 + 1, maskL)), __dmul_rn(g, sum.y));
+        if (!FUSED && shift) {
+          v.x = __dsub_rn(v.x, __dmul_rn(s, xv.x));
+          v.y = __dsub_rn(v.y, __dmul_rn(s, xv.y));
+        }
+        *reinterpret_cast<double2*>(y + i0) = v;
+        acc = fma(xv.x, v.x, acc);
+        acc = fma(xv.y, v.y, acc);
+      }
     }
   }
   if (P) {
+    __syncthreads();
     double tot = block_sum(acc, sm5);
     if (threadIdx.x == 0) P[blockIdx.x] = tot;
   }
@@ -1164,7 +1170,8 @@ int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shif
         return 1;
       }
       const int T = p.L_local < g_tfim_tile_log2 ? p.L_local : g_tfim_tile_log2;
-      const int64_t nb = ((int64_t)1 << p.L_local) >> T;
+      int64_t nb = ((int64_t)1 << p.L_local) >> T;
+      if (nb > DSEA_MAX_TFIM_BLOCKS) nb = DSEA_MAX_TFIM_BLOCKS;  // blocks then walk several tiles
       TfimFusedArgs fa = {nullptr, 0, nullptr, nullptr, nullptr};
 #define TFIM_CASE(TT) \
   case TT: KLAUNCH(ev, (k_spmv_tfim<TT, false>), (unsigned)nb, 256, st, p, x, y, shift, skip, P, fa); break;
@@ -1211,7 +1218,8 @@ int launch_tfim_fused(const OpDesc& op, const double* r, const double* nP, int n
   const TfimParams& p = op.tfim;
   if (p.L_local == 0) return -1;  // callers use the unfused sequence for a 1-row slab
   const int T = p.L_local < g_tfim_tile_log2 ? p.L_local : g_tfim_tile_log2;
-  const int64_t nb = ((int64_t)1 << p.L_local) >> T;
+  int64_t nb = ((int64_t)1 << p.L_local) >> T;
+  if (nb > DSEA_MAX_TFIM_BLOCKS) nb = DSEA_MAX_TFIM_BLOCKS;
   TfimFusedArgs fa = {nP, nCount, q_out, qs_out, beta_store};
   const double* nullc = nullptr;
 #define TFIM_FCASE(TT) \
