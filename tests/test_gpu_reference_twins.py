@@ -1,0 +1,131 @@
+"""GPU twins of the reference's own CUDA-gated unit tests (reference tests/test_Lanczos.py:33-98,
+tests/test_CG.py:49-98) and of tests/test_symeig.py on the device, same sizes and assertions, plus the edge
+cases the reference's design implies (k = 1, k = n, n = 1) and BASELINE config 3 in its well-posed restatement."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle  # noqa: E402
+from helpers import SeedDraws  # noqa: E402
+from dominantsparseeigenad_amd import engine  # noqa: E402
+from dominantsparseeigenad_amd.synthetic import normal_vector  # noqa: E402
+from dominantsparseeigenad_amd.operators import TFIMOperator, Stencil3Operator  # noqa: E402
+from DominantSparseEigenAD.Lanczos import symeigLanczos, Lanczos  # noqa: E402
+from DominantSparseEigenAD.CG import CG_torch  # noqa: E402
+from DominantSparseEigenAD.symeig import DominantSymeig  # noqa: E402
+
+F64 = torch.float64
+cuda = torch.device("cuda:0")
+
+
+def _pm(a, b):
+    return torch.allclose(a, b) or torch.allclose(a, -b)
+
+
+def test_normal_gpu_and_sparse_gpu():           # test_Lanczos.py:35-62, :82-98
+    torch.manual_seed(11)
+    n, k = 1000, 300
+    A = 0.1 * torch.rand(n, n, dtype=F64, device=cuda)
+    A = A + A.T
+    w, V = torch.linalg.eigh(A)
+    for args, kw in (((A, k), dict(device=cuda)), ((lambda v: A @ v, k), dict(device=cuda, sparse=True, dim=n))):
+        lo, vlo, hi, vhi = symeigLanczos(*args, **kw)
+        assert torch.allclose(lo, w[0]) and torch.allclose(hi, w[-1])
+        assert _pm(vlo, V[:, 0]) and _pm(vhi, V[:, -1])
+
+
+def test_fullrank_gpu_and_lowrank_gpu():        # test_CG.py:51-98
+    from scipy.stats import ortho_group
+    rng = np.random.RandomState(3)
+    n = 100
+    U = ortho_group.rvs(n, random_state=rng)
+    A = torch.from_numpy(U.dot(np.diag(1.0 + 10.0 * rng.rand(n))).dot(U.T)).to(cuda)
+    torch.manual_seed(12)
+    b, x0 = torch.randn(n, device=cuda, dtype=F64), torch.randn(n, device=cuda, dtype=F64)
+    x = CG_torch(A, b, x0)
+    assert torch.allclose(x, torch.inverse(A).matmul(b))
+    n = 300
+    S = torch.randn(n, n, device=cuda, dtype=F64)
+    S = S + S.T
+    w, V = torch.linalg.eigh(S)
+    v0 = V[:, 0]
+    Ap = S - w[0] * torch.eye(n, device=cuda, dtype=F64)
+    b = torch.randn(n, device=cuda, dtype=F64)
+    b = b - torch.matmul(v0, b) * v0
+    x0 = torch.randn(n, device=cuda, dtype=F64)
+    x0 = x0 - torch.matmul(v0, x0) * v0
+    res = CG_torch(Ap, b, x0)
+    assert torch.allclose(Ap @ res - b, torch.zeros(n, device=cuda, dtype=F64), atol=1e-6)
+    assert abs(float(res @ v0)) < 1e-6
+
+
+def test_dominant_symeig_gpu_matches_full_eigensolver_ad():   # test_symeig.py:5-46 on the device
+    torch.manual_seed(13)
+    N = 300
+    K = torch.randn(N, N, dtype=F64, device=cuda)
+    K = K + K.T
+    target = torch.randn(N, dtype=F64, device=cuda)
+    potential = torch.randn(N, dtype=F64, device=cuda, requires_grad=True)
+    H = K + torch.diag(potential)
+    w, V = torch.linalg.eigh(H)
+    loss_t = 1.0 - V[:, 0] @ target
+    (g_t,) = torch.autograd.grad(loss_t, potential)
+    _, psi = DominantSymeig.apply(H, 300, cuda)
+    loss_d = 1.0 - psi @ target
+    (g_d,) = torch.autograd.grad(loss_d, potential)
+    assert torch.allclose(loss_d, loss_t) or torch.allclose(loss_d, 2.0 - loss_t)
+    assert torch.allclose(g_d, g_t) or torch.allclose(g_d, -g_t)
+
+
+def test_edge_cases_k1_kn_n1():
+    g = torch.tensor([0.7], dtype=F64, device=cuda)
+    # k = 1: T is 1x1, the "eigenvector" is q0/||q0||
+    op = TFIMOperator(6, cuda, g=g)
+    q0 = torch.from_numpy(normal_vector(64, 31)).to(cuda)
+    lam, vec = symeigLanczos(op, 1, cuda, extreme="min", sparse=True, dim=64, q0=q0)
+    qn = q0 / q0.norm()
+    assert torch.allclose(vec, qn) and abs(lam.item() - float(qn @ op.H(qn))) < 1e-12
+    # k = n reproduces the full spectrum ends (5e-15)
+    model = oracle.TFIMTables(6, g=g.cpu())
+    w = torch.linalg.eigvalsh(model.dense())
+    lo, _, hi, _ = symeigLanczos(op, 64, cuda, sparse=True, dim=64, q0=q0)
+    assert abs(lo.item() - w[0].item()) < 1e-12 and abs(hi.item() - w[-1].item()) < 1e-12
+    # n = 2 and n = 1 slabs
+    op1 = TFIMOperator(1, cuda, g=g)
+    y = op1.H(torch.tensor([1.0, 2.0], dtype=F64, device=cuda))
+    assert torch.allclose(y.cpu(), torch.tensor([-1.0 - 0.7 * 2.0, -2.0 - 0.7 * 1.0], dtype=F64))
+    slab = TFIMOperator(3, cuda, g=g, L_local=0, row_offset=5)
+    y = slab.H(torch.tensor([2.0], dtype=F64, device=cuda))
+    d5 = oracle.TFIMTables(3).diag[5].item()
+    assert abs(y.item() - 2.0 * d5) < 1e-15
+    Qk, T = Lanczos(op, 3, cuda, sparse=True, dim=64, q0=q0)
+    assert Qk.shape == (64, 3) and T.shape == (3, 3)
+
+
+def test_config3_schrodinger_1e5_restated():
+    """BASELINE configs[2], N = 100000 grid.  As literally stated the reference is unconverged there and its CG
+    never terminates; the well-posed restatement: Lanczos coefficients vs the CPU oracle with the
+    same q0 (k = 64), and the first 50 CG iterates of the shifted system vs the oracle's."""
+    N, k = 100000, 64
+    h = 2.0 / N
+    xmesh = torch.from_numpy(np.linspace(-1.0, 1.0, num=N, endpoint=False))
+    V = 0.5 * xmesh ** 2
+    ref = oracle.Stencil3(N, h, V)
+    op = Stencil3Operator(N, h, V.to(cuda))
+    q0 = torch.from_numpy(normal_vector(N, 41))
+    Qo, ao, bo = oracle.lanczos_tridiag(ref.H, k, sparse=True, dim=N, draw=SeedDraws(41))
+    Qk, T = Lanczos(op, k, cuda, sparse=True, dim=N, q0=q0.to(cuda))
+    scale = float(ao.abs().max())
+    assert float((torch.diagonal(T).cpu() - ao).abs().max()) <= 1e-10 * scale
+    assert float((torch.diagonal(T, 1).cpu() - bo).abs().max()) <= 1e-10 * scale
+    # CG: 50 iterations of (H - theta) x = b, theta below the spectrum so the system is SPD
+    theta = torch.tensor(-1.0, dtype=F64)
+    b = torch.from_numpy(normal_vector(N, 42))
+    x0 = torch.from_numpy(normal_vector(N, 43))
+    st = {}
+    xo = oracle.cg_solve(lambda v: ref.H(v) - theta * v, b, x0, sparse=True, maxiter=50, stats=st)
+    x = engine.cg(b.to(cuda), x0.to(cuda), native=op, shift=theta.to(cuda), maxiter=50)
+    assert engine.last_cg.iters == st["iters"] == 50
+    assert float((x.cpu() - xo).abs().max()) <= 1e-10 * float(xo.abs().max())
