@@ -32,6 +32,11 @@ def _solve(A, b, initialx, sparse, shift=None, eps=None, maxiter=None):
     eps = EPS_DEFAULT if eps is None else eps   # read at call time: tests / users may tighten it
     cap = n if maxiter is None else int(maxiter)
     if b.is_cuda:
+        if b.dtype == torch.float32 and not sparse:
+            # dense fp32 system: promoted to fp64 for the fp64 kernels, result rounded back (see Lanczos.py)
+            x = _solve(A.to(torch.float64), b.to(torch.float64), initialx.to(torch.float64), False,
+                       None if shift is None else shift.to(torch.float64), eps, maxiter)
+            return x.to(torch.float32)
         if b.dtype != torch.float64:
             raise NotImplementedError("the HIP CG kernels are fp64; got %s" % b.dtype)
         native = engine.native_of(A) if sparse else None

@@ -39,16 +39,23 @@ def _lanczos_core(A, k, device, sparse, dim, q0):
         q0 = torch.randn(n, dtype=dtype, device=device)        # Lanczos.py:52
     torch.randn(n, dtype=dtype, device=device)                 # Lanczos.py:59 (value multiplies beta = 0)
     if device.type == "cuda":
-        if dtype != torch.float64:
-            raise NotImplementedError("the HIP Lanczos kernels are fp64; got %s on %s" % (dtype, device))
+        if dtype not in (torch.float64, torch.float32):
+            raise NotImplementedError("the HIP Lanczos kernels are fp64 (fp32 tensors are promoted); got %s" % dtype)
+        if dtype == torch.float32:
+            # dense fp32 input (reference Lanczos.py:47: the dense path follows A.dtype): the kernels are fp64, so
+            # the loop runs in fp64 on promoted operands and the outputs are rounded back to fp32 by the callers --
+            # at least as accurate as fp32 arithmetic, same dtypes in and out
+            A64 = A.to(torch.float64)
+            amap = lambda v: torch.matmul(A64, v)              # noqa: E731
+            q0 = q0.to(torch.float64)
         native = engine.native_of(A) if sparse else None
         if native is not None:
             Q, ldq, alphas, betas = engine.lanczos(A, k, n, device, q0, native=native)
         else:
             Q, ldq, alphas, betas = engine.lanczos(A, k, n, device, q0, callable_A=amap)
-        return ("cuda", Q, ldq, n, alphas, betas)
+        return ("cuda", Q, ldq, n, alphas, betas, dtype)
     Qk, alphas, betas = lanczos_host(amap, k, n, dtype, q0, device)
-    return ("cpu", Qk, None, n, alphas, betas)
+    return ("cpu", Qk, None, n, alphas, betas, dtype)
 
 
 def Lanczos(A, k, device=torch.device("cpu"), *, sparse=False, dim=None, q0=None):
@@ -56,17 +63,17 @@ def Lanczos(A, k, device=torch.device("cpu"), *, sparse=False, dim=None, q0=None
 
     On the GPU the basis is stored vector-contiguous, so ``Qk`` is the transposed view of a (k, ldq) buffer.
     """
-    where, Q, ldq, n, alphas, betas = _lanczos_core(A, k, device, sparse, dim, q0)
+    where, Q, ldq, n, alphas, betas, dtype = _lanczos_core(A, k, device, sparse, dim, q0)
     Qk = Q[:, :n].T if where == "cuda" else Q
     T = torch.diag(alphas) + torch.diag(betas, diagonal=1) + torch.diag(betas, diagonal=-1)
-    return Qk, T
+    return Qk.to(dtype), T.to(dtype)
 
 
 def symeigLanczos(A, k, device=torch.device("cpu"), extreme="both", *, sparse=False, dim=None, q0=None):
     """Extreme eigenvalue(s)/eigenvector(s); outputs as in Lanczos.py:88-105 (all torch tensors)."""
     if extreme not in ("both", "min", "max"):
         raise ValueError("extreme must be 'both', 'min' or 'max'")
-    where, Q, ldq, n, alphas, betas = _lanczos_core(A, k, device, sparse, dim, q0)
+    where, Q, ldq, n, alphas, betas, dtype = _lanczos_core(A, k, device, sparse, dim, q0)
     pairs = engine.tridiag_extreme(alphas, betas, extreme)
     out = []
     for val, s in pairs:
@@ -74,5 +81,5 @@ def symeigLanczos(A, k, device=torch.device("cpu"), extreme="both", *, sparse=Fa
             vec = engine.ritz_vector(Q, ldq, n, k, s, Q.device)
         else:
             vec = torch.matmul(Q, torch.from_numpy(s).to(Q.dtype))
-        out += [torch.tensor(val, dtype=alphas.dtype, device=alphas.device), vec]
+        out += [torch.tensor(val, dtype=dtype, device=alphas.device), vec.to(dtype)]
     return tuple(out)

@@ -129,3 +129,22 @@ def test_config3_schrodinger_1e5_restated():
     x = engine.cg(b.to(cuda), x0.to(cuda), native=op, shift=theta.to(cuda), maxiter=50)
     assert engine.last_cg.iters == st["iters"] == 50
     assert float((x.cpu() - xo).abs().max()) <= 1e-10 * float(xo.abs().max())
+
+
+def test_dense_float32_follows_input_dtype():
+    """the dense path follows A.dtype (float32 in -> float32 out, reference Lanczos.py:47).  The HIP
+    kernels are fp64: fp32 operands are promoted, outputs rounded back; results sit within fp32 tolerance of
+    the full eigensolver and gradients flow."""
+    torch.manual_seed(14)
+    n, k = 400, 200
+    A = torch.randn(n, n, dtype=torch.float32, device=cuda)
+    A = (A + A.T).requires_grad_(True)
+    lam, psi = DominantSymeig.apply(A, k, cuda)
+    assert lam.dtype == torch.float32 and psi.dtype == torch.float32
+    w, V = torch.linalg.eigh(A.detach().double())
+    assert abs(lam.item() - w[0].item()) < 1e-4 * abs(w[0].item())
+    assert min(float((psi.double() - V[:, 0]).abs().max()), float((psi.double() + V[:, 0]).abs().max())) < 1e-3
+    (gA,) = torch.autograd.grad(lam, A)
+    assert gA.dtype == torch.float32 and torch.isfinite(gA).all()
+    # Hellmann-Feynman: dlam/dA = psi psi^T
+    assert float((gA.double() - torch.outer(V[:, 0], V[:, 0])).abs().max()) < 1e-3
