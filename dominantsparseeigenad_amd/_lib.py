@@ -88,6 +88,10 @@ def load():
             "`python -c 'import __graft_entry__ as g; g.build()'` or "
             "`make -C dominantsparseeigenad_amd/csrc`.  There is no CPU fallback for CUDA tensors." % LIB_PATH
         )
+    # PyTorch-ROCm bundles its own HIP runtime (libamdhip64).  It must be the one already in the process when
+    # libdsea.so is mapped, otherwise the library binds to a second runtime instance (the system one) that
+    # shares no device context / streams with torch (observed: hipErrorNoDevice on the first call).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

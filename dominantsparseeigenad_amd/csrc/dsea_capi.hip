@@ -507,7 +507,13 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
     lds = w.shadow_ld;
   }
   double* lp_count = w.scal + 16;
-  if (hipMemsetAsync(lp_count, 0, 2 * sizeof(double), st) != hipSuccess) return DSEA_ERR_HIP;
+  {
+    hipError_t me = hipMemsetAsync(lp_count, 0, 2 * sizeof(double), st);
+    if (me != hipSuccess) {
+      g_last_hip = (int)me;
+      return DSEA_ERR_HIP;
+    }
+  }
   const int rps = n >= 512 * 2 * 512 ? 2 : 1;
   launch_dot(q0, q0, n, P, nrm2, st);
   launch_scale_store(q0, nrm2, Q, nullptr, n, st, Qs);
