@@ -40,6 +40,7 @@ _SIGNATURES = {
     "dsea_profile_end": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_double)]),
     "dsea_op_create_tfim": (c_int, [c_int, c_int, c_int64, c_void_p, c_double, c_double, POINTER(c_void_p)]),
     "dsea_op_create_csr": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
+    "dsea_op_create_sell": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
     "dsea_op_create_stencil3": (c_int, [c_int64, c_double, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
     "dsea_op_destroy": (c_int, [c_void_p]),
     "dsea_op_dim": (c_int, [c_void_p, POINTER(c_int64)]),

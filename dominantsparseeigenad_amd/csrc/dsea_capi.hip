@@ -102,6 +102,7 @@ int dsea_last_hip_error(void) { return g_last_hip; }
 int dsea_set_tuning(int key, int value) {
   switch (key) {
     case DSEA_TUNE_TFIM_TILE_LOG2: set_tfim_tile_log2(value); return DSEA_OK;
+    case DSEA_TUNE_CSR_GROUP: set_csr_group(value); return DSEA_OK;
     default: return DSEA_ERR_ARG;
   }
 }
@@ -255,6 +256,19 @@ int dsea_op_create_csr(int64_t n, int64_t nnz, const int64_t* rowptr, const int3
   op->d.kind = OP_CSR;
   op->d.n = n;
   op->d.csr = CsrParams{n, nnz, rowptr, colidx, vals};
+  *out = op;
+  return DSEA_OK;
+}
+
+int dsea_op_create_sell(int64_t n, int64_t nslices, const int64_t* slice_ptr, const int32_t* colidx,
+                        const double* vals, dsea_op_t* out) {
+  if (!out || n < 1 || nslices != (n + 63) / 64 || !slice_ptr || !colidx || !vals) return DSEA_ERR_ARG;
+  dsea_op_s* op = new (std::nothrow) dsea_op_s;
+  if (!op) return DSEA_ERR_ARG;
+  memset(&op->d, 0, sizeof(op->d));
+  op->d.kind = OP_SELL;
+  op->d.n = n;
+  op->d.sell = SellParams{n, nslices, slice_ptr, colidx, vals};
   *out = op;
   return DSEA_OK;
 }

@@ -28,6 +28,12 @@ struct CsrParams {
   const int32_t* colidx;
   const double* vals;
 };
+struct SellParams {
+  int64_t n, nslices;
+  const int64_t* slice_ptr;
+  const int32_t* colidx;
+  const double* vals;
+};
 struct Stencil3Params {
   int64_t n;
   double coef;
@@ -35,13 +41,14 @@ struct Stencil3Params {
   const double* halo_lo;
   const double* halo_hi;
 };
-enum OpKind { OP_TFIM = 1, OP_CSR = 2, OP_STENCIL3 = 3 };
+enum OpKind { OP_TFIM = 1, OP_CSR = 2, OP_STENCIL3 = 3, OP_SELL = 4 };
 struct OpDesc {
   OpKind kind;
   int64_t n;
   TfimParams tfim;
   CsrParams csr;
   Stencil3Params st3;
+  SellParams sell;
 };
 
 // how the rows of one vector are cut into wave tiles for the basis-streaming kernels
@@ -86,6 +93,7 @@ struct Workspace {
 };
 
 void set_tfim_tile_log2(int t);
+void set_csr_group(int g);
 void launch_finalize1(const double* P, int count, double* out, hipStream_t st);
 void launch_finalize_slot(const double* P, int count, double* out, const double* skip, hipStream_t st);
 void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* u,

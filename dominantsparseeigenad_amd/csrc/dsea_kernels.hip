@@ -987,6 +987,104 @@ __global__ __launch_bounds__(256) void k_spmv_csr(CsrParams p, const double* __r
   }
 }
 
+// CSR, streaming form: a block owns CSR_ROWS consecutive rows; their non-zeros are one contiguous range of
+// vals / colidx, which the block reads fully coalesced (thread t takes elements t, t+256, ...), multiplies
+// with the gathered x and parks in LDS; then one thread per row adds up its segment.  Blocks whose range
+// does not fit the LDS buffer (very long rows) fall back to 32 lanes per row inside the same kernel.
+#define CSR_ROWS 128
+#define CSR_CAP 6144
+__global__ __launch_bounds__(256) void k_spmv_csr_stream(CsrParams p, const double* __restrict__ x,
+                                                         double* __restrict__ y,
+                                                         const double* __restrict__ shift,
+                                                         const double* __restrict__ skip,
+                                                         double* __restrict__ P) {
+  __shared__ double prod[CSR_CAP];
+  __shared__ double sm4[4];
+  if (skip && skip[0] != 0.0) return;
+  const double s = shift ? shift[0] : 0.0;
+  double acc = 0.0;
+  const int64_t nchunks = (p.n + CSR_ROWS - 1) / CSR_ROWS;
+  for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const int64_t r0 = chunk * CSR_ROWS;
+    const int64_t r1 = (r0 + CSR_ROWS < p.n) ? r0 + CSR_ROWS : p.n;
+    const int64_t e0 = p.rowptr[r0], e1 = p.rowptr[r1];
+    __syncthreads();
+    if (e1 - e0 <= CSR_CAP) {
+      for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) prod[e - e0] = p.vals[e] * x[p.colidx[e]];
+      __syncthreads();
+      const int64_t row = r0 + threadIdx.x;
+      if (threadIdx.x < CSR_ROWS && row < r1) {
+        const int lo = (int)(p.rowptr[row] - e0), hi = (int)(p.rowptr[row + 1] - e0);
+        double sum = 0.0;
+        for (int e = lo; e < hi; ++e) sum += prod[e];
+        const double xi = x[row];
+        double v = sum;
+        if (shift) v = __dsub_rn(v, __dmul_rn(s, xi));
+        y[row] = v;
+        acc = fma(xi, v, acc);
+      }
+    } else {
+      const int sub = threadIdx.x & 31;
+      for (int64_t row = r0 + (threadIdx.x >> 5); row < r1; row += 8) {
+        double sum = 0.0;
+        for (int64_t e = p.rowptr[row] + sub; e < p.rowptr[row + 1]; e += 32) sum = fma(p.vals[e], x[p.colidx[e]], sum);
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
+        if (sub == 0) {
+          const double xi = x[row];
+          double v = sum;
+          if (shift) v = __dsub_rn(v, __dmul_rn(s, xi));
+          y[row] = v;
+          acc = fma(xi, v, acc);
+        }
+      }
+    }
+  }
+  if (P) {
+    __syncthreads();
+    double tot = block_sum(acc, sm4);
+    if (threadIdx.x == 0) P[blockIdx.x] = tot;
+  }
+}
+
+// Sliced ELLPACK (SELL-64): rows are grouped in slices of 64 (one wave), each slice stored column-major
+// (element k of lane l at slice_ptr[s] + 64 k + l) and padded to the slice's longest row with (col = own row,
+// val = 0).  Matrix loads are perfectly coalesced, and for the banded / structured operators of this domain the
+// gather x[col] of a wave hits consecutive addresses as well (lane = row).
+__global__ __launch_bounds__(256) void k_spmv_sell(SellParams p, const double* __restrict__ x,
+                                                   double* __restrict__ y, const double* __restrict__ shift,
+                                                   const double* __restrict__ skip, double* __restrict__ P) {
+  __shared__ double sm4[4];
+  if (skip && skip[0] != 0.0) return;
+  const double s = shift ? shift[0] : 0.0;
+  const int lane = threadIdx.x & 63;
+  double acc = 0.0;
+  for (int64_t sl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); sl < p.nslices; sl += (int64_t)gridDim.x * 4) {
+    const int64_t b0 = p.slice_ptr[sl], b1 = p.slice_ptr[sl + 1];
+    const int64_t row = sl * 64 + lane;
+    double s0 = 0.0, s1 = 0.0;
+    int64_t e = b0 + lane;
+    for (; e + 64 < b1; e += 128) {
+      const double v0 = p.vals[e], v1 = p.vals[e + 64];
+      const int c0 = p.colidx[e], c1 = p.colidx[e + 64];
+      s0 = fma(v0, x[c0], s0);
+      s1 = fma(v1, x[c1], s1);
+    }
+    if (e < b1) s0 = fma(p.vals[e], x[p.colidx[e]], s0);
+    if (row < p.n) {
+      const double xi = x[row];
+      double v = s0 + s1;
+      if (shift) v = __dsub_rn(v, __dmul_rn(s, xi));
+      y[row] = v;
+      acc = fma(xi, v, acc);
+    }
+  }
+  if (P) {
+    double tot = block_sum(acc, sm4);
+    if (threadIdx.x == 0) P[blockIdx.x] = tot;
+  }
+}
+
 // 3-point stencil + diagonal (schrodinger1D.py:18-27)
 __global__ __launch_bounds__(256) void k_spmv_stencil3(Stencil3Params p, const double* __restrict__ x,
                                                        double* __restrict__ y,
@@ -1016,6 +1114,10 @@ __global__ __launch_bounds__(256) void k_spmv_stencil3(Stencil3Params p, const d
 // ------------------------------------------------------------------------------------------
 // host-side launch wrappers (called from dsea_capi.hip)
 // ------------------------------------------------------------------------------------------
+static int g_csr_group = 0;  // 0 = automatic
+void set_csr_group(int g) {
+  if (g == 0 || g == 4 || g == 8 || g == 16 || g == 32 || g == 64) g_csr_group = g;
+}
 static int g_tfim_tile_log2 = DSEA_TFIM_TILE_LOG2;
 void set_tfim_tile_log2(int t) {
   if (t >= 6 && t <= 12) g_tfim_tile_log2 = t;
@@ -1186,8 +1288,16 @@ int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shif
     case OP_CSR: {
       const CsrParams& p = op.csr;
       const double avg = p.n > 0 ? (double)p.nnz / (double)p.n : 1.0;
+      if (g_csr_group == 0 && avg >= 4.0 && avg * CSR_ROWS <= CSR_CAP) {
+        // typical sparse operators (a few to ~48 non-zeros per row): coalesced streaming form
+        int64_t nbs = (p.n + CSR_ROWS - 1) / CSR_ROWS;
+        if (nbs > DSEA_MAX_TFIM_BLOCKS) nbs = DSEA_MAX_TFIM_BLOCKS;
+        KLAUNCH(ev, k_spmv_csr_stream, (unsigned)nbs, 256, st, p, x, y, shift, skip, P);
+        return (int)nbs;
+      }
       int G = 4;
       while (G < 64 && G < avg) G *= 2;
+      if (g_csr_group) G = g_csr_group;
       const int64_t rows_per_block = 256 / G;
       int64_t nb = (p.n + rows_per_block - 1) / rows_per_block;
       if (nb > DSEA_MAX_EW_BLOCKS) nb = DSEA_MAX_EW_BLOCKS;
@@ -1199,6 +1309,14 @@ int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shif
         case 32: KLAUNCH(ev, (k_spmv_csr<32>), (unsigned)nb, 256, st, p, x, y, shift, skip, P); break;
         default: KLAUNCH(ev, (k_spmv_csr<64>), (unsigned)nb, 256, st, p, x, y, shift, skip, P); break;
       }
+      return (int)nb;
+    }
+    case OP_SELL: {
+      const SellParams& p = op.sell;
+      int64_t nb = (p.nslices + 3) / 4;
+      if (nb > DSEA_MAX_TFIM_BLOCKS) nb = DSEA_MAX_TFIM_BLOCKS;
+      if (nb < 1) nb = 1;
+      KLAUNCH(ev, k_spmv_sell, (unsigned)nb, 256, st, p, x, y, shift, skip, P);
       return (int)nb;
     }
     case OP_STENCIL3: {

@@ -114,6 +114,30 @@ class TFIMOperator:
             raise RuntimeError("set the parameter g before using the operator")
         return self._H.handle
 
+    def to_csr(self, layout="sell"):
+        """The same operator as an explicit device CSR matrix (L + 1 entries per row, int32 columns): the
+        "generic sparse operand" form of BASELINE config 2.  Built on the device with index arithmetic."""
+        n, L = self.n, self.L_local
+        idx = torch.arange(n, dtype=torch.int64, device=self.device)
+        gi = idx + self.row_offset
+        rot = ((gi << 1) | (gi >> (self.N - 1))) & (self.dim - 1)
+        x = gi ^ rot
+        pop = torch.zeros_like(x)
+        for b in range(self.N):
+            pop += (x >> b) & 1
+        diag = (-(self.N - 2 * pop)).to(F64)
+        cols = torch.empty((n, L + 1), dtype=torch.int64, device=self.device)
+        vals = torch.empty((n, L + 1), dtype=F64, device=self.device)
+        cols[:, 0], vals[:, 0] = idx, diag
+        for j in range(L):
+            cols[:, j + 1] = idx ^ (1 << j)
+            vals[:, j + 1] = -self._g.detach()
+        order = torch.argsort(cols, dim=1)
+        cols = torch.gather(cols, 1, order)
+        vals = torch.gather(vals, 1, order)
+        rowptr = torch.arange(n + 1, dtype=torch.int64, device=self.device) * (L + 1)
+        return CSROperator(rowptr, cols.reshape(-1), vals.reshape(-1), n, layout=layout)
+
     def pHpg(self, v):
         """dH/dg v = -sum_j v[i xor (1<<j)]   (TFIM.py:58-65)"""
         return _SymmetricApply.apply(v, self._dHdg)
@@ -209,13 +233,16 @@ class _Stencil3Apply(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------ CSR
 class CSROperator:
-    """General sparse symmetric matrix in CSR (rowptr int64, colidx int32, vals fp64) on the device.
+    """General sparse symmetric matrix given in CSR (rowptr int64, colidx int32, vals fp64) on the device.
 
-    ``from_scipy`` / ``from_dense`` build it on the host once; the mat-vec is a HIP kernel."""
+    The mat-vec kernel reads a SELL-64 copy (sliced ELLPACK, slices of one wave = 64 rows, column-major inside a
+    slice) built once here on the device with torch index ops: matrix loads become perfectly coalesced and, for
+    banded / structured operators, so does the gather of x.  ``layout="csr"`` keeps the plain CSR kernel.
+    ``from_scipy`` / ``from_dense`` build the CSR arrays on the host once."""
 
     _native_methods = ("__call__",)
 
-    def __init__(self, rowptr, colidx, vals, n):
+    def __init__(self, rowptr, colidx, vals, n, layout="sell"):
         self.n = int(n)
         self.rowptr = rowptr.to(torch.int64).contiguous()
         self.colidx = colidx.to(torch.int32).contiguous()
@@ -224,23 +251,51 @@ class CSROperator:
         if self.device.type != "cuda":
             raise ValueError("CSROperator is a device operator")
         raw = c_void_p()
-        check(_lib.load().dsea_op_create_csr(self.n, int(self.vals.numel()), c_void_p(self.rowptr.data_ptr()),
-                                             c_void_p(self.colidx.data_ptr()), c_void_p(self.vals.data_ptr()),
-                                             byref(raw)), "dsea_op_create_csr")
-        self._H = _NativeView(_Handle(raw, self.n, (self.rowptr, self.colidx, self.vals)))
+        lib = _lib.load()
+        if layout == "sell":
+            n, dev = self.n, self.device
+            nsl = (n + 63) // 64
+            lens = self.rowptr[1:] - self.rowptr[:-1]
+            padded = torch.zeros(nsl * 64, dtype=torch.int64, device=dev)
+            padded[:n] = lens
+            width = padded.view(nsl, 64).max(dim=1).values
+            slice_ptr = torch.zeros(nsl + 1, dtype=torch.int64, device=dev)
+            slice_ptr[1:] = torch.cumsum(width * 64, 0)
+            total = int(slice_ptr[-1].item())
+            rows = torch.repeat_interleave(torch.arange(n, dtype=torch.int64, device=dev), lens)
+            k_in_row = torch.arange(rows.numel(), dtype=torch.int64, device=dev) - self.rowptr[rows]
+            dest = slice_ptr[rows // 64] + k_in_row * 64 + (rows % 64)
+            # padding entries: value 0, column = the lane's own row (clamped) so the gather stays in range
+            lane_row = torch.arange(max(total, 1), dtype=torch.int64, device=dev)
+            sl_of = torch.repeat_interleave(torch.arange(nsl, dtype=torch.int64, device=dev), width * 64)
+            pad_cols = torch.clamp(sl_of * 64 + (lane_row[:total] - slice_ptr[sl_of]) % 64, max=n - 1)
+            s_cols = pad_cols.to(torch.int32)
+            s_vals = torch.zeros(total, dtype=F64, device=dev)
+            s_cols[dest] = self.colidx
+            s_vals[dest] = self.vals
+            self._sell = (slice_ptr, s_cols.contiguous(), s_vals.contiguous())
+            check(lib.dsea_op_create_sell(n, nsl, c_void_p(slice_ptr.data_ptr()), c_void_p(self._sell[1].data_ptr()),
+                                          c_void_p(self._sell[2].data_ptr()), byref(raw)), "dsea_op_create_sell")
+            keep = self._sell
+        else:
+            check(lib.dsea_op_create_csr(self.n, int(self.vals.numel()), c_void_p(self.rowptr.data_ptr()),
+                                         c_void_p(self.colidx.data_ptr()), c_void_p(self.vals.data_ptr()),
+                                         byref(raw)), "dsea_op_create_csr")
+            keep = (self.rowptr, self.colidx, self.vals)
+        self._H = _NativeView(_Handle(raw, self.n, keep))
 
     @classmethod
-    def from_scipy(cls, M, device="cuda"):
+    def from_scipy(cls, M, device="cuda", layout="sell"):
         M = M.tocsr()
         M.sort_indices()
         return cls(torch.from_numpy(M.indptr.astype("int64")).to(device),
                    torch.from_numpy(M.indices.astype("int32")).to(device),
-                   torch.from_numpy(M.data.astype("float64")).to(device), M.shape[0])
+                   torch.from_numpy(M.data.astype("float64")).to(device), M.shape[0], layout=layout)
 
     @classmethod
-    def from_dense(cls, A, device="cuda"):
+    def from_dense(cls, A, device="cuda", layout="sell"):
         import scipy.sparse as sp
-        return cls.from_scipy(sp.csr_matrix(A.detach().cpu().numpy()), device)
+        return cls.from_scipy(sp.csr_matrix(A.detach().cpu().numpy()), device, layout=layout)
 
     @property
     def handle(self):

@@ -58,6 +58,7 @@ int dsea_last_hip_error(void);
 /* process-wide tuning knobs (measurement aid): key DSEA_TUNE_TFIM_TILE_LOG2 = log2 rows of x staged in LDS per
  * block of the TFIM mat-vec (6..12, default 11)                                                          */
 #define DSEA_TUNE_TFIM_TILE_LOG2 1
+#define DSEA_TUNE_CSR_GROUP 2 /* lanes per CSR row: 0 = automatic, or 4..64 */
 int dsea_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------ workspace
@@ -105,6 +106,13 @@ int dsea_op_create_tfim(int L, int L_local, int64_t row_offset, const double *g_
 /* CSR, caller-owned device arrays: rowptr int64 [n+1], colidx int32 [nnz], vals fp64 [nnz]. */
 int dsea_op_create_csr(int64_t n, int64_t nnz, const int64_t *rowptr, const int32_t *colidx,
                        const double *vals, dsea_op_t *out);
+
+/* Sliced ELLPACK with slices of 64 rows (SELL-64), caller-owned device arrays: slice_ptr int64 [nslices+1]
+ * (element offsets), and per slice s, column-major blocks: entry k of row 64 s + l at slice_ptr[s] + 64 k + l,
+ * padded per slice to its longest row with (colidx = any valid column, vals = 0).  nslices = ceil(n/64).
+ * This is the layout the CSR operand of the host layer is converted to: coalesced matrix loads.           */
+int dsea_op_create_sell(int64_t n, int64_t nslices, const int64_t *slice_ptr, const int32_t *colidx,
+                        const double *vals, dsea_op_t *out);
 
 /* 3-point stencil + diagonal (reference examples/schrodinger1D.py:18-27):
  *     y[i] = coef * ((-2 x[i] + x[i+1]) + x[i-1]) + V[i] * x[i],  x[-1] = *halo_lo, x[n] = *halo_hi

@@ -418,3 +418,34 @@ def test_large_slab_paths_agree():
     assert float((b1 - b2).abs().max()) <= 1e-11 * scale
     G = (Q2[:, :8].T @ Q2[:, :8]).cpu()
     assert float((G - torch.eye(8, dtype=F64)).abs().max()) < 1e-13
+
+
+def test_csr_layouts_ragged_and_native_lanczos():
+    """Generic sparse operand: ragged rows (empty rows, n not a multiple of the 64-row slice), both device
+    layouts (plain CSR kernel, SELL-64 kernel) against scipy; the TFIM operator as an explicit 21-nnz/row
+    matrix (BASELINE config 2, operand form ii) against the matrix-free kernel; native Lanczos + CG on it."""
+    import scipy.sparse as sp
+    rng = np.random.RandomState(7)
+    n = 1000 + 37
+    M = sp.random(n, n, density=0.01, random_state=rng, format="lil")
+    M[5, :] = 0
+    M[:, 5] = 0          # an empty row / column
+    M = sp.csr_matrix(M)
+    M = (M + M.T).tocsr()
+    v = torch.from_numpy(normal_vector(n, 9300))
+    ref = torch.from_numpy(M @ v.numpy())
+    for layout in ("csr", "sell"):
+        opm = CSROperator.from_scipy(M, dev(), layout=layout)
+        assert rel(opm(v.to(dev())).cpu(), ref) < 1e-13, layout
+    L = 13
+    g = torch.tensor([1.0], dtype=F64, device=dev())
+    tf = TFIMOperator(L, dev(), g=g)
+    x = torch.from_numpy(normal_vector(1 << L, 9301)).to(dev())
+    for layout in ("csr", "sell"):
+        assert rel(tf.to_csr(layout=layout)(x).cpu(), tf.H(x).cpu()) < 1e-13
+    # native loops on the explicit matrix == native loops on the matrix-free operator
+    k = 60
+    q0 = torch.from_numpy(normal_vector(1 << L, 9302)).to(dev())
+    _, T1 = Lanczos(tf, k, dev(), sparse=True, dim=1 << L, q0=q0)
+    _, T2 = Lanczos(tf.to_csr(), k, dev(), sparse=True, dim=1 << L, q0=q0)
+    assert float((T1 - T2).abs().max()) <= 1e-10 * float(T1.abs().max())
