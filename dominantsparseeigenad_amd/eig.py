@@ -7,8 +7,10 @@ DominantSparseEigenAD/eig.py.
 
 Scope note: in the reference the arithmetic of this path is not its
 own code but SciPy's ARPACK ``eigs`` and ``gmres`` on host NumPy arrays (eig.py:28-30,54-57), first order
-only.  It is outside the Lanczos/CG hot path this build accelerates, so the same third-party calls are
-kept (host pass-through, identical numerics); a device Arnoldi/GMRES is the "next" row f-1.
+only.  Host tensors / scipy ``LinearOperator``s keep exactly those third-party calls (identical numerics).
+CUDA tensors (``DominantEig``) and ``krylov.TorchLinearOperator`` operands (``DominantSparseEig``) -- which the
+reference cannot take at all (eig.py:28 ``.numpy()``) -- run the device Arnoldi / GMRES of ``krylov.py`` on the
+HIP orthogonalisation kernels; the adjoint hook then receives torch device vectors instead of numpy arrays.
 """
 from __future__ import annotations
 
@@ -40,11 +42,36 @@ def _dominant_pair(A, AT, k, which):
     return lam, l, r
 
 
+def _dominant_pair_device(mv, mvT, n, k, which, device):
+    from . import krylov
+    lam, r = krylov.arnoldi_dominant(mv, n, k, device, which)
+    lam_l, l = krylov.arnoldi_dominant(mvT, n, k, device, which)
+    assert abs(lam - lam_l) <= 1e-8 * max(abs(lam), 1e-300), "left / right eigenvalues disagree"
+    l = l / torch.dot(l, r)
+    return torch.tensor([lam], dtype=torch.float64, device=device), l, r
+
+
+def _adjoint_solves_device(mv, mvT, lam, l, r, g_l, g_r):
+    from . import krylov
+    lam_s = lam.reshape(())
+    rhs = g_l - r * torch.dot(l, g_l)                                            # eig.py:53
+    lam_l = krylov.gmres(lambda v: mv(v) - lam_s * v, rhs, rtol=_GMRES_TOL, atol=_GMRES_TOL)
+    rhs = g_r - l * torch.dot(r, g_r)                                            # eig.py:56
+    lam_r = krylov.gmres(lambda v: mvT(v) - lam_s * v, rhs, rtol=_GMRES_TOL, atol=_GMRES_TOL)
+    return lam_l, lam_r
+
+
 class DominantEig(torch.autograd.Function):
     """(eigval (1,), left eigenvector, right eigenvector) of a real diagonalisable matrix tensor."""
 
     @staticmethod
     def forward(ctx, A, k, which="LM"):
+        if A.is_cuda:
+            Ad = A.detach().to(torch.float64)
+            lam, l, r = _dominant_pair_device(lambda v: Ad @ v, lambda v: Ad.T @ v, Ad.shape[0], k, which, A.device)
+            ctx.device_path, ctx.Ad, ctx.trip = True, Ad, (lam, l, r)
+            return lam, l, r
+        ctx.device_path = False
         M = A.detach().cpu().numpy()
         lam, l, r = _dominant_pair(M, M.T, k, which)
         ctx.M, ctx.lam, ctx.l, ctx.r = M, lam, l, r
@@ -52,6 +79,11 @@ class DominantEig(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_lam, g_l, g_r):
+        if ctx.device_path:
+            Ad, (lam, l, r) = ctx.Ad, ctx.trip
+            lam_l, lam_r = _adjoint_solves_device(lambda v: Ad @ v, lambda v: Ad.T @ v, lam, l, r, g_l, g_r)
+            gA = g_lam * l[:, None] * r - l[:, None] * lam_l - lam_r[:, None] * r        # eig.py:58-60
+            return gA, None, None
         M, lam, l, r = ctx.M, ctx.lam, ctx.l, ctx.r
         g_l, g_r = g_l.numpy(), g_r.numpy()
         eye = np.eye(M.shape[0])
@@ -63,18 +95,33 @@ class DominantEig(torch.autograd.Function):
         return torch.from_numpy(gA), None, None
 
 
+def _on_device(op):
+    from .krylov import TorchLinearOperator
+    return isinstance(op, TorchLinearOperator) and op.device.type == "cuda"
+
+
 def _make_sparse_eig(A, AT, Aadjoint_to_gadjoint):
     class DominantSparseEig(torch.autograd.Function):
         """As DominantEig with A, A^T given as scipy LinearOperators; inputs (g, k) (eig.py:115-149)."""
 
         @staticmethod
         def forward(ctx, g, k):
+            ctx.device_path = _on_device(A)
+            if ctx.device_path:
+                lam, l, r = _dominant_pair_device(A.matvec, AT.matvec, A.shape[0], k, "LM", A.device)
+                ctx.trip = (lam, l, r)
+                return lam, l, r
             lam, l, r = _dominant_pair(A, AT, k, "LM")
             ctx.lam, ctx.l, ctx.r = lam, l, r
             return torch.from_numpy(lam), torch.from_numpy(l), torch.from_numpy(r)
 
         @staticmethod
         def backward(ctx, g_lam, g_l, g_r):
+            if ctx.device_path:
+                lam, l, r = ctx.trip
+                lam_l, lam_r = _adjoint_solves_device(A.matvec, AT.matvec, lam, l, r, g_l, g_r)
+                pieces = ((g_lam * l, r), (-l, lam_l), (-lam_r, r))                      # eig.py:145-147
+                return Aadjoint_to_gadjoint(pieces), None
             lam, l, r = ctx.lam, ctx.l, ctx.r
             g_lam, g_l, g_r = g_lam.numpy(), g_l.numpy(), g_r.numpy()
             shifted = sla.LinearOperator(A.shape, matvec=lambda v: A.matvec(v) - lam * v)

@@ -101,6 +101,52 @@ def native_of(A):
     return None
 
 
+# --------------------------------------------------------------------------- phase kernels as methods
+class Phases:
+    """The vector-phase entry points of include/dsea.h on n-vectors of one device (thin ctypes wrappers;
+    every argument is a torch tensor, scalars are 1-element device tensors)."""
+
+    def __init__(self, n, device, kmax=8):
+        self.lib = _lib.load()
+        self.n, self.device = int(n), torch.device(device)
+        self.ws = Workspace.get(self.n, kmax, self.device)
+
+    def reserve(self, k):
+        self.ws = Workspace.get(self.n, k, self.device)
+
+    def _st(self):
+        return _stream(self.device)
+
+    def empty(self, *shape):
+        return torch.empty(*shape, dtype=F64, device=self.device)
+
+    def zeros(self, *shape):
+        return torch.zeros(*shape, dtype=F64, device=self.device)
+
+    def axpy(self, a_host, a_dev, x, y):
+        check(self.lib.dsea_axpy(self.ws.handle, float(a_host), _ptr(a_dev), _ptr(x), _ptr(y), x.numel(), self._st()),
+              "dsea_axpy")
+
+    def dot(self, x, y, out):
+        check(self.lib.dsea_dot(self.ws.handle, _ptr(x), _ptr(y), x.numel(), _ptr(out), self._st()), "dsea_dot")
+
+    def scale_store(self, r, nrm2, q_out, beta_out):
+        check(self.lib.dsea_scale_store(self.ws.handle, _ptr(r), _ptr(nrm2), _ptr(q_out), _ptr(beta_out), r.numel(),
+                                        self._st()), "dsea_scale_store")
+
+    def rdots(self, Q, ldq, n, i, u, alpha, beta, r, c):
+        check(self.lib.dsea_lanczos_rdots(self.ws.handle, _ptr(Q), ldq, n, i, _ptr(u), _ptr(alpha), _ptr(beta),
+                                          _ptr(r), _ptr(c), self._st()), "dsea_lanczos_rdots")
+
+    def axpy_norm(self, Q, ldq, n, i, c, r, nrm2):
+        check(self.lib.dsea_lanczos_axpy_norm(self.ws.handle, _ptr(Q), ldq, n, i, _ptr(c), _ptr(r), _ptr(nrm2),
+                                              self._st()), "dsea_lanczos_axpy_norm")
+
+    def ritz(self, Q, ldq, n, k, s, out):
+        check(self.lib.dsea_ritz_combine(self.ws.handle, _ptr(Q), ldq, n, k, _ptr(s), _ptr(out), self._st()),
+              "dsea_ritz_combine")
+
+
 # --------------------------------------------------------------------------- Lanczos
 def lanczos(A, k, n, device, q0, native=None, callable_A=None):
     """k-step Lanczos on the GPU (reference Lanczos.py:49-77).

@@ -1,0 +1,157 @@
+"""Device-side Krylov solvers for the NON-symmetric primitives: what the
+reference delegates to SciPy on the host -- ARPACK ``eigs(A, k=1, which, ncv=k)`` (reference eig.py:29-30,
+116-117) and ``gmres(A - lambda I, b, tol=1e-12, atol=1e-12)`` (eig.py:52-57,137-144) -- restated on GPU
+vectors with the same HIP phase kernels the Lanczos path uses for its orthogonalisation:
+
+    arnoldi_dominant   explicitly restarted Arnoldi, ncv basis vectors, classical Gram-Schmidt applied twice
+                       (CGS2 = the dots / correction kernel pair, two rounds), Hessenberg eigen-solve on the
+                       host (ncv x ncv), restart from the wanted Ritz vector until the residual estimate
+                       |h_{m+1,m} e_m^T y| is at rounding level
+    gmres              restarted GMRES(20) with the same orthogonalisation, Givens rotations on the host
+
+ARPACK's implicitly restarted method and this explicitly restarted one converge to the same eigenpair
+(ARPACK is called with tol = 0 = machine precision); eigenvectors are compared up to the gauge the
+primitives fix afterwards (l.r = 1, r.r = 1, sign of r free).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import engine
+
+F64 = torch.float64
+
+
+def _select(evals, which):
+    if which == "LM":
+        return int(np.argmax(np.abs(evals)))
+    if which == "SM":
+        return int(np.argmin(np.abs(evals)))
+    if which == "LR":
+        return int(np.argmax(evals.real))
+    if which == "SR":
+        return int(np.argmin(evals.real))
+    raise ValueError("which must be one of LM, SM, LR, SR")
+
+
+def _cgs2(ph, V, ldq, n, j, w, zero, bufs):
+    """orthogonalise w against V[0..j] twice; returns (h (j+1,) device, w_orth, ||w_orth||^2 (1,) device)"""
+    w1, w2, h1, h2, nrm2 = bufs
+    i = j + 1
+    ph.rdots(V, ldq, n, i, w, zero, None, w1, h1)        # w1 = w, h1 = V^T w    (alpha = 0: no three-term part)
+    ph.axpy_norm(V, ldq, n, i, h1, w1, nrm2)             # w1 -= V h1
+    ph.rdots(V, ldq, n, i, w1, zero, None, w2, h2)       # second round on the corrected vector
+    ph.axpy_norm(V, ldq, n, i, h2, w2, nrm2)
+    return h1[:i] + h2[:i], w2, nrm2
+
+
+def arnoldi_dominant(matvec, n, ncv, device, which="LM", v0=None, tol=1e-13, max_restarts=60):
+    """Wanted eigenvalue (real, asserted as in eig.py:31-32) and unit-norm eigenvector of a real matrix
+    given by ``matvec`` (torch device vector -> torch device vector)."""
+    device = torch.device(device)
+    ncv = int(min(ncv, n))
+    ph = engine.Phases(n, device, kmax=ncv + 1)
+    ldq = engine.round_up(n, 32)
+    V = ph.empty(ncv + 1, ldq)
+    H = ph.zeros(ncv + 1, ncv)
+    zero = ph.zeros(1)
+    bufs = (ph.empty(n), ph.empty(n), ph.zeros(ncv + 2), ph.zeros(ncv + 2), ph.zeros(1))
+    v = torch.randn(n, dtype=F64, device=device) if v0 is None else engine.as_vector(v0, n).clone()
+    nrm2 = ph.zeros(1)
+    last_res, theta, x = None, None, None
+    for _ in range(max_restarts):
+        ph.dot(v, v, nrm2)
+        ph.scale_store(v, nrm2, V[0], None)
+        H.zero_()
+        for j in range(ncv):
+            w = engine.as_vector(matvec(V[j, :n]), n)
+            h, w_orth, wn2 = _cgs2(ph, V, ldq, n, j, w, zero, bufs)
+            H[: j + 1, j] = h
+            ph.scale_store(w_orth, wn2, V[j + 1], H[j + 1, j: j + 1])
+        Hh = H.cpu().numpy()
+        # invariant subspace reached (n <= ncv or lucky breakdown): use the leading block only
+        m = ncv
+        scale = np.abs(Hh[:ncv, :ncv]).max()
+        sub = np.array([abs(Hh[j + 1, j]) for j in range(ncv)])
+        bad = np.where(~np.isfinite(sub) | (sub <= 1e-13 * scale))[0]
+        if bad.size:
+            m = int(bad[0]) + 1
+        evals, evecs = np.linalg.eig(Hh[:m, :m])
+        idx = _select(evals, which)
+        theta, y = evals[idx], evecs[:, idx]
+        assert abs(theta.imag) <= 1e-9 * max(abs(theta), 1e-300), "The desired eigenvalue of the matrix must be real"
+        y = (y / y[np.argmax(np.abs(y))]).real
+        y = y / np.linalg.norm(y)
+        sub_m = 0.0 if m < ncv or not np.isfinite(sub[m - 1]) else sub[m - 1]
+        res = abs(sub_m * y[-1]) if m == ncv else 0.0
+        x = ph.empty(n)
+        ph.ritz(V, ldq, n, m, torch.from_numpy(np.ascontiguousarray(y)).to(device), x)
+        x = x / x.norm()
+        if res <= tol * abs(theta.real) or (last_res is not None and res >= 0.5 * last_res and res <= 1e-10 * abs(theta.real)):
+            break
+        last_res = res
+        v = x
+    return float(theta.real), x
+
+
+def gmres(matvec, b, rtol=1e-12, atol=1e-12, restart=20, maxiter=None):
+    """Restarted GMRES from x0 = 0; stops when ||b - A x|| <= max(rtol ||b||, atol) (scipy's rule)."""
+    device, n = b.device, b.numel()
+    b = engine.as_vector(b, n)
+    restart = int(min(restart, n))
+    ph = engine.Phases(n, device, kmax=restart + 1)
+    ldq = engine.round_up(n, 32)
+    V = ph.empty(restart + 1, ldq)
+    zero, nrm2 = ph.zeros(1), ph.zeros(1)
+    bufs = (ph.empty(n), ph.empty(n), ph.zeros(restart + 2), ph.zeros(restart + 2), ph.zeros(1))
+    x = ph.zeros(n)
+    target = max(rtol * float(b.norm()), atol)
+    cycles = 10 * n if maxiter is None else int(maxiter)
+    for _ in range(cycles):
+        r = b - engine.as_vector(matvec(x), n) if float(x.abs().max()) > 0 else b.clone()
+        beta = float(r.norm())
+        if beta <= target:
+            break
+        ph.dot(r, r, nrm2)
+        ph.scale_store(r, nrm2, V[0], None)
+        Hm = np.zeros((restart + 1, restart))
+        cs, sn = np.zeros(restart), np.zeros(restart)
+        gvec = np.zeros(restart + 1)
+        gvec[0] = beta
+        m = 0
+        for j in range(restart):
+            w = engine.as_vector(matvec(V[j, :n]), n)
+            h, w_orth, wn2 = _cgs2(ph, V, ldq, n, j, w, zero, bufs)
+            col = torch.cat((h, wn2.sqrt())).cpu().numpy()           # the one host round trip of the step
+            ph.scale_store(w_orth, wn2, V[j + 1], None)
+            for t in range(j):                                        # previous rotations
+                a, c2 = col[t], col[t + 1]
+                col[t], col[t + 1] = cs[t] * a + sn[t] * c2, -sn[t] * a + cs[t] * c2
+            rho = np.hypot(col[j], col[j + 1])
+            cs[j], sn[j] = (1.0, 0.0) if rho == 0.0 else (col[j] / rho, col[j + 1] / rho)
+            col[j], col[j + 1] = rho, 0.0
+            Hm[: j + 2, j] = col[: j + 2]
+            gvec[j + 1] = -sn[j] * gvec[j]
+            gvec[j] = cs[j] * gvec[j]
+            m = j + 1
+            if abs(gvec[j + 1]) <= target:
+                break
+        yv = np.linalg.solve(np.triu(Hm[:m, :m]), gvec[:m])
+        dx = ph.empty(n)
+        ph.ritz(V, ldq, n, m, torch.from_numpy(np.ascontiguousarray(yv)).to(device), dx)
+        x = x + dx
+    return x
+
+
+class TorchLinearOperator:
+    """Device counterpart of the scipy ``LinearOperator`` the reference's DominantSparseEig takes
+    (eig.py:96-100): ``shape`` and a ``matvec`` acting on torch vectors of ``device``."""
+
+    def __init__(self, shape, matvec, device):
+        self.shape = tuple(shape)
+        self.matvec = matvec
+        self.device = torch.device(device)
+
+    def __call__(self, v):
+        return self.matvec(v)
