@@ -29,13 +29,13 @@ def hook(pieces):
     return gA
 op, opT = krylov.TorchLinearOperator((n, n), fr, dev), krylov.TorchLinearOperator((n, n), fl, dev)
 eig.setDominantSparseEig(op, opT, hook)
-t1 = torch.randn(n, dtype=torch.float64, device=dev); t2 = torch.randn(n, dtype=torch.float64, device=dev)
+tv1 = torch.randn(n, dtype=torch.float64, device=dev); tv2 = torch.randn(n, dtype=torch.float64, device=dev)
 for it in range(3):
     count[0] = 0
     torch.cuda.synchronize(); t0 = time.perf_counter()
     lam, l, r = eig.DominantSparseEig.apply(A, k)
     torch.cuda.synchronize(); t1 = time.perf_counter(); c1 = count[0]
-    loss = lam.sum() + (l * t1).sum() * (r * t2).sum()   # b != 0 in both adjoint solves
+    loss = lam.sum() + (l * tv1).sum() * (r * tv2).sum()   # b != 0 in both adjoint solves
     (gA,) = torch.autograd.grad(loss, A)
     torch.cuda.synchronize(); t2 = time.perf_counter()
     print("D=%d n=%d k=%d  forward %.1f ms (%d mat-vecs)  backward %.1f ms (%d mat-vecs)  lambda=%.12f" % (
@@ -61,7 +61,7 @@ if D <= 128:   # the same problem through the host branch = the reference's arit
     lam_c, l_c, r_c = eig.DominantSparseEig.apply(Ac, k)
     tf = time.perf_counter()
     s = 1.0 if float(r_c @ r.detach().cpu()) > 0 else -1.0
-    loss = lam_c.sum() + (l_c * s * t1.cpu()).sum() * (r_c * s * t2.cpu()).sum()
+    loss = lam_c.sum() + (l_c * s * tv1.cpu()).sum() * (r_c * s * tv2.cpu()).sum()
     (gc,) = torch.autograd.grad(loss, Ac)
     tb = time.perf_counter()
     print("host branch (scipy, %d threads): forward %.2f s  backward %.2f s ; lambda diff %.1e ; grad rel diff %.1e" % (
