@@ -54,6 +54,8 @@ _SIGNATURES = {
                                    c_void_p, c_void_p, c_void_p]),
     "dsea_lanczos_axpy_norm": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p,
                                        c_void_p, c_void_p]),
+    "dsea_lanczos_store": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64,
+                                   c_void_p]),
     "dsea_ritz_combine": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "dsea_project_out": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "dsea_cg_init": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),

@@ -359,7 +359,8 @@ int dsea_lanczos_rdots(dsea_ws_t ws, const double* Q, int64_t ldq, int64_t n, in
   REQUIRE(i <= ws->w.kmax, DSEA_ERR_WORKSPACE);
   REQUIRE(aligned16(Q) && aligned16(u) && aligned16(r) && (ldq % 2 == 0), DSEA_ERR_ALIGN);
   TileGeom g = ws->w.geom(n);
-  launch_rdots(g, Q, ldq, n, i, u, alpha, beta, r, ws->w.partials, c_out, static_cast<hipStream_t>(stream));
+  launch_rdots(g, Q, ldq, n, i, u, alpha, beta, r, ws->w.partials, c_out, static_cast<hipStream_t>(stream),
+               nullptr, nullptr, 0, nullptr, true);
   return check_launch();
 }
 
@@ -367,8 +368,29 @@ int dsea_lanczos_axpy_norm(dsea_ws_t ws, const double* Q, int64_t ldq, int64_t n
                            double* r, double* nrm2_out, void* stream) {
   REQUIRE(ws && Q && c && r && nrm2_out && n >= 1 && i >= 1 && ldq >= n, DSEA_ERR_ARG);
   REQUIRE(aligned16(Q) && aligned16(r) && (ldq % 2 == 0), DSEA_ERR_ALIGN);
-  TileGeom g = ws->w.geom(n);
-  launch_axpy_norm(g, Q, ldq, n, i, c, r, ws->w.partials, nrm2_out, static_cast<hipStream_t>(stream));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Workspace& w = ws->w;
+  if (w.shadow && w.shadow_rows >= i && w.shadow_ld >= n) {
+    // a bf16 shadow of this basis is registered: stream it (premise checked on the device against c[i] = r.r)
+    double* nP = w.aux + DSEA_MAX_WAVE_TILES;
+    const int rps = n >= 512 * 2 * 512 ? 2 : 1;
+    int nn = launch_axpy_norm_lp(n, rps, Q, ldq, w.shadow, w.shadow_ld, i, c, w.lp_tau, r, nP, w.scal + 16, st);
+    launch_finalize1(nP, nn, nrm2_out, st);
+  } else {
+    TileGeom g = w.geom(n);
+    launch_axpy_norm(g, Q, ldq, n, i, c, r, w.partials, nrm2_out, st);
+  }
+  return check_launch();
+}
+
+int dsea_lanczos_store(dsea_ws_t ws, const double* r, const double* nrm2, double* Q, int64_t ldq, int row,
+                       double* beta_out, int64_t n, void* stream) {
+  REQUIRE(ws && r && nrm2 && Q && n >= 1 && row >= 0 && ldq >= n, DSEA_ERR_ARG);
+  REQUIRE(aligned16(r) && aligned16(Q) && (ldq % 2 == 0), DSEA_ERR_ALIGN);
+  Workspace& w = ws->w;
+  uint16_t* qs = nullptr;
+  if (w.shadow && w.shadow_rows > row && w.shadow_ld >= n) qs = w.shadow + (int64_t)row * w.shadow_ld;
+  launch_scale_store(r, nrm2, Q + (int64_t)row * ldq, beta_out, n, static_cast<hipStream_t>(stream), qs);
   return check_launch();
 }
 

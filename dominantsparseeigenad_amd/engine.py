@@ -178,26 +178,36 @@ def lanczos(A, k, n, device, q0, native=None, callable_A=None):
                 check(lib.dsea_ws_set_shadow(ws.handle, None, 0, 0, 0.0), "dsea_ws_set_shadow")
         return Q, ldq, alphas, betas[: k - 1]
 
+    # generic callable: the mat-vec is the caller's torch code, everything else is one phase call per stage;
+    # the bf16 shadow is kept current by dsea_lanczos_store and used by dsea_lanczos_axpy_norm
     nrm2 = ws.scal[0:1]
     r = torch.empty(n, dtype=F64, device=device)
-    c = torch.empty(max(k, 1), dtype=F64, device=device)
-    check(lib.dsea_nrm2sq(ws.handle, _ptr(q0), n, _ptr(nrm2), st), "dsea_nrm2sq")
-    check(lib.dsea_scale_store(ws.handle, _ptr(q0), _ptr(nrm2), _ptr(Q), None, n, st), "dsea_scale_store")
-    u = as_vector(callable_A(Q[0, :n]), n)
-    check(lib.dsea_dot(ws.handle, _ptr(Q), _ptr(u), n, _ptr(alphas), st), "dsea_dot")
+    c = torch.empty(k + 2, dtype=F64, device=device)
+    shadow = None
+    if USE_SHADOW and k > 1:
+        shadow = torch.empty((k, ldq), dtype=torch.bfloat16, device=device)
+        check(lib.dsea_ws_set_shadow(ws.handle, _ptr(shadow), ldq, int(k), float(SHADOW_TAU)), "dsea_ws_set_shadow")
     esz = 8
-    for i in range(1, k):
-        a_ptr = c_void_p(alphas.data_ptr() + (i - 1) * esz)
-        b_ptr = c_void_p(betas.data_ptr() + (i - 2) * esz) if i >= 2 else c_void_p(None)
-        check(lib.dsea_lanczos_rdots(ws.handle, _ptr(Q), ldq, n, i, _ptr(u), a_ptr, b_ptr, _ptr(r), _ptr(c), st),
-              "dsea_lanczos_rdots")
-        check(lib.dsea_lanczos_axpy_norm(ws.handle, _ptr(Q), ldq, n, i, _ptr(c), _ptr(r), _ptr(nrm2), st),
-              "dsea_lanczos_axpy_norm")
-        qi = Q[i]
-        check(lib.dsea_scale_store(ws.handle, _ptr(r), _ptr(nrm2), _ptr(qi),
-                                   c_void_p(betas.data_ptr() + (i - 1) * esz), n, st), "dsea_scale_store")
-        u = as_vector(callable_A(qi[:n]), n)
-        check(lib.dsea_dot(ws.handle, _ptr(qi), _ptr(u), n, c_void_p(alphas.data_ptr() + i * esz), st), "dsea_dot")
+    try:
+        check(lib.dsea_nrm2sq(ws.handle, _ptr(q0), n, _ptr(nrm2), st), "dsea_nrm2sq")
+        check(lib.dsea_lanczos_store(ws.handle, _ptr(q0), _ptr(nrm2), _ptr(Q), ldq, 0, None, n, st), "dsea_lanczos_store")
+        u = as_vector(callable_A(Q[0, :n]), n)
+        check(lib.dsea_dot(ws.handle, _ptr(Q), _ptr(u), n, _ptr(alphas), st), "dsea_dot")
+        for i in range(1, k):
+            a_ptr = c_void_p(alphas.data_ptr() + (i - 1) * esz)
+            b_ptr = c_void_p(betas.data_ptr() + (i - 2) * esz) if i >= 2 else c_void_p(None)
+            check(lib.dsea_lanczos_rdots(ws.handle, _ptr(Q), ldq, n, i, _ptr(u), a_ptr, b_ptr, _ptr(r), _ptr(c), st),
+                  "dsea_lanczos_rdots")
+            check(lib.dsea_lanczos_axpy_norm(ws.handle, _ptr(Q), ldq, n, i, _ptr(c), _ptr(r), _ptr(nrm2), st),
+                  "dsea_lanczos_axpy_norm")
+            check(lib.dsea_lanczos_store(ws.handle, _ptr(r), _ptr(nrm2), _ptr(Q), ldq, i,
+                                         c_void_p(betas.data_ptr() + (i - 1) * esz), n, st), "dsea_lanczos_store")
+            qi = Q[i]
+            u = as_vector(callable_A(qi[:n]), n)
+            check(lib.dsea_dot(ws.handle, _ptr(qi), _ptr(u), n, c_void_p(alphas.data_ptr() + i * esz), st), "dsea_dot")
+    finally:
+        if shadow is not None:
+            check(lib.dsea_ws_set_shadow(ws.handle, None, 0, 0, 0.0), "dsea_ws_set_shadow")
     return Q, ldq, alphas, betas[: k - 1]
 
 

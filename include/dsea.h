@@ -152,14 +152,21 @@ int dsea_scale_store(dsea_ws_t ws, const double *r, const double *nrm2, double *
 
 /* Phase 1 of step i (1 <= i < k), Lanczos.py:61 and the first half of :66:
  *     r = u - (*alpha) Q[i-1] - (*beta) Q[i-2]        (beta may be null: 0, the i = 1 case)
- *     c[j] = Q[j] . r   for j < i                      (local sums)                           */
+ *     c_out[j] = Q[j] . r   for j < i ;  c_out[i] = r . r     (local sums; c_out holds i+1 doubles)   */
 int dsea_lanczos_rdots(dsea_ws_t ws, const double *Q, int64_t ldq, int64_t n, int i,
                        const double *u, const double *alpha, const double *beta, double *r,
                        double *c_out, void *stream);
 
-/* Phase 2, second half of Lanczos.py:66 and :69:  r -= sum_j c[j] Q[j] ; *nrm2_out = ||r||^2 (local) */
+/* Phase 2, second half of Lanczos.py:66 and :69:  r -= sum_j c[j] Q[j] ; *nrm2_out = ||r||^2 (local).
+ * If a bf16 shadow of this basis is registered (dsea_ws_set_shadow, rows kept current by dsea_lanczos_store)
+ * the pass streams the shadow, subject to the device-side premise max|c_j| <= tau*sqrt(c[i]).            */
 int dsea_lanczos_axpy_norm(dsea_ws_t ws, const double *Q, int64_t ldq, int64_t n, int i,
                            const double *c, double *r, double *nrm2_out, void *stream);
+
+/* Q[row] = r / sqrt(*nrm2) (and the bf16 shadow row if registered) ; *beta_out = sqrt(*nrm2) (nullable)
+ * (Lanczos.py:53,69-70,75 writing into the vector-contiguous basis)                                       */
+int dsea_lanczos_store(dsea_ws_t ws, const double *r, const double *nrm2, double *Q, int64_t ldq, int row,
+                       double *beta_out, int64_t n, void *stream);
 
 /* out = sum_{j<k} s[j] Q[j]   (the one needed column of Qk @ eigvecs, Lanczos.py:99-105)      */
 int dsea_ritz_combine(dsea_ws_t ws, const double *Q, int64_t ldq, int64_t n, int k,

@@ -57,3 +57,26 @@ def test_schrodinger_example_optimises():
     torch.manual_seed(0)
     losses = ex.main()
     assert losses[-1] < losses[0] and losses[-1] < 0.02
+
+
+@pytest.mark.parametrize("N,k,idxs", [(16, 200, (0, 50, 99)), (20, 200, (25, 50, 75))])
+def test_full_size_curves_against_reference_data(N, k, idxs):
+    """The reference's stored N=16 / N=20 curves (examples/TFIM/datas/E0_N_{16,20}.npz, chiF_N_{16,20}.npz --
+    its own E0_sparseAD / chiF_sparseAD outputs, each point ~43 s fwd+bwd on its CPU path at N=20) re-computed
+    on the MI355X through the example counterparts, second derivatives and chi_F included."""
+    E0 = _load(os.path.join(ROOT, "examples", "TFIM", "E0.py"), "ex_E0_full%d" % N)
+    chi = _load(os.path.join(ROOT, "examples", "TFIM", "chiF.py"), "ex_chiF_full%d" % N)
+    curE = np.load(os.path.join(GOLDEN, "ref_datas", "E0_N_%d.npz" % N))
+    curC = np.load(os.path.join(GOLDEN, "ref_datas", "chiF_N_%d.npz" % N))
+    dev = torch.device("cuda:0")
+    model = E0.TFIM(N, dev)
+    torch.manual_seed(1)
+    for idx in idxs:
+        g = float(curE["gs"][idx])
+        model.g = torch.tensor([g], dtype=torch.float64, device=dev, requires_grad=True)
+        e, de, d2e = E0.E0_sparseAD(model, k)
+        assert abs(e - curE["E0s"][idx]) < 1e-6 * abs(curE["E0s"][idx]), (N, g, e, curE["E0s"][idx])
+        assert abs(de - curE["dE0s"][idx]) < 1e-5 * abs(curE["dE0s"][idx]), (N, g, de, curE["dE0s"][idx])
+        assert abs(d2e - curE["d2E0s"][idx]) < 2e-3 * abs(curE["d2E0s"][idx]), (N, g, d2e, curE["d2E0s"][idx])
+        _, _, c = chi.chiF_sparseAD(model, k)
+        assert abs(c - curC["chiFs"][idx]) < 2e-3 * abs(curC["chiFs"][idx]), (N, g, c, curC["chiFs"][idx])

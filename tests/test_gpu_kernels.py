@@ -76,7 +76,7 @@ def test_reorth_pair(n, i, rpl):
         u = vec(n, 12)
         ab = torch.tensor([0.7, -1.3], dtype=F64, device=dev())
         r = torch.empty(n, dtype=F64, device=dev())
-        c = torch.zeros(i, dtype=F64, device=dev())
+        c = torch.zeros(i + 1, dtype=F64, device=dev())   # i coefficients + r.r
         beta_ptr = c_void_p(ab.data_ptr() + 8) if i >= 2 else c_void_p(None)
         _lib.check(lib.dsea_lanczos_rdots(ws.handle, _ptr(Q), ldq, n, i, _ptr(u), _ptr(ab), beta_ptr, _ptr(r),
                                           _ptr(c), st))
@@ -85,7 +85,9 @@ def test_reorth_pair(n, i, rpl):
         assert torch.equal(r, r_ref)  # same rounding sequence as the torch expression
         c_ref = Qn @ r_ref
         tol = 1e-13 * float(r_ref.norm()) * float(Qn.norm(dim=1).max())
-        assert float((c - c_ref).abs().max()) <= tol
+        assert float((c[:i] - c_ref).abs().max()) <= tol
+        assert abs(c[i].item() - float(r_ref.dot(r_ref))) <= 1e-13 * float(r_ref.dot(r_ref))
+        c = c[:i].clone()
         nrm2 = torch.zeros(1, dtype=F64, device=dev())
         _lib.check(lib.dsea_lanczos_axpy_norm(ws.handle, _ptr(Q), ldq, n, i, _ptr(c), _ptr(r), _ptr(nrm2), st))
         r2_ref = r_ref - Qn.T @ c
@@ -111,7 +113,7 @@ def test_run_to_run_determinism():
     outs = []
     for _ in range(2):
         r = torch.empty(n, dtype=F64, device=dev())
-        c = torch.zeros(i, dtype=F64, device=dev())
+        c = torch.zeros(i + 1, dtype=F64, device=dev())
         _lib.check(lib.dsea_lanczos_rdots(ws.handle, _ptr(Q), ldq, n, i, _ptr(u), _ptr(a), None, _ptr(r), _ptr(c), st))
         outs.append(c.clone())
     assert torch.equal(outs[0], outs[1])

@@ -89,8 +89,9 @@ def test_partitioned_hip_backend(world, backend):
     psi = torch.cat([ret[r][1] for r in range(world)])
     sgn = 1.0 if float(psi @ psi_o.detach()) > 0 else -1.0
     (g_o,) = torch.autograd.grad(E_o + sgn * psi_o.matmul(t), model.g)
-    assert abs(ret[0][0] - E_o.item()) < 1e-10 * abs(E_o.item())
-    assert float((psi * sgn - psi_o.detach()).abs().max()) < 1e-10
-    assert abs(ret[0][2] - g_o.item()) < 1e-9 * abs(g_o.item()), (ret[0][2], g_o.item())
+    info = {r: (ret[r][0], ret[r][2], ret[r][3]) for r in range(world)}
+    assert abs(ret[0][0] - E_o.item()) < 1e-10 * abs(E_o.item()), (info, E_o.item())
+    assert float((psi * sgn - psi_o.detach()).abs().max()) < 1e-10, (info, float((psi * sgn - psi_o.detach()).abs().max()))
+    assert abs(ret[0][2] - g_o.item()) < 1e-9 * abs(g_o.item()), (info, g_o.item())
     for r in range(world):
-        assert ret[r][0] == ret[0][0] and ret[r][3] == ret[0][3]
+        assert ret[r][0] == ret[0][0] and ret[r][3] == ret[0][3], info

@@ -22,7 +22,7 @@ ldq = n + args.ldq_pad
 Q = torch.randn((i + 1, ldq), dtype=torch.float64, device=dev)
 u = torch.randn(n, dtype=torch.float64, device=dev)
 r = torch.empty(n, dtype=torch.float64, device=dev)
-c = torch.zeros(i + 1, dtype=torch.float64, device=dev)
+c = torch.zeros(i + 2, dtype=torch.float64, device=dev)
 ab = torch.tensor([0.5, 0.25], dtype=torch.float64, device=dev)
 nrm2 = torch.zeros(1, dtype=torch.float64, device=dev)
 ws = Workspace.get(n, i + 1, dev)
