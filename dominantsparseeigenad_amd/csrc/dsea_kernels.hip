@@ -470,7 +470,6 @@ __global__ __launch_bounds__(256) void k_axpy_norm_lp(const double* __restrict__
 // ------------------------------------------------------------------------------------------
 // streaming elementwise kernels with a fused reduction (grid-stride, double2)
 // ------------------------------------------------------------------------------------------
-enum { EW_DOT = 0, EW_NRM2, EW_SHIFT_DOT, EW_CG_INIT, EW_CG_UPDATE, EW_PROJECT_DOT };
 
 // Generic two-vector reduction kernels.  Each block writes one partial (P[blockIdx.x]).
 __global__ __launch_bounds__(256) void k_dot(const double* __restrict__ x, const double* __restrict__ y,

@@ -24,31 +24,26 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import engine as _engine_mod
+
 F64 = torch.float64
 
 
 # =========================================================================== product backend (HIP)
-class HipBackend:
-    """Slab-local numerics through the C ABI.  ``L``/``L_local``/``row_offset`` describe this rank's slab."""
+class HipBackend(_engine_mod.Phases):
+    """Slab-local numerics through the C ABI (the vector phases come from ``engine.Phases``).
+    ``L``/``L_local``/``row_offset`` describe this rank's slab."""
 
     def __init__(self, L, L_local, row_offset, g, device):
-        from . import _lib, engine
+        from . import _lib
         from .operators import TFIMOperator
-        self.lib = _lib.load()
+        super().__init__(1 << L_local, device, kmax=8)
         self._lib_mod = _lib
-        self.engine = engine
-        self.device = torch.device(device)
-        self.n = 1 << L_local
+        self.engine = _engine_mod
         self.op = TFIMOperator(L, self.device, g=g, L_local=L_local, row_offset=row_offset)
-        self.ws = engine.Workspace.get(self.n, 8, self.device)
-
-    def reserve(self, k):
-        self.ws = self.engine.Workspace.get(self.n, k, self.device)
+        self._shadow = None
 
     # -- helpers
-    def _st(self):
-        return c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-
     @staticmethod
     def _p(t):
         return c_void_p(t.data_ptr()) if t is not None else c_void_p(None)
@@ -56,41 +51,10 @@ class HipBackend:
     def _ck(self, rc, what):
         self._lib_mod.check(rc, what)
 
-    def empty(self, *shape):
-        return torch.empty(*shape, dtype=F64, device=self.device)
-
-    def zeros(self, *shape):
-        return torch.zeros(*shape, dtype=F64, device=self.device)
-
     # -- operator (slab-local part)
     def tfim_local(self, x, y, which="H"):
         handle = self.op.handle if which == "H" else self.op._dHdg.handle
         self._ck(self.lib.dsea_spmv(handle, None, self._p(x), self._p(y), None, None, None, self._st()), "dsea_spmv")
-
-    # -- vector phases
-    def axpy(self, a_host, a_dev, x, y):
-        self._ck(self.lib.dsea_axpy(self.ws.handle, float(a_host), self._p(a_dev), self._p(x), self._p(y), x.numel(),
-                                    self._st()), "dsea_axpy")
-
-    def dot(self, x, y, out):
-        self._ck(self.lib.dsea_dot(self.ws.handle, self._p(x), self._p(y), x.numel(), self._p(out), self._st()),
-                 "dsea_dot")
-
-    def scale_store(self, r, nrm2, q_out, beta_out):
-        self._ck(self.lib.dsea_scale_store(self.ws.handle, self._p(r), self._p(nrm2), self._p(q_out),
-                                           self._p(beta_out), r.numel(), self._st()), "dsea_scale_store")
-
-    def rdots(self, Q, ldq, n, i, u, alpha, beta, r, c):
-        self._ck(self.lib.dsea_lanczos_rdots(self.ws.handle, self._p(Q), ldq, n, i, self._p(u), self._p(alpha),
-                                             self._p(beta), self._p(r), self._p(c), self._st()), "dsea_lanczos_rdots")
-
-    def axpy_norm(self, Q, ldq, n, i, c, r, nrm2):
-        self._ck(self.lib.dsea_lanczos_axpy_norm(self.ws.handle, self._p(Q), ldq, n, i, self._p(c), self._p(r),
-                                                 self._p(nrm2), self._st()), "dsea_lanczos_axpy_norm")
-
-    def ritz(self, Q, ldq, n, k, s, out):
-        self._ck(self.lib.dsea_ritz_combine(self.ws.handle, self._p(Q), ldq, n, k, self._p(s), self._p(out),
-                                            self._st()), "dsea_ritz_combine")
 
     # -- macro phases of the partitioned Lanczos step (include/dsea.h "row-partitioned macro phases")
     def set_shadow(self, k, ldq):
