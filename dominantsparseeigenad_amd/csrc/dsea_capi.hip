@@ -77,6 +77,20 @@ TileGeom Workspace::geom(int64_t n_rows) const {
   if (g.ntiles < 1) g.ntiles = 1;
   g.nw = (int)(g.ntiles < DSEA_MAX_WAVE_TILES ? g.ntiles : DSEA_MAX_WAVE_TILES);
   g.pstride = DSEA_MAX_WAVE_TILES;
+  // small n: a block of W waves per 128-row tile, the basis vectors split between the waves (latency-bound
+  // regime).  Measured on MI355X at i = 199 (tools/kbench.py), dots pass one-wave-per-tile -> split:
+  // n = 2^12: 27.7 -> 8.2 us, 2^14: 42.3 -> 8.7 us, 2^16: 46.4 -> 26.7 us, 2^17: 51.4 -> 43.9 us, 2^18: no gain.
+  g.split_w = 0;
+  const int64_t tiles128 = (n_rows + 127) / 128;
+  int sw = split_override;
+  if (sw < 0 && rpl_override == 0) sw = tiles128 <= 256 ? 16 : (tiles128 <= 1024 ? 8 : 0);
+  if (sw == 4 || sw == 8 || sw == 16) {
+    g.split_w = sw;
+    g.rpl = 2;
+    g.ntiles = tiles128;
+    g.nw = (int)tiles128;
+    if (tiles128 > DSEA_MAX_WAVE_TILES) g.split_w = 0;  // cannot happen for automatic selection
+  }
   return g;
 }
 
@@ -126,6 +140,7 @@ int dsea_ws_create(void* device_buffer, size_t bytes, int64_t n, int kmax, dsea_
   ws->w.npad = L.npad;
   ws->w.kmax = kmax;
   ws->w.rpl_override = 0;
+  ws->w.split_override = -1;
   ws->w.prof = nullptr;
   ws->w.shadow = nullptr;
   ws->w.shadow_ld = 0;
@@ -229,6 +244,13 @@ int dsea_ws_set_rows_per_lane(dsea_ws_t ws, int rpl) {
   if (!ws) return DSEA_ERR_ARG;
   if (rpl != 0 && rpl != 2 && rpl != 4 && rpl != 8 && rpl != 16) return DSEA_ERR_ARG;
   ws->w.rpl_override = rpl;
+  return DSEA_OK;
+}
+
+int dsea_ws_set_split(dsea_ws_t ws, int waves) {
+  if (!ws) return DSEA_ERR_ARG;
+  if (waves != -1 && waves != 0 && waves != 4 && waves != 8 && waves != 16) return DSEA_ERR_ARG;
+  ws->w.split_override = waves;
   return DSEA_OK;
 }
 
@@ -370,7 +392,7 @@ int dsea_lanczos_axpy_norm(dsea_ws_t ws, const double* Q, int64_t ldq, int64_t n
   REQUIRE(aligned16(Q) && aligned16(r) && (ldq % 2 == 0), DSEA_ERR_ALIGN);
   hipStream_t st = static_cast<hipStream_t>(stream);
   Workspace& w = ws->w;
-  if (w.shadow && w.shadow_rows >= i && w.shadow_ld >= n) {
+  if (w.shadow && w.shadow_rows >= i && w.shadow_ld >= n && !w.geom(n).split_w) {
     // a bf16 shadow of this basis is registered: stream it (premise checked on the device against c[i] = r.r)
     double* nP = w.aux + DSEA_MAX_WAVE_TILES;
     const int rps = n >= 512 * 2 * 512 ? 2 : 1;
@@ -490,7 +512,7 @@ int dsea_plz_correct_matvec(dsea_op_t op, dsea_ws_t ws, const double* Q, int64_t
   double* nP = w.aux + DSEA_MAX_WAVE_TILES;
   if (row >= 1) {
     REQUIRE(Q && c && ldq >= n && (ldq % 2 == 0) && aligned16(Q), DSEA_ERR_ARG);
-    if (w.shadow && w.shadow_rows > row && w.shadow_ld >= n) {
+    if (w.shadow && w.shadow_rows > row && w.shadow_ld >= n && !w.geom(n).split_w) {
       const int rps = n >= 512 * 2 * 512 ? 2 : 1;
       int nn = launch_axpy_norm_lp(n, rps, Q, ldq, w.shadow, w.shadow_ld, row, c, w.lp_tau, r, nP, w.scal + 16, st);
       launch_finalize1(nP, nn, pair_out, st);
@@ -538,8 +560,8 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
   // optional bf16 shadow of the basis for the correction pass (see k_axpy_norm_lp)
   uint16_t* Qs = nullptr;
   int64_t lds = 0;
-  if (w.shadow && w.shadow_rows >= k && w.shadow_ld >= n) {
-    Qs = w.shadow;
+  if (w.shadow && w.shadow_rows >= k && w.shadow_ld >= n && !w.geom(n).split_w) {
+    Qs = w.shadow;   // (small slabs are latency-bound, not bandwidth-bound: they keep the fp64 split kernels)
     lds = w.shadow_ld;
   }
   double* lp_count = w.scal + 16;

@@ -57,6 +57,7 @@ struct TileGeom {
   int nw;          // waves launched (<= DSEA_MAX_WAVE_TILES); wave w handles tiles w, w+nw, ...
   int64_t ntiles;  // ceil(n / (64*rpl))
   int pstride;     // stride between the partial rows of two basis vectors (>= nw)
+  int split_w;     // 0, or W = waves of one block that share a 128-row tile and split the basis (small n)
 };
 
 // optional per-launch HIP-event timing of the dominant kernels (bench.py roofline); host objects only
@@ -79,6 +80,7 @@ struct Workspace {
   int64_t n, npad;
   int kmax;
   int rpl_override;
+  int split_override;  // -1 automatic, 0 off, 4/8/16 forced
   double* partials;  // DSEA_MAX_WAVE_TILES * max(kmax,1) doubles (also >= DSEA_MAX_EW_BLOCKS)
   double* aux;       // 4 * DSEA_MAX_WAVE_TILES doubles: small partial buffers that must not alias `partials`
   double* coef;      // kmax doubles

@@ -350,6 +350,122 @@ __global__ __launch_bounds__(256) void k_axpy_norm(const double* __restrict__ Q,
 }
 
 // ------------------------------------------------------------------------------------------
+// Small-n form of the two passes ("split"): with fewer than ~1000 row tiles a wave that walks all i basis
+// vectors alone is bound by the latency of its serial trips, not by bandwidth.  Here a block of W waves shares
+// ONE row tile of 128 rows (2 per lane) and splits the basis vectors between its waves in chunks of four
+// (chunk c -> wave c mod W).  Dots: every c_j is still produced by exactly one wave (same partial layout).
+// Correction: the W partial sums of a tile are combined through LDS in wave order -- deterministic.
+// ------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(W * 64) void k_rdots_split(const double* __restrict__ Q, int64_t ldq, int i,
+                                                        int64_t n, const double* __restrict__ u,
+                                                        const double* __restrict__ alpha,
+                                                        const double* __restrict__ beta, double* __restrict__ r,
+                                                        double* __restrict__ P, int64_t pstride,
+                                                        const double* __restrict__ aP, int aCount,
+                                                        double* __restrict__ a_store, int want_rr) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t tile = blockIdx.x;
+  const int64_t row = tile * 128 + lane * 2;
+  double a;
+  if (aCount > 0) {
+    a = sum_partials_wave(aP, aCount, lane);
+    if (tile == 0 && wv == 0 && lane == 0) a_store[0] = a;
+  } else {
+    a = alpha[0];
+  }
+  const double b = beta ? beta[0] : 0.0;
+  const double* __restrict__ q1 = Q + (int64_t)(i - 1) * ldq;
+  const double2 uu = ld2<true>(u, row, n), qa = ld2<true>(q1, row, n);
+  double2 qb = make_double2(0.0, 0.0);
+  if (i >= 2) qb = ld2<true>(Q + (int64_t)(i - 2) * ldq, row, n);
+  double2 rv;
+  rv.x = __dsub_rn(__dsub_rn(uu.x, __dmul_rn(a, qa.x)), __dmul_rn(b, qb.x));
+  rv.y = __dsub_rn(__dsub_rn(uu.y, __dmul_rn(a, qa.y)), __dmul_rn(b, qb.y));
+  if (wv == 0) {
+    st2<true>(r, row, n, rv);
+    if (want_rr) {
+      double acc = wave_sum(fma(rv.x, rv.x, rv.y * rv.y));
+      if (lane == 0) P[(int64_t)i * pstride + tile] = acc;
+    }
+  }
+  const int nchunks = (i + 3) / 4;
+  for (int cc = wv; cc < nchunks; cc += W) {
+    const int j = 4 * cc;
+    double acc[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      double2 q = make_double2(0.0, 0.0);
+      if (j + v < i) q = ld2_stream<true>(Q + (int64_t)(j + v) * ldq, row, n);
+      acc[v] = fma(q.x, rv.x, q.y * rv.y);
+    }
+    const bool hi32 = (lane & 32) != 0, hi16 = (lane & 16) != 0;
+    double a0 = hi32 ? acc[2] : acc[0], s0 = hi32 ? acc[0] : acc[2];
+    double a1 = hi32 ? acc[3] : acc[1], s1 = hi32 ? acc[1] : acc[3];
+    a0 += __shfl_xor(s0, 32, 64);
+    a1 += __shfl_xor(s1, 32, 64);
+    double bsum = hi16 ? a1 : a0, bs = hi16 ? a0 : a1;
+    bsum += __shfl_xor(bs, 16, 64);
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) bsum += __shfl_xor(bsum, m, 64);
+    const int jj = j + (lane >> 4);
+    if ((lane & 15) == 0 && jj < i) P[(int64_t)jj * pstride + tile] = bsum;
+  }
+}
+
+// MODE 0: r -= sum_j c_j Q_j, partial ||r||^2 ; MODE 1: out = sum_j c_j Q_j (Ritz vector)
+template <int W, int MODE>
+__global__ __launch_bounds__(W * 64) void k_axpy_norm_split(const double* __restrict__ Q, int64_t ldq, int i,
+                                                            int64_t n, const double* __restrict__ c,
+                                                            double* __restrict__ r, double* __restrict__ P) {
+  __shared__ double2 part[W][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t tile = blockIdx.x;
+  const int64_t row = tile * 128 + lane * 2;
+  double2 w = make_double2(0.0, 0.0);
+  const int nchunks = (i + 3) / 4;
+  for (int cc = wv; cc < nchunks; cc += W) {
+    const int j = 4 * cc;
+    double2 q[4];
+    double cj[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      q[v] = make_double2(0.0, 0.0);
+      cj[v] = 0.0;
+      if (j + v < i) {
+        q[v] = ld2_stream<true>(Q + (int64_t)(j + v) * ldq, row, n);
+        cj[v] = c[j + v];
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      w.x = fma(cj[v], q[v].x, w.x);
+      w.y = fma(cj[v], q[v].y, w.y);
+    }
+  }
+  part[wv][lane] = w;
+  __syncthreads();
+  if (wv == 0) {
+    double2 tot = part[0][lane];
+#pragma unroll
+    for (int k2 = 1; k2 < W; ++k2) {
+      tot.x += part[k2][lane].x;
+      tot.y += part[k2][lane].y;
+    }
+    if (MODE == 0) {
+      double2 rv = ld2<true>(r, row, n);
+      rv.x -= tot.x;
+      rv.y -= tot.y;
+      st2<true>(r, row, n, rv);
+      double acc = wave_sum(fma(rv.x, rv.x, rv.y * rv.y));
+      if (lane == 0) P[tile] = acc;
+    } else {
+      st2<true>(r, row, n, tot);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Lanczos phase 2 reading a bf16 SHADOW of the basis (storage precision only; all arithmetic is fp64).
 //
 // Why this is exact to working precision: with full re-orthogonalisation every step the coefficients
@@ -1156,6 +1272,18 @@ void launch_finalize1(const double* P, int count, double* out, hipStream_t st) {
 void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* u,
                   const double* alpha, const double* beta, double* r, double* P, double* c_out,
                   hipStream_t st, EventPair* ev, const double* aP, int aCount, double* a_store, bool want_rr) {
+  if (g.split_w) {
+    const unsigned tiles = (unsigned)g.ntiles;
+    const int wr = want_rr ? 1 : 0;
+    switch (g.split_w) {
+      case 4: KLAUNCH(ev, (k_rdots_split<4>), tiles, 256, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, aP, aCount, a_store, wr); break;
+      case 8: KLAUNCH(ev, (k_rdots_split<8>), tiles, 512, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, aP, aCount, a_store, wr); break;
+      default: KLAUNCH(ev, (k_rdots_split<16>), tiles, 1024, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, aP, aCount, a_store, wr); break;
+    }
+    hipLaunchKernelGGL(k_finalize_multi, dim3(want_rr ? i + 1 : i), dim3(256), 0, st, (const double*)P,
+                       (int64_t)g.pstride, g.nw, c_out);
+    return;
+  }
   const int grid = (g.nw + 3) / 4;
   LAUNCH_RPL(ev, k_rdots, g.rpl, grid, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, g.nw,
              g.ntiles, aP, aCount, a_store, want_rr ? 1 : 0);
@@ -1166,6 +1294,16 @@ void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, in
 
 void launch_axpy_norm(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* c,
                       double* r, double* P, double* nrm2_out, hipStream_t st, EventPair* ev) {
+  if (g.split_w) {
+    const unsigned tiles = (unsigned)g.ntiles;
+    switch (g.split_w) {
+      case 4: KLAUNCH(ev, (k_axpy_norm_split<4, 0>), tiles, 256, st, Q, ldq, i, n, c, r, P); break;
+      case 8: KLAUNCH(ev, (k_axpy_norm_split<8, 0>), tiles, 512, st, Q, ldq, i, n, c, r, P); break;
+      default: KLAUNCH(ev, (k_axpy_norm_split<16, 0>), tiles, 1024, st, Q, ldq, i, n, c, r, P); break;
+    }
+    if (nrm2_out) launch_finalize1(P, g.nw, nrm2_out, st);
+    return;
+  }
   const int grid = (g.nw + 3) / 4;
   switch (g.rpl) {
     case 2: KLAUNCH(ev, (k_axpy_norm<2, 0>), grid, 256, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles); break;
@@ -1195,8 +1333,18 @@ int launch_axpy_norm_lp(int64_t n, int rps, const double* Q, int64_t ldq, const 
 
 void launch_ritz(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int k, const double* s,
                  double* out, hipStream_t st) {
-  const int grid = (g.nw + 3) / 4;
   double* nullP = nullptr;
+  if (g.split_w) {
+    const unsigned tiles = (unsigned)g.ntiles;
+    EventPair* ev = nullptr;
+    switch (g.split_w) {
+      case 4: KLAUNCH(ev, (k_axpy_norm_split<4, 1>), tiles, 256, st, Q, ldq, k, n, s, out, nullP); break;
+      case 8: KLAUNCH(ev, (k_axpy_norm_split<8, 1>), tiles, 512, st, Q, ldq, k, n, s, out, nullP); break;
+      default: KLAUNCH(ev, (k_axpy_norm_split<16, 1>), tiles, 1024, st, Q, ldq, k, n, s, out, nullP); break;
+    }
+    return;
+  }
+  const int grid = (g.nw + 3) / 4;
   switch (g.rpl) {
     case 2: hipLaunchKernelGGL((k_axpy_norm<2, 1>), dim3(grid), dim3(256), 0, st, Q, ldq, k, n, s, out, nullP, g.nw, g.ntiles); break;
     case 4: hipLaunchKernelGGL((k_axpy_norm<4, 1>), dim3(grid), dim3(256), 0, st, Q, ldq, k, n, s, out, nullP, g.nw, g.ntiles); break;

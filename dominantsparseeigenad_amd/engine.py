@@ -85,6 +85,9 @@ class Workspace:
     def set_rows_per_lane(self, rpl):
         check(self.lib.dsea_ws_set_rows_per_lane(self.handle, int(rpl)), "dsea_ws_set_rows_per_lane")
 
+    def set_split(self, waves):
+        check(self.lib.dsea_ws_set_split(self.handle, int(waves)), "dsea_ws_set_split")
+
 
 def round_up(v, m):
     return (v + m - 1) // m * m

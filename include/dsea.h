@@ -69,6 +69,10 @@ int dsea_ws_create(void *device_buffer, size_t bytes, int64_t n, int kmax, dsea_
 int dsea_ws_destroy(dsea_ws_t ws);
 /* tuning knob (0 = automatic): rows handled per lane in the basis-streaming kernels {2,4,8,16} */
 int dsea_ws_set_rows_per_lane(dsea_ws_t ws, int rpl);
+/* tuning knob: small-n "split" form of the basis-streaming kernels -- a block of `waves` waves shares one
+ * 128-row tile and splits the basis vectors between its waves.  -1 = automatic (on below ~1.3e5 rows),
+ * 0 = off, 4 / 8 / 16 = forced.                                                                          */
+int dsea_ws_set_split(dsea_ws_t ws, int waves);
 
 /* Optional bf16 SHADOW of the Krylov basis (caller-owned, `rows` x `ld` uint16, ld % 8 == 0, 16-byte
  * aligned; null = off).  When registered, dsea_lanczos_run also stores every new basis vector rounded to

@@ -147,3 +147,40 @@ def test_cg_phases_match_reference_sequence(n):
     xo = oracle.cg_solve(A.cpu(), b.cpu(), x0.cpu(), eps=1e-9, stats=stt)
     assert engine.last_cg.iters == stt["iters"]
     assert float((x.cpu() - xo).abs().max()) <= 1e-10 * float(xo.abs().max())
+
+
+@pytest.mark.parametrize("waves", [4, 8, 16])
+@pytest.mark.parametrize("n,i", [(1, 1), (129, 5), (1000, 37), (100000, 23), (40000, 201)])
+def test_reorth_pair_split_form(n, i, waves):
+    """Small-n form of the two passes (a block of W waves per 128-row tile, basis vectors split between the
+    waves): same results as the torch expressions, for every W, ragged n, i not a multiple of 4."""
+    lib = _lib.load()
+    ws = Workspace.get(n, 256, dev())
+    ws.set_split(waves)
+    try:
+        st = _stream(dev())
+        Q, ldq = basis(i, n, 61)
+        u = vec(n, 62)
+        ab = torch.tensor([0.7, -1.3], dtype=F64, device=dev())
+        r = torch.empty(n, dtype=F64, device=dev())
+        c = torch.zeros(i + 1, dtype=F64, device=dev())
+        beta_ptr = c_void_p(ab.data_ptr() + 8) if i >= 2 else c_void_p(None)
+        _lib.check(lib.dsea_lanczos_rdots(ws.handle, _ptr(Q), ldq, n, i, _ptr(u), _ptr(ab), beta_ptr, _ptr(r),
+                                          _ptr(c), st))
+        Qn = Q[:, :n]
+        r_ref = u - 0.7 * Qn[i - 1] - ((-1.3) * Qn[i - 2] if i >= 2 else 0.0)
+        assert torch.equal(r, r_ref)
+        c_ref = Qn @ r_ref
+        assert float((c[:i] - c_ref).abs().max()) <= 1e-13 * float(r_ref.norm()) * float(Qn.norm(dim=1).max())
+        assert abs(c[i].item() - float(r_ref.dot(r_ref))) <= 1e-13 * float(r_ref.dot(r_ref))
+        cc = c[:i].clone()
+        nrm2 = torch.zeros(1, dtype=F64, device=dev())
+        _lib.check(lib.dsea_lanczos_axpy_norm(ws.handle, _ptr(Q), ldq, n, i, _ptr(cc), _ptr(r), _ptr(nrm2), st))
+        r2_ref = r_ref - Qn.T @ cc
+        assert float((r - r2_ref).abs().max()) <= 1e-12 * float(r_ref.abs().max() + (Qn.T @ cc).abs().max())
+        assert abs(nrm2.item() - float(r2_ref.dot(r2_ref))) <= 1e-12 * float(r2_ref.dot(r2_ref))
+        out = torch.empty(n, dtype=F64, device=dev())
+        _lib.check(lib.dsea_ritz_combine(ws.handle, _ptr(Q), ldq, n, i, _ptr(cc), _ptr(out), st))
+        assert float((out - Qn.T @ cc).abs().max()) <= 1e-12 * float((Qn.T @ cc).abs().max() + 1e-300)
+    finally:
+        ws.set_split(-1)

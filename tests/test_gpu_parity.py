@@ -365,8 +365,8 @@ def test_shadow_basis_pass_is_exact_to_working_precision(monkeypatch):
     the tridiagonal, orthonormality of the basis -- agree to rounding level; every step takes the shadow path
     on a healthy run; tau = 0 forces the in-kernel fp64 fallback on every step.  (Late Lanczos coefficients
     are ill-conditioned functions of the data -- any two rounding-different fp64 runs disagree there too --
-    so they are not compared.)"""
-    L, k = 14, 120
+    so they are not compared.)  n = 2^18: above the small-n regime, where the split kernels keep the fp64 basis."""
+    L, k = 18, 120
     n = 1 << L
     g = torch.tensor([1.0], dtype=F64, device=dev())
     op = TFIMOperator(L, dev(), g=g)

@@ -45,6 +45,13 @@ print("torch copy 2 GiB->2 GiB: %.3f ms  %.0f GB/s (read+write)" % (t, 2 * big.n
 t = timeit(lambda: big.sum())
 print("torch sum 2 GiB: %.3f ms  %.0f GB/s (read)" % (t, big.numel() * 8 / t / 1e6))
 del big, big2
+for sw in (4, 8, 16):
+    ws.set_rows_per_lane(0); ws.set_split(sw)
+    t1 = timeit(lambda: lib.dsea_lanczos_rdots(ws.handle, _ptr(Q), ldq, n, i, _ptr(u), _ptr(ab), c_void_p(ab.data_ptr() + 8), _ptr(r), _ptr(c), st))
+    t2 = timeit(lambda: lib.dsea_lanczos_axpy_norm(ws.handle, _ptr(Q), ldq, n, i, _ptr(c), _ptr(r), _ptr(nrm2), st))
+    print("split W=%2d  rdots(+finalize) %.1f us  %.0f GB/s | axpy_norm(+finalize) %.1f us  %.0f GB/s" % (
+        sw, t1 * 1e3, (i + 5) * GB / t1 * 1e3, t2 * 1e3, (i + 2) * GB / t2 * 1e3))
+ws.set_split(0)
 for rpl in [int(x) for x in args.rpls.split(",")]:
     ws.set_rows_per_lane(rpl)
     t1 = timeit(lambda: lib.dsea_lanczos_rdots(ws.handle, _ptr(Q), ldq, n, i, _ptr(u), _ptr(ab), c_void_p(ab.data_ptr() + 8), _ptr(r), _ptr(c), st))
