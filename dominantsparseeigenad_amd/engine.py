@@ -70,17 +70,25 @@ class Workspace:
         except Exception:
             pass
 
+    _CACHE_LIMIT = 8   # workspaces kept alive (one per (n, device)); the oldest is dropped beyond this
+
     @classmethod
     def get(cls, n, kmax, device):
         device = torch.device(device)
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
         key = (int(n), str(device))
-        ws = cls._cache.get(key)
+        ws = cls._cache.pop(key, None)
         if ws is None or ws.kmax < kmax:
             ws = cls(n, max(int(kmax), 8), device)
-            cls._cache[key] = ws
+        cls._cache[key] = ws            # re-insert: dict order = recency
+        while len(cls._cache) > cls._CACHE_LIMIT:
+            cls._cache.pop(next(iter(cls._cache)))
         return ws
+
+    @classmethod
+    def clear_cache(cls):
+        cls._cache.clear()
 
     def set_rows_per_lane(self, rpl):
         check(self.lib.dsea_ws_set_rows_per_lane(self.handle, int(rpl)), "dsea_ws_set_rows_per_lane")
@@ -235,12 +243,28 @@ def tridiag_extreme(alphas, betas, which):
     e = betas.detach().cpu().numpy()
     k = d.shape[0]
     out = []
-    if k == 1:
-        return [(float(d[0]), np.ones(1))] * (2 if which == "both" else 1)
-    picks = {"min": [0], "max": [k - 1], "both": [0, k - 1]}[which]
+    m = k
+    if k > 1:
+        # The reference has no breakdown test (Lanczos.py:69-70 divides by beta whatever it is; SURVEY Q8: with
+        # k beyond the Krylov dimension it normalises rounding noise and returns spurious Ritz values without
+        # any error).  Here the invariant subspace is recognised: the tridiagonal is cut at the first
+        # negligible beta -- its leading block carries exact eigenpairs of A -- and the caller is told.
+        scale = max(float(np.abs(d).max()), float(np.abs(e).max()), 1e-300)
+        bad = np.where(~np.isfinite(e) | (np.abs(e) <= 1e-13 * scale))[0]
+        if bad.size:
+            import warnings
+            m = int(bad[0]) + 1
+            warnings.warn("Lanczos breakdown: beta_%d = %.3e relative to %.3e -- the Krylov space from this start "
+                          "vector has dimension %d < k = %d; the Ritz pair is taken from the leading %d x %d block"
+                          % (m - 1, float(np.abs(e[m - 1])), scale, m, k, m, m), RuntimeWarning)
+    if m == 1:
+        return [(float(d[0]), np.eye(1, k)[0].copy())] * (2 if which == "both" else 1)
+    picks = {"min": [0], "max": [m - 1], "both": [0, m - 1]}[which]
     for idx in picks:
-        w, v = eigh_tridiagonal(d, e, select="i", select_range=(idx, idx))
-        out.append((float(w[0]), np.ascontiguousarray(v[:, 0])))
+        w, v = eigh_tridiagonal(d[:m], e[:m - 1], select="i", select_range=(idx, idx))
+        s_full = np.zeros(k)
+        s_full[:m] = v[:, 0]
+        out.append((float(w[0]), s_full))
     return out
 
 

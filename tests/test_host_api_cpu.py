@@ -188,3 +188,19 @@ def test_dominant_sparse_eig_matches_dense():
     (g_sparse,) = torch.autograd.grad(lam2.sum(), p)
     assert abs(lam.item() - lam2.item()) < 1e-10
     assert abs(g_dense.item() - g_sparse.item()) < 1e-8
+
+
+def test_breakdown_is_reported_not_hidden():
+    """the reference silently normalises rounding noise once k exceeds the Krylov dimension
+    (Lanczos.py:69-70) and returns spurious Ritz values.  Here the tridiagonal is cut at the negligible beta
+    (exact eigenpairs of the invariant subspace) and a RuntimeWarning tells the caller."""
+    import warnings
+    n = 40
+    A = torch.diag(torch.arange(1, n + 1, dtype=torch.float64))
+    q0 = torch.zeros(n, dtype=torch.float64)
+    q0[[3, 7, 11]] = torch.tensor([1.0, 2.0, -1.0], dtype=torch.float64)   # 3-dimensional invariant subspace
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        lo, vlo = symeigLanczos(A, 10, extreme="min", q0=q0)
+    assert any("breakdown" in str(w.message) for w in rec)
+    assert abs(lo.item() - 4.0) < 1e-9          # smallest eigenvalue present in the start vector
