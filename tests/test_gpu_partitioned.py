@@ -69,7 +69,7 @@ def _worker(rank, world, port, backend, ret):
         t = torch.from_numpy(normal_vector(nloc, 5103, offset=off)).to(dev)
         E0, psi, grad = solver.forward_backward(K, q0, x0, t)
         torch.cuda.synchronize()
-        ret[rank] = (E0.item(), psi.cpu(), grad.item(), solver.last_cg_iters)
+        ret[rank] = (E0.item(), psi.cpu().numpy().copy(), grad.item(), solver.last_cg_iters)  # by value, not shm
     finally:
         dist.destroy_process_group()
 
@@ -86,7 +86,7 @@ def test_partitioned_hip_backend(world, backend):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), backend, ret), nprocs=world, join=True)
-    psi = torch.cat([ret[r][1] for r in range(world)])
+    psi = torch.cat([torch.from_numpy(ret[r][1]) for r in range(world)])
     sgn = 1.0 if float(psi @ psi_o.detach()) > 0 else -1.0
     (g_o,) = torch.autograd.grad(E_o + sgn * psi_o.matmul(t), model.g)
     info = {r: (ret[r][0], ret[r][2], ret[r][3]) for r in range(world)}

@@ -43,7 +43,7 @@ def _worker(rank, world, port, ret):
         x0 = torch.from_numpy(normal_vector(nloc, 5002, offset=off))
         t = torch.from_numpy(normal_vector(nloc, 5003, offset=off))
         E0, psi, grad = solver.forward_backward(K, q0, x0, t)
-        ret[rank] = (E0.item(), psi.clone(), grad.item(), solver.last_cg_iters)
+        ret[rank] = (E0.item(), psi.numpy().copy(), grad.item(), solver.last_cg_iters)  # by value, not shm
     finally:
         dist.destroy_process_group()
 
@@ -64,7 +64,7 @@ def test_partitioned_matches_single_process_oracle(world):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert len(ret) == world
-    psi = torch.cat([ret[r][1] for r in range(world)])
+    psi = torch.cat([torch.from_numpy(ret[r][1]) for r in range(world)])
     sgn = 1.0 if float(psi @ psi_o.detach()) > 0 else -1.0
     for r in range(world):
         assert ret[r][0] == ret[0][0] and ret[r][2] == ret[0][2]      # replicated scalars are bit-identical
