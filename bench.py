@@ -209,7 +209,7 @@ def main():
     # ---- per-launch durations of the dominant kernels: the same K steps again, this time with a HIP event
     # pair recorded on the launch stream around every reorth / mat-vec launch (the event records cost ~4 %
     # of a step, which is why they are kept out of the timed region above)
-    use_events = (not partitioned_path) and not args.no_kernel_events
+    use_events = not args.no_kernel_events   # rank 0 reports its local kernels also in the partitioned run
     launches = (c_int64 * 3)()
     total_ms = (c_double * 3)()
     dt_instr = None
@@ -245,7 +245,7 @@ def main():
                        "E0_per_site": E0.item() / L, "E0_per_site_closed_form": analytic_E0_per_site(L, 1.0),
                        "dloss_dg": float(gl.reshape(-1)[0].item())},
         }
-        if use_events and launches[0] > 0:
+        if use_events and launches[0] > 0 and launches[1] > 0:
             dots_b, axpy_b = reorth_bytes_per_launch(nloc, k)
             per = {
                 "k_rdots": (dots_b, total_ms[0] / launches[0], launches[0]),
@@ -260,7 +260,7 @@ def main():
                     traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            lp, fb = engine.lanczos_lp_stats(nloc, dev)
+            lp, fb = engine.lanczos_lp_stats(nloc, dev) if not partitioned_path else (launches[1], 0)
             out["roofline"] = {
                 "kernel": name, "bound": "hbm", "achieved": round(b / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -270,8 +270,9 @@ def main():
                 "spmv_avg_launch_ms": round(total_ms[2] / max(launches[2], 1), 5),
                 "measured": "HIP events on the launch stream, %d instrumented steps run right after the timed "
                             "region (%.3f ms/step with events)" % (args.steps, dt_instr / args.steps * 1e3),
-                "note": "k_axpy_norm streams the bf16 shadow of the basis on %d of %d steps (fp64 fallback %d): "
-                        "its real traffic is ~1/4 of its algorithmic bytes" % (lp, lp + fb, fb),
+                "note": ("k_axpy_norm streams the bf16 shadow of the basis on %d of %d steps (fp64 fallback %d): "
+                         "its real traffic is ~1/4 of its algorithmic bytes" % (lp, lp + fb, fb)) if not partitioned_path
+                        else "rank 0's local kernels in the row-partitioned run (correction pass on the bf16 shadow)",
             }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(L, args.cpu_k, args.cpu_cg_cap)

@@ -381,8 +381,9 @@ int dsea_lanczos_rdots(dsea_ws_t ws, const double* Q, int64_t ldq, int64_t n, in
   REQUIRE(i <= ws->w.kmax, DSEA_ERR_WORKSPACE);
   REQUIRE(aligned16(Q) && aligned16(u) && aligned16(r) && (ldq % 2 == 0), DSEA_ERR_ALIGN);
   TileGeom g = ws->w.geom(n);
+  Profiler* prof = ws->w.prof;
   launch_rdots(g, Q, ldq, n, i, u, alpha, beta, r, ws->w.partials, c_out, static_cast<hipStream_t>(stream),
-               nullptr, nullptr, 0, nullptr, true);
+               prof ? prof->next(PROF_RDOTS) : nullptr, nullptr, 0, nullptr, true);
   return check_launch();
 }
 
@@ -497,8 +498,9 @@ int dsea_plz_dots(dsea_ws_t ws, const double* Q, int64_t ldq, int64_t n, int i, 
   REQUIRE(i <= ws->w.kmax, DSEA_ERR_WORKSPACE);
   REQUIRE(aligned16(Q) && aligned16(u) && aligned16(r) && (ldq % 2 == 0), DSEA_ERR_ALIGN);
   TileGeom g = ws->w.geom(n);
+  Profiler* prof = ws->w.prof;
   launch_rdots(g, Q, ldq, n, i, u, alpha, beta, r, ws->w.partials, c_out, static_cast<hipStream_t>(stream),
-               nullptr, nullptr, 0, nullptr, true);
+               prof ? prof->next(PROF_RDOTS) : nullptr, nullptr, 0, nullptr, true);
   return check_launch();
 }
 
@@ -514,16 +516,17 @@ int dsea_plz_correct_matvec(dsea_op_t op, dsea_ws_t ws, const double* Q, int64_t
     REQUIRE(Q && c && ldq >= n && (ldq % 2 == 0) && aligned16(Q), DSEA_ERR_ARG);
     if (w.shadow && w.shadow_rows > row && w.shadow_ld >= n && !w.geom(n).split_w) {
       const int rps = n >= 512 * 2 * 512 ? 2 : 1;
-      int nn = launch_axpy_norm_lp(n, rps, Q, ldq, w.shadow, w.shadow_ld, row, c, w.lp_tau, r, nP, w.scal + 16, st);
+      int nn = launch_axpy_norm_lp(n, rps, Q, ldq, w.shadow, w.shadow_ld, row, c, w.lp_tau, r, nP, w.scal + 16, st,
+                                   w.prof ? w.prof->next(PROF_AXPY) : nullptr);
       launch_finalize1(nP, nn, pair_out, st);
     } else {
       TileGeom g = w.geom(n);
-      launch_axpy_norm(g, Q, ldq, n, row, c, r, w.partials, pair_out, st);
+      launch_axpy_norm(g, Q, ldq, n, row, c, r, w.partials, pair_out, st, w.prof ? w.prof->next(PROF_AXPY) : nullptr);
     }
   } else {
     launch_dot(r, r, n, w.partials, pair_out, st);
   }
-  int nb = launch_spmv(op->d, r, y, nullptr, nullptr, nullptr, st);
+  int nb = launch_spmv(op->d, r, y, nullptr, nullptr, nullptr, st, w.prof ? w.prof->next(PROF_SPMV) : nullptr);
   if (nb < 0) return DSEA_ERR_UNSUPPORTED;
   return check_launch();
 }
