@@ -578,7 +578,9 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
   const int rps = n >= 512 * 2 * 512 ? 2 : 1;
   launch_dot(q0, q0, n, P, nrm2, st);
   launch_scale_store(q0, nrm2, Q, nullptr, n, st, Qs);
-  if (op->d.kind == OP_TFIM && op->d.tfim.L_local >= 1) {
+  const bool has_fused_tail = (op->d.kind == OP_TFIM && op->d.tfim.L_local >= 1) || op->d.kind == OP_SELL ||
+                              op->d.kind == OP_STENCIL3;
+  if (has_fused_tail) {
     // Fused sequence, 4 launches per step and no stand-alone scalar reductions: the mat-vec leaves
     // per-block partials of alpha (aP), the dots kernel sums them in its prologue; the axpy kernel leaves
     // per-wave partials of ||r||^2 (nP), the fused scale + mat-vec kernel sums those.

@@ -1166,11 +1166,18 @@ __global__ __launch_bounds__(256) void k_spmv_csr_stream(CsrParams p, const doub
 // (element k of lane l at slice_ptr[s] + 64 k + l) and padded to the slice's longest row with (col = own row,
 // val = 0).  Matrix loads are perfectly coalesced, and for the banded / structured operators of this domain the
 // gather x[col] of a wave hits consecutive addresses as well (lane = row).
+template <bool FUSED>
 __global__ __launch_bounds__(256) void k_spmv_sell(SellParams p, const double* __restrict__ x,
                                                    double* __restrict__ y, const double* __restrict__ shift,
-                                                   const double* __restrict__ skip, double* __restrict__ P) {
-  __shared__ double sm4[4];
-  if (skip && skip[0] != 0.0) return;
+                                                   const double* __restrict__ skip, double* __restrict__ P,
+                                                   TfimFusedArgs fa) {
+  __shared__ double sm5[5];
+  if (!FUSED && skip && skip[0] != 0.0) return;
+  double beta = 1.0;
+  if (FUSED) {  // Lanczos tail: x is the un-normalised r; q = r/beta is stored and used for every gather
+    beta = sqrt(sum_partials_block(fa.nP, fa.nCount, sm5));
+    if (blockIdx.x == 0 && threadIdx.x == 0) fa.beta_store[0] = beta;
+  }
   const double s = shift ? shift[0] : 0.0;
   const int lane = threadIdx.x & 63;
   double acc = 0.0;
@@ -1182,46 +1189,75 @@ __global__ __launch_bounds__(256) void k_spmv_sell(SellParams p, const double* _
     for (; e + 64 < b1; e += 128) {
       const double v0 = p.vals[e], v1 = p.vals[e + 64];
       const int c0 = p.colidx[e], c1 = p.colidx[e + 64];
-      s0 = fma(v0, x[c0], s0);
-      s1 = fma(v1, x[c1], s1);
+      double x0 = x[c0], x1 = x[c1];
+      if (FUSED) {
+        x0 = x0 / beta;
+        x1 = x1 / beta;
+      }
+      s0 = fma(v0, x0, s0);
+      s1 = fma(v1, x1, s1);
     }
-    if (e < b1) s0 = fma(p.vals[e], x[p.colidx[e]], s0);
+    if (e < b1) {
+      double x0 = x[p.colidx[e]];
+      if (FUSED) x0 = x0 / beta;
+      s0 = fma(p.vals[e], x0, s0);
+    }
     if (row < p.n) {
-      const double xi = x[row];
+      double xi = x[row];
+      if (FUSED) {
+        xi = xi / beta;
+        fa.q_out[row] = xi;
+        if (fa.qs_out) fa.qs_out[row] = f64_to_bf16(xi);
+      }
       double v = s0 + s1;
-      if (shift) v = __dsub_rn(v, __dmul_rn(s, xi));
+      if (!FUSED && shift) v = __dsub_rn(v, __dmul_rn(s, xi));
       y[row] = v;
       acc = fma(xi, v, acc);
     }
   }
   if (P) {
-    double tot = block_sum(acc, sm4);
+    __syncthreads();
+    double tot = block_sum(acc, sm5);
     if (threadIdx.x == 0) P[blockIdx.x] = tot;
   }
 }
 
 // 3-point stencil + diagonal (schrodinger1D.py:18-27)
+template <bool FUSED>
 __global__ __launch_bounds__(256) void k_spmv_stencil3(Stencil3Params p, const double* __restrict__ x,
                                                        double* __restrict__ y,
                                                        const double* __restrict__ shift,
                                                        const double* __restrict__ skip,
-                                                       double* __restrict__ P) {
-  __shared__ double sm4[4];
-  if (skip && skip[0] != 0.0) return;
+                                                       double* __restrict__ P, TfimFusedArgs fa) {
+  __shared__ double sm5[5];
+  if (!FUSED && skip && skip[0] != 0.0) return;
+  double beta = 1.0;
+  if (FUSED) {
+    beta = sqrt(sum_partials_block(fa.nP, fa.nCount, sm5));
+    if (blockIdx.x == 0 && threadIdx.x == 0) fa.beta_store[0] = beta;
+  }
   const double s = shift ? shift[0] : 0.0;
   double acc = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * 256) {
-    const double xi = x[i];
-    const double up = (i + 1 < p.n) ? x[i + 1] : (p.halo_hi ? p.halo_hi[0] : 0.0);
-    const double dn = (i > 0) ? x[i - 1] : (p.halo_lo ? p.halo_lo[0] : 0.0);
+    double xi = x[i];
+    double up = (i + 1 < p.n) ? x[i + 1] : (p.halo_hi ? p.halo_hi[0] : 0.0);
+    double dn = (i > 0) ? x[i - 1] : (p.halo_lo ? p.halo_lo[0] : 0.0);
+    if (FUSED) {  // the same divisions the separate scale kernel would have done: bit-identical q, u
+      xi = xi / beta;
+      if (i + 1 < p.n) up = up / beta;
+      if (i > 0) dn = dn / beta;
+      fa.q_out[i] = xi;
+      if (fa.qs_out) fa.qs_out[i] = f64_to_bf16(xi);
+    }
     const double lap = __dadd_rn(__dadd_rn(__dmul_rn(-2.0, xi), up), dn);
     double v = __dadd_rn(__dmul_rn(p.coef, lap), __dmul_rn(p.V[i], xi));
-    if (shift) v = __dsub_rn(v, __dmul_rn(s, xi));
+    if (!FUSED && shift) v = __dsub_rn(v, __dmul_rn(s, xi));
     y[i] = v;
     acc = fma(xi, v, acc);
   }
   if (P) {
-    double tot = block_sum(acc, sm4);
+    __syncthreads();
+    double tot = block_sum(acc, sm5);
     if (threadIdx.x == 0) P[blockIdx.x] = tot;
   }
 }
@@ -1463,7 +1499,8 @@ int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shif
       int64_t nb = (p.nslices + 3) / 4;
       if (nb > DSEA_MAX_TFIM_BLOCKS) nb = DSEA_MAX_TFIM_BLOCKS;
       if (nb < 1) nb = 1;
-      KLAUNCH(ev, k_spmv_sell, (unsigned)nb, 256, st, p, x, y, shift, skip, P);
+      TfimFusedArgs fa0 = {nullptr, 0, nullptr, nullptr, nullptr};
+      KLAUNCH(ev, (k_spmv_sell<false>), (unsigned)nb, 256, st, p, x, y, shift, skip, P, fa0);
       return (int)nb;
     }
     case OP_STENCIL3: {
@@ -1471,22 +1508,41 @@ int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shif
       int64_t nb = (p.n + 255) / 256;
       if (nb > DSEA_MAX_EW_BLOCKS) nb = DSEA_MAX_EW_BLOCKS;
       if (nb < 1) nb = 1;
-      KLAUNCH(ev, k_spmv_stencil3, (unsigned)nb, 256, st, p, x, y, shift, skip, P);
+      TfimFusedArgs fa0 = {nullptr, 0, nullptr, nullptr, nullptr};
+      KLAUNCH(ev, (k_spmv_stencil3<false>), (unsigned)nb, 256, st, p, x, y, shift, skip, P, fa0);
       return (int)nb;
     }
   }
   return -1;
 }
 
+// Fused Lanczos tail (beta from the ||r||^2 partials, q = r/beta -> Q[i] (+shadow), u = A q, alpha partials)
+// for the operator kinds that have one; returns the number of alpha partials or -1 (caller falls back to the
+// unfused sequence scale_store + mat-vec + finalize).
 int launch_tfim_fused(const OpDesc& op, const double* r, const double* nP, int nCount, double* q_out, double* y,
                       double* beta_store, double* P, hipStream_t st, EventPair* ev, uint16_t* qs_out) {
+  TfimFusedArgs fa = {nP, nCount, q_out, qs_out, beta_store};
+  const double* nullc = nullptr;
+  if (op.kind == OP_SELL) {
+    const SellParams& p = op.sell;
+    int64_t nb = (p.nslices + 3) / 4;
+    if (nb > DSEA_MAX_TFIM_BLOCKS) nb = DSEA_MAX_TFIM_BLOCKS;
+    KLAUNCH(ev, (k_spmv_sell<true>), (unsigned)nb, 256, st, p, r, y, nullc, nullc, P, fa);
+    return (int)nb;
+  }
+  if (op.kind == OP_STENCIL3) {
+    const Stencil3Params& p = op.st3;
+    int64_t nb = (p.n + 255) / 256;
+    if (nb > DSEA_MAX_EW_BLOCKS) nb = DSEA_MAX_EW_BLOCKS;
+    KLAUNCH(ev, (k_spmv_stencil3<true>), (unsigned)nb, 256, st, p, r, y, nullc, nullc, P, fa);
+    return (int)nb;
+  }
+  if (op.kind != OP_TFIM) return -1;
   const TfimParams& p = op.tfim;
   if (p.L_local == 0) return -1;  // callers use the unfused sequence for a 1-row slab
   const int T = p.L_local < g_tfim_tile_log2 ? p.L_local : g_tfim_tile_log2;
   int64_t nb = ((int64_t)1 << p.L_local) >> T;
   if (nb > DSEA_MAX_TFIM_BLOCKS) nb = DSEA_MAX_TFIM_BLOCKS;
-  TfimFusedArgs fa = {nP, nCount, q_out, qs_out, beta_store};
-  const double* nullc = nullptr;
 #define TFIM_FCASE(TT) \
   case TT: KLAUNCH(ev, (k_spmv_tfim<TT, true>), (unsigned)nb, 256, st, p, r, y, nullc, nullc, P, fa); break;
   switch (T) {
