@@ -80,3 +80,27 @@ def test_full_size_curves_against_reference_data(N, k, idxs):
         assert abs(d2e - curE["d2E0s"][idx]) < 2e-3 * abs(curE["d2E0s"][idx]), (N, g, d2e, curE["d2E0s"][idx])
         _, _, c = chi.chiF_sparseAD(model, k)
         assert abs(c - curC["chiFs"][idx]) < 2e-3 * abs(curC["chiFs"][idx]), (N, g, c, curC["chiFs"][idx])
+
+
+def test_vumps_example_on_device():
+    """BASELINE config 4 caller (reference examples/TFIM_vumps/general.py) on the device path: dense and
+    operator forms agree on the same tensor, and a short LBFGS run moves the variational energy towards the
+    reference's stored values (datas/E0_sum.npz: exact -1.27323954 at g = 1; datas/E0s_general/g_1.00.npz:
+    -1.27322273 at D = 5 after its 60 epochs)."""
+    ex = _load(os.path.join(ROOT, "examples", "TFIM_vumps", "general.py"), "ex_vumps")
+    exact = float(np.load(os.path.join(GOLDEN, "ref_datas", "vumps_E0_sum.npz"))["E0s"][4])
+    stored_D5 = float(np.load(os.path.join(GOLDEN, "ref_datas", "vumps_E0s_general_g_1.00.npz"))["E0s"][0])
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    model = ex.TFIM(8, 40, dev)
+    model.seth(1.0)
+    model.setparameters()
+    Ed = model.matrix_forward()
+    (gd,) = torch.autograd.grad(Ed, model.A)
+    Es = model.sparse_forward()
+    (gs,) = torch.autograd.grad(Es, model.A)
+    assert abs(Ed.item() - Es.item()) < 1e-10 * abs(Ed.item())
+    assert float((gd - gs).abs().max()) < 1e-7 * float(gd.abs().max())
+    torch.manual_seed(42)
+    E0, _ = ex.optimise(1.0, 5, 10, 8, dev, verbose=False)
+    assert exact - 1e-9 <= E0 < -1.2730, (E0, exact, stored_D5)
