@@ -148,3 +148,24 @@ def test_dense_float32_follows_input_dtype():
     assert gA.dtype == torch.float32 and torch.isfinite(gA).all()
     # Hellmann-Feynman: dlam/dA = psi psi^T
     assert float((gA.double() - torch.outer(V[:, 0], V[:, 0])).abs().max()) < 1e-3
+
+
+def test_runs_on_a_side_stream():
+    """Every library call takes the caller's current stream (include/dsea.h): results on a non-default stream
+    equal those on the default stream, and the work is really ordered on that stream."""
+    L, k = 12, 60
+    n = 1 << L
+    g = torch.tensor([1.0], dtype=F64, device=cuda)
+    op = TFIMOperator(L, cuda, g=g)
+    q0 = torch.from_numpy(normal_vector(n, 77)).to(cuda)
+    lo0, v0 = symeigLanczos(op, k, cuda, extreme="min", sparse=True, dim=n, q0=q0)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        lo1, v1 = symeigLanczos(op, k, cuda, extreme="min", sparse=True, dim=n, q0=q0)
+        b = v1 - torch.dot(v1, q0) / torch.dot(q0, q0) * q0
+        x = engine.cg(b - torch.dot(v1, b) * v1, torch.zeros_like(b), native=op, shift=lo1 - 1.0, eps=1e-10)
+    side.synchronize()
+    assert lo0.item() == lo1.item() and torch.equal(v0, v1)
+    res = op.H(x) - (lo1 - 1.0) * x - (b - torch.dot(v1, b) * v1)
+    assert float(res.norm()) < 1e-8
