@@ -492,6 +492,15 @@ int dsea_axpy_multi_dot(dsea_ws_t ws, double a_host, const double* a_dev, const 
   return check_launch();
 }
 
+int dsea_hypercube_flipsum(const double* xT, double* zT, int P, int64_t chunk, void* stream) {
+  REQUIRE(xT && zT && xT != zT && P >= 1 && chunk >= 1, DSEA_ERR_ARG);
+  int p = 0;
+  while ((1 << p) < P) ++p;
+  REQUIRE((1 << p) == P, DSEA_ERR_ARG);
+  launch_hypercube_flipsum(xT, zT, P, p, chunk, static_cast<hipStream_t>(stream));
+  return check_launch();
+}
+
 int dsea_plz_dots(dsea_ws_t ws, const double* Q, int64_t ldq, int64_t n, int i, const double* u,
                   const double* alpha, const double* beta, double* r, double* c_out, void* stream) {
   REQUIRE(ws && Q && u && alpha && r && c_out && n >= 1 && i >= 1 && ldq >= n, DSEA_ERR_ARG);

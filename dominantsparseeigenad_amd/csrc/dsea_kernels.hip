@@ -715,6 +715,23 @@ __global__ __launch_bounds__(256) void k_axpy_multi_dot(double a_host, const dou
   if (threadIdx.x == 0) P[blockIdx.x] = t;
 }
 
+// Transposed form of the hypercube exchange (row-partitioned TFIM, P = 2^p ranks): after an all-to-all the
+// buffer xT holds, for every source rank s, chunk number `me` of its slab.  Flipping top bit b of the global
+// row index maps source rank s to s ^ (1<<b), so the sum over the p top-bit flips is local here:
+//     zT[s][m] = sum_{b<p} xT[s ^ (1<<b)][m]
+// (a second all-to-all sends zT[s] back to rank s).
+__global__ __launch_bounds__(256) void k_hypercube_flipsum(const double* __restrict__ xT, double* __restrict__ zT,
+                                                           int P, int p, int64_t chunk) {
+  const int64_t total = (int64_t)P * chunk;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
+    const int64_t s = e / chunk, m = e - s * chunk;
+    double acc = 0.0;
+    for (int b = 0; b < p; ++b) acc += xT[(s ^ ((int64_t)1 << b)) * chunk + m];
+    zT[e] = acc;
+  }
+}
+
 // pair = [||r||^2, r.Ar] (global).  beta = sqrt(pair[0]) ; q = r/beta (+ bf16 shadow) ; u = y/beta ;
 // alpha = pair[1]/pair[0]  (= q.Aq by linearity of the mat-vec; Lanczos.py:69-75)
 __global__ __launch_bounds__(256) void k_plz_finish(const double* __restrict__ r, const double* __restrict__ y,
@@ -1576,6 +1593,13 @@ void launch_axpy_multi_dot(double a_host, const double* a_dev, const double* con
   const int nb = ew_blocks(n);
   hipLaunchKernelGGL(k_axpy_multi_dot, dim3(nb), dim3(256), 0, st, a_host, a_dev, ms, shift, skip, x, y, n, P);
   hipLaunchKernelGGL(k_cg_finalize_slot, dim3(1), dim3(256), 0, st, (const double*)P, nb, dot_out, skip);
+}
+
+void launch_hypercube_flipsum(const double* xT, double* zT, int P, int p, int64_t chunk, hipStream_t st) {
+  int64_t nb = ((int64_t)P * chunk + 255) / 256;
+  if (nb > DSEA_MAX_EW_BLOCKS) nb = DSEA_MAX_EW_BLOCKS;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(k_hypercube_flipsum, dim3((unsigned)nb), dim3(256), 0, st, xT, zT, P, p, chunk);
 }
 
 void launch_plz_finish(const double* r, const double* y, const double* pair, double* q, uint16_t* qs, double* u,

@@ -66,6 +66,10 @@ class HipBackend(_engine_mod.Phases):
         self._ck(self.lib.dsea_ws_set_shadow(self.ws.handle, None, 0, 0, 0.0), "dsea_ws_set_shadow")
         self._shadow = None
 
+    def flipsum(self, xT, zT, P):
+        self._ck(self.lib.dsea_hypercube_flipsum(self._p(xT), self._p(zT), int(P), xT.numel() // int(P), self._st()),
+                 "dsea_hypercube_flipsum")
+
     def plz_dots(self, Q, ldq, n, i, u, alpha, beta, r, c):
         self._ck(self.lib.dsea_plz_dots(self.ws.handle, self._p(Q), ldq, n, i, self._p(u), self._p(alpha),
                                         self._p(beta), self._p(r), self._p(c), self._st()), "dsea_plz_dots")
@@ -134,6 +138,22 @@ class TorchDistComm:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
 
+    def all_to_all(self, src, dst):
+        """chunk j of src goes to rank j, chunk j of dst comes from rank j (equal chunks; own chunk copied).
+        Written as one group of point-to-point operations (what RCCL's all-to-all is, too), so the same code
+        runs over gloo in the CPU tests."""
+        P, me = self.world, self.rank
+        chunk = src.numel() // P
+        dst[me * chunk:(me + 1) * chunk].copy_(src[me * chunk:(me + 1) * chunk])
+        ops = []
+        for j in range(P):
+            if j != me:
+                ops.append(dist.P2POp(dist.isend, src[j * chunk:(j + 1) * chunk], j, group=self.group))
+                ops.append(dist.P2POp(dist.irecv, dst[j * chunk:(j + 1) * chunk], j, group=self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
 
 # =========================================================================== the partitioned solver
 CG_RR, CG_DAD, CG_RRNEW, CG_ALPHA, CG_BETA, CG_RESNORM, CG_DONE, CG_ITERS = range(8)
@@ -164,8 +184,15 @@ class PartitionedTFIM:
         self.use_shadow = True
         self.last_cg_iters = 0
         self.last_cg_resnorm = float("nan")
-        self._recv = [self.be.empty(self.nloc) for _ in range(self.p)]
-        self._one = None
+        # top-bit flips: pairwise slab exchange for P = 2; from P = 4 on the transposed form -- all-to-all,
+        # local flip sum, all-to-all back -- which puts 1/P of a slab on each of the P-1 links per phase instead
+        # of a whole slab on log2(P) links (P = 8: a quarter of the transfer time)
+        self.transposed = self.world >= 4 and self.nloc >= self.world and hasattr(self.be, "flipsum")
+        if self.transposed:
+            self._xT, self._zT, self._z = self.be.empty(self.nloc), self.be.empty(self.nloc), self.be.empty(self.nloc)
+            self._recv = []
+        else:
+            self._recv = [self.be.empty(self.nloc) for _ in range(self.p)]
 
     # ---------------------------------------------------------------- collectives
     def _allreduce(self, t):
@@ -175,6 +202,11 @@ class PartitionedTFIM:
         """receive the slabs of the p hypercube partners (rank ^ (1<<b)); returns the list of buffers"""
         if self.p == 0:
             return []
+        if self.transposed:   # returns ONE buffer holding the sum over all partner slabs
+            self.comm.all_to_all(x, self._xT)
+            self.be.flipsum(self._xT, self._zT, self.world)
+            self.comm.all_to_all(self._zT, self._z)
+            return [self._z]
         self.comm.exchange(x, self._recv, [self.rank ^ (1 << b) for b in range(self.p)])
         return self._recv
 

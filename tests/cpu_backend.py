@@ -36,6 +36,16 @@ class CpuBackend:
         else:
             y.copy_(-s)
 
+    def flipsum(self, xT, zT, P):
+        chunk = xT.numel() // P
+        X = xT.view(P, chunk)
+        Z = torch.zeros_like(X)
+        b = 1
+        while b < P:
+            Z += X[[s ^ b for s in range(P)]]
+            b <<= 1
+        zT.copy_(Z.reshape(-1))
+
     def axpy(self, a_host, a_dev, x, y):
         a = a_host * (a_dev.reshape(-1)[0] if a_dev is not None else 1.0)
         y.add_(a * x)

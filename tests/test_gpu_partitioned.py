@@ -1,8 +1,9 @@
 """Row-partitioned driver on the real HIP backend.  The GPU box has one MI355X, so:
   * world_size 1 over "nccl" (= RCCL): the whole distributed code path with real kernels, against the
     single-GPU primitive;
-  * world_size 2, both ranks on cuda:0, collectives over gloo (RCCL refuses two ranks on one device): real
-    slab operators (L_local < L, row_offset != 0), real exchange + axpy of partner slabs, real phase kernels.
+  * world_size 2 and 4, all ranks on cuda:0, collectives over gloo (RCCL refuses two ranks on one device): real
+    slab operators (L_local < L, row_offset != 0), real phase kernels; 2 ranks = pairwise slab exchange,
+    4 ranks = transposed all-to-all form with the HIP flip-sum kernel.
 The 8-GPU run itself is the driver's; its logic is also covered by tests/test_partitioned_gloo.py."""
 import os
 import socket
@@ -46,6 +47,12 @@ def _host_staged_comm():
             for dst, src in zip(recv, hr):
                 dst.copy_(src)
 
+        def all_to_all(self, src, dst):
+            hs = src.cpu()
+            hd = torch.empty_like(hs)
+            super().all_to_all(hs, hd)
+            dst.copy_(hd)
+
     return HostStagedComm()
 
 
@@ -74,7 +81,7 @@ def _worker(rank, world, port, backend, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo")])
+@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (4, "gloo")])
 def test_partitioned_hip_backend(world, backend):
     assert torch.cuda.is_available()
     n = 1 << L

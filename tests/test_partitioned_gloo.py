@@ -1,4 +1,4 @@
-"""world_size 2 and 4 over gloo on CPU: the row-partitioned driver (partition, hypercube exchange, all-reduce
+"""world_size 2, 4 and 8 over gloo on CPU (2: pairwise slab exchange; 4, 8: transposed all-to-all form): the row-partitioned driver (partition, hypercube exchange, all-reduce
 placement, identical branch on all ranks) against the single-process CPU oracle.  The slab-local numerics
 come from a torch-CPU test double (tests/cpu_backend.py); on the GPU box the same driver runs on HipBackend."""
 import os
@@ -48,7 +48,7 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_partitioned_matches_single_process_oracle(world):
     n = 1 << L
     model = oracle.TFIMTables(L)
