@@ -183,10 +183,21 @@ def main():
         dist.all_reduce(nrm)
         tvec = tvec / nrm.sqrt()
         solver = partitioned.PartitionedTFIM(L, g, dev)
+        last = {}
 
         def step():
             E0, psi, gl = solver.forward_backward(k, draws[0], draws[2], tvec)
+            last["psi"] = psi
             return E0, gl
+
+        def eigen_residual(E0, psi):
+            """||H psi - E0 psi|| over all ranks: the self-check of the distributed run (outside the timed region)"""
+            w = torch.empty_like(psi)
+            solver.matvec(psi, w)
+            res = w - E0 * psi
+            nrm = res.dot(res).reshape(1)
+            dist.all_reduce(nrm)
+            return float(nrm.sqrt())
 
         def barrier():
             torch.cuda.synchronize()
@@ -200,6 +211,25 @@ def main():
     for _ in range(args.warmup):
         E0, gl = step()
     barrier()
+    overlap_note = None
+    if partitioned_path:
+        # the overlapped exchange is verified before anything is timed; if the eigen-residual is not at the
+        # level Lanczos with k vectors reaches on one GPU, the run falls back to the sequential exchange
+        resid = eigen_residual(E0, last["psi"])
+        if solver.transposed and solver.overlap:
+            solver.overlap = False
+            E0s, _ = step()
+            resid_seq = eigen_residual(E0s, last["psi"])
+            solver.overlap = True
+            if not (resid <= 10.0 * resid_seq + 1e-9):
+                solver.overlap = False
+                overlap_note = "overlapped exchange failed its self-check (residual %.2e vs %.2e sequential): " \
+                               "sequential exchange timed instead" % (resid, resid_seq)
+            else:
+                overlap_note = "overlapped exchange verified: eigen-residual %.2e (sequential %.2e)" % (resid, resid_seq)
+        else:
+            overlap_note = "eigen-residual %.2e" % resid
+        barrier()
     # ---- timed region: exactly K steps, no instrumentation inside
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -245,6 +275,8 @@ def main():
                        "E0_per_site": E0.item() / L, "E0_per_site_closed_form": analytic_E0_per_site(L, 1.0),
                        "dloss_dg": float(gl.reshape(-1)[0].item())},
         }
+        if overlap_note:
+            out["config"]["distributed_self_check"] = overlap_note
         if use_events and launches[0] > 0 and launches[1] > 0:
             dots_b, axpy_b = reorth_bytes_per_launch(nloc, k)
             per = {

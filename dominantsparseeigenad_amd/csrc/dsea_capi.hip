@@ -492,6 +492,18 @@ int dsea_axpy_multi_dot(dsea_ws_t ws, double a_host, const double* a_dev, const 
   return check_launch();
 }
 
+int dsea_lanczos_form_r(dsea_ws_t ws, const double* Q, int64_t ldq, int64_t n, int i, const double* u,
+                        const double* alpha, const double* beta, double* r, double* r_copy, void* stream) {
+  (void)ws;
+  REQUIRE(Q && u && alpha && r && n >= 1 && i >= 1 && ldq >= n, DSEA_ERR_ARG);
+  REQUIRE(aligned16(Q) && aligned16(u) && aligned16(r) && (!r_copy || aligned16(r_copy)) && (ldq % 2 == 0),
+          DSEA_ERR_ALIGN);
+  const double* q1 = Q + (int64_t)(i - 1) * ldq;
+  const double* q2 = (i >= 2) ? Q + (int64_t)(i - 2) * ldq : nullptr;
+  launch_form_r(u, q1, q2, alpha, beta, r, r_copy, n, static_cast<hipStream_t>(stream));
+  return check_launch();
+}
+
 int dsea_hypercube_flipsum(const double* xT, double* zT, int P, int64_t chunk, void* stream) {
   REQUIRE(xT && zT && xT != zT && P >= 1 && chunk >= 1, DSEA_ERR_ARG);
   int p = 0;

@@ -134,6 +134,8 @@ void launch_cg_direction(const double* r, double* d, const double* state, int64_
 void launch_axpy_multi_dot(double a_host, const double* a_dev, const double* const* xs, int count,
                            const double* shift, const double* skip, const double* x, double* y, int64_t n,
                            double* P, double* dot_out, hipStream_t st);
+void launch_form_r(const double* u, const double* q1, const double* q2, const double* alpha, const double* beta,
+                   double* r, double* r_copy, int64_t n, hipStream_t st);
 void launch_hypercube_flipsum(const double* xT, double* zT, int P, int p, int64_t chunk, hipStream_t st);
 void launch_plz_finish(const double* r, const double* y, const double* pair, double* q, uint16_t* qs, double* u,
                        double* alpha_out, double* beta_out, int64_t n, hipStream_t st);

@@ -715,6 +715,27 @@ __global__ __launch_bounds__(256) void k_axpy_multi_dot(double a_host, const dou
   if (threadIdx.x == 0) P[blockIdx.x] = t;
 }
 
+// r = u - alpha q1 - beta q2 (Lanczos.py:61) as a stand-alone pass, written twice: `r` (worked on in place by
+// the following dots / correction passes) and `r_copy` (a snapshot the overlapped slab exchange reads from)
+__global__ __launch_bounds__(256) void k_form_r(const double* __restrict__ u, const double* __restrict__ q1,
+                                                const double* __restrict__ q2, const double* __restrict__ alpha,
+                                                const double* __restrict__ beta, double* __restrict__ r,
+                                                double* __restrict__ r_copy, int64_t n) {
+  const double a = alpha[0];
+  const double b = (beta && q2) ? beta[0] : 0.0;
+  const int64_t stride = (int64_t)gridDim.x * 512;
+  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; row < n; row += stride) {
+    double2 uu = ld2<true>(u, row, n), qa = ld2<true>(q1, row, n);
+    double2 qb = make_double2(0.0, 0.0);
+    if (q2) qb = ld2<true>(q2, row, n);
+    double2 rv;
+    rv.x = __dsub_rn(__dsub_rn(uu.x, __dmul_rn(a, qa.x)), __dmul_rn(b, qb.x));
+    rv.y = __dsub_rn(__dsub_rn(uu.y, __dmul_rn(a, qa.y)), __dmul_rn(b, qb.y));
+    st2<true>(r, row, n, rv);
+    if (r_copy) st2<true>(r_copy, row, n, rv);
+  }
+}
+
 // Transposed form of the hypercube exchange (row-partitioned TFIM, P = 2^p ranks): after an all-to-all the
 // buffer xT holds, for every source rank s, chunk number `me` of its slab.  Flipping top bit b of the global
 // row index maps source rank s to s ^ (1<<b), so the sum over the p top-bit flips is local here:
@@ -1593,6 +1614,11 @@ void launch_axpy_multi_dot(double a_host, const double* a_dev, const double* con
   const int nb = ew_blocks(n);
   hipLaunchKernelGGL(k_axpy_multi_dot, dim3(nb), dim3(256), 0, st, a_host, a_dev, ms, shift, skip, x, y, n, P);
   hipLaunchKernelGGL(k_cg_finalize_slot, dim3(1), dim3(256), 0, st, (const double*)P, nb, dot_out, skip);
+}
+
+void launch_form_r(const double* u, const double* q1, const double* q2, const double* alpha, const double* beta,
+                   double* r, double* r_copy, int64_t n, hipStream_t st) {
+  hipLaunchKernelGGL(k_form_r, dim3(ew_blocks(n)), dim3(256), 0, st, u, q1, q2, alpha, beta, r, r_copy, n);
 }
 
 void launch_hypercube_flipsum(const double* xT, double* zT, int P, int p, int64_t chunk, hipStream_t st) {

@@ -66,6 +66,11 @@ class HipBackend(_engine_mod.Phases):
         self._ck(self.lib.dsea_ws_set_shadow(self.ws.handle, None, 0, 0, 0.0), "dsea_ws_set_shadow")
         self._shadow = None
 
+    def form_r(self, Q, ldq, n, i, u, alpha, beta, r, r_copy):
+        self._ck(self.lib.dsea_lanczos_form_r(self.ws.handle, self._p(Q), ldq, n, i, self._p(u), self._p(alpha),
+                                              self._p(beta), self._p(r), self._p(r_copy), self._st()),
+                 "dsea_lanczos_form_r")
+
     def flipsum(self, xT, zT, P):
         self._ck(self.lib.dsea_hypercube_flipsum(self._p(xT), self._p(zT), int(P), xT.numel() // int(P), self._st()),
                  "dsea_hypercube_flipsum")
@@ -123,6 +128,7 @@ class TorchDistComm:
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self._side = None
 
     def allreduce(self, t):
         if self.world > 1:
@@ -137,6 +143,33 @@ class TorchDistComm:
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+
+    def start_flip_exchange(self, be, x_send, xT, zT, z):
+        """z = sum over the top-bit partner slabs of x_send, in the transposed form (all-to-all, local flip sum,
+        all-to-all back), started NOW and left running: on a device the three stages are enqueued on a side
+        stream that waits for the producer of x_send, so they overlap whatever the caller enqueues next on its
+        own stream.  Returns a token for ``finish_flip_exchange``.  (Host tensors / gloo: done synchronously.)"""
+        if not x_send.is_cuda:
+            self.all_to_all(x_send, xT)
+            be.flipsum(xT, zT, self.world)
+            self.all_to_all(zT, z)
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=x_send.device)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(x_send.device))
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ready)
+            self.all_to_all(x_send, xT)
+            be.flipsum(xT, zT, self.world)
+            self.all_to_all(zT, z)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        return done
+
+    def finish_flip_exchange(self, token, device):
+        if token is not None:
+            torch.cuda.current_stream(device).wait_event(token)
 
     def all_to_all(self, src, dst):
         """chunk j of src goes to rank j, chunk j of dst comes from rank j (equal chunks; own chunk copied).
@@ -182,6 +215,11 @@ class PartitionedTFIM:
         self.eps = float(eps)
         self.poll_every = int(poll_every)
         self.use_shadow = True
+        # Overlap of the slab exchange with the dots / correction passes (transposed form only): the remote part
+        # of u = A r' is then taken from the UN-corrected r (its exchange starts before the coefficients c are
+        # known).  r - r' = Q c lies at the 1e-14 relative level per element (|c_j| <= ~1e-15 ||r||), i.e. at the
+        # level of the mat-vec's own rounding error; the local part uses the corrected r'.
+        self.overlap = True
         self.last_cg_iters = 0
         self.last_cg_resnorm = float("nan")
         # top-bit flips: pairwise slab exchange for P = 2; from P = 4 on the transposed form -- all-to-all,
@@ -247,12 +285,30 @@ class PartitionedTFIM:
         if use_shadow:
             be.set_shadow(k, ldq)
         try:
+            overlap = self.transposed and self.overlap and hasattr(be, "form_r")
+            zero = be.zeros(1)
+            r_send = be.empty(n) if overlap else None
             for i in range(k):
-                if i >= 1:
-                    be.plz_dots(Q, ldq, n, i, u, alphas[i - 1:i], betas[i - 2:i - 1] if i >= 2 else None, r, c)
-                    self._allreduce(c[:i + 1])
-                be.plz_correct_matvec(Q, ldq, i, c, r, y, pair)
-                recv = self._exchange(r)
+                token = None
+                if overlap:
+                    # the exchange of the (un-corrected) r runs behind the dots and correction passes
+                    if i >= 1:
+                        be.form_r(Q, ldq, n, i, u, alphas[i - 1:i], betas[i - 2:i - 1] if i >= 2 else None, r, r_send)
+                    else:
+                        r_send.copy_(r)
+                    token = self.comm.start_flip_exchange(be, r_send, self._xT, self._zT, self._z)
+                    if i >= 1:
+                        be.plz_dots(Q, ldq, n, i, r, zero, None, r, c)        # alpha = 0: r stays, c = Q^T r, c[i] = r.r
+                        self._allreduce(c[:i + 1])
+                    be.plz_correct_matvec(Q, ldq, i, c, r, y, pair)
+                    self.comm.finish_flip_exchange(token, self.device)
+                    recv = [self._z]
+                else:
+                    if i >= 1:
+                        be.plz_dots(Q, ldq, n, i, u, alphas[i - 1:i], betas[i - 2:i - 1] if i >= 2 else None, r, c)
+                        self._allreduce(c[:i + 1])
+                    be.plz_correct_matvec(Q, ldq, i, c, r, y, pair)
+                    recv = self._exchange(r)
                 be.axpy_multi_dot(-1.0, self.g.detach(), recv, None, None, r, y, pair[1:2])
                 self._allreduce(pair)
                 be.plz_finish(r, y, pair, Q[i], i, u, alphas[i:i + 1], betas[i - 1:i] if i >= 1 else None)

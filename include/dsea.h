@@ -217,6 +217,11 @@ int dsea_cg_direction(dsea_ws_t ws, const double *r, double *d, const double *st
  * i.e. two latency-bound all-reduces and one slab exchange per step.  The mat-vec is applied to the
  * un-normalised r (linearity): beta = sqrt(pair[0]), alpha = pair[1]/pair[0], q = r/beta, u = (A r)/beta.   */
 
+/* r = u - (*alpha) Q[i-1] - (*beta) Q[i-2] (Lanczos.py:61) as a stand-alone pass; r_copy (nullable) receives a
+ * second copy -- the snapshot an overlapped slab exchange sends while r is corrected in place.            */
+int dsea_lanczos_form_r(dsea_ws_t ws, const double *Q, int64_t ldq, int64_t n, int i, const double *u,
+                        const double *alpha, const double *beta, double *r, double *r_copy, void *stream);
+
 /* Top-bit flips of the row-partitioned TFIM mat-vec in TRANSPOSED form (P = 2^p ranks, P >= 4): the caller
  * all-to-alls its slab (chunk c of every rank's slab goes to rank c), calls this on the received buffer
  * xT[P][chunk]:  zT[s][m] = sum_{b<p} xT[s ^ (1<<b)][m],  and all-to-alls zT back (zT[s] to rank s).  Every

@@ -36,6 +36,11 @@ class CpuBackend:
         else:
             y.copy_(-s)
 
+    def form_r(self, Q, ldq, n, i, u, alpha, beta, r, r_copy):
+        r.copy_(u - alpha[0] * Q[i - 1, :n] - (beta[0] * Q[i - 2, :n] if (beta is not None and i >= 2) else 0.0))
+        if r_copy is not None:
+            r_copy.copy_(r)
+
     def flipsum(self, xT, zT, P):
         chunk = xT.numel() // P
         X = xT.view(P, chunk)
