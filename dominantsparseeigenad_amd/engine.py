@@ -34,6 +34,9 @@ def _ptr(t):
 
 def as_vector(t, n=None):
     """contiguous, fp64, 16-byte aligned device vector (copies only when it has to)."""
+    if not t.is_cuda:
+        raise ValueError("the HIP path was selected (device='cuda') but got a %s tensor; operator, parameters and "
+                         "vectors must live on the same GPU (as in the reference, Lanczos.py:49-52)" % t.device)
     if t.dtype != F64:
         t = t.to(F64)
     if not t.is_contiguous():

@@ -169,3 +169,11 @@ def test_runs_on_a_side_stream():
     assert lo0.item() == lo1.item() and torch.equal(v0, v1)
     res = op.H(x) - (lo1 - 1.0) * x - (b - torch.dot(v1, b) * v1)
     assert float(res.norm()) < 1e-8
+
+
+def test_mixed_devices_fail_loudly():
+    """device='cuda' with a host matrix: no silent host computation, no device fault -- a clear error."""
+    A = torch.randn(50, 50, dtype=F64)
+    A = A + A.T
+    with pytest.raises((ValueError, RuntimeError)):
+        symeigLanczos(A, 10, cuda)
