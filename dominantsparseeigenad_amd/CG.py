@@ -80,6 +80,31 @@ class CGSubspace(torch.autograd.Function):
         return grad_A, grad_b, grad_alpha
 
 
+class CGSubspaceShifted(torch.autograd.Function):
+    """(A - E0 I) x = b, alpha.x = 0 for a DENSE symmetric tensor A without materialising A - E0 I (the
+    reference builds it with ``torch.eye``, symeig.py:25: two extra n x n tensors).  Same structure as the
+    matrix-free primitive (CG.py:119-138) with the outer product as the adjoint map:
+    backward returns (-bbar x^T, bbar.x, bbar, -x (alpha.xbar))."""
+
+    @staticmethod
+    def forward(ctx, A, E0, b, alpha):
+        initialx = torch.randn(b.shape[0], device=b.device, dtype=b.dtype)        # CG.py:58
+        initialx = _project(initialx, alpha.detach())
+        x = _solve(A.detach(), b.detach(), initialx, False, shift=E0.detach())
+        ctx.save_for_backward(A, E0, alpha, x)
+        return x
+
+    @staticmethod
+    def backward(ctx, grad_x):
+        A, E0, alpha, x = ctx.saved_tensors
+        b = _project(grad_x, alpha)
+        grad_b = CGSubspaceShifted.apply(A, E0, b, alpha)
+        grad_A = -grad_b[:, None] * x                                            # CG.py:69
+        grad_E0 = torch.matmul(grad_b, x)                                        # CG.py:136 with v1 = -grad_b
+        grad_alpha = -x * torch.matmul(alpha, grad_x)
+        return grad_A, grad_E0, grad_b, grad_alpha
+
+
 def _make_sparse_cg(A, Aadjoint_to_gadjoint):
     class CGSubspaceSparse(torch.autograd.Function):
         """(A - E0 I) x = b, alpha.x = 0 with A matrix-free; inputs (g, E0, b, alpha) (CG.py:119-138)."""

@@ -32,9 +32,13 @@ class DominantSymeig(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_eigval, grad_eigvector):
         A, eigval, eigvector = ctx.saved_tensors
-        Aprime = A - eigval * torch.eye(A.shape[0], device=A.device, dtype=A.dtype)      # symeig.py:25
         b = grad_eigvector - torch.matmul(eigvector, grad_eigvector) * eigvector         # symeig.py:27
-        lambda0 = _CG.CGSubspace.apply(Aprime, b, eigvector)                             # symeig.py:28
+        if A.is_cuda:
+            # the shift is applied inside the CG kernels: no A - lambda*I copy, no n x n identity (symeig.py:25)
+            lambda0 = _CG.CGSubspaceShifted.apply(A, eigval, b, eigvector)
+        else:
+            Aprime = A - eigval * torch.eye(A.shape[0], device=A.device, dtype=A.dtype)  # symeig.py:25
+            lambda0 = _CG.CGSubspace.apply(Aprime, b, eigvector)                         # symeig.py:28
         grad_A = (grad_eigval * eigvector - lambda0)[:, None] * eigvector                # symeig.py:29
         return grad_A, None, None
 

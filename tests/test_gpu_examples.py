@@ -104,3 +104,20 @@ def test_vumps_example_on_device():
     torch.manual_seed(42)
     E0, _ = ex.optimise(1.0, 5, 10, 8, dev, verbose=False)
     assert exact - 1e-9 <= E0 < -1.2730, (E0, exact, stored_D5)
+
+
+def test_dense_primitive_second_order_on_device():
+    """DominantSymeig on the dense Hamiltonian tensor on the GPU (reference E0.py:38-51, E0_matrixAD): first and
+    second derivative through the shift-in-kernel projected CG (no A - lambda*I copy) against the closed form."""
+    E0 = _load(os.path.join(ROOT, "examples", "TFIM", "E0.py"), "ex_E0_dense")
+    dev = torch.device("cuda:0")
+    model = E0.TFIM(8, dev)
+    torch.manual_seed(2)
+    for g in (0.8, 1.0, 1.3):
+        model.g = torch.tensor([g], dtype=torch.float64, device=dev, requires_grad=True)
+        model.setHmatrix()
+        e, de, d2e = E0.E0_matrixAD(model, 200)
+        ea, dea, d2ea = E0.E0_analytic(model)
+        assert abs(e - ea) < 1e-10 * abs(ea)
+        assert abs(de - dea) < 1e-6 * abs(dea)
+        assert abs(d2e - d2ea) < 1e-5 * abs(d2ea), (g, d2e, d2ea)
