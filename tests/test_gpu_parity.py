@@ -449,3 +449,36 @@ def test_csr_layouts_ragged_and_native_lanczos():
     _, T1 = Lanczos(tf, k, dev(), sparse=True, dim=1 << L, q0=q0)
     _, T2 = Lanczos(tf.to_csr(), k, dev(), sparse=True, dim=1 << L, q0=q0)
     assert float((T1 - T2).abs().max()) <= 1e-10 * float(T1.abs().max())
+
+
+def test_full_size_properties_L20():
+    """BASELINE configs[1] at full size (n = 2^20, k = 200) through size-independent properties:
+    symmetry of the mat-vec, orthonormality of the whole basis, the Lanczos relation
+    A Q_k = Q_k T + beta_k q_{k+1} e_k^T on its leading columns, the eigen-residual of the Ritz pair, and the
+    adjoint system solved by CG to its stopping tolerance with the solution orthogonal to psi."""
+    L, k = 20, 200
+    n = 1 << L
+    g = torch.tensor([1.0], dtype=F64, device=dev())
+    op = TFIMOperator(L, dev(), g=g)
+    x = torch.from_numpy(normal_vector(n, 9400)).to(dev())
+    y = torch.from_numpy(normal_vector(n, 9401)).to(dev())
+    a, b = float(y @ op.H(x)), float(x @ op.H(y))
+    assert abs(a - b) <= 1e-12 * max(abs(a), 1.0)                       # <y, Hx> = <Hy, x>
+    lin = op.H(2.0 * x - 0.5 * y) - (2.0 * op.H(x) - 0.5 * op.H(y))
+    assert float(lin.abs().max()) <= 1e-11                               # linearity
+    q0 = torch.from_numpy(normal_vector(n, 9402)).to(dev())
+    Qk, T = Lanczos(op, k, dev(), sparse=True, dim=n, q0=q0)
+    G = Qk.T @ Qk
+    assert float((G - torch.eye(k, dtype=F64, device=dev())).abs().max()) < 1e-13
+    for j in (0, 1, 57, 120, 198):                                       # A q_j = beta_{j-1} q_{j-1} + alpha_j q_j + beta_j q_{j+1}
+        lhs = op.H(Qk[:, j].contiguous())
+        rhs = T[j, j] * Qk[:, j] + T[j + 1, j] * Qk[:, j + 1] + (T[j - 1, j] * Qk[:, j - 1] if j > 0 else 0.0)
+        assert float((lhs - rhs).norm()) < 1e-12 * float(T.abs().max())
+    lam, psi = symeigLanczos(op, k, dev(), extreme="min", sparse=True, dim=n, q0=q0)
+    assert float((op.H(psi) - lam * psi).norm()) < 1e-11
+    rhs = y - (psi @ y) * psi
+    x0 = x - (psi @ x) * psi
+    sol = engine.cg(rhs, x0, native=op, shift=lam, eps=1e-7)
+    assert engine.last_cg.converged and 40 < engine.last_cg.iters < 400
+    assert float((op.H(sol) - lam * sol - rhs).norm()) < 1e-6            # CG.py:25 stopping rule, recursive residual
+    assert abs(float(sol @ psi)) < 1e-8                                  # stays in the complement of psi
