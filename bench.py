@@ -98,11 +98,20 @@ def cpu_baseline(L, k_sample, cg_cap):
     dt = time.time() - t0
     m = stats[0]["iters"]
     gbs = algorithmic_bytes(n, k_sample, m) / dt / 1e9
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {
         "value": round(gbs, 3), "unit": "GB/s", "cores": torch.get_num_threads(), "kind": "port",
         "sample": "oracle (torch-CPU port of reference Lanczos.py/CG.py/TFIM.H), TFIM L=%d, k=%d Lanczos vectors, "
-                  "CG capped at %d iterations (ran %d), fwd+bwd %.1f s, table build %.1f s not timed"
-                  % (L, k_sample, cg_cap, m, dt, t_init),
+                  "CG capped at %d iterations (ran %d), fwd+bwd %.1f s, table build %.1f s not timed; host: %s, "
+                  "os.cpu_count()=%d, torch threads=%d"
+                  % (L, k_sample, cg_cap, m, dt, t_init, cpu_model, os.cpu_count() or 0, torch.get_num_threads()),
     }
 
 
@@ -118,6 +127,9 @@ def main():
     ap.add_argument("--cpu-cg-cap", type=int, default=60)
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--rpl", type=int, default=0)
+    ap.add_argument("--operator", choices=["matrix-free", "sell", "csr"], default="matrix-free",
+                    help="operand form of the TFIM operator at N=1: native matrix-free kernel (headline) or the "
+                         "explicit 21-nnz/row matrix in SELL-64 / CSR layout")
     ap.add_argument("--force-partitioned", action="store_true",
                     help="run the row-partitioned driver even with one rank (measures its host overhead)")
     args = ap.parse_args()
@@ -159,7 +171,10 @@ def main():
         tvec = tvec / tvec.norm()
         op = TFIMOperator(L, dev)
         op.g = g
-        symeig.setDominantSparseSymeig(op.H, op.Hadjoint_to_gadjoint)
+        A_operand = op.H
+        if args.operator != "matrix-free":
+            A_operand = op.to_csr(layout=args.operator)      # explicit matrix (values fixed at the current g)
+        symeig.setDominantSparseSymeig(A_operand, op.Hadjoint_to_gadjoint)
         f = symeig.DominantSparseSymeig.apply
 
         def step():
@@ -269,7 +284,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "TFIM L=%d (n=2^%d, %d rows/GPU) DominantSparseSymeig k=%d fwd+bwd, g=1.0, "
-                                   "loss=E0+psi.t" % (L, L, nloc, k),
+                                   "loss=E0+psi.t, operand=%s" % (L, L, nloc, k, args.operator),
                        "cg_iterations": int(m), "algorithmic_bytes_per_step": total_bytes,
                        "frac_of_hbm_peak_whole_step": round(value / (HBM_PEAK_GBS * world), 4),
                        "E0_per_site": E0.item() / L, "E0_per_site_closed_form": analytic_E0_per_site(L, 1.0),
