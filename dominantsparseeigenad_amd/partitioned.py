@@ -173,9 +173,14 @@ class TorchDistComm:
 
     def all_to_all(self, src, dst):
         """chunk j of src goes to rank j, chunk j of dst comes from rank j (equal chunks; own chunk copied).
-        Written as one group of point-to-point operations (what RCCL's all-to-all is, too), so the same code
-        runs over gloo in the CPU tests."""
+        Over RCCL this is ``all_to_all_single``; elsewhere (gloo in the CPU tests) the same exchange is written
+        as one group of point-to-point operations, which is what an all-to-all is."""
         P, me = self.world, self.rank
+        if src.is_cuda and dist.get_backend(self.group) == "nccl":
+            # RCCL: one call (a Python-level group of 2(P-1) point-to-point ops costs more host time per step
+            # than the whole step takes on the device)
+            dist.all_to_all_single(dst, src, group=self.group)
+            return
         chunk = src.numel() // P
         dst[me * chunk:(me + 1) * chunk].copy_(src[me * chunk:(me + 1) * chunk])
         ops = []
