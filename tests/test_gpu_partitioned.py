@@ -75,6 +75,11 @@ def _worker(rank, world, port, backend, ret):
         x0 = torch.from_numpy(normal_vector(nloc, 5102, offset=off)).to(dev)
         t = torch.from_numpy(normal_vector(nloc, 5103, offset=off)).to(dev)
         E0, psi, grad = solver.forward_backward(K, q0, x0, t)
+        if backend == "nccl":   # the RCCL all-to-all call itself (degenerate at world size 1: a copy)
+            src = torch.arange(1024, dtype=torch.float64, device=dev)
+            dst = torch.zeros_like(src)
+            solver.comm.all_to_all(src, dst)
+            assert torch.equal(src, dst)
         torch.cuda.synchronize()
         ret[rank] = (E0.item(), psi.cpu().numpy().copy(), grad.item(), solver.last_cg_iters)  # by value, not shm
     finally:
