@@ -223,6 +223,16 @@ def main():
     if args.rpl:
         ws.set_rows_per_lane(args.rpl)
 
+    fallback_note = None
+    if partitioned_path and solver.transposed:
+        # first contact with the collectives of this stack: if the transposed all-to-all form raises, every rank
+        # raises alike, and all switch to the pairwise slab exchange
+        try:
+            E0, gl = step()
+        except Exception as exc:  # noqa: BLE001
+            fallback_note = "transposed exchange unavailable (%s: %s): pairwise slab exchange used" % (
+                type(exc).__name__, str(exc)[:120])
+            solver.use_pairwise_exchange()
     for _ in range(args.warmup):
         E0, gl = step()
     barrier()
@@ -292,6 +302,8 @@ def main():
         }
         if overlap_note:
             out["config"]["distributed_self_check"] = overlap_note
+        if fallback_note:
+            out["config"]["distributed_fallback"] = fallback_note
         if use_events and launches[0] > 0 and launches[1] > 0:
             dots_b, axpy_b = reorth_bytes_per_launch(nloc, k)
             per = {

@@ -237,6 +237,12 @@ class PartitionedTFIM:
         else:
             self._recv = [self.be.empty(self.nloc) for _ in range(self.p)]
 
+    def use_pairwise_exchange(self):
+        """switch to the pairwise hypercube exchange (one full slab per partner), e.g. if the transposed form is
+        unavailable on some stack"""
+        self.transposed = False
+        self._recv = [self.be.empty(self.nloc) for _ in range(self.p)]
+
     # ---------------------------------------------------------------- collectives
     def _allreduce(self, t):
         self.comm.allreduce(t)
