@@ -95,8 +95,12 @@ def arnoldi_dominant(matvec, n, ncv, device, which="LM", v0=None, tol=1e-13, max
     return float(theta.real), x
 
 
-def gmres(matvec, b, rtol=1e-12, atol=1e-12, restart=20, maxiter=None):
-    """Restarted GMRES from x0 = 0; stops when ||b - A x|| <= max(rtol ||b||, atol) (scipy's rule)."""
+def gmres(matvec, b, rtol=1e-12, atol=1e-12, restart=20, maxiter=None, check_every=5):
+    """Restarted GMRES from x0 = 0; stops when ||b - A x|| <= max(rtol ||b||, atol) (scipy's rule).
+
+    The Hessenberg columns stay on the device; the host pulls them (one small D2H copy = one sync) only every
+    ``check_every`` inner steps to advance the Givens rotations and test the residual, instead of after every
+    step -- the vectors here are small (2 MB at D = 512) and each step is latency-bound."""
     device, n = b.device, b.numel()
     b = engine.as_vector(b, n)
     restart = int(min(restart, n))
@@ -105,11 +109,14 @@ def gmres(matvec, b, rtol=1e-12, atol=1e-12, restart=20, maxiter=None):
     V = ph.empty(restart + 1, ldq)
     zero, nrm2 = ph.zeros(1), ph.zeros(1)
     bufs = (ph.empty(n), ph.empty(n), ph.zeros(restart + 2), ph.zeros(restart + 2), ph.zeros(1))
+    Hdev = ph.zeros(restart, restart + 1)          # row j = column j of the Hessenberg matrix
     x = ph.zeros(n)
     target = max(rtol * float(b.norm()), atol)
     cycles = 10 * n if maxiter is None else int(maxiter)
+    first = True
     for _ in range(cycles):
-        r = b - engine.as_vector(matvec(x), n) if float(x.abs().max()) > 0 else b.clone()
+        r = b.clone() if first else b - engine.as_vector(matvec(x), n)
+        first = False
         beta = float(r.norm())
         if beta <= target:
             break
@@ -119,24 +126,33 @@ def gmres(matvec, b, rtol=1e-12, atol=1e-12, restart=20, maxiter=None):
         cs, sn = np.zeros(restart), np.zeros(restart)
         gvec = np.zeros(restart + 1)
         gvec[0] = beta
-        m = 0
+        m, done_cols, converged = 0, 0, False
+        Hdev.zero_()
         for j in range(restart):
             w = engine.as_vector(matvec(V[j, :n]), n)
             h, w_orth, wn2 = _cgs2(ph, V, ldq, n, j, w, zero, bufs)
-            col = torch.cat((h, wn2.sqrt())).cpu().numpy()           # the one host round trip of the step
-            ph.scale_store(w_orth, wn2, V[j + 1], None)
-            for t in range(j):                                        # previous rotations
-                a, c2 = col[t], col[t + 1]
-                col[t], col[t + 1] = cs[t] * a + sn[t] * c2, -sn[t] * a + cs[t] * c2
-            rho = np.hypot(col[j], col[j + 1])
-            cs[j], sn[j] = (1.0, 0.0) if rho == 0.0 else (col[j] / rho, col[j + 1] / rho)
-            col[j], col[j + 1] = rho, 0.0
-            Hm[: j + 2, j] = col[: j + 2]
-            gvec[j + 1] = -sn[j] * gvec[j]
-            gvec[j] = cs[j] * gvec[j]
+            Hdev[j, : j + 1] = h
+            ph.scale_store(w_orth, wn2, V[j + 1], Hdev[j, j + 1: j + 2])
             m = j + 1
-            if abs(gvec[j + 1]) <= target:
-                break
+            if m % check_every == 0 or m == restart:
+                cols = Hdev[done_cols:m].cpu().numpy()                  # the host round trip
+                for jj in range(done_cols, m):
+                    col = cols[jj - done_cols, : jj + 2].copy()
+                    for t in range(jj):                                  # previous rotations
+                        a, c2 = col[t], col[t + 1]
+                        col[t], col[t + 1] = cs[t] * a + sn[t] * c2, -sn[t] * a + cs[t] * c2
+                    rho = np.hypot(col[jj], col[jj + 1])
+                    cs[jj], sn[jj] = (1.0, 0.0) if rho == 0.0 else (col[jj] / rho, col[jj + 1] / rho)
+                    col[jj], col[jj + 1] = rho, 0.0
+                    Hm[: jj + 2, jj] = col
+                    gvec[jj + 1] = -sn[jj] * gvec[jj]
+                    gvec[jj] = cs[jj] * gvec[jj]
+                    if abs(gvec[jj + 1]) <= target:
+                        m, converged = jj + 1, True
+                        break
+                done_cols = m
+                if converged:
+                    break
         yv = np.linalg.solve(np.triu(Hm[:m, :m]), gvec[:m])
         dx = ph.empty(n)
         ph.ritz(V, ldq, n, m, torch.from_numpy(np.ascontiguousarray(yv)).to(device), dx)
