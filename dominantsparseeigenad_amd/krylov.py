@@ -3,10 +3,10 @@ reference delegates to SciPy on the host -- ARPACK ``eigs(A, k=1, which, ncv=k)`
 116-117) and ``gmres(A - lambda I, b, tol=1e-12, atol=1e-12)`` (eig.py:52-57,137-144) -- restated on GPU
 vectors with the same HIP phase kernels the Lanczos path uses for its orthogonalisation:
 
-    arnoldi_dominant   explicitly restarted Arnoldi, ncv basis vectors, classical Gram-Schmidt applied twice
-                       (CGS2 = the dots / correction kernel pair, two rounds), Hessenberg eigen-solve on the
-                       host (ncv x ncv), restart from the wanted Ritz vector until the residual estimate
-                       |h_{m+1,m} e_m^T y| is at rounding level
+    arnoldi_dominant   explicitly restarted Arnoldi, ncv basis vectors, classical Gram-Schmidt on the dots /
+                       correction kernel pair with a second round when the DGKS test asks for it (ARPACK's
+                       rule), Hessenberg eigen-solve on the host (ncv x ncv), restart from the wanted Ritz
+                       vector until the residual estimate |h_{m+1,m} e_m^T y| is at rounding level
     gmres              restarted GMRES(20) with the same orthogonalisation, Givens rotations on the host
 
 ARPACK's implicitly restarted method and this explicitly restarted one converge to the same eigenpair
@@ -46,6 +46,22 @@ def _cgs2(ph, V, ldq, n, j, w, zero, bufs):
     return h1[:i] + h2[:i], w2, nrm2
 
 
+def _cgs_dgks(ph, V, ldq, n, j, w, zero, bufs):
+    """Classical Gram-Schmidt with the second round only when the DGKS test asks for it (what ARPACK does):
+    re-orthogonalise iff ||w - V V^T w||^2 < 1/2 ||w||^2.  The test needs two scalars on the host (one small
+    D2H copy per step); for long bases it saves a full dots + correction pass on almost every step."""
+    w1, w2, h1, h2, nrm2 = bufs
+    i = j + 1
+    ph.rdots(V, ldq, n, i, w, zero, None, w1, h1)        # w1 = w, h1 = V^T w, h1[i] = w.w
+    ph.axpy_norm(V, ldq, n, i, h1, w1, nrm2)             # w1 -= V h1, nrm2 = ||w1||^2
+    before, after = torch.stack((h1[i], nrm2[0])).tolist()
+    if after >= 0.5 * before:
+        return h1[:i], w1, nrm2
+    ph.rdots(V, ldq, n, i, w1, zero, None, w2, h2)
+    ph.axpy_norm(V, ldq, n, i, h2, w2, nrm2)
+    return h1[:i] + h2[:i], w2, nrm2
+
+
 def arnoldi_dominant(matvec, n, ncv, device, which="LM", v0=None, tol=1e-13, max_restarts=60):
     """Wanted eigenvalue (real, asserted as in eig.py:31-32) and unit-norm eigenvector of a real matrix
     given by ``matvec`` (torch device vector -> torch device vector)."""
@@ -66,7 +82,7 @@ def arnoldi_dominant(matvec, n, ncv, device, which="LM", v0=None, tol=1e-13, max
         H.zero_()
         for j in range(ncv):
             w = engine.as_vector(matvec(V[j, :n]), n)
-            h, w_orth, wn2 = _cgs2(ph, V, ldq, n, j, w, zero, bufs)
+            h, w_orth, wn2 = _cgs_dgks(ph, V, ldq, n, j, w, zero, bufs)
             H[: j + 1, j] = h
             ph.scale_store(w_orth, wn2, V[j + 1], H[j + 1, j: j + 1])
         Hh = H.cpu().numpy()
