@@ -78,6 +78,8 @@ class TFIMOperator:
         self.device = torch.device(device if device is not None else "cuda")
         if self.device.type != "cuda":
             raise ValueError("TFIMOperator is a device operator; use device='cuda'")
+        if self.device.index is None:   # "cuda" -> "cuda:<current>", so that tensors on the device compare equal
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self._g = None
         self._H = None
         lib = _lib.load()
