@@ -1,0 +1,42 @@
+"""bench.py contract on a small workload: ONE JSON line as the last line of stdout, the required keys, the roofline
+and cpu_baseline objects, and the row-partitioned code path (one rank over RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+from conftest import ROOT  # noqa: E402
+
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config"}
+
+
+def _run(extra):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--L-local", "14", "--k", "48", "--steps", "2",
+           "--warmup", "1", "--cpu-k", "8", "--cpu-cg-cap", "5"] + extra
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.strip()]
+    return json.loads(lines[-1])          # the JSON line must be the LAST line
+
+
+def test_bench_line_single_gpu():
+    d = _run([])
+    assert REQUIRED <= set(d) and d["n_gpus"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and "workload" in d["config"]
+    assert abs(d["config"]["E0_per_site"] - d["config"]["E0_per_site_closed_form"]) < 1e-9
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+
+
+def test_bench_line_partitioned_path():
+    d = _run(["--force-partitioned", "--no-cpu-baseline"])
+    assert REQUIRED <= set(d) and d["scaling"] == "weak"
+    assert "distributed_self_check" in d["config"]
+    assert abs(d["config"]["E0_per_site"] - d["config"]["E0_per_site_closed_form"]) < 1e-9
