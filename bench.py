@@ -38,8 +38,11 @@ def algorithmic_bytes(n, k, m):
 
 
 def analytic_E0_per_site(L, g):
-    """closed form of reference examples/TFIM/E0.py:15-18 (sanity value printed next to the measured one)"""
-    ks = np.linspace(-(L - 1) / 2, (L - 1) / 2, num=L) / L * 2 * np.pi
+    """Closed-form ground-state energy per site of the periodic chain (sanity value printed next to the measured
+    one): free fermions with the momenta of the even-parity sector, k = (2m+1) pi / L.  For even L this is the set
+    used by reference examples/TFIM/E0.py:15-18; for odd L (the N = 2 and N = 8 weak-scaling points) the
+    reference's linspace would pick integer momenta, which is not the ground-state sector."""
+    ks = (2 * np.arange(L) + 1) * np.pi / L
     return float(-0.5 * (2 * np.sqrt(g * g - 2 * g * np.cos(ks) + 1)).sum() / L)
 
 
