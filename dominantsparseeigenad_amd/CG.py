@@ -22,6 +22,7 @@ import torch
 
 from . import engine
 from ._cpu_plumbing import cg_host
+from ._space import LOCAL, space_of
 
 EPS_DEFAULT = 1e-7   # CG.py:25; module-level so that the autograd primitives (whose ``apply`` signature is
                      # fixed by the reference API) can be run at a tighter tolerance: ``CG.EPS_DEFAULT = 1e-13``
@@ -30,6 +31,11 @@ EPS_DEFAULT = 1e-7   # CG.py:25; module-level so that the autograd primitives (w
 def _solve(A, b, initialx, sparse, shift=None, eps=None, maxiter=None):
     n = b.shape[0]
     eps = EPS_DEFAULT if eps is None else eps   # read at call time: tests / users may tighten it
+    part = engine.native_of(A) if sparse else None
+    if part is not None and getattr(part, "partitioned", False):
+        # row-partitioned operator: b, initialx are slabs; iteration cap = the GLOBAL dimension (CG.py:32)
+        x0 = initialx.detach().to(torch.float64).contiguous().clone()
+        return part.solve_shifted(shift, b.detach().to(torch.float64).contiguous(), x0, eps=eps, maxiter=maxiter)
     cap = n if maxiter is None else int(maxiter)
     if b.is_cuda:
         if b.dtype == torch.float32 and not sparse:
@@ -54,8 +60,8 @@ def CG_torch(A, b, initialx, sparse=False, *, eps=None, maxiter=None):
     return _solve(A, b.detach(), initialx.detach(), sparse, eps=eps, maxiter=maxiter)
 
 
-def _project(v, unit):
-    return v - torch.matmul(unit, v) * unit
+def _project(v, unit, sp=LOCAL):
+    return v - sp.scale(sp.dot(unit, v), unit)
 
 
 class CGSubspace(torch.autograd.Function):
@@ -106,13 +112,15 @@ class CGSubspaceShifted(torch.autograd.Function):
 
 
 def _make_sparse_cg(A, Aadjoint_to_gadjoint):
+    sp = space_of(A)   # one device: plain torch expressions; row-partitioned operator: global inner products
+
     class CGSubspaceSparse(torch.autograd.Function):
         """(A - E0 I) x = b, alpha.x = 0 with A matrix-free; inputs (g, E0, b, alpha) (CG.py:119-138)."""
 
         @staticmethod
         def forward(ctx, g, E0, b, alpha):
             initialx = torch.randn(b.shape[0], device=b.device, dtype=b.dtype)    # CG.py:121
-            initialx = _project(initialx, alpha.detach())                        # CG.py:122
+            initialx = _project(initialx, alpha.detach(), sp)                    # CG.py:122
             x = _solve(A, b.detach(), initialx, True, shift=E0.detach())          # CG.py:120,123
             ctx.g = g
             ctx.save_for_backward(E0, alpha, x)
@@ -122,11 +130,11 @@ def _make_sparse_cg(A, Aadjoint_to_gadjoint):
         def backward(ctx, grad_x):
             g = ctx.g
             E0, alpha, x = ctx.saved_tensors
-            b = _project(grad_x, alpha)                                          # CG.py:132
+            b = _project(grad_x, alpha, sp)                                      # CG.py:132
             grad_b = CGSubspaceSparse.apply(g, E0, b, alpha)                     # CG.py:133
             v1, v2 = -grad_b, x
-            grad_alpha = -x * torch.matmul(alpha, grad_x)                        # CG.py:135
-            grad_E0 = -torch.matmul(v1, v2)                                      # CG.py:136
+            grad_alpha = -sp.scale(sp.dot(alpha, grad_x), x)                     # CG.py:135
+            grad_E0 = -sp.dot(v1, v2)                                            # CG.py:136
             grad_g = Aadjoint_to_gadjoint(v1, v2)                                # CG.py:137
             return grad_g, grad_E0, grad_b, grad_alpha
 

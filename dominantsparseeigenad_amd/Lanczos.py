@@ -34,6 +34,16 @@ def _resolve(A, device, sparse, dim):
 
 def _lanczos_core(A, k, device, sparse, dim, q0):
     device = torch.device(device)
+    part = engine.native_of(A) if sparse else None
+    if part is not None and getattr(part, "partitioned", False):
+        # row-partitioned operator (partitioned.py): ``dim`` is the global dimension, every vector is this rank's
+        # slab; the two draws of Lanczos.py:52,59 are made per slab (seed the ranks differently)
+        nloc, dev = part.nloc, part.device
+        if q0 is None:
+            q0 = torch.randn(nloc, dtype=torch.float64, device=dev)
+        torch.randn(nloc, dtype=torch.float64, device=dev)
+        Q, ldq, alphas, betas = part.lanczos(k, q0)
+        return (part, Q, ldq, nloc, alphas, betas, torch.float64)
     n, dtype, amap = _resolve(A, device, sparse, dim)
     if q0 is None:
         q0 = torch.randn(n, dtype=dtype, device=device)        # Lanczos.py:52
@@ -64,7 +74,7 @@ def Lanczos(A, k, device=torch.device("cpu"), *, sparse=False, dim=None, q0=None
     On the GPU the basis is stored vector-contiguous, so ``Qk`` is the transposed view of a (k, ldq) buffer.
     """
     where, Q, ldq, n, alphas, betas, dtype = _lanczos_core(A, k, device, sparse, dim, q0)
-    Qk = Q[:, :n].T if where == "cuda" else Q
+    Qk = Q if where == "cpu" else Q[:, :n].T
     T = torch.diag(alphas) + torch.diag(betas, diagonal=1) + torch.diag(betas, diagonal=-1)
     return Qk.to(dtype), T.to(dtype)
 
@@ -79,6 +89,8 @@ def symeigLanczos(A, k, device=torch.device("cpu"), extreme="both", *, sparse=Fa
     for val, s in pairs:
         if where == "cuda":
             vec = engine.ritz_vector(Q, ldq, n, k, s, Q.device)
+        elif where != "cpu":
+            vec = where.ritz_vector(Q, ldq, k, s)           # row-partitioned: this rank's slab of the Ritz vector
         else:
             vec = torch.matmul(Q, torch.from_numpy(s).to(Q.dtype))
         out += [torch.tensor(val, dtype=dtype, device=alphas.device), vec.to(dtype)]

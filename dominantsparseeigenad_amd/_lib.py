@@ -69,6 +69,7 @@ _SIGNATURES = {
     "dsea_hypercube_flipsum": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "dsea_plz_dots": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_void_p]),
+    "dsea_plz_correct": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dsea_plz_correct_matvec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p]),
     "dsea_axpy_multi_dot": (c_int, [c_void_p, c_double, c_void_p, POINTER(c_void_p), c_int, c_void_p, c_void_p,

@@ -525,11 +525,10 @@ int dsea_plz_dots(dsea_ws_t ws, const double* Q, int64_t ldq, int64_t n, int i, 
   return check_launch();
 }
 
-int dsea_plz_correct_matvec(dsea_op_t op, dsea_ws_t ws, const double* Q, int64_t ldq, int row, const double* c,
-                            double* r, double* y, double* pair_out, void* stream) {
-  REQUIRE(op && ws && r && y && pair_out && row >= 0 && r != y, DSEA_ERR_ARG);
-  const int64_t n = op->d.n;
-  REQUIRE(aligned16(r) && aligned16(y), DSEA_ERR_ALIGN);
+int dsea_plz_correct(dsea_ws_t ws, const double* Q, int64_t ldq, int64_t n, int row, const double* c, double* r,
+                     double* pair_out, void* stream) {
+  REQUIRE(ws && r && pair_out && row >= 0 && n >= 1, DSEA_ERR_ARG);
+  REQUIRE(aligned16(r), DSEA_ERR_ALIGN);
   hipStream_t st = static_cast<hipStream_t>(stream);
   Workspace& w = ws->w;
   double* nP = w.aux + DSEA_MAX_WAVE_TILES;
@@ -547,7 +546,18 @@ int dsea_plz_correct_matvec(dsea_op_t op, dsea_ws_t ws, const double* Q, int64_t
   } else {
     launch_dot(r, r, n, w.partials, pair_out, st);
   }
-  int nb = launch_spmv(op->d, r, y, nullptr, nullptr, nullptr, st, w.prof ? w.prof->next(PROF_SPMV) : nullptr);
+  return check_launch();
+}
+
+int dsea_plz_correct_matvec(dsea_op_t op, dsea_ws_t ws, const double* Q, int64_t ldq, int row, const double* c,
+                            double* r, double* y, double* pair_out, void* stream) {
+  REQUIRE(op && ws && r && y && pair_out && row >= 0 && r != y, DSEA_ERR_ARG);
+  REQUIRE(aligned16(y), DSEA_ERR_ALIGN);
+  int rc = dsea_plz_correct(ws, Q, ldq, op->d.n, row, c, r, pair_out, stream);
+  if (rc != DSEA_OK) return rc;
+  Workspace& w = ws->w;
+  int nb = launch_spmv(op->d, r, y, nullptr, nullptr, nullptr, static_cast<hipStream_t>(stream),
+                       w.prof ? w.prof->next(PROF_SPMV) : nullptr);
   if (nb < 0) return DSEA_ERR_UNSUPPORTED;
   return check_launch();
 }

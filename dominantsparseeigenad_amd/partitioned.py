@@ -1,16 +1,31 @@
-"""Row-partitioned dominant eigenpair + adjoint across P = 2^p GPUs (one process per GPU).
+"""Row-partitioned operators: the dominant-eigenpair primitives across P GPUs (one process per GPU) BEHIND THE
+REFERENCE API.
 
-New capability (the reference is single-device).  Every n-vector -- Krylov basis
-vectors, CG vectors -- is cut into P contiguous slabs of n/P rows, one per rank:
+New capability (the reference is single-device).  A row-partitioned operator is handed to
+the unchanged entry points
 
-  * all vector algebra is slab-local and runs in the same HIP phase kernels as the single-GPU generic
-    path (include/dsea.h "vector phases"); each phase leaves its LOCAL partial sum in a device scalar;
-  * inner products are closed by ``torch.distributed.all_reduce`` on those device scalars (backend
-    "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests): per Lanczos step one all-reduce of
-    the i re-orthogonalisation coefficients, one of ||r||^2, one of alpha; per CG iteration two scalars;
-    all ranks therefore hold bit-identical scalars and take the same branch in the CG stopping test;
-  * the TFIM mat-vec flips the low L-p bits inside the slab (HIP kernel) and obtains the top p bits from the
-    partner slabs rank ^ (1<<b) by a pairwise exchange (hypercube), then  y -= g * x_partner.
+    op = PartitionedTFIMOperator(L, g, device)            # or PartitionedStencil3Operator(...)
+    symeig.setDominantSparseSymeig(op.H, op.Hadjoint_to_gadjoint)        reference symeig.py:33
+    E0, psi = symeig.DominantSparseSymeig.apply(g, k, op.dim, device)    reference symeig.py:71
+    loss = E0 + op.dot(psi, t);  torch.autograd.grad(loss, g, create_graph=True) ...
+
+and every n-vector (``psi``, ``t``, the Krylov basis, the CG vectors) is THIS RANK'S SLAB of n/P contiguous rows:
+
+  * all vector algebra is slab-local and runs in the same HIP phase kernels as the single-GPU path
+    (include/dsea.h "vector phases" / "row-partitioned macro phases"); each phase leaves its LOCAL partial
+    sum in a device scalar;
+  * inner products are closed by ``torch.distributed.all_reduce`` on those device scalars (backend "nccl" =
+    RCCL over xGMI on the GPU box, "gloo" in the CPU tests): per Lanczos step two small all-reduces, per CG
+    iteration two scalars; all ranks hold bit-identical scalars and take the same branch in the CG stopping
+    test (reference CG.py:28,35);
+  * the mat-vec exchanges what the operator's coupling needs: TFIM -- the low L-p bit flips are slab-local,
+    the top p bits come from the partner slabs rank ^ (1<<b) (pairwise hypercube exchange for P = 2, transposed
+    all-to-all form from P = 4 on); 3-point stencil (reference examples/schrodinger1D.py:18-27) -- one halo
+    element per neighbour;
+  * the autograd glue of symeig.py / CG.py is shared with the single-GPU path; its inner products and
+    scalar-vector products go through ``PartitionedSpace`` (differentiable global dot, see _space.py), so the
+    re-entrant backward -- d2E0/dg2, the fidelity susceptibility -- works distributed exactly as reference
+    symeig.py:77-86 / CG.py:128-138 do on one device.
 
 The numerical kernels are reached through a small backend object; the product backend is ``HipBackend``
 (libdsea.so, no fallback).  The CPU tests inject a torch-CPU test double to exercise the partition /
@@ -18,7 +33,7 @@ exchange / all-reduce logic with gloo on machines without GPUs.
 """
 from __future__ import annotations
 
-from ctypes import c_void_p
+from ctypes import byref, c_void_p
 
 import numpy as np
 import torch
@@ -27,20 +42,19 @@ import torch.distributed as dist
 from . import engine as _engine_mod
 
 F64 = torch.float64
+CG_RR, CG_DAD, CG_RRNEW, CG_ALPHA, CG_BETA, CG_RESNORM, CG_DONE, CG_ITERS = range(8)
 
 
 # =========================================================================== product backend (HIP)
 class HipBackend(_engine_mod.Phases):
-    """Slab-local numerics through the C ABI (the vector phases come from ``engine.Phases``).
-    ``L``/``L_local``/``row_offset`` describe this rank's slab."""
+    """Slab-local numerics through the C ABI (the vector phases come from ``engine.Phases``)."""
 
-    def __init__(self, L, L_local, row_offset, g, device):
+    def __init__(self, n_local, device):
         from . import _lib
-        from .operators import TFIMOperator
-        super().__init__(1 << L_local, device, kmax=8)
+        super().__init__(int(n_local), device, kmax=8)
         self._lib_mod = _lib
         self.engine = _engine_mod
-        self.op = TFIMOperator(L, self.device, g=g, L_local=L_local, row_offset=row_offset)
+        self.op = None          # slab-local operator object (exposes .handle), set by attach_*
         self._shadow = None
 
     # -- helpers
@@ -51,10 +65,32 @@ class HipBackend(_engine_mod.Phases):
     def _ck(self, rc, what):
         self._lib_mod.check(rc, what)
 
-    # -- operator (slab-local part)
+    # -- slab-local operators
+    def attach_tfim(self, L, L_local, row_offset, g):
+        from .operators import TFIMOperator
+        self.op = TFIMOperator(L, self.device, g=g, L_local=L_local, row_offset=row_offset)
+        return self.op
+
     def tfim_local(self, x, y, which="H"):
         handle = self.op.handle if which == "H" else self.op._dHdg.handle
         self._ck(self.lib.dsea_spmv(handle, None, self._p(x), self._p(y), None, None, None, self._st()), "dsea_spmv")
+
+    def attach_stencil(self, n_local, coef, V, halo, has_lo, has_hi):
+        """3-point stencil on this slab; halo[0] / halo[1] are the neighbours' edge elements (device doubles
+        filled by the halo exchange); a missing neighbour is the Dirichlet zero of schrodinger1D.py:20-21"""
+        from .operators import _Handle, _NativeView
+        raw = c_void_p()
+        lo = c_void_p(halo.data_ptr()) if has_lo else c_void_p(None)
+        hi = c_void_p(halo.data_ptr() + 8) if has_hi else c_void_p(None)
+        self._ck(self.lib.dsea_op_create_stencil3(int(n_local), float(coef), self._p(V), lo, hi, byref(raw)),
+                 "dsea_op_create_stencil3")
+        self.op = _NativeView(_Handle(raw, n_local, (V, halo)))
+        return self.op
+
+    def stencil_local(self, x, y, shift, out, skip):
+        """y = A_slab x - shift x (halo already exchanged) ; out = local x.y"""
+        self._ck(self.lib.dsea_spmv(self.op.handle, self.ws.handle, self._p(x), self._p(y), self._p(shift),
+                                    self._p(out), self._p(skip), self._st()), "dsea_spmv")
 
     # -- macro phases of the partitioned Lanczos step (include/dsea.h "row-partitioned macro phases")
     def set_shadow(self, k, ldq):
@@ -79,6 +115,10 @@ class HipBackend(_engine_mod.Phases):
         self._ck(self.lib.dsea_plz_dots(self.ws.handle, self._p(Q), ldq, n, i, self._p(u), self._p(alpha),
                                         self._p(beta), self._p(r), self._p(c), self._st()), "dsea_plz_dots")
 
+    def plz_correct(self, Q, ldq, n, row, c, r, pair):
+        self._ck(self.lib.dsea_plz_correct(self.ws.handle, self._p(Q), ldq, n, int(row), self._p(c), self._p(r),
+                                           self._p(pair), self._st()), "dsea_plz_correct")
+
     def plz_correct_matvec(self, Q, ldq, row, c, r, y, pair):
         self._ck(self.lib.dsea_plz_correct_matvec(self.op.handle, self.ws.handle, self._p(Q), ldq, int(row),
                                                   self._p(c), self._p(r), self._p(y), self._p(pair), self._st()),
@@ -94,10 +134,6 @@ class HipBackend(_engine_mod.Phases):
         self._ck(self.lib.dsea_plz_finish(self.ws.handle, self._p(r), self._p(y), self._p(pair), self._p(q_out),
                                           int(row), self._p(u_out), self._p(alpha_out), self._p(beta_out),
                                           r.numel(), self._st()), "dsea_plz_finish")
-
-    def shift_dot(self, x, y, shift, out, skip):
-        self._ck(self.lib.dsea_shift_dot(self.ws.handle, self._p(x), self._p(y), self._p(shift), self._p(out),
-                                         self._p(skip), x.numel(), self._st()), "dsea_shift_dot")
 
     def cg_init(self, b, Ax0, r, d, state):
         self._ck(self.lib.dsea_cg_init(self.ws.handle, self._p(b), self._p(Ax0), self._p(r), self._p(d),
@@ -134,15 +170,19 @@ class TorchDistComm:
         if self.world > 1:
             dist.all_reduce(t, group=self.group)
 
-    def exchange(self, x, recv, peers):
-        """send slab x to every peer, receive theirs into recv[b] (pairwise, all at once)"""
+    def sendrecv(self, items):
+        """items = [(send tensor, receive buffer, peer rank), ...]: all posted at once, then waited for"""
         ops = []
-        for buf, peer in zip(recv, peers):
-            ops.append(dist.P2POp(dist.isend, x, peer, group=self.group))
-            ops.append(dist.P2POp(dist.irecv, buf, peer, group=self.group))
+        for snd, rcv, peer in items:
+            ops.append(dist.P2POp(dist.isend, snd, peer, group=self.group))
+            ops.append(dist.P2POp(dist.irecv, rcv, peer, group=self.group))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+
+    def exchange(self, x, recv, peers):
+        """send slab x to every peer, receive theirs into recv[b] (pairwise, all at once)"""
+        self.sendrecv([(x, buf, peer) for buf, peer in zip(recv, peers)])
 
     def start_flip_exchange(self, be, x_send, xT, zT, z):
         """z = sum over the top-bit partner slabs of x_send, in the transposed form (all-to-all, local flip sum,
@@ -183,59 +223,304 @@ class TorchDistComm:
             return
         chunk = src.numel() // P
         dst[me * chunk:(me + 1) * chunk].copy_(src[me * chunk:(me + 1) * chunk])
-        ops = []
-        for j in range(P):
-            if j != me:
-                ops.append(dist.P2POp(dist.isend, src[j * chunk:(j + 1) * chunk], j, group=self.group))
-                ops.append(dist.P2POp(dist.irecv, dst[j * chunk:(j + 1) * chunk], j, group=self.group))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+        self.sendrecv([(src[j * chunk:(j + 1) * chunk], dst[j * chunk:(j + 1) * chunk], j) for j in range(P) if j != me])
 
 
-# =========================================================================== the partitioned solver
-CG_RR, CG_DAD, CG_RRNEW, CG_ALPHA, CG_BETA, CG_RESNORM, CG_DONE, CG_ITERS = range(8)
+def _vec(v):
+    """detached, fp64, contiguous, 16-byte aligned (what the phase kernels take); copies only when it has to"""
+    v = v.detach()
+    if v.dtype != F64:
+        v = v.to(F64)
+    if not v.is_contiguous():
+        v = v.contiguous()
+    if v.is_cuda and v.data_ptr() % 16:
+        v = v.clone()
+    return v
 
 
-class PartitionedTFIM:
-    """Ground state of the TFIM chain of L sites and d(loss)/dg with vectors row-partitioned over the
-    default process group.  ``g`` is the (1,) parameter tensor on this rank's device (same value on all
-    ranks)."""
+# =========================================================================== the vector space of slabs
+class _GlobalDot(torch.autograd.Function):
+    """s = sum over ranks of a_slab . b_slab (replicated 0-dim tensor).  Gradients of replicated quantities are
+    kept FULL on every rank, so the backward needs no communication: a-bar = s-bar b, b-bar = s-bar a."""
 
-    def __init__(self, L, g, device, backend=None, group=None, eps=1e-7, poll_every=8, comm=None):
-        self.comm = comm if comm is not None else TorchDistComm(group)
-        self.rank, self.world = self.comm.rank, self.comm.world
-        self.p = int(round(np.log2(self.world)))
-        if (1 << self.p) != self.world:
-            raise ValueError("the row partition needs a power-of-two world size, got %d" % self.world)
-        if self.p > L:
-            raise ValueError("more ranks than rows")
-        self.L, self.Lloc = int(L), int(L) - self.p
-        self.nloc = 1 << self.Lloc
-        self.n = 1 << self.L
-        self.row_offset = self.rank * self.nloc
-        self.g = g
+    @staticmethod
+    def forward(ctx, a, b, space):
+        ctx.space = space
+        ctx.save_for_backward(a, b)
+        out = torch.zeros(1, dtype=F64, device=a.device)
+        space.be.dot(_vec(a), _vec(b), out)
+        space.comm.allreduce(out)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, gs):
+        a, b = ctx.saved_tensors
+        sp = ctx.space
+        return sp.scale(gs, b), sp.scale(gs, a), None
+
+
+class _Scale(torch.autograd.Function):
+    """v_out = s * v_slab for a replicated scalar s.  s-bar = GLOBAL dot(v_out-bar, v) -- the reason this is
+    not a plain multiplication: autograd's own rule would leave only this rank's part of the sum."""
+
+    @staticmethod
+    def forward(ctx, s, v, space):
+        ctx.space = space
+        ctx.save_for_backward(s, v)
+        return s.detach().reshape(()) * v.detach()
+
+    @staticmethod
+    def backward(ctx, gv):
+        s, v = ctx.saved_tensors
+        sp = ctx.space
+        gs = sp.dot(gv, v).reshape(s.shape) if ctx.needs_input_grad[0] else None
+        gvv = sp.scale(s, gv) if ctx.needs_input_grad[1] else None
+        return gs, gvv, None
+
+
+class PartitionedSpace:
+    """Inner products / scalar products of slab vectors (see _space.py): ``dot`` is closed by an all-reduce and
+    both operations are mutually re-entrant autograd Functions, so derivatives of any order are consistent."""
+
+    partitioned = True
+
+    def __init__(self, comm, be):
+        self.comm, self.be = comm, be
+
+    def dot(self, a, b):
+        return _GlobalDot.apply(a, b, self)
+
+    def scale(self, s, v):
+        if not torch.is_tensor(s):
+            s = torch.tensor(float(s), dtype=v.dtype, device=v.device)
+        return _Scale.apply(s, v, self)
+
+
+# =========================================================================== operators
+class _LanczosState:
+    pass
+
+
+class PartitionedOperator:
+    """Base of the row-partitioned operators: owns the communicator, the slab backend and the two distributed
+    loops (Lanczos forward, projected-CG adjoint); subclasses provide the mat-vec with its exchange."""
+
+    partitioned = True
+    _native_methods = ("H", "__call__", "Hsparse")
+
+    def __init__(self, n_global, n_local, row_offset, device, comm, be):
+        self.comm = comm
+        self.rank, self.world = comm.rank, comm.world
+        self.dim, self.n = int(n_global), int(n_global)
+        self.nloc, self.row_offset = int(n_local), int(row_offset)
         self.device = torch.device(device)
-        self.be = backend if backend is not None else HipBackend(self.L, self.Lloc, self.row_offset, g, self.device)
-        self.eps = float(eps)
-        self.poll_every = int(poll_every)
+        self.be = be
+        self.space = PartitionedSpace(comm, be)
         self.use_shadow = True
-        # Overlap of the slab exchange with the dots / correction passes (transposed form only): the remote part
-        # of u = A r' is then taken from the UN-corrected r (its exchange starts before the coefficients c are
-        # known).  r - r' = Q c lies at the 1e-14 relative level per element (|c_j| <= ~1e-15 ||r||), i.e. at the
-        # level of the mat-vec's own rounding error; the local part uses the corrected r'.
-        self.overlap = True
+        self.poll_every = 8
+        # world size 1: the slab is the whole operator, so the in-library single-GPU loops apply; set this to run
+        # the distributed driver anyway (tests, host-overhead measurements)
+        self.force_driver = False
         self.last_cg_iters = 0
         self.last_cg_resnorm = float("nan")
+
+    # ---- to be provided by subclasses
+    def apply_shift_dot(self, x, y, shift, out, skip):
+        """y = (A - shift) x over all ranks ; out = LOCAL x.y (1-element tensor or None)"""
+        raise NotImplementedError
+
+    def _local_native(self):
+        """the slab operator as a native single-GPU operand (world size 1) or None"""
+        return None
+
+    # ---- helpers for users
+    def dot(self, a, b):
+        """global inner product of two slab vectors (differentiable, replicated result)"""
+        return self.space.dot(a, b)
+
+    def slab(self, full):
+        """this rank's rows of a replicated full-length vector"""
+        return full[self.row_offset:self.row_offset + self.nloc]
+
+    def global_dot_(self, x, y, out):
+        self.be.dot(x, y, out)
+        self.comm.allreduce(out)
+
+    # ---- forward: Lanczos (reference Lanczos.py:49-77)
+    def lanczos_step(self, i, S):
+        """[dots] -> all-reduce(c, ||r||^2) -> [correction] -> mat-vec with its exchange (+ local r.Ar) ->
+        all-reduce(||r||^2, r.Ar) -> [normalise, store].  The mat-vec acts on the un-normalised r (linearity),
+        which is what lets the two scalar reductions of the tail travel together."""
+        be = self.be
+        if i >= 1:
+            be.plz_dots(S.Q, S.ldq, S.n, i, S.u, S.alphas[i - 1:i], S.betas[i - 2:i - 1] if i >= 2 else None, S.r, S.c)
+            self.comm.allreduce(S.c[:i + 1])
+        be.plz_correct(S.Q, S.ldq, S.n, i, S.c, S.r, S.pair)
+        self.apply_shift_dot(S.r, S.y, None, S.pair[1:2], None)
+        self.comm.allreduce(S.pair)
+        be.plz_finish(S.r, S.y, S.pair, S.Q[i], i, S.u, S.alphas[i:i + 1], S.betas[i - 1:i] if i >= 1 else None)
+
+    def lanczos(self, k, q0_slab):
+        """k-step Lanczos with full re-orthogonalisation on slabs.  Returns (Q (k, ldq) slab basis, ldq,
+        alphas (k,), betas (k-1,)) -- the scalars replicated bit-identically on every rank."""
+        native = self._local_native()
+        if self.world == 1 and native is not None and not self.force_driver:
+            return _engine_mod.lanczos(native, k, self.nloc, self.device, q0_slab, native=native)
+        be, n = self.be, self.nloc
+        if hasattr(be, "reserve"):
+            be.reserve(k)
+        S = _LanczosState()
+        S.n, S.k = n, k
+        S.ldq = (n + 31) // 32 * 32
+        S.Q = be.empty(k, S.ldq)
+        S.alphas, S.betas = be.zeros(k), be.zeros(max(k - 1, 1))
+        S.c, S.pair = be.zeros(k + 2), be.zeros(2)
+        S.r, S.u, S.y = q0_slab.detach().to(F64).clone(), be.empty(n), be.empty(n)
+        use_shadow = self.use_shadow and _engine_mod.USE_SHADOW and k > 1 and hasattr(be, "set_shadow")
+        if use_shadow:
+            be.set_shadow(k, S.ldq)
+        try:
+            for i in range(k):
+                self.lanczos_step(i, S)
+        finally:
+            if use_shadow:
+                be.clear_shadow()
+        return S.Q, S.ldq, S.alphas, S.betas[:k - 1]
+
+    def ritz_vector(self, Q, ldq, k, s_host):
+        out = self.be.empty(self.nloc)
+        s = torch.from_numpy(np.ascontiguousarray(s_host, dtype=np.float64)).to(self.device)
+        self.be.ritz(Q, ldq, self.nloc, int(k), s, out)
+        return out
+
+    # ---- backward: CG on (A - E0) x = b (reference CG.py:24-41 with the closure of :120)
+    def solve_shifted(self, E0, b, x0, eps=1e-7, maxiter=None):
+        """x0 is overwritten and returned.  The stopping test runs on the device on replicated scalars; the host
+        polls the flag every ``poll_every`` iterations."""
+        native = self._local_native()
+        if self.world == 1 and native is not None and not self.force_driver:
+            x = _engine_mod.cg(b, x0, native=native, shift=E0, eps=eps, maxiter=self.dim if maxiter is None else maxiter)
+            self.last_cg_iters, self.last_cg_resnorm = _engine_mod.last_cg.iters, _engine_mod.last_cg.resnorm
+            return x
+        be, n = self.be, self.nloc
+        state = be.zeros(8)
+        r, d, Ad = be.empty(n), be.empty(n), be.empty(n)
+        x = x0
+        shift = E0.detach().reshape(-1)[:1].to(F64).contiguous() if E0 is not None else None
+        self.apply_shift_dot(x, Ad, shift, state[CG_DAD:CG_DAD + 1], None)
+        be.cg_init(b, Ad, r, d, state)
+        self.comm.allreduce(state[CG_RR:CG_RR + 1])
+        be.cg_init_check(state, eps)
+        done = state[CG_DONE:CG_DONE + 1]
+        issued, cap = 0, (self.dim if maxiter is None else int(maxiter))
+        host = state.cpu()
+        while host[CG_DONE].item() == 0.0 and issued < cap:
+            for _ in range(min(self.poll_every, cap - issued)):
+                self.apply_shift_dot(d, Ad, shift, state[CG_DAD:CG_DAD + 1], done)
+                self.comm.allreduce(state[CG_DAD:CG_DAD + 1])
+                be.cg_update(x, r, d, Ad, state)
+                self.comm.allreduce(state[CG_RRNEW:CG_RRNEW + 1])
+                be.cg_check(state, eps)
+                be.cg_direction(r, d, state)
+                issued += 1
+            host = state.cpu()
+        self.last_cg_iters = int(host[CG_ITERS].item())
+        self.last_cg_resnorm = float(host[CG_RESNORM].item())
+        info = _engine_mod.last_cg
+        info.iters, info.resnorm, info.converged = self.last_cg_iters, self.last_cg_resnorm, host[CG_DONE].item() != 0.0
+        return x
+
+    # ---- plain (non-differentiable) mat-vec on buffers
+    def matvec(self, x, y, which="H"):
+        if which != "H":
+            raise ValueError("this operator has no '%s' map" % which)
+        self.apply_shift_dot(x, y, None, None, None)
+
+
+class _PartApply(torch.autograd.Function):
+    """y = M v over all ranks for a symmetric M that does not depend on differentiable parameters
+    (``which`` selects the map); dy/dv^T g = M g, re-entrant."""
+
+    @staticmethod
+    def forward(ctx, v, op, which):
+        ctx.op, ctx.which = op, which
+        vv = _as_slab(v, op)
+        y = op.be.empty(op.nloc)
+        op.matvec(vv, y, which)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        return _PartApply.apply(gy, ctx.op, ctx.which), None, None
+
+
+def _as_slab(v, op):
+    if v.numel() != op.nloc:
+        raise ValueError("expected this rank's slab of %d rows, got %d" % (op.nloc, v.numel()))
+    return _vec(v)
+
+
+# ------------------------------------------------------------------------------------------ TFIM
+class _PartTFIMApply(torch.autograd.Function):
+    """H(g) v on slabs (reference TFIM.py:91-98), differentiable in v and in the replicated parameter g."""
+
+    @staticmethod
+    def forward(ctx, v, g, op):
+        ctx.op = op
+        ctx.save_for_backward(v, g)
+        vv = _as_slab(v, op)
+        y = op.be.empty(op.nloc)
+        op.matvec(vv, y, "H")
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        v, g = ctx.saved_tensors
+        op = ctx.op
+        gv = _PartTFIMApply.apply(gy, g, op) if ctx.needs_input_grad[0] else None
+        gg = op.space.dot(op.pHpg(v), gy).reshape(g.shape) if ctx.needs_input_grad[1] else None
+        return gv, gg, None
+
+
+class PartitionedTFIMOperator(PartitionedOperator):
+    """Transverse-field Ising chain of L sites (reference examples/TFIM/TFIM.py:39-101) with every vector
+    row-partitioned over the P = 2^p ranks of ``group``; ``g`` is the (1,) parameter tensor on this rank's
+    device (same value on all ranks).  Attribute names follow the reference model class / ``TFIMOperator``."""
+
+    def __init__(self, L, g, device, backend=None, group=None, comm=None, overlap="auto"):
+        comm = comm if comm is not None else TorchDistComm(group)
+        p = int(round(np.log2(comm.world)))
+        if (1 << p) != comm.world:
+            raise ValueError("the TFIM row partition needs a power-of-two world size, got %d" % comm.world)
+        if p > L:
+            raise ValueError("more ranks than rows")
+        self.L = self.N = int(L)
+        self.p, self.Lloc = p, int(L) - p
+        nloc = 1 << self.Lloc
+        device = torch.device(device)
+        if backend is None:
+            backend = HipBackend(nloc, device)
+        backend.attach_tfim(self.L, self.Lloc, comm.rank * nloc, g)
+        super().__init__(1 << self.L, nloc, comm.rank * nloc, device, comm, backend)
+        self.g = g
+        # Overlap of the slab exchange with the dots / correction passes (transposed form only): the remote part
+        # of u = A r' is then taken from the UN-corrected r (its exchange starts before the coefficients c are
+        # known).  r - r' = Q c lies at the 1e-14 relative level per element while |c_j| <= ~1e-15 ||r||, the
+        # level of the mat-vec's own rounding error.  That premise is CHECKED every step (max|c_j| <= tau ||r||,
+        # the same bound the bf16-shadow pass uses); a step that violates it redoes the exchange with the
+        # corrected r.  The check costs one small D2H copy per step, so "auto" enables the overlap only where a
+        # step is long compared with a host round trip (>= 2^22 rows per rank).
+        self.overlap = (self.nloc >= (1 << 22)) if overlap == "auto" else bool(overlap)
+        self.overlap_fallbacks = 0
         # top-bit flips: pairwise slab exchange for P = 2; from P = 4 on the transposed form -- all-to-all,
         # local flip sum, all-to-all back -- which puts 1/P of a slab on each of the P-1 links per phase instead
         # of a whole slab on log2(P) links (P = 8: a quarter of the transfer time)
         self.transposed = self.world >= 4 and self.nloc >= self.world and hasattr(self.be, "flipsum")
         if self.transposed:
-            self._xT, self._zT, self._z = self.be.empty(self.nloc), self.be.empty(self.nloc), self.be.empty(self.nloc)
+            self._xT, self._zT, self._z = self.be.empty(nloc), self.be.empty(nloc), self.be.empty(nloc)
             self._recv = []
         else:
-            self._recv = [self.be.empty(self.nloc) for _ in range(self.p)]
+            self._recv = [self.be.empty(nloc) for _ in range(self.p)]
 
     def use_pairwise_exchange(self):
         """switch to the pairwise hypercube exchange (one full slab per partner), e.g. if the transposed form is
@@ -243,10 +528,10 @@ class PartitionedTFIM:
         self.transposed = False
         self._recv = [self.be.empty(self.nloc) for _ in range(self.p)]
 
-    # ---------------------------------------------------------------- collectives
-    def _allreduce(self, t):
-        self.comm.allreduce(t)
+    def _local_native(self):
+        return getattr(self.be, "op", None)
 
+    # ---- exchange
     def _exchange(self, x):
         """receive the slabs of the p hypercube partners (rank ^ (1<<b)); returns the list of buffers"""
         if self.p == 0:
@@ -259,7 +544,7 @@ class PartitionedTFIM:
         self.comm.exchange(x, self._recv, [self.rank ^ (1 << b) for b in range(self.p)])
         return self._recv
 
-    # ---------------------------------------------------------------- operator
+    # ---- mat-vec on buffers
     def matvec(self, x, y, which="H"):
         """y = H x (or dH/dg x) on this slab: local low-bit part in HIP, top-bit flips from the partners"""
         self.be.tfim_local(x, y, which)
@@ -269,110 +554,196 @@ class PartitionedTFIM:
             else:
                 self.be.axpy(-1.0, None, buf, y)                 # dH/dg: y -= x_partner (TFIM.py:64)
 
-    def matvec_shift_dot(self, x, y, shift, out, skip):
+    def apply_shift_dot(self, x, y, shift, out, skip):
         """y = (H - shift) x with the remote part, the shift and the local x.y in ONE kernel after the exchange"""
         self.be.tfim_local(x, y, "H")
         recv = self._exchange(x)
+        if out is None:
+            out = self.be.zeros(1)
         self.be.axpy_multi_dot(-1.0, self.g.detach(), recv, shift, skip, x, y, out)
 
-    def global_dot(self, x, y, out):
-        self.be.dot(x, y, out)
-        self._allreduce(out)
-
-    # ---------------------------------------------------------------- forward: Lanczos (Lanczos.py:49-105)
-    def forward(self, k, q0_slab):
-        """Per step: [dots] -> all-reduce(c, ||r||^2) -> [correction + local mat-vec] -> slab exchange ->
-        [remote part + r.Ar] -> all-reduce(||r||^2, r.Ar) -> [normalise, store].  The mat-vec acts on the
-        un-normalised r (linearity), which is what lets the two scalar reductions travel together."""
-        be, n = self.be, self.nloc
-        if hasattr(be, "reserve"):
-            be.reserve(k)
-        ldq = (n + 31) // 32 * 32
-        Q = be.empty(k, ldq)
-        alphas, betas = be.zeros(k), be.zeros(max(k - 1, 1))
-        c, pair = be.zeros(k + 2), be.zeros(2)
-        r, u, y = q0_slab.clone(), be.empty(n), be.empty(n)
-        use_shadow = self.use_shadow and k > 1 and hasattr(be, "set_shadow")
-        if use_shadow:
-            be.set_shadow(k, ldq)
-        try:
-            overlap = self.transposed and self.overlap and hasattr(be, "form_r")
-            zero = be.zeros(1)
-            r_send = be.empty(n) if overlap else None
-            for i in range(k):
-                token = None
-                if overlap:
-                    # the exchange of the (un-corrected) r runs behind the dots and correction passes
-                    if i >= 1:
-                        be.form_r(Q, ldq, n, i, u, alphas[i - 1:i], betas[i - 2:i - 1] if i >= 2 else None, r, r_send)
-                    else:
-                        r_send.copy_(r)
-                    token = self.comm.start_flip_exchange(be, r_send, self._xT, self._zT, self._z)
-                    if i >= 1:
-                        be.plz_dots(Q, ldq, n, i, r, zero, None, r, c)        # alpha = 0: r stays, c = Q^T r, c[i] = r.r
-                        self._allreduce(c[:i + 1])
-                    be.plz_correct_matvec(Q, ldq, i, c, r, y, pair)
-                    self.comm.finish_flip_exchange(token, self.device)
-                    recv = [self._z]
-                else:
-                    if i >= 1:
-                        be.plz_dots(Q, ldq, n, i, u, alphas[i - 1:i], betas[i - 2:i - 1] if i >= 2 else None, r, c)
-                        self._allreduce(c[:i + 1])
-                    be.plz_correct_matvec(Q, ldq, i, c, r, y, pair)
-                    recv = self._exchange(r)
-                be.axpy_multi_dot(-1.0, self.g.detach(), recv, None, None, r, y, pair[1:2])
-                self._allreduce(pair)
-                be.plz_finish(r, y, pair, Q[i], i, u, alphas[i:i + 1], betas[i - 1:i] if i >= 1 else None)
-        finally:
-            if use_shadow:
-                be.clear_shadow()
-        # Ritz pair: T is replicated (identical scalars on all ranks), solved on the host (Lanczos.py:98)
-        from scipy.linalg import eigh_tridiagonal
-        d, e = alphas.cpu().numpy(), betas[:k - 1].cpu().numpy()
-        if k == 1:
-            lam, s = float(d[0]), np.ones(1)
+    # ---- Lanczos step with the fused correction + local mat-vec and the overlapped exchange
+    def lanczos_step(self, i, S):
+        be, n = self.be, S.n
+        overlap = self.transposed and self.overlap and hasattr(be, "form_r")
+        prev_a = S.alphas[i - 1:i] if i >= 1 else None
+        prev_b = S.betas[i - 2:i - 1] if i >= 2 else None
+        if overlap:
+            if not hasattr(S, "r_send"):
+                S.r_send, S.zero = be.empty(n), be.zeros(1)
+            # the exchange of the (un-corrected) r runs behind the dots and correction passes
+            if i >= 1:
+                be.form_r(S.Q, S.ldq, n, i, S.u, prev_a, prev_b, S.r, S.r_send)
+            else:
+                S.r_send.copy_(S.r)
+            token = self.comm.start_flip_exchange(be, S.r_send, self._xT, self._zT, self._z)
+            premise_ok = True
+            if i >= 1:
+                be.plz_dots(S.Q, S.ldq, n, i, S.r, S.zero, None, S.r, S.c)    # alpha = 0: r stays, c = Q^T r, c[i] = r.r
+                self.comm.allreduce(S.c[:i + 1])
+                tau = _engine_mod.SHADOW_TAU
+                premise_ok = bool((S.c[:i].abs().max() <= tau * S.c[i].sqrt()).item())
+            be.plz_correct_matvec(S.Q, S.ldq, i, S.c, S.r, S.y, S.pair)
+            self.comm.finish_flip_exchange(token, self.device)
+            if premise_ok:
+                recv = [self._z]
+            else:   # identical decision on every rank (c is replicated): redo the exchange with the corrected r
+                self.overlap_fallbacks += 1
+                recv = self._exchange(S.r)
         else:
-            w, v = eigh_tridiagonal(d, e, select="i", select_range=(0, 0))
-            lam, s = float(w[0]), np.ascontiguousarray(v[:, 0])
-        psi = be.empty(n)
-        be.ritz(Q, ldq, n, k, torch.from_numpy(s).to(self.device), psi)
+            if i >= 1:
+                be.plz_dots(S.Q, S.ldq, n, i, S.u, prev_a, prev_b, S.r, S.c)
+                self.comm.allreduce(S.c[:i + 1])
+            be.plz_correct_matvec(S.Q, S.ldq, i, S.c, S.r, S.y, S.pair)
+            recv = self._exchange(S.r)
+        be.axpy_multi_dot(-1.0, self.g.detach(), recv, None, None, S.r, S.y, S.pair[1:2])
+        self.comm.allreduce(S.pair)
+        be.plz_finish(S.r, S.y, S.pair, S.Q[i], i, S.u, S.alphas[i:i + 1], S.betas[i - 1:i] if i >= 1 else None)
+
+    # ---- differentiable user surface (names of the reference model class, TFIM.py:58-65,91-101)
+    def H(self, v):
+        return _PartTFIMApply.apply(v, self.g, self)
+
+    __call__ = H
+
+    def pHpg(self, v):
+        """dH/dg v = -sum_j v[i xor (1<<j)] over all L sites"""
+        return _PartApply.apply(v, self, "dHdg")
+
+    def Hadjoint_to_gadjoint(self, v1, v2):
+        """adjoint hook of TFIM.py:100-101:  g-bar = v1^T (dH/dg) v2 (global), shape (1,)"""
+        return self.space.dot(self.pHpg(v2), v1)[None]
+
+
+# ------------------------------------------------------------------------------------------ 3-point stencil
+class _PartStencilApply(torch.autograd.Function):
+    """H(V) v on slabs (reference schrodinger1D.py:18-27); dV = gy o v is slab-local (:29-34)."""
+
+    @staticmethod
+    def forward(ctx, v, V, op):
+        ctx.op = op
+        ctx.save_for_backward(v, V)
+        vv = _as_slab(v, op)
+        y = op.be.empty(op.nloc)
+        op.matvec(vv, y, "H")
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        v, V = ctx.saved_tensors
+        gv = _PartStencilApply.apply(gy, V, ctx.op) if ctx.needs_input_grad[0] else None
+        gV = gy * v if ctx.needs_input_grad[1] else None
+        return gv, gV, None
+
+
+def stencil_partition(n, world, rank):
+    """(rows, first row) of rank's contiguous slab: the first n % world ranks hold one row more"""
+    base, extra = divmod(int(n), int(world))
+    rows = base + (1 if rank < extra else 0)
+    off = rank * base + min(rank, extra)
+    return rows, off
+
+
+class PartitionedStencil3Operator(PartitionedOperator):
+    """H v = -0.5/h^2 (-2 v + v_{+1} + v_{-1}) + V o v with Dirichlet ends (reference
+    examples/schrodinger1D.py:18-27) on a grid of n points cut into contiguous slabs; ``potential_slab`` is this
+    rank's part of the parameter tensor.  One halo element travels to each neighbour per mat-vec."""
+
+    def __init__(self, n, h, potential_slab, device=None, backend=None, group=None, comm=None):
+        comm = comm if comm is not None else TorchDistComm(group)
+        rows, off = stencil_partition(n, comm.world, comm.rank)
+        if rows < 1:
+            raise ValueError("more ranks than grid points")
+        if potential_slab.numel() != rows:
+            raise ValueError("rank %d holds rows %d..%d: expected a potential slab of %d elements, got %d"
+                             % (comm.rank, off, off + rows, rows, potential_slab.numel()))
+        device = torch.device(device) if device is not None else potential_slab.device
+        self.h = float(h)
+        self.coef = -0.5 / self.h ** 2
+        self._V = potential_slab
+        self._Vdata = potential_slab.detach().to(F64).contiguous()
+        self.has_lo, self.has_hi = comm.rank > 0, comm.rank < comm.world - 1
+        if backend is None:
+            backend = HipBackend(rows, device)
+        self._halo = backend.zeros(2)
+        backend.attach_stencil(rows, self.coef, self._Vdata, self._halo, self.has_lo, self.has_hi)
+        super().__init__(n, rows, off, device, comm, backend)
+
+    @property
+    def potential(self):
+        return self._V
+
+    def _local_native(self):
+        return getattr(self.be, "op", None)
+
+    def _halo_exchange(self, x):
+        items = []
+        if self.has_lo:
+            items.append((x[0:1], self._halo[0:1], self.rank - 1))
+        if self.has_hi:
+            items.append((x[self.nloc - 1:self.nloc], self._halo[1:2], self.rank + 1))
+        if items:
+            self.comm.sendrecv(items)
+
+    def apply_shift_dot(self, x, y, shift, out, skip):
+        self._halo_exchange(x)
+        self.be.stencil_local(x, y, shift, out, skip)
+
+    def H(self, v):
+        return _PartStencilApply.apply(v, self._V, self)
+
+    __call__ = H
+    Hsparse = H
+
+    @staticmethod
+    def Hadjoint_to_padjoint(v1, v2):
+        """adjoint hook of schrodinger1D.py:29-34: potential-bar = v1 o v2 (this rank's slab)"""
+        return v1 * v2
+
+
+# =========================================================================== convenience driver
+class PartitionedTFIM:
+    """Hand-written forward + first-order backward on a ``PartitionedTFIMOperator`` (loss = E0 + psi.t) WITHOUT
+    autograd: an independent statement of reference symeig.py:77-86 used by the tests to cross-check the autograd
+    path, and by the host-overhead tool.  The product surface is the operator + the reference API."""
+
+    def __init__(self, L, g, device, backend=None, group=None, eps=1e-7, poll_every=8, comm=None):
+        self.op = PartitionedTFIMOperator(L, g, device, backend=backend, group=group, comm=comm)
+        self.op.force_driver = True
+        self.op.poll_every = int(poll_every)
+        self.eps = float(eps)
+        self.comm, self.rank, self.world = self.op.comm, self.op.rank, self.op.world
+        self.be, self.nloc, self.n, self.device, self.g = self.op.be, self.op.nloc, self.op.dim, self.op.device, g
+
+    transposed = property(lambda self: self.op.transposed)
+    last_cg_iters = property(lambda self: self.op.last_cg_iters)
+    last_cg_resnorm = property(lambda self: self.op.last_cg_resnorm)
+
+    @property
+    def overlap(self):
+        return self.op.overlap
+
+    @overlap.setter
+    def overlap(self, v):
+        self.op.overlap = bool(v)
+
+    def use_pairwise_exchange(self):
+        self.op.use_pairwise_exchange()
+
+    def matvec(self, x, y, which="H"):
+        self.op.matvec(x, y, which)
+
+    def forward(self, k, q0_slab):
+        Q, ldq, alphas, betas = self.op.lanczos(k, q0_slab)
+        (lam, s), = _engine_mod.tridiag_extreme(alphas, betas, "min")
+        psi = self.op.ritz_vector(Q, ldq, k, s)
         return torch.tensor(lam, dtype=F64, device=self.device), psi
 
-    # ---------------------------------------------------------------- projected CG (CG.py:24-41,119-123)
     def _project_out(self, v, unit, scratch):
         """v <- v - (unit.v) unit  in place (CG.py:122, symeig.py:80)"""
-        self.global_dot(unit, v, scratch)
+        self.op.global_dot_(unit, v, scratch)
         self.be.axpy(-1.0, scratch, unit, v)
 
-    def solve_shifted(self, E0, b, x0):
-        """(H - E0) x = b by CG from x0 (both already orthogonal to psi); returns x (overwrites x0)."""
-        be, n = self.be, self.nloc
-        state = be.zeros(8)
-        r, d, Ad = be.empty(n), be.empty(n), be.empty(n)
-        x = x0
-        shift = E0.reshape(1)
-        self.matvec_shift_dot(x, Ad, shift, state[CG_DAD:CG_DAD + 1], None)
-        be.cg_init(b, Ad, r, d, state)
-        self._allreduce(state[CG_RR:CG_RR + 1])
-        be.cg_init_check(state, self.eps)
-        done = state[CG_DONE:CG_DONE + 1]
-        issued, cap = 0, self.n
-        host = state.cpu()
-        while host[CG_DONE].item() == 0.0 and issued < cap:
-            for _ in range(min(self.poll_every, cap - issued)):
-                self.matvec_shift_dot(d, Ad, shift, state[CG_DAD:CG_DAD + 1], done)
-                self._allreduce(state[CG_DAD:CG_DAD + 1])
-                be.cg_update(x, r, d, Ad, state)
-                self._allreduce(state[CG_RRNEW:CG_RRNEW + 1])
-                be.cg_check(state, self.eps)
-                be.cg_direction(r, d, state)
-                issued += 1
-            host = state.cpu()
-        self.last_cg_iters = int(host[CG_ITERS].item())
-        self.last_cg_resnorm = float(host[CG_RESNORM].item())
-        return x
-
-    # ---------------------------------------------------------------- backward (symeig.py:77-86)
     def backward(self, E0, psi, grad_E0, grad_psi, x0_slab):
         """d(loss)/dg for loss with dloss/dE0 = grad_E0 (float) and dloss/dpsi = grad_psi (slab)."""
         be, n = self.be, self.nloc
@@ -381,12 +752,12 @@ class PartitionedTFIM:
         self._project_out(b, psi, scratch)                       # symeig.py:80
         x0 = x0_slab.clone()
         self._project_out(x0, psi, scratch)                      # CG.py:122
-        lam0 = self.solve_shifted(E0, b, x0)                     # symeig.py:81
+        lam0 = self.op.solve_shifted(E0, b, x0, eps=self.eps)    # symeig.py:81
         v1 = psi * float(grad_E0) - lam0                         # symeig.py:82
         w = be.empty(n)
-        self.matvec(psi, w, which="dHdg")                        # hook: (dH/dg v2).v1  (TFIM.py:100-101)
+        self.op.matvec(psi, w, which="dHdg")                     # hook: (dH/dg v2).v1  (TFIM.py:100-101)
         out = be.zeros(1)
-        self.global_dot(w, v1, out)
+        self.op.global_dot_(w, v1, out)
         return out
 
     def forward_backward(self, k, q0_slab, x0_slab, t_slab):

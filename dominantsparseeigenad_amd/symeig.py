@@ -16,6 +16,7 @@ import torch
 
 from .Lanczos import symeigLanczos
 from . import CG as _CG
+from ._space import space_of
 
 
 class DominantSymeig(torch.autograd.Function):
@@ -44,22 +45,24 @@ class DominantSymeig(torch.autograd.Function):
 
 
 def _make_sparse_symeig(A, Aadjoint_to_gadjoint, cg_cls):
+    sp = space_of(A)   # one device: plain torch expressions; row-partitioned operator: global inner products
+
     class DominantSparseSymeig(torch.autograd.Function):
         """Smallest eigenpair of a matrix-free real symmetric operator depending on parameters g."""
 
         @staticmethod
         def forward(ctx, g, k, dim, device=torch.device("cpu")):
             device = g.device if g.is_cuda else torch.device(device)
-            eigval, eigvector = symeigLanczos(A, k, device=device, extreme="min", sparse=True, dim=dim)
+            eigval, eigvector = symeigLanczos(A, k, device=device, extreme="min", sparse=True, dim=dim)  # symeig.py:72-73
             ctx.save_for_backward(g, eigval, eigvector)
             return eigval, eigvector
 
         @staticmethod
         def backward(ctx, grad_eigval, grad_eigvector):
             g, eigval, eigvector = ctx.saved_tensors
-            b = grad_eigvector - torch.matmul(eigvector, grad_eigvector) * eigvector     # symeig.py:80
+            b = grad_eigvector - sp.scale(sp.dot(eigvector, grad_eigvector), eigvector)  # symeig.py:80
             lambda0 = cg_cls.apply(g, eigval, b, eigvector)                              # symeig.py:81
-            v1, v2 = grad_eigval * eigvector - lambda0, eigvector                        # symeig.py:82-83
+            v1, v2 = sp.scale(grad_eigval, eigvector) - lambda0, eigvector               # symeig.py:82-83
             grad_g = Aadjoint_to_gadjoint(v1, v2)                                        # symeig.py:84
             return grad_g, None, None, None
 

@@ -232,7 +232,11 @@ int dsea_hypercube_flipsum(const double *xT, double *zT, int P, int64_t chunk, v
 int dsea_plz_dots(dsea_ws_t ws, const double *Q, int64_t ldq, int64_t n, int i, const double *u,
                   const double *alpha, const double *beta, double *r, double *c_out, void *stream);
 /* row >= 1: r -= sum_{j<row} c[j] Q[j] (bf16 shadow if registered and the premise holds) ; pair_out[0] = ||r||^2
- * (local).  row == 0: only pair_out[0] = r.r.  Then y = A_local r (slab-local part of the mat-vec).       */
+ * (local).  row == 0: only pair_out[0] = r.r.                                                              */
+int dsea_plz_correct(dsea_ws_t ws, const double *Q, int64_t ldq, int64_t n, int row, const double *c,
+                     double *r, double *pair_out, void *stream);
+/* the same followed by y = A_local r (operators whose remote part is ADDED after the local one, e.g. TFIM;
+ * halo-type operators call dsea_plz_correct, exchange the halo, then dsea_spmv)                            */
 int dsea_plz_correct_matvec(dsea_op_t op, dsea_ws_t ws, const double *Q, int64_t ldq, int row,
                             const double *c, double *r, double *y, double *pair_out, void *stream);
 /* y += a_host*(*a_dev) * (xs[0] + ... + xs[count-1]) - (*shift) x ; *dot_out = x.y (local).  count <= 6,

@@ -8,10 +8,20 @@ RR, DAD, RRNEW, ALPHA, BETA, RESNORM, DONE, ITERS = range(8)
 
 
 class CpuBackend:
-    def __init__(self, L, L_local, row_offset, g):
-        self.L, self.Lloc, self.off, self.g = L, L_local, row_offset, g
+    def __init__(self, n_local):
         self.device = torch.device("cpu")
-        self.n = 1 << L_local
+        self.n = int(n_local)
+        self.op = None      # no native single-GPU operand: the distributed driver always runs
+
+    def empty(self, *shape):
+        return torch.zeros(*shape, dtype=F64)
+
+    zeros = empty
+
+    # ---- slab-local operators
+    def attach_tfim(self, L, L_local, row_offset, g):
+        assert (1 << L_local) == self.n
+        self.L, self.Lloc, self.off, self.g = L, L_local, row_offset, g
         idx = torch.arange(self.n, dtype=torch.int64)
         gi = idx + row_offset
         rot = ((gi << 1) | (gi >> (L - 1))) & ((1 << L) - 1)
@@ -22,11 +32,6 @@ class CpuBackend:
         self.diag = (-(L - 2 * pop)).to(F64)
         self.idx = idx
 
-    def empty(self, *shape):
-        return torch.zeros(*shape, dtype=F64)
-
-    zeros = empty
-
     def tfim_local(self, x, y, which="H"):
         s = torch.zeros(self.n, dtype=F64)
         for j in range(self.Lloc):
@@ -35,6 +40,23 @@ class CpuBackend:
             y.copy_(x * self.diag - self.g.detach() * s)
         else:
             y.copy_(-s)
+
+    def attach_stencil(self, n_local, coef, V, halo, has_lo, has_hi):
+        assert n_local == self.n
+        self.coef, self.V, self.halo, self.has_lo, self.has_hi = coef, V, halo, has_lo, has_hi
+
+    def stencil_local(self, x, y, shift, out, skip):
+        if skip is not None and skip[0] != 0:
+            return
+        lo = self.halo[0:1] if self.has_lo else torch.zeros(1, dtype=F64)
+        hi = self.halo[1:2] if self.has_hi else torch.zeros(1, dtype=F64)
+        xp = torch.cat([lo, x, hi])
+        res = self.coef * ((-2.0 * x + xp[2:]) + xp[:-2]) + self.V * x
+        if shift is not None:
+            res = res - shift[0] * x
+        y.copy_(res)
+        if out is not None:
+            out[0] = torch.dot(x, y)
 
     def form_r(self, Q, ldq, n, i, u, alpha, beta, r, r_copy):
         r.copy_(u - alpha[0] * Q[i - 1, :n] - (beta[0] * Q[i - 2, :n] if (beta is not None and i >= 2) else 0.0))
@@ -80,11 +102,13 @@ class CpuBackend:
         self.rdots(Q, ldq, n, i, u, alpha, beta, r, c)
         c[i] = torch.dot(r, r)
 
-    def plz_correct_matvec(self, Q, ldq, row, c, r, y, pair):
-        n = r.numel()
+    def plz_correct(self, Q, ldq, n, row, c, r, pair):
         if row >= 1:
             r.sub_(Q[:row, :n].T @ c[:row])
         pair[0] = torch.dot(r, r)
+
+    def plz_correct_matvec(self, Q, ldq, row, c, r, y, pair):
+        self.plz_correct(Q, ldq, r.numel(), row, c, r, pair)
         self.tfim_local(r, y, "H")
 
     def axpy_multi_dot(self, a_host, a_dev, xs, shift, skip, x, y, out):

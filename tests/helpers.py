@@ -6,15 +6,17 @@ from dominantsparseeigenad_amd.synthetic import normal_vector
 
 
 class SeedDraws:
-    """draw #c -> normal_vector(n, base + c); callable as oracle ``draw(n, dtype)``."""
+    """draw #c -> normal_vector(n, base + c); callable as oracle ``draw(n, dtype)``.
+    ``offset``: first global row of a slab (row-partitioned runs draw their slab of the same global vector)."""
 
-    def __init__(self, base, device="cpu"):
+    def __init__(self, base, device="cpu", offset=0):
         self.base = int(base)
         self.count = 0
         self.device = device
+        self.offset = int(offset)
 
     def __call__(self, n, dtype=torch.float64):
-        v = torch.from_numpy(normal_vector(int(n), self.base + self.count)).to(dtype).to(self.device)
+        v = torch.from_numpy(normal_vector(int(n), self.base + self.count, offset=self.offset)).to(dtype).to(self.device)
         self.count += 1
         return v
 
@@ -23,8 +25,8 @@ class PatchRandn:
     """Context manager replacing ``torch.randn`` by SeedDraws -- pins the product modules exactly
     the way tests/golden/make_golden.py pinned the reference (same call order: q0, dummy, x0...)."""
 
-    def __init__(self, base):
-        self.draws = SeedDraws(base)
+    def __init__(self, base, offset=0):
+        self.draws = SeedDraws(base, offset=offset)
         self._orig = None
 
     def _randn(self, *size, dtype=None, device=None, **kw):

@@ -35,6 +35,19 @@ def test_bench_line_single_gpu():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
 
 
+def test_bench_line_bounded_cpu_sample_option():
+    d = _run(["--cpu-sample", "--no-extras"])
+    assert "capped" in d["cpu_baseline"]["sample"] and "config3" not in d["config"]
+
+
+def test_bench_line_carries_honest_extras():
+    """the all-fp64-basis step time next to the headline, and the config-3 figures driver-timed"""
+    d = _run(["--no-cpu-baseline"])
+    assert d["config"]["ms_per_step_fp64_basis"] > 0 and d["config"]["bf16_shadow_of_basis"] is True
+    c3 = d["config"]["config3"]
+    assert c3["cg_iterations"] == 1000 and c3["cg_us_per_iteration"] > 0 and c3["lanczos_k300_ms"] > 0
+
+
 def test_bench_line_partitioned_path():
     d = _run(["--force-partitioned", "--no-cpu-baseline"])
     assert REQUIRED <= set(d) and d["scaling"] == "weak"

@@ -1,13 +1,17 @@
-"""Row-partitioned driver on the real HIP backend.  The GPU box has one MI355X, so:
-  * world_size 1 over "nccl" (= RCCL): the whole distributed code path with real kernels, against the
-    single-GPU primitive;
-  * world_size 2 and 4, all ranks on cuda:0, collectives over gloo (RCCL refuses two ranks on one device): real
-    slab operators (L_local < L, row_offset != 0), real phase kernels; 2 ranks = pairwise slab exchange,
-    4 ranks = transposed all-to-all form with the HIP flip-sum kernel.
+"""Row-partitioned operators on the real HIP backend.  The GPU box has one MI355X, so:
+  * world_size 1 over "nccl" (= RCCL): the whole distributed code path with real kernels and real RCCL calls --
+    at the FULL slab size of the headline configuration (2^20 rows, k = 200, bf16 shadow on, non-split kernels)
+    against the reference-generated L = 20 scalars, through the reference API;
+  * world_size 2 and 4, all ranks on cuda:0, collectives over gloo staged through the host (RCCL refuses two
+    ranks on one device): real slab operators (L_local < L, row_offset != 0), real phase kernels; 2 ranks =
+    pairwise slab exchange, 4 ranks = transposed all-to-all form with the HIP flip-sum kernel; first and second
+    order through the reference API against the reference's fixtures; the 3-point stencil with halo exchange.
 The 8-GPU run itself is the driver's; its logic is also covered by tests/test_partitioned_gloo.py."""
 import os
 import socket
+import sys
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
@@ -17,9 +21,10 @@ pytestmark = pytest.mark.gpu
 
 import oracle  # noqa: E402
 from dominantsparseeigenad_amd.synthetic import normal_vector  # noqa: E402
-from helpers import SeedDraws  # noqa: E402
+from helpers import SeedDraws, signed_close, unit  # noqa: E402
 
 L, K, G = 12, 150, 1.0
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def _free_port():
@@ -40,11 +45,10 @@ def _host_staged_comm():
             dist.all_reduce(h)
             t.copy_(h)
 
-        def exchange(self, x, recv, peers):
-            hx = x.cpu()
-            hr = [torch.empty_like(hx) for _ in peers]
-            super().exchange(hx, hr, peers)
-            for dst, src in zip(recv, hr):
+        def sendrecv(self, items):
+            hs = [(s.cpu(), torch.empty(r.shape, dtype=r.dtype), peer) for s, r, peer in items]
+            super().sendrecv(hs)
+            for (_, dst, _), (_, src, _) in zip(items, hs):
                 dst.copy_(src)
 
         def all_to_all(self, src, dst):
@@ -56,7 +60,110 @@ def _host_staged_comm():
     return HostStagedComm()
 
 
-def _worker(rank, world, port, backend, ret):
+def _comm(backend):
+    return None if backend == "nccl" else _host_staged_comm()
+
+
+def _case_driver(rank, world, backend, dev):
+    from dominantsparseeigenad_amd.partitioned import PartitionedTFIM
+    p = world.bit_length() - 1
+    nloc = 1 << (L - p)
+    off = rank * nloc
+    g = torch.tensor([G], dtype=torch.float64, device=dev)
+    solver = PartitionedTFIM(L, g, dev, eps=1e-12, comm=_comm(backend))
+    q0 = torch.from_numpy(normal_vector(nloc, 5100, offset=off)).to(dev)
+    x0 = torch.from_numpy(normal_vector(nloc, 5102, offset=off)).to(dev)
+    t = torch.from_numpy(normal_vector(nloc, 5103, offset=off)).to(dev)
+    E0, psi, grad = solver.forward_backward(K, q0, x0, t)
+    if backend == "nccl":   # the RCCL all-to-all call itself (degenerate at world size 1: a copy)
+        src = torch.arange(1024, dtype=torch.float64, device=dev)
+        dst = torch.zeros_like(src)
+        solver.comm.all_to_all(src, dst)
+        assert torch.equal(src, dst)
+    torch.cuda.synchronize()
+    return (E0.item(), psi.cpu().numpy().copy(), grad.item(), solver.last_cg_iters)
+
+
+def _case_api_tfim(rank, world, backend, dev, tag, second_order, force_driver):
+    """reference API on a row-partitioned TFIM operator (HIP slab kernels)"""
+    from helpers import PatchRandn
+    import dominantsparseeigenad_amd.symeig as symeig
+    from dominantsparseeigenad_amd.partitioned import PartitionedTFIMOperator
+    gd = np.load(os.path.join(GOLDEN, "tfim_" + tag + ".npz"))
+    Lg, k, g0 = int(gd["L"]), int(gd["k"]), float(gd["g"])
+    p = world.bit_length() - 1
+    nloc = 1 << (Lg - p)
+    off = rank * nloc
+    g = torch.tensor([g0], dtype=torch.float64, device=dev, requires_grad=True)
+    op = PartitionedTFIMOperator(Lg, g, dev, comm=_comm(backend))
+    op.force_driver = force_driver
+    symeig.setDominantSparseSymeig(op.H, op.Hadjoint_to_gadjoint)
+    f = symeig.DominantSparseSymeig.apply
+    tvec = op.slab(unit(1 << Lg, int(gd["seed_t"]))).to(dev)
+    out = {}
+    with PatchRandn(int(gd["seed_draw_E"]), offset=off) as draws:
+        E0, psi = f(g, k, op.dim, dev)
+        (dE0,) = torch.autograd.grad(E0, g, create_graph=second_order)
+        if second_order:
+            (d2E0,) = torch.autograd.grad(dE0, g)
+            out["d2E0"] = d2E0.item()
+        out["ndraw_E"] = draws.count
+    out.update(E0=E0.item(), dE0=dE0.item(), psi_head=psi.detach()[:64].cpu().numpy().copy(),
+               psi_norm=float(op.dot(psi.detach(), psi.detach()).sqrt()))
+    if "psi" in gd.files:
+        out["psi"] = psi.detach().cpu().numpy().copy()
+        ref_slab = op.slab(torch.from_numpy(gd["psi"])).to(dev)
+        sgn = 1.0 if op.dot(psi.detach(), ref_slab).item() > 0 else -1.0
+    else:   # large cases store the head of psi only: rank 0 decides, the decision is broadcast
+        flag = torch.zeros(1, dtype=torch.float64, device=dev)
+        if rank == 0:
+            flag[0] = float(psi.detach()[:64].cpu() @ torch.from_numpy(gd["psi_head"]))
+        op.comm.allreduce(flag)
+        sgn = 1.0 if flag.item() > 0 else -1.0
+    out["sgn"] = sgn
+    with PatchRandn(int(gd["seed_draw_E"]), offset=off):
+        E0, psi = f(g, k, op.dim, dev)
+        loss = E0 + op.dot(psi, tvec) * sgn
+        (gl,) = torch.autograd.grad(loss, g)
+    out.update(loss=loss.item(), dloss=gl.item())
+    # size-independent property: distributed eigen-residual
+    w = op.H(psi.detach())
+    res = w - E0.detach() * psi.detach()
+    out["resid"] = float(op.dot(res, res).sqrt())
+    if second_order:
+        with PatchRandn(int(gd["seed_draw_E"]), offset=off):
+            E0, psi = f(g, k, op.dim, dev)
+            logF = torch.log(op.dot(psi.detach(), psi))
+            (dlogF,) = torch.autograd.grad(logF, g, create_graph=True)
+            (d2logF,) = torch.autograd.grad(dlogF, g)
+        out["chiF"] = -d2logF.item()
+    out["cg_iters"] = op.last_cg_iters
+    torch.cuda.synchronize()
+    return out
+
+
+def _case_api_stencil(rank, world, backend, dev):
+    from helpers import PatchRandn
+    import dominantsparseeigenad_amd.symeig as symeig
+    from dominantsparseeigenad_amd.partitioned import PartitionedStencil3Operator, stencil_partition
+    gd = np.load(os.path.join(GOLDEN, "schrodinger.npz"))
+    N, k, h = int(gd["N"]), int(gd["k"]), float(gd["h"])
+    rows, off = stencil_partition(N, world, rank)
+    xmesh = torch.from_numpy(np.linspace(-1.0, 1.0, num=N, endpoint=False))
+    potential = (0.5 * xmesh ** 2)[off:off + rows].clone().to(dev).requires_grad_(True)
+    op = PartitionedStencil3Operator(N, h, potential, dev, comm=_comm(backend))
+    op.force_driver = True
+    target = torch.from_numpy(gd["target"])[off:off + rows].to(dev)
+    symeig.setDominantSparseSymeig(op.Hsparse, op.Hadjoint_to_padjoint)
+    with PatchRandn(int(gd["seed_draw"]), offset=off):
+        E, psi = symeig.DominantSparseSymeig.apply(potential, k, N, dev)
+        loss = 1.0 - op.dot(psi.abs(), target)
+        (gp,) = torch.autograd.grad(loss, potential)
+    torch.cuda.synchronize()
+    return dict(E=E.item(), psi=psi.detach().cpu().numpy().copy(), loss=loss.item(), grad=gp.cpu().numpy().copy())
+
+
+def _worker(rank, world, port, backend, case, args, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
@@ -65,25 +172,18 @@ def _worker(rank, world, port, backend, ret):
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from dominantsparseeigenad_amd.partitioned import PartitionedTFIM
-        p = world.bit_length() - 1
-        nloc = 1 << (L - p)
-        off = rank * nloc
-        g = torch.tensor([G], dtype=torch.float64, device=dev)
-        solver = PartitionedTFIM(L, g, dev, eps=1e-12, comm=None if backend == "nccl" else _host_staged_comm())
-        q0 = torch.from_numpy(normal_vector(nloc, 5100, offset=off)).to(dev)
-        x0 = torch.from_numpy(normal_vector(nloc, 5102, offset=off)).to(dev)
-        t = torch.from_numpy(normal_vector(nloc, 5103, offset=off)).to(dev)
-        E0, psi, grad = solver.forward_backward(K, q0, x0, t)
-        if backend == "nccl":   # the RCCL all-to-all call itself (degenerate at world size 1: a copy)
-            src = torch.arange(1024, dtype=torch.float64, device=dev)
-            dst = torch.zeros_like(src)
-            solver.comm.all_to_all(src, dst)
-            assert torch.equal(src, dst)
-        torch.cuda.synchronize()
-        ret[rank] = (E0.item(), psi.cpu().numpy().copy(), grad.item(), solver.last_cg_iters)  # by value, not shm
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        ret[rank] = globals()[case](rank, world, backend, dev, *args)  # by value, not shm
     finally:
         dist.destroy_process_group()
+
+
+def _run(world, backend, case, *args):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), backend, case, args, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    return [ret[r] for r in range(world)]
 
 
 @pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (4, "gloo")])
@@ -95,9 +195,7 @@ def test_partitioned_hip_backend(world, backend):
     f = oracle.make_sparse_dominant_symeig(model.H, model.adjoint_hook, draw=SeedDraws(5100), eps=1e-12).apply
     t = torch.from_numpy(normal_vector(n, 5103))
     E_o, psi_o = f(model.g, K, n)
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), backend, ret), nprocs=world, join=True)
+    ret = _run(world, backend, "_case_driver")
     psi = torch.cat([torch.from_numpy(ret[r][1]) for r in range(world)])
     sgn = 1.0 if float(psi @ psi_o.detach()) > 0 else -1.0
     (g_o,) = torch.autograd.grad(E_o + sgn * psi_o.matmul(t), model.g)
@@ -107,3 +205,53 @@ def test_partitioned_hip_backend(world, backend):
     assert abs(ret[0][2] - g_o.item()) < 1e-9 * abs(g_o.item()), (info, g_o.item())
     for r in range(world):
         assert ret[r][0] == ret[0][0] and ret[r][3] == ret[0][3], info
+
+
+@pytest.mark.parametrize("force_driver", [True, False])
+def test_full_slab_world1_over_rccl_matches_reference_L20_scalars(force_driver):
+    """BASELINE configs[1] size on the DISTRIBUTED driver: 2^20 rows on one rank over RCCL (all-reduce calls
+    really issued), k = 200, bf16 shadow on, non-split kernels -- against the reference's own L = 20 outputs.
+    force_driver=False: the world-size-1 shortcut into the in-library loops gives the same numbers."""
+    gd = np.load(os.path.join(GOLDEN, "tfim_L20_k200_g1.0.npz"))
+    (o,) = _run(1, "nccl", "_case_api_tfim", "L20_k200_g1.0", False, force_driver)
+    assert o["ndraw_E"] == int(gd["ndraw_E"])
+    assert abs(o["E0"] - float(gd["E0"])) < 1e-10 * abs(float(gd["E0"]))
+    assert np.max(np.abs(o["psi_head"] * o["sgn"] - gd["psi_head"])) < 1e-9 * np.max(np.abs(gd["psi_head"]))
+    assert abs(o["psi_norm"] - 1.0) < 1e-12
+    assert abs(o["dE0"] - float(gd["dE0"][0])) < 2e-8 * abs(float(gd["dE0"][0]))      # CG eps = 1e-7 (CG.py:25)
+    assert abs(o["loss"] - float(gd["loss"])) < 1e-10 * abs(float(gd["loss"]))
+    assert abs(o["dloss"] - float(gd["dloss"][0])) < 2e-8 * abs(float(gd["dloss"][0]))
+    assert o["resid"] < 1e-9
+
+
+@pytest.mark.parametrize("world,tag", [(2, "L10_k300_g1.0"), (4, "L12_k200_g1.0")])
+def test_reference_api_second_order_on_partitioned_hip_operator(world, tag):
+    """E0, psi, dE0, d2E0, loss gradient and chi_F (E0.py:53-67, chiF.py:40-53) with the vectors cut over 2 / 4
+    ranks: the re-entrant distributed backward against the reference's own outputs."""
+    gd = np.load(os.path.join(GOLDEN, "tfim_" + tag + ".npz"))
+    ret = _run(world, "gloo", "_case_api_tfim", tag, True, True)
+    for r in range(1, world):
+        for key in ("E0", "dE0", "d2E0", "loss", "dloss", "chiF"):
+            assert ret[r][key] == ret[0][key], (key, ret[r][key], ret[0][key])
+    o = ret[0]
+    assert o["ndraw_E"] == int(gd["ndraw_E"])
+    psi = np.concatenate([ret[r]["psi"] for r in range(world)])
+    assert abs(o["E0"] - float(gd["E0"])) < 1e-10 * abs(float(gd["E0"]))
+    assert signed_close(psi, gd["psi"], 1e-10)[0]
+    assert abs(o["dE0"] - float(gd["dE0"][0])) < 2e-8 * abs(float(gd["dE0"][0]))
+    assert abs(o["d2E0"] - float(gd["d2E0"][0])) < 1e-6 * abs(float(gd["d2E0"][0]))
+    assert abs(o["loss"] - float(gd["loss"])) < 1e-10
+    assert abs(o["dloss"] - float(gd["dloss"][0])) < 2e-8 * abs(float(gd["dloss"][0]))
+    assert abs(o["chiF"] - float(gd["chiF"][0])) < 1e-7 * abs(float(gd["chiF"][0]))
+
+
+@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (3, "gloo")])
+def test_reference_api_on_partitioned_hip_stencil(world, backend):
+    gd = np.load(os.path.join(GOLDEN, "schrodinger.npz"))
+    ret = _run(world, backend, "_case_api_stencil")
+    psi = np.concatenate([ret[r]["psi"] for r in range(world)])
+    grad = np.concatenate([ret[r]["grad"] for r in range(world)])
+    assert abs(ret[0]["E"] - float(gd["E"])) < 1e-10 * abs(float(gd["E"]))
+    assert signed_close(psi, gd["psi"], 1e-9)[0]
+    assert abs(ret[0]["loss"] - float(gd["loss"])) < 1e-9
+    assert np.max(np.abs(grad - gd["grad"])) < 1e-5 * np.max(np.abs(gd["grad"]))

@@ -204,3 +204,21 @@ def test_breakdown_is_reported_not_hidden():
         lo, vlo = symeigLanczos(A, 10, extreme="min", q0=q0)
     assert any("breakdown" in str(w.message) for w in rec)
     assert abs(lo.item() - 4.0) < 1e-9          # smallest eigenvalue present in the start vector
+
+
+def test_bench_self_launches_one_worker_per_gpu():
+    """`python bench.py --gpus 2` without a launcher must start its own workers (torch.distributed.run, one process
+    per GPU) BEFORE touching the GPU.  Without GPUs here each worker stops at the no-CPU-fallback assertion -- what
+    is checked is that two ranks were started with WORLD_SIZE=2 and that the launcher reports the failure."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        assert out.returncode == 0 and '"n_gpus": 2' in out.stdout.strip().splitlines()[-1]
+    else:
+        assert out.returncode != 0
+        assert out.stderr.count("bench.py needs the MI355X") >= 2 or "local_rank: 1" in out.stderr, out.stderr[-1500:]

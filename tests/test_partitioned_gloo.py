@@ -1,9 +1,13 @@
-"""world_size 2, 4 and 8 over gloo on CPU (2: pairwise slab exchange; 4, 8: transposed all-to-all form): the row-partitioned driver (partition, hypercube exchange, all-reduce
-placement, identical branch on all ranks) against the single-process CPU oracle.  The slab-local numerics
-come from a torch-CPU test double (tests/cpu_backend.py); on the GPU box the same driver runs on HipBackend."""
+"""world_size 2, 3, 4 and 8 over gloo on CPU: the row-partitioned operators BEHIND THE REFERENCE API
+(setDominantSparseSymeig / DominantSparseSymeig.apply / autograd.grad, second order included) against the
+reference-generated fixtures and the single-process CPU oracle.  2 ranks: pairwise slab exchange; 4, 8: transposed
+all-to-all form; stencil: halo exchange on uneven slabs.  The slab-local numerics come from a torch-CPU test
+double (tests/cpu_backend.py); on the GPU box the same driver runs on HipBackend (tests/test_gpu_partitioned.py)."""
 import os
 import socket
+import sys
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
@@ -11,9 +15,10 @@ import torch.multiprocessing as mp
 
 import oracle
 from dominantsparseeigenad_amd.synthetic import normal_vector
-from helpers import SeedDraws
+from helpers import SeedDraws, signed_close, unit
 
 L, K, G = 8, 120, 1.0
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def _free_port():
@@ -24,28 +29,99 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, ret):
+def _case_driver(rank, world):
+    """hand-written forward + backward of partitioned.PartitionedTFIM (no autograd)"""
+    from cpu_backend import CpuBackend
+    from dominantsparseeigenad_amd.partitioned import PartitionedTFIM
+    p = world.bit_length() - 1
+    nloc = 1 << (L - p)
+    off = rank * nloc
+    g = torch.tensor([G], dtype=torch.float64)
+    solver = PartitionedTFIM(L, g, "cpu", backend=CpuBackend(nloc), eps=1e-12)
+    q0 = torch.from_numpy(normal_vector(nloc, 5000, offset=off))
+    x0 = torch.from_numpy(normal_vector(nloc, 5002, offset=off))
+    t = torch.from_numpy(normal_vector(nloc, 5003, offset=off))
+    E0, psi, grad = solver.forward_backward(K, q0, x0, t)
+    return (E0.item(), psi.numpy().copy(), grad.item(), solver.last_cg_iters)
+
+
+def _case_api_tfim(rank, world, tag):
+    """E0, dE0, d2E0, loss gradient, chi_F through the reference API on a row-partitioned operator"""
+    from cpu_backend import CpuBackend
+    from helpers import PatchRandn
+    import dominantsparseeigenad_amd.symeig as symeig
+    from dominantsparseeigenad_amd.partitioned import PartitionedTFIMOperator
+    gd = np.load(os.path.join(GOLDEN, "tfim_" + tag + ".npz"))
+    Lg, k, g0 = int(gd["L"]), int(gd["k"]), float(gd["g"])
+    p = world.bit_length() - 1
+    nloc = 1 << (Lg - p)
+    off = rank * nloc
+    g = torch.tensor([g0], dtype=torch.float64, requires_grad=True)
+    op = PartitionedTFIMOperator(Lg, g, "cpu", backend=CpuBackend(nloc))
+    symeig.setDominantSparseSymeig(op.H, op.Hadjoint_to_gadjoint)
+    f = symeig.DominantSparseSymeig.apply
+    tvec = op.slab(unit(1 << Lg, int(gd["seed_t"])))
+    out = {}
+    with PatchRandn(int(gd["seed_draw_E"]), offset=off) as draws:
+        E0, psi = f(g, k, op.dim, "cpu")
+        (dE0,) = torch.autograd.grad(E0, g, create_graph=True)
+        (d2E0,) = torch.autograd.grad(dE0, g)
+        out["ndraw_E"] = draws.count
+    out.update(E0=E0.item(), psi=psi.detach().numpy().copy(), dE0=dE0.item(), d2E0=d2E0.item())
+    sgn_probe = op.dot(psi.detach(), op.slab(torch.from_numpy(gd["psi"]))).item()
+    sgn = 1.0 if sgn_probe > 0 else -1.0
+    with PatchRandn(int(gd["seed_draw_E"]), offset=off):
+        E0, psi = f(g, k, op.dim, "cpu")
+        loss = E0 + op.dot(psi, tvec) * sgn
+        (gl,) = torch.autograd.grad(loss, g)
+    out.update(loss=loss.item(), dloss=gl.item())
+    with PatchRandn(int(gd["seed_draw_E"]), offset=off):
+        E0, psi = f(g, k, op.dim, "cpu")
+        logF = torch.log(op.dot(psi.detach(), psi))
+        (dlogF,) = torch.autograd.grad(logF, g, create_graph=True)
+        (d2logF,) = torch.autograd.grad(dlogF, g)
+    out["chiF"] = -d2logF.item()
+    return out
+
+
+def _case_api_stencil(rank, world):
+    """1-D Schroedinger problem (schrodinger1D.py:64-73 semantics) on uneven slabs with halo exchange"""
+    from cpu_backend import CpuBackend
+    from helpers import PatchRandn
+    import dominantsparseeigenad_amd.symeig as symeig
+    from dominantsparseeigenad_amd.partitioned import PartitionedStencil3Operator, stencil_partition
+    gd = np.load(os.path.join(GOLDEN, "schrodinger.npz"))
+    N, k, h = int(gd["N"]), int(gd["k"]), float(gd["h"])
+    rows, off = stencil_partition(N, world, rank)
+    xmesh = torch.from_numpy(np.linspace(-1.0, 1.0, num=N, endpoint=False))
+    potential = (0.5 * xmesh ** 2)[off:off + rows].clone().requires_grad_(True)
+    op = PartitionedStencil3Operator(N, h, potential, "cpu", backend=CpuBackend(rows))
+    target = torch.from_numpy(gd["target"])[off:off + rows]
+    symeig.setDominantSparseSymeig(op.Hsparse, op.Hadjoint_to_padjoint)
+    with PatchRandn(int(gd["seed_draw"]), offset=off):
+        E, psi = symeig.DominantSparseSymeig.apply(potential, k, N, "cpu")
+        loss = 1.0 - op.dot(psi.abs(), target)
+        (gp,) = torch.autograd.grad(loss, potential)
+    return dict(E=E.item(), psi=psi.detach().numpy().copy(), loss=loss.item(), grad=gp.numpy().copy(), off=off)
+
+
+def _worker(rank, world, port, case, args, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        import sys
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-        from cpu_backend import CpuBackend
-        from dominantsparseeigenad_amd.partitioned import PartitionedTFIM
-        p = world.bit_length() - 1
-        nloc = 1 << (L - p)
-        off = rank * nloc
-        g = torch.tensor([G], dtype=torch.float64)
-        be = CpuBackend(L, L - p, off, g)
-        solver = PartitionedTFIM(L, g, "cpu", backend=be, eps=1e-12)
-        q0 = torch.from_numpy(normal_vector(nloc, 5000, offset=off))
-        x0 = torch.from_numpy(normal_vector(nloc, 5002, offset=off))
-        t = torch.from_numpy(normal_vector(nloc, 5003, offset=off))
-        E0, psi, grad = solver.forward_backward(K, q0, x0, t)
-        ret[rank] = (E0.item(), psi.numpy().copy(), grad.item(), solver.last_cg_iters)  # by value, not shm
+        ret[rank] = globals()[case](rank, world, *args)   # results by value, not shm
     finally:
         dist.destroy_process_group()
+
+
+def _run(world, case, *args):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), case, args, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    return [ret[r] for r in range(world)]
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
@@ -59,11 +135,7 @@ def test_partitioned_matches_single_process_oracle(world):
     E_o, psi_o = f(model.g, K, n)
     (g_o,) = torch.autograd.grad(E_o + psi_o.matmul(t), model.g)
 
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    port = _free_port()
-    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
-    assert len(ret) == world
+    ret = _run(world, "_case_driver")
     psi = torch.cat([torch.from_numpy(ret[r][1]) for r in range(world)])
     sgn = 1.0 if float(psi @ psi_o.detach()) > 0 else -1.0
     for r in range(world):
@@ -75,3 +147,37 @@ def test_partitioned_matches_single_process_oracle(world):
     if sgn < 0:
         (g_o,) = torch.autograd.grad(E_o - psi_o.matmul(t), model.g)
     assert abs(ret[0][2] - g_o.item()) < 1e-9 * abs(g_o.item()), (ret[0][2], g_o.item())
+
+
+@pytest.mark.parametrize("world,tag", [(2, "L10_k300_g1.0"), (4, "L10_k300_g1.0"), (4, "L12_k200_g1.0")])
+def test_reference_api_on_partitioned_tfim_matches_reference_fixtures(world, tag):
+    """The REFERENCE'S OWN outputs (tests/golden/make_golden.py ran reference symeig.py / CG.py / E0.py:53-67 /
+    chiF.py:40-53) reproduced with the vectors cut over ``world`` ranks: same call sequence, same number of RNG
+    draws, first and second order."""
+    gd = np.load(os.path.join(GOLDEN, "tfim_" + tag + ".npz"))
+    ret = _run(world, "_case_api_tfim", tag)
+    for r in range(1, world):          # replicated scalars: bit-identical on all ranks
+        for key in ("E0", "dE0", "d2E0", "loss", "dloss", "chiF"):
+            assert ret[r][key] == ret[0][key], (key, ret[r][key], ret[0][key])
+    o = ret[0]
+    assert o["ndraw_E"] == int(gd["ndraw_E"])
+    psi = np.concatenate([ret[r]["psi"] for r in range(world)])
+    assert abs(o["E0"] - float(gd["E0"])) < 1e-10 * abs(float(gd["E0"]))
+    assert signed_close(psi, gd["psi"], 1e-10)[0]
+    assert abs(o["dE0"] - float(gd["dE0"][0])) < 2e-8 * abs(float(gd["dE0"][0]))     # CG eps = 1e-7 (CG.py:25)
+    assert abs(o["d2E0"] - float(gd["d2E0"][0])) < 1e-6 * abs(float(gd["d2E0"][0]))
+    assert abs(o["loss"] - float(gd["loss"])) < 1e-10
+    assert abs(o["dloss"] - float(gd["dloss"][0])) < 2e-8 * abs(float(gd["dloss"][0]))
+    assert abs(o["chiF"] - float(gd["chiF"][0])) < 1e-7 * abs(float(gd["chiF"][0]))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_reference_api_on_partitioned_stencil_matches_reference_fixture(world):
+    gd = np.load(os.path.join(GOLDEN, "schrodinger.npz"))
+    ret = _run(world, "_case_api_stencil")
+    psi = np.concatenate([ret[r]["psi"] for r in range(world)])
+    grad = np.concatenate([ret[r]["grad"] for r in range(world)])
+    assert abs(ret[0]["E"] - float(gd["E"])) < 1e-10 * abs(float(gd["E"]))
+    assert signed_close(psi, gd["psi"], 1e-9)[0]
+    assert abs(ret[0]["loss"] - float(gd["loss"])) < 1e-9
+    assert np.max(np.abs(grad - gd["grad"])) < 1e-5 * np.max(np.abs(gd["grad"]))   # CG hits the n-iteration cap (SURVEY 8d C3)

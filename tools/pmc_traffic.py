@@ -38,9 +38,20 @@ for name in sorted(fetch):
     out[name] = {"launches": n, "fetch_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                  "hbm_bytes_per_launch": rd + wr}
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# whole-step traffic: the profiled command runs STEPS forward+backward passes (warmup included)
+STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+out["_steps_profiled"] = STEPS
+out["_total_hbm_bytes_per_step"] = sum(v["launches"] * v["hbm_bytes_per_launch"] for kname, v in out.items()
+                                       if kname.startswith("k_")) / STEPS
+try:
+    import subprocess
+    out["_commit"] = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True,
+                                    text=True).stdout.strip() or os.environ.get("DSEA_COMMIT", "unknown")
+except Exception:
+    out["_commit"] = os.environ.get("DSEA_COMMIT", "unknown")
 with open(os.path.join(root, "profiles", "pmc_traffic.json"), "w") as f:
     json.dump(out, f, indent=1)
 for k, v in out.items():
-    if k != "_method":
+    if not k.startswith("_"):
         print("%-24s launches %5d  read %10.1f MB  write %8.1f MB  total %10.1f MB" % (
             k, v["launches"], v["fetch_bytes_per_launch"] / 1e6, v["write_bytes_per_launch"] / 1e6, v["hbm_bytes_per_launch"] / 1e6))
