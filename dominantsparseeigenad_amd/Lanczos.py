@@ -32,7 +32,7 @@ def _resolve(A, device, sparse, dim):
     return n, dtype, amap
 
 
-def _lanczos_core(A, k, device, sparse, dim, q0):
+def _lanczos_core(A, k, device, sparse, dim, q0, arena=False):
     device = torch.device(device)
     part = engine.native_of(A) if sparse else None
     if part is not None and getattr(part, "partitioned", False):
@@ -42,7 +42,7 @@ def _lanczos_core(A, k, device, sparse, dim, q0):
         if q0 is None:
             q0 = torch.randn(nloc, dtype=torch.float64, device=dev)
         torch.randn(nloc, dtype=torch.float64, device=dev)
-        Q, ldq, alphas, betas = part.lanczos(k, q0)
+        Q, ldq, alphas, betas = part.lanczos(k, q0, arena=arena)
         return (part, Q, ldq, nloc, alphas, betas, torch.float64)
     n, dtype, amap = _resolve(A, device, sparse, dim)
     if q0 is None:
@@ -60,9 +60,9 @@ def _lanczos_core(A, k, device, sparse, dim, q0):
             q0 = q0.to(torch.float64)
         native = engine.native_of(A) if sparse else None
         if native is not None:
-            Q, ldq, alphas, betas = engine.lanczos(A, k, n, device, q0, native=native)
+            Q, ldq, alphas, betas = engine.lanczos(A, k, n, device, q0, native=native, arena=arena)
         else:
-            Q, ldq, alphas, betas = engine.lanczos(A, k, n, device, q0, callable_A=amap)
+            Q, ldq, alphas, betas = engine.lanczos(A, k, n, device, q0, callable_A=amap, arena=arena)
         return ("cuda", Q, ldq, n, alphas, betas, dtype)
     Qk, alphas, betas = lanczos_host(amap, k, n, dtype, q0, device)
     return ("cpu", Qk, None, n, alphas, betas, dtype)
@@ -83,7 +83,8 @@ def symeigLanczos(A, k, device=torch.device("cpu"), extreme="both", *, sparse=Fa
     """Extreme eigenvalue(s)/eigenvector(s); outputs as in Lanczos.py:88-105 (all torch tensors)."""
     if extreme not in ("both", "min", "max"):
         raise ValueError("extreme must be 'both', 'min' or 'max'")
-    where, Q, ldq, n, alphas, betas, dtype = _lanczos_core(A, k, device, sparse, dim, q0)
+    # the basis is transient here (only Ritz vectors are returned): it lives in the persistent arena
+    where, Q, ldq, n, alphas, betas, dtype = _lanczos_core(A, k, device, sparse, dim, q0, arena=True)
     pairs = engine.tridiag_extreme(alphas, betas, extreme)
     out = []
     for val, s in pairs:
@@ -92,6 +93,6 @@ def symeigLanczos(A, k, device=torch.device("cpu"), extreme="both", *, sparse=Fa
         elif where != "cpu":
             vec = where.ritz_vector(Q, ldq, k, s)           # row-partitioned: this rank's slab of the Ritz vector
         else:
-            vec = torch.matmul(Q, torch.from_numpy(s).to(Q.dtype))
+            vec = torch.matmul(Q[:, :s.shape[0]], torch.from_numpy(s).to(Q.dtype))
         out += [torch.tensor(val, dtype=dtype, device=alphas.device), vec.to(dtype)]
     return tuple(out)

@@ -18,6 +18,7 @@ _lib = None
 CG_RR, CG_DAD, CG_RRNEW, CG_ALPHA, CG_BETA, CG_RESNORM, CG_DONE, CG_ITERS = range(8)
 CG_STATE_LEN = 8
 ERR_NOT_CONVERGED = -5
+ERR_BREAKDOWN = -7
 
 
 class DseaError(RuntimeError):
@@ -29,7 +30,7 @@ _SIGNATURES = {
     "dsea_version": (c_int, []),
     "dsea_error_string": (c_char_p, [c_int]),
     "dsea_last_hip_error": (c_int, []),
-    "dsea_set_tuning": (c_int, [c_int, c_int]),
+    "dsea_op_set_tuning": (c_int, [c_void_p, c_int, c_int]),
     "dsea_ws_bytes": (c_int, [c_int64, c_int, POINTER(c_size_t)]),
     "dsea_ws_create": (c_int, [c_void_p, c_size_t, c_int64, c_int, POINTER(c_void_p)]),
     "dsea_ws_destroy": (c_int, [c_void_p]),
@@ -78,6 +79,7 @@ _SIGNATURES = {
                                 c_void_p, c_int64, c_void_p]),
     "dsea_lanczos_run": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                  c_void_p]),
+    "dsea_lanczos_status": (c_int, [c_void_p, POINTER(c_int), c_void_p]),
     "dsea_cg_run": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int64,
                             c_int, POINTER(c_int64), POINTER(c_double), c_void_p]),
 }

@@ -107,16 +107,24 @@ const char* dsea_error_string(int status) {
     case DSEA_ERR_HIP: return "HIP runtime error";
     case DSEA_ERR_NOT_CONVERGED: return "CG did not converge within maxiter";
     case DSEA_ERR_UNSUPPORTED: return "unsupported configuration";
+    case DSEA_ERR_BREAKDOWN: return "Lanczos breakdown: the Krylov space is smaller than k";
     default: return "unknown status";
   }
 }
 
 int dsea_last_hip_error(void) { return g_last_hip; }
 
-int dsea_set_tuning(int key, int value) {
+int dsea_op_set_tuning(dsea_op_t op, int key, int value) {
+  if (!op) return DSEA_ERR_ARG;
   switch (key) {
-    case DSEA_TUNE_TFIM_TILE_LOG2: set_tfim_tile_log2(value); return DSEA_OK;
-    case DSEA_TUNE_CSR_GROUP: set_csr_group(value); return DSEA_OK;
+    case DSEA_TUNE_TFIM_TILE_LOG2:
+      if (value < 6 || value > 12) return DSEA_ERR_ARG;
+      op->d.tune_tile_log2 = value;
+      return DSEA_OK;
+    case DSEA_TUNE_CSR_GROUP:
+      if (value != 0 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64) return DSEA_ERR_ARG;
+      op->d.tune_csr_group = value;
+      return DSEA_OK;
     default: return DSEA_ERR_ARG;
   }
 }
@@ -262,6 +270,7 @@ int dsea_op_create_tfim(int L, int L_local, int64_t row_offset, const double* g_
   dsea_op_s* op = new (std::nothrow) dsea_op_s;
   if (!op) return DSEA_ERR_ARG;
   memset(&op->d, 0, sizeof(op->d));
+  op->d.tune_tile_log2 = DSEA_TFIM_TILE_LOG2;
   op->d.kind = OP_TFIM;
   op->d.n = (int64_t)1 << L_local;
   op->d.tfim = TfimParams{L, L_local, row_offset, g_dev, g_const, diag_scale};
@@ -275,6 +284,7 @@ int dsea_op_create_csr(int64_t n, int64_t nnz, const int64_t* rowptr, const int3
   dsea_op_s* op = new (std::nothrow) dsea_op_s;
   if (!op) return DSEA_ERR_ARG;
   memset(&op->d, 0, sizeof(op->d));
+  op->d.tune_tile_log2 = DSEA_TFIM_TILE_LOG2;
   op->d.kind = OP_CSR;
   op->d.n = n;
   op->d.csr = CsrParams{n, nnz, rowptr, colidx, vals};
@@ -288,6 +298,7 @@ int dsea_op_create_sell(int64_t n, int64_t nslices, const int64_t* slice_ptr, co
   dsea_op_s* op = new (std::nothrow) dsea_op_s;
   if (!op) return DSEA_ERR_ARG;
   memset(&op->d, 0, sizeof(op->d));
+  op->d.tune_tile_log2 = DSEA_TFIM_TILE_LOG2;
   op->d.kind = OP_SELL;
   op->d.n = n;
   op->d.sell = SellParams{n, nslices, slice_ptr, colidx, vals};
@@ -301,6 +312,7 @@ int dsea_op_create_stencil3(int64_t n, double coef, const double* V_dev, const d
   dsea_op_s* op = new (std::nothrow) dsea_op_s;
   if (!op) return DSEA_ERR_ARG;
   memset(&op->d, 0, sizeof(op->d));
+  op->d.tune_tile_log2 = DSEA_TFIM_TILE_LOG2;
   op->d.kind = OP_STENCIL3;
   op->d.n = n;
   op->d.st3 = Stencil3Params{n, coef, V_dev, halo_lo, halo_hi};
@@ -599,8 +611,9 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
     lds = w.shadow_ld;
   }
   double* lp_count = w.scal + 16;
+  double* brk = w.scal + DSEA_SCAL_BREAK;  // [0] breakdown step (0 = none), [1] running max |alpha|,|beta|
   {
-    hipError_t me = hipMemsetAsync(lp_count, 0, 2 * sizeof(double), st);
+    hipError_t me = hipMemsetAsync(lp_count, 0, (DSEA_SCAL_BREAK + 2 - 16) * sizeof(double), st);
     if (me != hipSuccess) {
       g_last_hip = (int)me;
       return DSEA_ERR_HIP;
@@ -622,17 +635,19 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
     for (int i = 1; i < k; ++i) {
       const double* beta_prev = (i >= 2) ? betas + (i - 2) : nullptr;
       launch_rdots(g, Q, ldq, n, i, u, nullptr, beta_prev, r, P, w.coef, st,
-                   prof ? prof->next(PROF_RDOTS) : nullptr, aP, na, alphas + (i - 1), Qs != nullptr);
+                   prof ? prof->next(PROF_RDOTS) : nullptr, aP, na, alphas + (i - 1), Qs != nullptr, brk);
       int nn = g.nw;
       if (Qs)
         nn = launch_axpy_norm_lp(n, rps, Q, ldq, Qs, lds, i, w.coef, w.lp_tau, r, nP, lp_count, st,
-                                 prof ? prof->next(PROF_AXPY) : nullptr);
+                                 prof ? prof->next(PROF_AXPY) : nullptr, brk);
       else
-        launch_axpy_norm(g, Q, ldq, n, i, w.coef, r, nP, nullptr, st, prof ? prof->next(PROF_AXPY) : nullptr);
+        launch_axpy_norm(g, Q, ldq, n, i, w.coef, r, nP, nullptr, st, prof ? prof->next(PROF_AXPY) : nullptr, brk);
+      // beta_{i-1} ~ 0 (relative to the running |alpha|, |beta| scale): the tail records step i in brk and every
+      // later launch of this run returns at once (Lanczos.py:69-70 would divide by it)
       na = launch_tfim_fused(op->d, r, nP, nn, Q + (int64_t)i * ldq, u, betas + (i - 1), aP, st,
-                             prof ? prof->next(PROF_SPMV) : nullptr, Qs ? Qs + (int64_t)i * lds : nullptr);
+                             prof ? prof->next(PROF_SPMV) : nullptr, Qs ? Qs + (int64_t)i * lds : nullptr, brk, i);
     }
-    launch_finalize1(aP, na, alphas + (k - 1), st);
+    launch_finalize_slot(aP, na, alphas + (k - 1), brk, st);
     return check_launch();
   }
   int nb = launch_spmv(op->d, Q, u, nullptr, nullptr, P, st, prof ? prof->next(PROF_SPMV) : nullptr);
@@ -641,21 +656,35 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
   for (int i = 1; i < k; ++i) {
     const double* beta_prev = (i >= 2) ? betas + (i - 2) : nullptr;
     launch_rdots(g, Q, ldq, n, i, u, alphas + (i - 1), beta_prev, r, P, w.coef, st,
-                 prof ? prof->next(PROF_RDOTS) : nullptr, nullptr, 0, nullptr, Qs != nullptr);
+                 prof ? prof->next(PROF_RDOTS) : nullptr, nullptr, 0, nullptr, Qs != nullptr, brk);
     if (Qs) {
       double* nP = w.aux + DSEA_MAX_WAVE_TILES;
       int nn = launch_axpy_norm_lp(n, rps, Q, ldq, Qs, lds, i, w.coef, w.lp_tau, r, nP, lp_count, st,
-                                   prof ? prof->next(PROF_AXPY) : nullptr);
-      launch_finalize1(nP, nn, nrm2, st);
+                                   prof ? prof->next(PROF_AXPY) : nullptr, brk);
+      launch_finalize_slot(nP, nn, nrm2, brk, st);
     } else {
-      launch_axpy_norm(g, Q, ldq, n, i, w.coef, r, P, nrm2, st, prof ? prof->next(PROF_AXPY) : nullptr);
+      launch_axpy_norm(g, Q, ldq, n, i, w.coef, r, P, nullptr, st, prof ? prof->next(PROF_AXPY) : nullptr, brk);
+      launch_finalize_slot(P, g.nw, nrm2, brk, st);
     }
     double* qi = Q + (int64_t)i * ldq;
-    launch_scale_store(r, nrm2, qi, betas + (i - 1), n, st, Qs ? Qs + (int64_t)i * lds : nullptr);
-    nb = launch_spmv(op->d, qi, u, nullptr, nullptr, P, st, prof ? prof->next(PROF_SPMV) : nullptr);
-    launch_finalize1(P, nb, alphas + i, st);
+    launch_scale_store(r, nrm2, qi, betas + (i - 1), n, st, Qs ? Qs + (int64_t)i * lds : nullptr, brk, i);
+    nb = launch_spmv(op->d, qi, u, nullptr, brk, P, st, prof ? prof->next(PROF_SPMV) : nullptr);
+    launch_finalize_slot(P, nb, alphas + i, brk, st);
   }
   return check_launch();
+}
+
+int dsea_lanczos_status(dsea_ws_t ws, int* break_step, void* stream) {
+  if (!ws) return DSEA_ERR_ARG;
+  double h[2] = {0.0, 0.0};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemcpyAsync(h, ws->w.scal + DSEA_SCAL_BREAK, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess) {
+    g_last_hip = (int)hipGetLastError();
+    return DSEA_ERR_HIP;
+  }
+  if (break_step) *break_step = (int)h[0];
+  return h[0] != 0.0 ? DSEA_ERR_BREAKDOWN : DSEA_OK;
 }
 
 int dsea_cg_run(dsea_op_t op, dsea_ws_t ws, const double* shift, const double* b, double* x, double* state,

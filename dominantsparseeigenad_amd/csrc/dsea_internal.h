@@ -12,6 +12,7 @@
 #define DSEA_TFIM_TILE_LOG2 11    /* rows of x staged in LDS per block of the TFIM mat-vec    */
 #define DSEA_MAX_TFIM_BLOCKS 4096 /* grid cap of the TFIM mat-vec (<= DSEA_MAX_WAVE_TILES partial slots)   */
 #define DSEA_SCALARS 64
+#define DSEA_SCAL_BREAK 20    /* scal[20] = breakdown step, scal[21] = running scale (see broken())     */
 
 namespace dsea {
 
@@ -45,6 +46,8 @@ enum OpKind { OP_TFIM = 1, OP_CSR = 2, OP_STENCIL3 = 3, OP_SELL = 4 };
 struct OpDesc {
   OpKind kind;
   int64_t n;
+  int tune_tile_log2;  // TFIM: log2 rows of x staged in LDS per block (6..12)
+  int tune_csr_group;  // CSR: lanes per row, 0 = automatic
   TfimParams tfim;
   CsrParams csr;
   Stencil3Params st3;
@@ -94,26 +97,25 @@ struct Workspace {
   TileGeom geom(int64_t n_rows) const;
 };
 
-void set_tfim_tile_log2(int t);
-void set_csr_group(int g);
 void launch_finalize1(const double* P, int count, double* out, hipStream_t st);
 void launch_finalize_slot(const double* P, int count, double* out, const double* skip, hipStream_t st);
 void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* u,
                   const double* alpha, const double* beta, double* r, double* P, double* c_out,
                   hipStream_t st, EventPair* ev = nullptr, const double* aP = nullptr, int aCount = 0,
-                  double* a_store = nullptr, bool want_rr = false);
+                  double* a_store = nullptr, bool want_rr = false, double* brk = nullptr);
 int launch_axpy_norm_lp(int64_t n, int rps, const double* Q, int64_t ldq, const uint16_t* Qs, int64_t lds, int i,
                         const double* c, double tau, double* r, double* P, double* lp_count, hipStream_t st,
-                        EventPair* ev = nullptr);
+                        EventPair* ev = nullptr, const double* brk = nullptr);
 int launch_tfim_fused(const OpDesc& op, const double* r, const double* nP, int nCount, double* q_out, double* y,
                       double* beta_store, double* P, hipStream_t st, EventPair* ev = nullptr,
-                      uint16_t* qs_out = nullptr);
+                      uint16_t* qs_out = nullptr, double* brk = nullptr, int step = 0);
 int launch_cg_update_fused(double* x, double* r, const double* d, const double* Ad, const double* state,
                            int parity, const double* dP, int dCount, int64_t n, double* P, hipStream_t st);
 void launch_cg_direction_fused(const double* r, double* d, double* state, int parity, const double* rP,
                                int rCount, double eps, int64_t n, hipStream_t st);
 void launch_axpy_norm(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* c,
-                      double* r, double* P, double* nrm2_out, hipStream_t st, EventPair* ev = nullptr);
+                      double* r, double* P, double* nrm2_out, hipStream_t st, EventPair* ev = nullptr,
+                      const double* brk = nullptr);
 void launch_ritz(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int k, const double* s,
                  double* out, hipStream_t st);
 void launch_dot(const double* x, const double* y, int64_t n, double* P, double* out, hipStream_t st);
@@ -121,7 +123,7 @@ void launch_shift_dot(const double* x, double* y, const double* shift, const dou
                       double* P, double* out, hipStream_t st);
 void launch_axpy(double a_host, const double* a_dev, const double* x, double* y, int64_t n, hipStream_t st);
 void launch_scale_store(const double* r, const double* nrm2, double* q, double* beta_out, int64_t n,
-                        hipStream_t st, uint16_t* qs = nullptr);
+                        hipStream_t st, uint16_t* qs = nullptr, double* brk = nullptr, int step = 0);
 void launch_project_apply(const double* v, const double* a, const double* dot, double* out, int64_t n,
                           hipStream_t st);
 void launch_cg_init(const double* b, const double* Ax0, double* r, double* d, double* state, int64_t n,

@@ -89,6 +89,12 @@ __device__ __forceinline__ void st_bf16x2(uint16_t* __restrict__ p, int64_t row,
   }
 }
 
+// Breakdown record of a native Lanczos run: brk[0] = step at which beta ~ 0 was found (0 = none),
+// brk[1] = running max of |alpha_j|, |beta_j| (the scale beta is compared with).  Every kernel of the loop
+// starts with broken(brk): once the record is set the remaining launches of the run are no-ops.
+#define DSEA_BREAK_TOL 1e-13
+__device__ __forceinline__ bool broken(const double* __restrict__ brk) { return brk && brk[0] != 0.0; }
+
 // ------------------------------------------------------------------------------------------
 // stage-2 reductions (deterministic)
 // ------------------------------------------------------------------------------------------
@@ -104,8 +110,10 @@ __global__ __launch_bounds__(256) void k_finalize1(const double* __restrict__ pa
 
 // c[j] = sum_{w<nw} P[j*pstride + w]   (one 256-thread block per j, 4 independent loads in flight per lane)
 __global__ __launch_bounds__(256) void k_finalize_multi(const double* __restrict__ P, int64_t pstride,
-                                                        int nw, double* __restrict__ c) {
+                                                        int nw, double* __restrict__ c,
+                                                        const double* __restrict__ brk) {
   __shared__ double sm4[4];
+  if (broken(brk)) return;
   const int j = blockIdx.x;
   const double* __restrict__ row = P + (int64_t)j * pstride;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -255,10 +263,12 @@ __global__ __launch_bounds__(256) void k_rdots(const double* __restrict__ Q, int
                                                const double* __restrict__ beta, double* __restrict__ r,
                                                double* __restrict__ P, int64_t pstride, int nw,
                                                int64_t ntiles, const double* __restrict__ aP, int aCount,
-                                               double* __restrict__ a_store, int want_rr) {
+                                               double* __restrict__ a_store, int want_rr,
+                                               double* __restrict__ brk) {
   const int lane = threadIdx.x & 63;
   const int64_t widx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (widx >= nw) return;
+  if (broken(brk)) return;
   // alpha_{i-1}: either finalised already (phase API) or still as the mat-vec's per-block partials
   double a;
   if (aCount > 0) {
@@ -268,6 +278,8 @@ __global__ __launch_bounds__(256) void k_rdots(const double* __restrict__ Q, int
     a = alpha[0];
   }
   const double b = beta ? beta[0] : 0.0;
+  // (read by the tail kernel of this step -- a later launch -- only)
+  if (brk && widx == 0 && lane == 0) brk[1] = fmax(brk[1], fmax(fabs(a), fabs(b)));
   constexpr int64_t TILE = 64 * RPL;
   bool first = true;
   for (int64_t tile = widx; tile < ntiles; tile += nw) {
@@ -330,10 +342,11 @@ template <int RPL, int MODE>
 __global__ __launch_bounds__(256) void k_axpy_norm(const double* __restrict__ Q, int64_t ldq, int i,
                                                    int64_t n, const double* __restrict__ c,
                                                    double* __restrict__ r, double* __restrict__ P,
-                                                   int nw, int64_t ntiles) {
+                                                   int nw, int64_t ntiles, const double* __restrict__ brk) {
   const int lane = threadIdx.x & 63;
   const int64_t widx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (widx >= nw) return;
+  if (broken(brk)) return;
   constexpr int64_t TILE = 64 * RPL;
   double acc = 0.0;
   for (int64_t tile = widx; tile < ntiles; tile += nw) {
@@ -363,10 +376,12 @@ __global__ __launch_bounds__(W * 64) void k_rdots_split(const double* __restrict
                                                         const double* __restrict__ beta, double* __restrict__ r,
                                                         double* __restrict__ P, int64_t pstride,
                                                         const double* __restrict__ aP, int aCount,
-                                                        double* __restrict__ a_store, int want_rr) {
+                                                        double* __restrict__ a_store, int want_rr,
+                                                        double* __restrict__ brk) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t tile = blockIdx.x;
   const int64_t row = tile * 128 + lane * 2;
+  if (broken(brk)) return;
   double a;
   if (aCount > 0) {
     a = sum_partials_wave(aP, aCount, lane);
@@ -375,6 +390,7 @@ __global__ __launch_bounds__(W * 64) void k_rdots_split(const double* __restrict
     a = alpha[0];
   }
   const double b = beta ? beta[0] : 0.0;
+  if (brk && tile == 0 && wv == 0 && lane == 0) brk[1] = fmax(brk[1], fmax(fabs(a), fabs(b)));
   const double* __restrict__ q1 = Q + (int64_t)(i - 1) * ldq;
   const double2 uu = ld2<true>(u, row, n), qa = ld2<true>(q1, row, n);
   double2 qb = make_double2(0.0, 0.0);
@@ -417,8 +433,10 @@ __global__ __launch_bounds__(W * 64) void k_rdots_split(const double* __restrict
 template <int W, int MODE>
 __global__ __launch_bounds__(W * 64) void k_axpy_norm_split(const double* __restrict__ Q, int64_t ldq, int i,
                                                             int64_t n, const double* __restrict__ c,
-                                                            double* __restrict__ r, double* __restrict__ P) {
+                                                            double* __restrict__ r, double* __restrict__ P,
+                                                            const double* __restrict__ brk) {
   __shared__ double2 part[W][64];
+  if (broken(brk)) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t tile = blockIdx.x;
   const int64_t row = tile * 128 + lane * 2;
@@ -556,10 +574,12 @@ __global__ __launch_bounds__(256) void k_axpy_norm_lp(const double* __restrict__
                                                       const uint16_t* __restrict__ Qs, int64_t lds, int i,
                                                       int64_t n, const double* __restrict__ c, double tau2,
                                                       double* __restrict__ r, double* __restrict__ P, int nw,
-                                                      int64_t ntiles, double* __restrict__ lp_count) {
+                                                      int64_t ntiles, double* __restrict__ lp_count,
+                                                      const double* __restrict__ brk) {
   const int lane = threadIdx.x & 63;
   const int64_t widx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (widx >= nw) return;
+  if (broken(brk)) return;
   // premise check, identical in every wave: max_j c_j^2 <= tau^2 ||r||^2   (c[i] = ||r||^2 from the dots pass)
   double m = 0.0;
   for (int b = lane; b < i; b += 64) {
@@ -642,9 +662,15 @@ __global__ __launch_bounds__(256) void k_axpy(double a_host, const double* __res
 __global__ __launch_bounds__(256) void k_scale_store(const double* __restrict__ r,
                                                      const double* __restrict__ nrm2,
                                                      double* __restrict__ q, double* __restrict__ beta_out,
-                                                     int64_t n, uint16_t* __restrict__ qs) {
+                                                     int64_t n, uint16_t* __restrict__ qs,
+                                                     double* __restrict__ brk, int step) {
+  if (broken(brk)) return;
   const double beta = sqrt(nrm2[0]);
   if (beta_out && blockIdx.x == 0 && threadIdx.x == 0) beta_out[0] = beta;
+  if (brk && !(beta > DSEA_BREAK_TOL * brk[1])) {  // also catches a NaN beta; same decision in every block
+    if (blockIdx.x == 0 && threadIdx.x == 0) brk[0] = (double)step;
+    return;
+  }
   const int64_t stride = (int64_t)gridDim.x * 512;
   for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; row < n; row += stride) {
     double2 v = ld2<true>(r, row, n);
@@ -911,7 +937,21 @@ struct TfimFusedArgs {
   double* q_out;         // Q[i]
   uint16_t* qs_out;      // bf16 shadow row or null
   double* beta_store;    // betas[i-1]
+  double* brk;           // breakdown record (see broken()) or null
+  int step;              // Lanczos step i (recorded on breakdown)
 };
+
+// beta of the fused Lanczos tail + the breakdown decision (identical in every block); returns false to stop
+__device__ __forceinline__ bool fused_beta(const TfimFusedArgs& fa, double* sm5, double& beta) {
+  if (broken(fa.brk)) return false;
+  beta = sqrt(sum_partials_block(fa.nP, fa.nCount, sm5));
+  if (blockIdx.x == 0 && threadIdx.x == 0) fa.beta_store[0] = beta;
+  if (fa.brk && !(beta > DSEA_BREAK_TOL * fa.brk[1])) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) fa.brk[0] = (double)fa.step;
+    return false;
+  }
+  return true;
+}
 
 __device__ __forceinline__ double tfim_diag(const TfimParams& p, int64_t i, uint64_t maskL) {
   const uint64_t gi = (uint64_t)(p.row_offset + i);
@@ -933,10 +973,7 @@ __global__ __launch_bounds__(256) void k_spmv_tfim(TfimParams p, const double* _
   __shared__ double sm5[5];
   if (!FUSED && skip && skip[0] != 0.0) return;
   double beta = 1.0;
-  if (FUSED) {
-    beta = sqrt(sum_partials_block(fa.nP, fa.nCount, sm5));
-    if (blockIdx.x == 0 && threadIdx.x == 0) fa.beta_store[0] = beta;
-  }
+  if (FUSED && !fused_beta(fa, sm5, beta)) return;
   const double g = p.g_dev ? p.g_dev[0] : p.g_const;
   const double s = shift ? shift[0] : 0.0;
   const uint64_t maskL = (p.L >= 64) ? ~0ull : ((1ull << p.L) - 1ull);
@@ -1212,10 +1249,8 @@ __global__ __launch_bounds__(256) void k_spmv_sell(SellParams p, const double* _
   __shared__ double sm5[5];
   if (!FUSED && skip && skip[0] != 0.0) return;
   double beta = 1.0;
-  if (FUSED) {  // Lanczos tail: x is the un-normalised r; q = r/beta is stored and used for every gather
-    beta = sqrt(sum_partials_block(fa.nP, fa.nCount, sm5));
-    if (blockIdx.x == 0 && threadIdx.x == 0) fa.beta_store[0] = beta;
-  }
+  // Lanczos tail: x is the un-normalised r; q = r/beta is stored and used for every gather
+  if (FUSED && !fused_beta(fa, sm5, beta)) return;
   const double s = shift ? shift[0] : 0.0;
   const int lane = threadIdx.x & 63;
   double acc = 0.0;
@@ -1270,10 +1305,7 @@ __global__ __launch_bounds__(256) void k_spmv_stencil3(Stencil3Params p, const d
   __shared__ double sm5[5];
   if (!FUSED && skip && skip[0] != 0.0) return;
   double beta = 1.0;
-  if (FUSED) {
-    beta = sqrt(sum_partials_block(fa.nP, fa.nCount, sm5));
-    if (blockIdx.x == 0 && threadIdx.x == 0) fa.beta_store[0] = beta;
-  }
+  if (FUSED && !fused_beta(fa, sm5, beta)) return;
   const double s = shift ? shift[0] : 0.0;
   double acc = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * 256) {
@@ -1303,14 +1335,7 @@ __global__ __launch_bounds__(256) void k_spmv_stencil3(Stencil3Params p, const d
 // ------------------------------------------------------------------------------------------
 // host-side launch wrappers (called from dsea_capi.hip)
 // ------------------------------------------------------------------------------------------
-static int g_csr_group = 0;  // 0 = automatic
-void set_csr_group(int g) {
-  if (g == 0 || g == 4 || g == 8 || g == 16 || g == 32 || g == 64) g_csr_group = g;
-}
-static int g_tfim_tile_log2 = DSEA_TFIM_TILE_LOG2;
-void set_tfim_tile_log2(int t) {
-  if (t >= 6 && t <= 12) g_tfim_tile_log2 = t;
-}
+// (tuning knobs live in the operator descriptor: OpDesc::tune_tile_log2, OpDesc::tune_csr_group)
 
 static inline int ew_blocks(int64_t n) {
   int64_t nb = (n + 2047) / 2048;  // 256 threads x double2 x 4 iterations
@@ -1345,45 +1370,46 @@ void launch_finalize1(const double* P, int count, double* out, hipStream_t st) {
 
 void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* u,
                   const double* alpha, const double* beta, double* r, double* P, double* c_out,
-                  hipStream_t st, EventPair* ev, const double* aP, int aCount, double* a_store, bool want_rr) {
+                  hipStream_t st, EventPair* ev, const double* aP, int aCount, double* a_store, bool want_rr,
+                  double* brk) {
   if (g.split_w) {
     const unsigned tiles = (unsigned)g.ntiles;
     const int wr = want_rr ? 1 : 0;
     switch (g.split_w) {
-      case 4: KLAUNCH(ev, (k_rdots_split<4>), tiles, 256, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, aP, aCount, a_store, wr); break;
-      case 8: KLAUNCH(ev, (k_rdots_split<8>), tiles, 512, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, aP, aCount, a_store, wr); break;
-      default: KLAUNCH(ev, (k_rdots_split<16>), tiles, 1024, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, aP, aCount, a_store, wr); break;
+      case 4: KLAUNCH(ev, (k_rdots_split<4>), tiles, 256, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, aP, aCount, a_store, wr, brk); break;
+      case 8: KLAUNCH(ev, (k_rdots_split<8>), tiles, 512, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, aP, aCount, a_store, wr, brk); break;
+      default: KLAUNCH(ev, (k_rdots_split<16>), tiles, 1024, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, aP, aCount, a_store, wr, brk); break;
     }
     hipLaunchKernelGGL(k_finalize_multi, dim3(want_rr ? i + 1 : i), dim3(256), 0, st, (const double*)P,
-                       (int64_t)g.pstride, g.nw, c_out);
+                       (int64_t)g.pstride, g.nw, c_out, (const double*)brk);
     return;
   }
   const int grid = (g.nw + 3) / 4;
   LAUNCH_RPL(ev, k_rdots, g.rpl, grid, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, g.nw,
-             g.ntiles, aP, aCount, a_store, want_rr ? 1 : 0);
+             g.ntiles, aP, aCount, a_store, want_rr ? 1 : 0, brk);
   // want_rr: one more row of partials (||r||^2) -> c_out[i]
   hipLaunchKernelGGL(k_finalize_multi, dim3(want_rr ? i + 1 : i), dim3(256), 0, st, (const double*)P,
-                     (int64_t)g.pstride, g.nw, c_out);
+                     (int64_t)g.pstride, g.nw, c_out, (const double*)brk);
 }
 
 void launch_axpy_norm(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* c,
-                      double* r, double* P, double* nrm2_out, hipStream_t st, EventPair* ev) {
+                      double* r, double* P, double* nrm2_out, hipStream_t st, EventPair* ev, const double* brk) {
   if (g.split_w) {
     const unsigned tiles = (unsigned)g.ntiles;
     switch (g.split_w) {
-      case 4: KLAUNCH(ev, (k_axpy_norm_split<4, 0>), tiles, 256, st, Q, ldq, i, n, c, r, P); break;
-      case 8: KLAUNCH(ev, (k_axpy_norm_split<8, 0>), tiles, 512, st, Q, ldq, i, n, c, r, P); break;
-      default: KLAUNCH(ev, (k_axpy_norm_split<16, 0>), tiles, 1024, st, Q, ldq, i, n, c, r, P); break;
+      case 4: KLAUNCH(ev, (k_axpy_norm_split<4, 0>), tiles, 256, st, Q, ldq, i, n, c, r, P, brk); break;
+      case 8: KLAUNCH(ev, (k_axpy_norm_split<8, 0>), tiles, 512, st, Q, ldq, i, n, c, r, P, brk); break;
+      default: KLAUNCH(ev, (k_axpy_norm_split<16, 0>), tiles, 1024, st, Q, ldq, i, n, c, r, P, brk); break;
     }
     if (nrm2_out) launch_finalize1(P, g.nw, nrm2_out, st);
     return;
   }
   const int grid = (g.nw + 3) / 4;
   switch (g.rpl) {
-    case 2: KLAUNCH(ev, (k_axpy_norm<2, 0>), grid, 256, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles); break;
-    case 4: KLAUNCH(ev, (k_axpy_norm<4, 0>), grid, 256, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles); break;
-    case 8: KLAUNCH(ev, (k_axpy_norm<8, 0>), grid, 256, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles); break;
-    default: KLAUNCH(ev, (k_axpy_norm<16, 0>), grid, 256, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles); break;
+    case 2: KLAUNCH(ev, (k_axpy_norm<2, 0>), grid, 256, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles, brk); break;
+    case 4: KLAUNCH(ev, (k_axpy_norm<4, 0>), grid, 256, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles, brk); break;
+    case 8: KLAUNCH(ev, (k_axpy_norm<8, 0>), grid, 256, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles, brk); break;
+    default: KLAUNCH(ev, (k_axpy_norm<16, 0>), grid, 256, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles, brk); break;
   }
   if (nrm2_out) launch_finalize1(P, g.nw, nrm2_out, st);  // null: the consumer sums the g.nw partials itself
 }
@@ -1391,7 +1417,7 @@ void launch_axpy_norm(const TileGeom& g, const double* Q, int64_t ldq, int64_t n
 // returns the number of partials written
 int launch_axpy_norm_lp(int64_t n, int rps, const double* Q, int64_t ldq, const uint16_t* Qs, int64_t lds, int i,
                         const double* c, double tau, double* r, double* P, double* lp_count, hipStream_t st,
-                        EventPair* ev) {
+                        EventPair* ev, const double* brk) {
   const int64_t tile = 512 * (int64_t)rps;
   int64_t ntiles = (n + tile - 1) / tile;
   if (ntiles < 1) ntiles = 1;
@@ -1399,31 +1425,32 @@ int launch_axpy_norm_lp(int64_t n, int rps, const double* Q, int64_t ldq, const 
   const int grid = (nw + 3) / 4;
   const double tau2 = tau * tau;
   if (rps == 1)
-    KLAUNCH(ev, (k_axpy_norm_lp<1>), grid, 256, st, Q, ldq, Qs, lds, i, n, c, tau2, r, P, nw, ntiles, lp_count);
+    KLAUNCH(ev, (k_axpy_norm_lp<1>), grid, 256, st, Q, ldq, Qs, lds, i, n, c, tau2, r, P, nw, ntiles, lp_count, brk);
   else
-    KLAUNCH(ev, (k_axpy_norm_lp<2>), grid, 256, st, Q, ldq, Qs, lds, i, n, c, tau2, r, P, nw, ntiles, lp_count);
+    KLAUNCH(ev, (k_axpy_norm_lp<2>), grid, 256, st, Q, ldq, Qs, lds, i, n, c, tau2, r, P, nw, ntiles, lp_count, brk);
   return nw;
 }
 
 void launch_ritz(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int k, const double* s,
                  double* out, hipStream_t st) {
   double* nullP = nullptr;
+  const double* nullc = nullptr;
   if (g.split_w) {
     const unsigned tiles = (unsigned)g.ntiles;
     EventPair* ev = nullptr;
     switch (g.split_w) {
-      case 4: KLAUNCH(ev, (k_axpy_norm_split<4, 1>), tiles, 256, st, Q, ldq, k, n, s, out, nullP); break;
-      case 8: KLAUNCH(ev, (k_axpy_norm_split<8, 1>), tiles, 512, st, Q, ldq, k, n, s, out, nullP); break;
-      default: KLAUNCH(ev, (k_axpy_norm_split<16, 1>), tiles, 1024, st, Q, ldq, k, n, s, out, nullP); break;
+      case 4: KLAUNCH(ev, (k_axpy_norm_split<4, 1>), tiles, 256, st, Q, ldq, k, n, s, out, nullP, nullc); break;
+      case 8: KLAUNCH(ev, (k_axpy_norm_split<8, 1>), tiles, 512, st, Q, ldq, k, n, s, out, nullP, nullc); break;
+      default: KLAUNCH(ev, (k_axpy_norm_split<16, 1>), tiles, 1024, st, Q, ldq, k, n, s, out, nullP, nullc); break;
     }
     return;
   }
   const int grid = (g.nw + 3) / 4;
   switch (g.rpl) {
-    case 2: hipLaunchKernelGGL((k_axpy_norm<2, 1>), dim3(grid), dim3(256), 0, st, Q, ldq, k, n, s, out, nullP, g.nw, g.ntiles); break;
-    case 4: hipLaunchKernelGGL((k_axpy_norm<4, 1>), dim3(grid), dim3(256), 0, st, Q, ldq, k, n, s, out, nullP, g.nw, g.ntiles); break;
-    case 8: hipLaunchKernelGGL((k_axpy_norm<8, 1>), dim3(grid), dim3(256), 0, st, Q, ldq, k, n, s, out, nullP, g.nw, g.ntiles); break;
-    default: hipLaunchKernelGGL((k_axpy_norm<16, 1>), dim3(grid), dim3(256), 0, st, Q, ldq, k, n, s, out, nullP, g.nw, g.ntiles); break;
+    case 2: hipLaunchKernelGGL((k_axpy_norm<2, 1>), dim3(grid), dim3(256), 0, st, Q, ldq, k, n, s, out, nullP, g.nw, g.ntiles, nullc); break;
+    case 4: hipLaunchKernelGGL((k_axpy_norm<4, 1>), dim3(grid), dim3(256), 0, st, Q, ldq, k, n, s, out, nullP, g.nw, g.ntiles, nullc); break;
+    case 8: hipLaunchKernelGGL((k_axpy_norm<8, 1>), dim3(grid), dim3(256), 0, st, Q, ldq, k, n, s, out, nullP, g.nw, g.ntiles, nullc); break;
+    default: hipLaunchKernelGGL((k_axpy_norm<16, 1>), dim3(grid), dim3(256), 0, st, Q, ldq, k, n, s, out, nullP, g.nw, g.ntiles, nullc); break;
   }
 }
 
@@ -1446,8 +1473,8 @@ void launch_axpy(double a_host, const double* a_dev, const double* x, double* y,
 }
 
 void launch_scale_store(const double* r, const double* nrm2, double* q, double* beta_out, int64_t n,
-                        hipStream_t st, uint16_t* qs) {
-  hipLaunchKernelGGL(k_scale_store, dim3(ew_blocks(n)), dim3(256), 0, st, r, nrm2, q, beta_out, n, qs);
+                        hipStream_t st, uint16_t* qs, double* brk, int step) {
+  hipLaunchKernelGGL(k_scale_store, dim3(ew_blocks(n)), dim3(256), 0, st, r, nrm2, q, beta_out, n, qs, brk, step);
 }
 
 void launch_project_apply(const double* v, const double* a, const double* dot, double* out, int64_t n,
@@ -1492,10 +1519,10 @@ int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shif
         KLAUNCH(ev, k_spmv_tfim_single, 1, 1, st, p, x, y, shift, skip, P);
         return 1;
       }
-      const int T = p.L_local < g_tfim_tile_log2 ? p.L_local : g_tfim_tile_log2;
+      const int T = p.L_local < op.tune_tile_log2 ? p.L_local : op.tune_tile_log2;
       int64_t nb = ((int64_t)1 << p.L_local) >> T;
       if (nb > DSEA_MAX_TFIM_BLOCKS) nb = DSEA_MAX_TFIM_BLOCKS;  // blocks then walk several tiles
-      TfimFusedArgs fa = {nullptr, 0, nullptr, nullptr, nullptr};
+      TfimFusedArgs fa = {nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
 #define TFIM_CASE(TT) \
   case TT: KLAUNCH(ev, (k_spmv_tfim<TT, false>), (unsigned)nb, 256, st, p, x, y, shift, skip, P, fa); break;
       switch (T) {
@@ -1509,7 +1536,7 @@ int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shif
     case OP_CSR: {
       const CsrParams& p = op.csr;
       const double avg = p.n > 0 ? (double)p.nnz / (double)p.n : 1.0;
-      if (g_csr_group == 0 && avg >= 4.0 && avg * CSR_ROWS <= CSR_CAP) {
+      if (op.tune_csr_group == 0 && avg >= 4.0 && avg * CSR_ROWS <= CSR_CAP) {
         // typical sparse operators (a few to ~48 non-zeros per row): coalesced streaming form
         int64_t nbs = (p.n + CSR_ROWS - 1) / CSR_ROWS;
         if (nbs > DSEA_MAX_TFIM_BLOCKS) nbs = DSEA_MAX_TFIM_BLOCKS;
@@ -1518,7 +1545,7 @@ int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shif
       }
       int G = 4;
       while (G < 64 && G < avg) G *= 2;
-      if (g_csr_group) G = g_csr_group;
+      if (op.tune_csr_group) G = op.tune_csr_group;
       const int64_t rows_per_block = 256 / G;
       int64_t nb = (p.n + rows_per_block - 1) / rows_per_block;
       if (nb > DSEA_MAX_EW_BLOCKS) nb = DSEA_MAX_EW_BLOCKS;
@@ -1537,7 +1564,7 @@ int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shif
       int64_t nb = (p.nslices + 3) / 4;
       if (nb > DSEA_MAX_TFIM_BLOCKS) nb = DSEA_MAX_TFIM_BLOCKS;
       if (nb < 1) nb = 1;
-      TfimFusedArgs fa0 = {nullptr, 0, nullptr, nullptr, nullptr};
+      TfimFusedArgs fa0 = {nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
       KLAUNCH(ev, (k_spmv_sell<false>), (unsigned)nb, 256, st, p, x, y, shift, skip, P, fa0);
       return (int)nb;
     }
@@ -1546,7 +1573,7 @@ int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shif
       int64_t nb = (p.n + 255) / 256;
       if (nb > DSEA_MAX_EW_BLOCKS) nb = DSEA_MAX_EW_BLOCKS;
       if (nb < 1) nb = 1;
-      TfimFusedArgs fa0 = {nullptr, 0, nullptr, nullptr, nullptr};
+      TfimFusedArgs fa0 = {nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
       KLAUNCH(ev, (k_spmv_stencil3<false>), (unsigned)nb, 256, st, p, x, y, shift, skip, P, fa0);
       return (int)nb;
     }
@@ -1558,8 +1585,9 @@ int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shif
 // for the operator kinds that have one; returns the number of alpha partials or -1 (caller falls back to the
 // unfused sequence scale_store + mat-vec + finalize).
 int launch_tfim_fused(const OpDesc& op, const double* r, const double* nP, int nCount, double* q_out, double* y,
-                      double* beta_store, double* P, hipStream_t st, EventPair* ev, uint16_t* qs_out) {
-  TfimFusedArgs fa = {nP, nCount, q_out, qs_out, beta_store};
+                      double* beta_store, double* P, hipStream_t st, EventPair* ev, uint16_t* qs_out, double* brk,
+                      int step) {
+  TfimFusedArgs fa = {nP, nCount, q_out, qs_out, beta_store, brk, step};
   const double* nullc = nullptr;
   if (op.kind == OP_SELL) {
     const SellParams& p = op.sell;
@@ -1578,7 +1606,7 @@ int launch_tfim_fused(const OpDesc& op, const double* r, const double* nP, int n
   if (op.kind != OP_TFIM) return -1;
   const TfimParams& p = op.tfim;
   if (p.L_local == 0) return -1;  // callers use the unfused sequence for a 1-row slab
-  const int T = p.L_local < g_tfim_tile_log2 ? p.L_local : g_tfim_tile_log2;
+  const int T = p.L_local < op.tune_tile_log2 ? p.L_local : op.tune_tile_log2;
   int64_t nb = ((int64_t)1 << p.L_local) >> T;
   if (nb > DSEA_MAX_TFIM_BLOCKS) nb = DSEA_MAX_TFIM_BLOCKS;
 #define TFIM_FCASE(TT) \

@@ -46,7 +46,8 @@ def _dominant_pair_device(mv, mvT, n, k, which, device):
     from . import krylov
     lam, r = krylov.arnoldi_dominant(mv, n, k, device, which)
     lam_l, l = krylov.arnoldi_dominant(mvT, n, k, device, which)
-    assert abs(lam - lam_l) <= 1e-8 * max(abs(lam), 1e-300), "left / right eigenvalues disagree"
+    if abs(lam - lam_l) > 1e-8 * max(abs(lam), 1e-300):
+        raise RuntimeError("left / right eigenvalues disagree: %.15e vs %.15e" % (lam, lam_l))
     l = l / torch.dot(l, r)
     return torch.tensor([lam], dtype=torch.float64, device=device), l, r
 

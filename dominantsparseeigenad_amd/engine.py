@@ -22,6 +22,7 @@ F64 = torch.float64
 USE_SHADOW = True
 SHADOW_TAU = 1e-12
 last_lp_steps = (0, 0)
+last_break = 0
 
 
 def _stream(device):
@@ -73,14 +74,18 @@ class Workspace:
         except Exception:
             pass
 
-    _CACHE_LIMIT = 8   # workspaces kept alive (one per (n, device)); the oldest is dropped beyond this
+    _CACHE_LIMIT = 8   # workspaces kept alive (one per (n, device, stream)); the oldest is dropped beyond this
 
     @classmethod
     def get(cls, n, kmax, device):
+        """The workspace of (n, device, CURRENT STREAM).  include/dsea.h: one workspace per stream, a workspace is
+        not re-entrant -- two streams (or threads driving different streams) solving problems of the same size get
+        distinct partial-sum / scalar / CG-state buffers.  A solver invoked from INSIDE a user mat-vec of another
+        solver of the same size on the same stream would share them: not supported."""
         device = torch.device(device)
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
-        key = (int(n), str(device))
+        key = (int(n), str(device), int(torch.cuda.current_stream(device).cuda_stream))
         ws = cls._cache.pop(key, None)
         if ws is None or ws.kmax < kmax:
             ws = cls(n, max(int(kmax), 8), device)
@@ -102,6 +107,43 @@ class Workspace:
 
 def round_up(v, m):
     return (v + m - 1) // m * m
+
+
+class BasisArena:
+    """Persistent device buffers for the TRANSIENT Krylov basis (and its bf16 shadow) of the eigen-solves.
+
+    The basis is the one large object of the path (8 n k bytes: 1.7 GB at the headline size, 215 GB at L = 28,
+    k = 100).  ``symeigLanczos`` only hands the Ritz vector on, so the basis of one call is dead when the next call
+    starts: allocating it afresh every time makes the caching allocator carve, split and re-map blocks of that size
+    (at L = 28 the second call failed with 200 GiB "reserved but unallocated").  One buffer per (device, stream,
+    tag), grown on demand, reused by every call.  ``Lanczos()`` -- which returns the basis to the caller -- does not
+    use it.  ``release()`` gives the memory back."""
+
+    _bufs = {}
+
+    @classmethod
+    def get(cls, device, tag, nbytes):
+        device = torch.device(device)
+        key = (str(device), int(torch.cuda.current_stream(device).cuda_stream) if device.type == "cuda" else 0, tag)
+        buf = cls._bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            if buf is not None:
+                del cls._bufs[key], buf
+                if device.type == "cuda":
+                    torch.cuda.empty_cache()
+            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            cls._bufs[key] = buf
+        return buf
+
+    @classmethod
+    def matrix(cls, device, tag, rows, cols, dtype):
+        esz = torch.empty(0, dtype=dtype).element_size()
+        buf = cls.get(device, tag, rows * cols * esz)
+        return buf[: rows * cols * esz].view(dtype).view(rows, cols)
+
+    @classmethod
+    def release(cls):
+        cls._bufs.clear()
 
 
 def native_of(A):
@@ -162,34 +204,47 @@ class Phases:
 
 
 # --------------------------------------------------------------------------- Lanczos
-def lanczos(A, k, n, device, q0, native=None, callable_A=None):
+def lanczos(A, k, n, device, q0, native=None, callable_A=None, arena=False):
     """k-step Lanczos on the GPU (reference Lanczos.py:49-77).
 
     native     : operator object exposing ``.handle`` -> whole loop in dsea_lanczos_run
     callable_A : python callable v -> A v (torch tensors on ``device``) -> one C-ABI phase call per
                  stage, the mat-vec itself is the user's code
-    Returns (Q (k, ldq) basis, ldq, alphas (k,), betas (k-1,)).
+    Returns (Q (k, ldq) basis, ldq, alphas (k,), betas (k-1,)).  ``last_break`` (module attribute) holds the step
+    at which the native loop met beta ~ 0 and stopped itself (0 = none; include/dsea.h dsea_lanczos_status).
     """
+    global last_break
+    last_break = 0
     lib = _lib.load()
     device = torch.device(device)
     ws = Workspace.get(n, k, device)
     st = _stream(device)
     ldq = round_up(n, 32)
-    Q = torch.empty((k, ldq), dtype=F64, device=device)
+    # arena: the caller does not keep the basis (symeigLanczos) -> persistent buffer instead of a fresh allocation
+    Q = BasisArena.matrix(device, "Q", k, ldq, F64) if arena else torch.empty((k, ldq), dtype=F64, device=device)
+    new_shadow = (lambda: BasisArena.matrix(device, "Qs", k, ldq, torch.bfloat16)) if arena else \
+        (lambda: torch.empty((k, ldq), dtype=torch.bfloat16, device=device))
     alphas = torch.empty(k, dtype=F64, device=device)
     betas = torch.empty(max(k - 1, 1), dtype=F64, device=device)
     q0 = as_vector(q0, n)
     if native is not None:
         shadow = None
         if USE_SHADOW and k > 1:
-            shadow = torch.empty((k, ldq), dtype=torch.bfloat16, device=device)
+            shadow = new_shadow()
             check(lib.dsea_ws_set_shadow(ws.handle, _ptr(shadow), ldq, int(k), float(SHADOW_TAU)), "dsea_ws_set_shadow")
         try:
             check(lib.dsea_lanczos_run(native.handle, ws.handle, int(k), _ptr(q0), _ptr(Q), ldq, _ptr(alphas),
                                        _ptr(betas), st), "dsea_lanczos_run")
+            brk = ctypes.c_int(0)
+            check(lib.dsea_lanczos_status(ws.handle, byref(brk), st), "dsea_lanczos_status", allow=(_lib.ERR_BREAKDOWN,))
+            last_break = int(brk.value)
         finally:
             if shadow is not None:
                 check(lib.dsea_ws_set_shadow(ws.handle, None, 0, 0, 0.0), "dsea_ws_set_shadow")
+        if last_break:
+            # entries behind the breakdown were never written (torch.empty): make them recognisable
+            alphas[last_break:] = float("nan")
+            betas[last_break - 1:] = 0.0 if last_break - 1 < betas.numel() else 0.0
         return Q, ldq, alphas, betas[: k - 1]
 
     # generic callable: the mat-vec is the caller's torch code, everything else is one phase call per stage;
@@ -199,7 +254,7 @@ def lanczos(A, k, n, device, q0, native=None, callable_A=None):
     c = torch.empty(k + 2, dtype=F64, device=device)
     shadow = None
     if USE_SHADOW and k > 1:
-        shadow = torch.empty((k, ldq), dtype=torch.bfloat16, device=device)
+        shadow = new_shadow()
         check(lib.dsea_ws_set_shadow(ws.handle, _ptr(shadow), ldq, int(k), float(SHADOW_TAU)), "dsea_ws_set_shadow")
     esz = 8
     try:
@@ -234,11 +289,12 @@ def lanczos_lp_stats(n, device):
     return a.value, b.value
 
 
-def tridiag_extreme(alphas, betas, which):
+def tridiag_extreme(alphas, betas, which, break_at=None):
     """Extreme eigenpair(s) of the k x k tridiagonal T (reference Lanczos.py:98: dense symeig of T).
 
     T is tiny (k ~ 200): it is solved on the host with LAPACK through scipy (one 3 kB D2H copy,
-    which is also the only host sync of the forward pass).  Returns [(eigval, s (k,) numpy), ...].
+    which is also the only host sync of the forward pass).  Returns [(eigval, s (m,) numpy), ...] with m = k, or
+    the dimension of the Krylov space if the process broke down earlier.
     """
     from scipy.linalg import eigh_tridiagonal
 
@@ -247,34 +303,46 @@ def tridiag_extreme(alphas, betas, which):
     k = d.shape[0]
     out = []
     m = k
+    if break_at is not None and 0 < int(break_at) < k:
+        m = int(break_at)           # the device loop stopped itself there (dsea_lanczos_status)
     if k > 1:
         # The reference has no breakdown test (Lanczos.py:69-70 divides by beta whatever it is; SURVEY Q8: with
         # k beyond the Krylov dimension it normalises rounding noise and returns spurious Ritz values without
-        # any error).  Here the invariant subspace is recognised: the tridiagonal is cut at the first
-        # negligible beta -- its leading block carries exact eigenpairs of A -- and the caller is told.
-        scale = max(float(np.abs(d).max()), float(np.abs(e).max()), 1e-300)
-        bad = np.where(~np.isfinite(e) | (np.abs(e) <= 1e-13 * scale))[0]
+        # any error; with an EXACT breakdown, beta = 0, it produces NaNs from there on).  Here the invariant
+        # subspace is recognised: the tridiagonal is cut at the first j where beta_j is zero, non-finite or
+        # negligible, or where alpha_{j+1} is non-finite -- its leading block carries exact eigenpairs of A --
+        # and the caller is told.  The scale is taken over the finite entries only (a NaN must not poison it).
+        fin_d, fin_e = d[np.isfinite(d)], e[np.isfinite(e)]
+        scale = max(float(np.abs(fin_d).max()) if fin_d.size else 0.0,
+                    float(np.abs(fin_e).max()) if fin_e.size else 0.0, 1e-300)
+        bad_e = ~np.isfinite(e[:m - 1]) | (np.abs(e[:m - 1]) <= 1e-13 * scale)
+        bad_d = ~np.isfinite(d[1:m])
+        bad = np.where(bad_e | bad_d)[0]
         if bad.size:
-            import warnings
             m = int(bad[0]) + 1
+        if m < k:
+            import warnings
+            bval = float(np.abs(e[m - 1])) if np.isfinite(e[m - 1]) else float("nan")
             warnings.warn("Lanczos breakdown: beta_%d = %.3e relative to %.3e -- the Krylov space from this start "
                           "vector has dimension %d < k = %d; the Ritz pair is taken from the leading %d x %d block"
-                          % (m - 1, float(np.abs(e[m - 1])), scale, m, k, m, m), RuntimeWarning)
+                          % (m - 1, bval, scale, m, k, m, m), RuntimeWarning)
+    # the coefficient vectors have length m (<= k): only the leading m basis vectors enter the Ritz vector (the
+    # ones behind a breakdown are not defined)
     if m == 1:
-        return [(float(d[0]), np.eye(1, k)[0].copy())] * (2 if which == "both" else 1)
+        return [(float(d[0]), np.ones(1))] * (2 if which == "both" else 1)
     picks = {"min": [0], "max": [m - 1], "both": [0, m - 1]}[which]
     for idx in picks:
         w, v = eigh_tridiagonal(d[:m], e[:m - 1], select="i", select_range=(idx, idx))
-        s_full = np.zeros(k)
-        s_full[:m] = v[:, 0]
-        out.append((float(w[0]), s_full))
+        out.append((float(w[0]), np.ascontiguousarray(v[:, 0])))
     return out
 
 
 def ritz_vector(Q, ldq, n, k, s_host, device):
+    """sum_j s[j] Q[j] over the len(s) <= k leading basis vectors"""
     lib = _lib.load()
     ws = Workspace.get(n, k, device)
     s = torch.from_numpy(np.asarray(s_host, dtype=np.float64)).to(device)
+    k = int(s.numel())
     out = torch.empty(n, dtype=F64, device=device)
     check(lib.dsea_ritz_combine(ws.handle, _ptr(Q), ldq, n, int(k), _ptr(s), _ptr(out), _stream(device)),
           "dsea_ritz_combine")

@@ -23,6 +23,14 @@ from . import engine
 F64 = torch.float64
 
 
+class ArnoldiNoConvergence(RuntimeError):
+    """restart budget exhausted; carries the last Ritz pair and its residual estimate (like ARPACK's exception)"""
+
+    def __init__(self, msg, eigenvalue, eigenvector, residual):
+        super().__init__(msg)
+        self.eigenvalue, self.eigenvector, self.residual = eigenvalue, eigenvector, residual
+
+
 def _select(evals, which):
     if which == "LM":
         return int(np.argmax(np.abs(evals)))
@@ -75,7 +83,7 @@ def arnoldi_dominant(matvec, n, ncv, device, which="LM", v0=None, tol=1e-13, max
     bufs = (ph.empty(n), ph.empty(n), ph.zeros(ncv + 2), ph.zeros(ncv + 2), ph.zeros(1))
     v = torch.randn(n, dtype=F64, device=device) if v0 is None else engine.as_vector(v0, n).clone()
     nrm2 = ph.zeros(1)
-    last_res, theta, x = None, None, None
+    last_res, theta, x, res, converged = None, None, None, float("inf"), False
     for _ in range(max_restarts):
         ph.dot(v, v, nrm2)
         ph.scale_store(v, nrm2, V[0], None)
@@ -96,7 +104,8 @@ def arnoldi_dominant(matvec, n, ncv, device, which="LM", v0=None, tol=1e-13, max
         evals, evecs = np.linalg.eig(Hh[:m, :m])
         idx = _select(evals, which)
         theta, y = evals[idx], evecs[:, idx]
-        assert abs(theta.imag) <= 1e-9 * max(abs(theta), 1e-300), "The desired eigenvalue of the matrix must be real"
+        if abs(theta.imag) > 1e-9 * max(abs(theta), 1e-300):
+            raise ValueError("The desired eigenvalue of the matrix must be real")      # eig.py:31-32
         y = (y / y[np.argmax(np.abs(y))]).real
         y = y / np.linalg.norm(y)
         sub_m = 0.0 if m < ncv or not np.isfinite(sub[m - 1]) else sub[m - 1]
@@ -105,9 +114,16 @@ def arnoldi_dominant(matvec, n, ncv, device, which="LM", v0=None, tol=1e-13, max
         ph.ritz(V, ldq, n, m, torch.from_numpy(np.ascontiguousarray(y)).to(device), x)
         x = x / x.norm()
         if res <= tol * abs(theta.real) or (last_res is not None and res >= 0.5 * last_res and res <= 1e-10 * abs(theta.real)):
+            converged = True
             break
         last_res = res
         v = x
+    if not converged:
+        # ARPACK raises ArpackNoConvergence here (eig.py:29-30 would propagate it); an unconverged pair must not
+        # reach the backward pass, whose solves of (A - theta I) assume an exact eigenvalue
+        raise ArnoldiNoConvergence("Arnoldi did not converge in %d restarts of %d vectors: residual estimate %.3e "
+                                   "relative to |theta| = %.3e" % (max_restarts, ncv, res, abs(theta.real)),
+                                   float(theta.real), x, res)
     return float(theta.real), x
 
 

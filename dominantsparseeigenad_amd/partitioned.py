@@ -93,8 +93,14 @@ class HipBackend(_engine_mod.Phases):
                                     self._p(out), self._p(skip), self._st()), "dsea_spmv")
 
     # -- macro phases of the partitioned Lanczos step (include/dsea.h "row-partitioned macro phases")
-    def set_shadow(self, k, ldq):
-        self._shadow = torch.empty((k, ldq), dtype=torch.bfloat16, device=self.device)
+    def basis(self, k, ldq, arena):
+        if arena:
+            return self.engine.BasisArena.matrix(self.device, "Q", k, ldq, F64)
+        return self.empty(k, ldq)
+
+    def set_shadow(self, k, ldq, arena=False):
+        self._shadow = self.engine.BasisArena.matrix(self.device, "Qs", k, ldq, torch.bfloat16) if arena else \
+            torch.empty((k, ldq), dtype=torch.bfloat16, device=self.device)
         self._ck(self.lib.dsea_ws_set_shadow(self.ws.handle, self._p(self._shadow), ldq, int(k),
                                              float(self.engine.SHADOW_TAU)), "dsea_ws_set_shadow")
 
@@ -360,25 +366,26 @@ class PartitionedOperator:
         self.comm.allreduce(S.pair)
         be.plz_finish(S.r, S.y, S.pair, S.Q[i], i, S.u, S.alphas[i:i + 1], S.betas[i - 1:i] if i >= 1 else None)
 
-    def lanczos(self, k, q0_slab):
+    def lanczos(self, k, q0_slab, arena=False):
         """k-step Lanczos with full re-orthogonalisation on slabs.  Returns (Q (k, ldq) slab basis, ldq,
-        alphas (k,), betas (k-1,)) -- the scalars replicated bit-identically on every rank."""
+        alphas (k,), betas (k-1,)) -- the scalars replicated bit-identically on every rank.  ``arena``: the caller
+        does not keep the basis, so it may live in the persistent arena (engine.BasisArena)."""
         native = self._local_native()
         if self.world == 1 and native is not None and not self.force_driver:
-            return _engine_mod.lanczos(native, k, self.nloc, self.device, q0_slab, native=native)
+            return _engine_mod.lanczos(native, k, self.nloc, self.device, q0_slab, native=native, arena=arena)
         be, n = self.be, self.nloc
         if hasattr(be, "reserve"):
             be.reserve(k)
         S = _LanczosState()
         S.n, S.k = n, k
         S.ldq = (n + 31) // 32 * 32
-        S.Q = be.empty(k, S.ldq)
+        S.Q = be.basis(k, S.ldq, arena) if hasattr(be, "basis") else be.empty(k, S.ldq)
         S.alphas, S.betas = be.zeros(k), be.zeros(max(k - 1, 1))
         S.c, S.pair = be.zeros(k + 2), be.zeros(2)
         S.r, S.u, S.y = q0_slab.detach().to(F64).clone(), be.empty(n), be.empty(n)
         use_shadow = self.use_shadow and _engine_mod.USE_SHADOW and k > 1 and hasattr(be, "set_shadow")
         if use_shadow:
-            be.set_shadow(k, S.ldq)
+            be.set_shadow(k, S.ldq, arena)
         try:
             for i in range(k):
                 self.lanczos_step(i, S)
@@ -390,7 +397,7 @@ class PartitionedOperator:
     def ritz_vector(self, Q, ldq, k, s_host):
         out = self.be.empty(self.nloc)
         s = torch.from_numpy(np.ascontiguousarray(s_host, dtype=np.float64)).to(self.device)
-        self.be.ritz(Q, ldq, self.nloc, int(k), s, out)
+        self.be.ritz(Q, ldq, self.nloc, int(s.numel()), s, out)
         return out
 
     # ---- backward: CG on (A - E0) x = b (reference CG.py:24-41 with the closure of :120)

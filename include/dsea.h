@@ -48,6 +48,7 @@ extern "C" {
 #define DSEA_ERR_HIP (-4)       /* a HIP runtime call failed (see dsea_last_hip_error) */
 #define DSEA_ERR_NOT_CONVERGED (-5) /* dsea_cg_run hit maxiter                   */
 #define DSEA_ERR_UNSUPPORTED (-6)
+#define DSEA_ERR_BREAKDOWN (-7) /* dsea_lanczos_status: the run met beta ~ 0 and stopped itself */
 
 typedef struct dsea_op_s *dsea_op_t; /* operator descriptor (host struct, device pointers inside) */
 typedef struct dsea_ws_s *dsea_ws_t; /* workspace descriptor                                     */
@@ -55,11 +56,6 @@ typedef struct dsea_ws_s *dsea_ws_t; /* workspace descriptor                    
 int dsea_version(void);
 const char *dsea_error_string(int status);
 int dsea_last_hip_error(void);
-/* process-wide tuning knobs (measurement aid): key DSEA_TUNE_TFIM_TILE_LOG2 = log2 rows of x staged in LDS per
- * block of the TFIM mat-vec (6..12, default 11)                                                          */
-#define DSEA_TUNE_TFIM_TILE_LOG2 1
-#define DSEA_TUNE_CSR_GROUP 2 /* lanes per CSR row: 0 = automatic, or 4..64 */
-int dsea_set_tuning(int key, int value);
 
 /* ------------------------------------------------------------------ workspace
  * Scratch for partial sums, reorthogonalisation coefficients and four work vectors.
@@ -123,6 +119,13 @@ int dsea_op_create_sell(int64_t n, int64_t nslices, const int64_t *slice_ptr, co
  * (null halo pointer = 0, the Dirichlet padding of the reference).                            */
 int dsea_op_create_stencil3(int64_t n, double coef, const double *V_dev, const double *halo_lo,
                             const double *halo_hi, dsea_op_t *out);
+
+/* per-operator tuning knobs (measurement aid; nothing process-wide): key DSEA_TUNE_TFIM_TILE_LOG2 = log2 rows of
+ * x staged in LDS per block of the TFIM mat-vec (6..12, default 11); DSEA_TUNE_CSR_GROUP = lanes per CSR row
+ * (0 = automatic, or 4..64)                                                                                */
+#define DSEA_TUNE_TFIM_TILE_LOG2 1
+#define DSEA_TUNE_CSR_GROUP 2
+int dsea_op_set_tuning(dsea_op_t op, int key, int value);
 
 int dsea_op_destroy(dsea_op_t op);
 int dsea_op_dim(dsea_op_t op, int64_t *n);
@@ -255,6 +258,12 @@ int dsea_plz_finish(dsea_ws_t ws, const double *r, const double *y, const double
  *   Q       : k x ldq basis (output), alphas[k], betas[max(k-1,1)] (outputs, device)            */
 int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double *q0, double *Q, int64_t ldq,
                      double *alphas, double *betas, void *stream);
+/* Breakdown (the reference has no test: Lanczos.py:69-70 divides by beta whatever it is): the run compares every
+ * beta_{i-1} ON THE DEVICE with 1e-13 * max_j(|alpha_j|, |beta_j|); at the first one below it records step i,
+ * leaves Q[i..], alphas[i..], betas[i..] untouched and turns its remaining launches into no-ops.  This call
+ * SYNCHRONISES the stream and returns DSEA_OK, or DSEA_ERR_BREAKDOWN with *break_step = i: the Krylov space of q0
+ * has dimension i and the leading i x i block of T holds exact eigenpairs of the operator.                      */
+int dsea_lanczos_status(dsea_ws_t ws, int *break_step, void *stream);
 
 /* CG on (A - (*shift) I) x = b from x (in: start vector, out: solution).  Stops when ||r|| < eps
  * (absolute, CG.py:25) or after maxiter iterations.  The loop runs on the device; the host polls the

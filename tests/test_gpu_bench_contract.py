@@ -35,10 +35,12 @@ def test_bench_line_single_gpu():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
 
 
-def test_bench_line_full_cpu_baseline_option():
-    d = _run(["--cpu-full", "--cpu-threads", "4", "--no-extras"])
+def test_bench_line_cpu_baseline_forms():
+    d = _run(["--cpu-threads", "4", "--no-extras"])
     assert "FULL workload" in d["cpu_baseline"]["sample"] and "config3" not in d["config"]
     assert d["cpu_baseline"]["runs"][0]["threads"] == 4
+    d = _run(["--cpu-sample", "--no-extras"])
+    assert "capped" in d["cpu_baseline"]["sample"]
 
 
 def test_bench_line_carries_honest_extras():

@@ -1,0 +1,105 @@
+"""Robustness items: on-device Lanczos breakdown record, per-stream workspaces, per-operator tuning knobs,
+persistent basis arena."""
+import warnings
+from ctypes import c_void_p
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from dominantsparseeigenad_amd import _lib, engine  # noqa: E402
+from dominantsparseeigenad_amd.Lanczos import symeigLanczos, Lanczos  # noqa: E402
+from dominantsparseeigenad_amd.operators import CSROperator, TFIMOperator, Stencil3Operator  # noqa: E402
+from helpers import unit  # noqa: E402
+
+F64 = torch.float64
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("layout", ["sell", "csr"])
+def test_device_breakdown_record_stops_the_run(layout):
+    """Reference Lanczos.py:69-70 divides by beta whatever it is.  The native loop compares beta with the running
+    |alpha|,|beta| scale ON THE DEVICE, records the step and turns its remaining launches into no-ops
+    (sell: fused tail kernel; csr: scale/store kernel)."""
+    n = 40
+    A = torch.diag(torch.arange(1, n + 1, dtype=F64))
+    op = CSROperator.from_dense(A, dev(), layout=layout)
+    q0 = torch.zeros(n, dtype=F64)
+    q0[[3, 7, 11]] = torch.tensor([1.0, 2.0, -1.0], dtype=F64)      # 3-dimensional invariant subspace
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        lo, vlo = symeigLanczos(op, 10, dev(), extreme="min", sparse=True, dim=n, q0=q0.to(dev()))
+    assert engine.last_break == 3
+    assert any("breakdown" in str(w.message) for w in rec)
+    assert abs(lo.item() - 4.0) < 1e-12 and torch.isfinite(vlo).all()
+    assert abs(vlo.norm().item() - 1.0) < 1e-13
+    assert float((op(vlo) - lo * vlo).norm()) < 1e-12
+    # exact breakdown at the first step: A = I
+    eye = CSROperator.from_dense(torch.eye(6, dtype=F64), dev(), layout=layout)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        lo, v = symeigLanczos(eye, 4, dev(), extreme="min", sparse=True, dim=6, q0=unit(6, 11).to(dev()))
+    assert engine.last_break == 1 and abs(lo.item() - 1.0) < 1e-14 and torch.isfinite(v).all()
+    # and no false alarm on a healthy run
+    op2 = TFIMOperator(10, dev(), g=torch.tensor([1.0], dtype=F64, device=dev()))
+    symeigLanczos(op2, 60, dev(), extreme="min", sparse=True, dim=1024, q0=unit(1024, 5).to(dev()))
+    assert engine.last_break == 0
+
+
+def test_workspace_is_per_stream_and_streams_do_not_interfere():
+    n = 1 << 14
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(s1):
+        w1 = engine.Workspace.get(n, 8, dev())
+    with torch.cuda.stream(s2):
+        w2 = engine.Workspace.get(n, 8, dev())
+    assert w1 is not w2 and w1.buffer.data_ptr() != w2.buffer.data_ptr()
+    assert engine.Workspace.get(n, 8, dev()) is not w1                      # default stream: a third one
+    # two CG solves of the same size in flight on two streams: each equals its own sequential result
+    op = TFIMOperator(14, dev(), g=torch.tensor([1.3], dtype=F64, device=dev()))
+    shift = torch.tensor(-30.0, dtype=F64, device=dev())
+    bs = [unit(n, 40 + c).to(dev()) for c in range(2)]
+    x0 = torch.zeros(n, dtype=F64, device=dev())
+    ref = [engine.cg(b, x0, native=op, shift=shift, eps=1e-10) for b in bs]
+    torch.cuda.synchronize()
+    outs = [None, None]
+    for rep in range(3):
+        with torch.cuda.stream(s1):
+            outs[0] = engine.cg(bs[0], x0, native=op, shift=shift, eps=1e-10, poll_every=1000)
+        with torch.cuda.stream(s2):
+            outs[1] = engine.cg(bs[1], x0, native=op, shift=shift, eps=1e-10, poll_every=1000)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], ref[0]) and torch.equal(outs[1], ref[1])
+
+
+def test_tuning_knobs_are_per_operator():
+    lib = _lib.load()
+    L = 13
+    g = torch.tensor([0.9], dtype=F64, device=dev())
+    a, b = TFIMOperator(L, dev(), g=g), TFIMOperator(L, dev(), g=g)
+    _lib.check(lib.dsea_op_set_tuning(a.handle, 1, 8), "dsea_op_set_tuning")
+    assert lib.dsea_op_set_tuning(a.handle, 1, 99) != 0 and lib.dsea_op_set_tuning(a.handle, 7, 1) != 0
+    x = unit(1 << L, 77).to(dev())
+    ya, yb = a(x), b(x)            # tile 2^8 vs the default 2^11: same operator, neighbour sums in another order
+    assert float((ya - yb).abs().max()) < 1e-13
+
+
+def test_basis_arena_is_reused_and_not_handed_to_users():
+    n, k = 1 << 12, 40
+    op = TFIMOperator(12, dev(), g=torch.tensor([1.0], dtype=F64, device=dev()))
+    q0 = unit(n, 3).to(dev())
+    engine.BasisArena.release()
+    lo1, v1 = symeigLanczos(op, k, dev(), extreme="min", sparse=True, dim=n, q0=q0)
+    bufs = {key: t.data_ptr() for key, t in engine.BasisArena._bufs.items()}
+    assert any(key[2] == "Q" for key in bufs)
+    lo2, v2 = symeigLanczos(op, k, dev(), extreme="min", sparse=True, dim=n, q0=q0)
+    assert {key: t.data_ptr() for key, t in engine.BasisArena._bufs.items()} == bufs       # same buffers again
+    assert torch.equal(v1, v2) and lo1.item() == lo2.item()
+    Qk, T = Lanczos(op, k, dev(), sparse=True, dim=n, q0=q0)                                 # user-visible basis
+    assert Qk.untyped_storage().data_ptr() not in bufs.values()
+    assert float((Qk.T @ Qk - torch.eye(k, dtype=F64, device=dev())).abs().max()) < 1e-13

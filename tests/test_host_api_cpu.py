@@ -206,6 +206,28 @@ def test_breakdown_is_reported_not_hidden():
     assert abs(lo.item() - 4.0) < 1e-9          # smallest eigenvalue present in the start vector
 
 
+def test_exact_breakdown_identity_and_axis_start():
+    """EXACT breakdown (beta = 0): the reference divides by it and every later alpha / beta / q is NaN
+    (Lanczos.py:69-70).  A = I with any start vector, and a diagonal A with q0 = e_1, have a one-dimensional
+    Krylov space: the first Ritz pair is exact and must be returned, with the warning."""
+    import warnings
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        lo, v = symeigLanczos(torch.eye(6, dtype=torch.float64), 4, extreme="min")
+        both = symeigLanczos(torch.eye(6, dtype=torch.float64), 4, extreme="both")
+    assert any("breakdown" in str(w.message) for w in rec)
+    assert abs(lo.item() - 1.0) < 1e-14 and torch.isfinite(v).all() and abs(v.norm().item() - 1.0) < 1e-14
+    assert abs(both[0].item() - 1.0) < 1e-14 and abs(both[2].item() - 1.0) < 1e-14
+    A = torch.diag(torch.tensor([3.0, -2.0, 5.0, 7.0, 1.0], dtype=torch.float64))
+    q0 = torch.zeros(5, dtype=torch.float64)
+    q0[0] = 1.0
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        lo, v = symeigLanczos(A, 5, extreme="min", q0=q0)
+    assert any("breakdown" in str(w.message) for w in rec)
+    assert abs(lo.item() - 3.0) < 1e-14 and torch.allclose(v.abs(), q0)
+
+
 def test_bench_self_launches_one_worker_per_gpu():
     """`python bench.py --gpus 2` without a launcher must start its own workers (torch.distributed.run, one process
     per GPU) BEFORE touching the GPU.  Without GPUs here each worker stops at the no-CPU-fallback assertion -- what

@@ -25,10 +25,10 @@ def timeit(fn, reps=100):
     return e0.elapsed_time(e1) / reps * 1e3
 t1 = timeit(lambda: lib.dsea_spmv(op.handle, ws.handle, _ptr(x), _ptr(y1), None, _ptr(out), None, st))
 for G in (4, 8, 16, 32):
-    lib.dsea_set_tuning(2, G)
+    lib.dsea_op_set_tuning(csr.handle, 2, G)
     tt = timeit(lambda: lib.dsea_spmv(csr.handle, ws.handle, _ptr(x), _ptr(y2), None, _ptr(out), None, st))
     print("G=%d: %.1f us" % (G, tt))
-lib.dsea_set_tuning(2, 0)
+lib.dsea_op_set_tuning(csr.handle, 2, 0)
 t2 = timeit(lambda: lib.dsea_spmv(csr.handle, ws.handle, _ptr(x), _ptr(y2), None, _ptr(out), None, st))
 t3 = timeit(lambda: lib.dsea_spmv(sell.handle, ws.handle, _ptr(x), _ptr(y2), None, _ptr(out), None, st))
 print("SELL-64: %.1f us  maxdiff %.1e" % (t3, float((y1 - y2).abs().max())))

@@ -25,7 +25,7 @@ def timeit(fn, reps=200):
     return e0.elapsed_time(e1) / reps * 1e3
 ref = None
 for T in (8, 9, 10, 11, 12):
-    lib.dsea_set_tuning(1, T)
+    lib.dsea_op_set_tuning(op.handle, 1, T)
     t = timeit(lambda: lib.dsea_spmv(op.handle, ws.handle, _ptr(x), _ptr(y), None, _ptr(out), None, st))
     if ref is None: ref = y.clone()
     print("T=%2d  spmv+dot+finalize %.2f us   (%.0f GB/s algorithmic)  maxdiff %.1e" % (T, t, 16.0 * n / t / 1e3, float((y - ref).abs().max())))
