@@ -107,6 +107,7 @@ const char* dsea_error_string(int status) {
     case DSEA_ERR_HIP: return "HIP runtime error";
     case DSEA_ERR_NOT_CONVERGED: return "CG did not converge within maxiter";
     case DSEA_ERR_UNSUPPORTED: return "unsupported configuration";
+    case DSEA_ERR_TIMEOUT: return "a workgroup of a persistent launch did not arrive in time";
     case DSEA_ERR_BREAKDOWN: return "Lanczos breakdown: the Krylov space is smaller than k";
     default: return "unknown status";
   }
@@ -149,6 +150,7 @@ int dsea_ws_create(void* device_buffer, size_t bytes, int64_t n, int kmax, dsea_
   ws->w.kmax = kmax;
   ws->w.rpl_override = 0;
   ws->w.split_override = -1;
+  ws->w.persist_override = -1;
   ws->w.prof = nullptr;
   ws->w.shadow = nullptr;
   ws->w.shadow_ld = 0;
@@ -255,6 +257,13 @@ int dsea_ws_set_rows_per_lane(dsea_ws_t ws, int rpl) {
   return DSEA_OK;
 }
 
+int dsea_ws_set_persist(dsea_ws_t ws, int mode) {
+  if (!ws) return DSEA_ERR_ARG;
+  if (mode != -1 && mode != 0 && mode != 1 && mode != 2 && mode != 4) return DSEA_ERR_ARG;
+  ws->w.persist_override = mode;
+  return DSEA_OK;
+}
+
 int dsea_ws_set_split(dsea_ws_t ws, int waves) {
   if (!ws) return DSEA_ERR_ARG;
   if (waves != -1 && waves != 0 && waves != 4 && waves != 8 && waves != 16) return DSEA_ERR_ARG;
@@ -309,6 +318,7 @@ int dsea_op_create_sell(int64_t n, int64_t nslices, const int64_t* slice_ptr, co
 int dsea_op_create_stencil3(int64_t n, double coef, const double* V_dev, const double* halo_lo,
                             const double* halo_hi, dsea_op_t* out) {
   if (!out || n < 1 || !V_dev) return DSEA_ERR_ARG;
+  if (!aligned16(V_dev)) return DSEA_ERR_ALIGN;  // read as row pairs (16-byte loads)
   dsea_op_s* op = new (std::nothrow) dsea_op_s;
   if (!op) return DSEA_ERR_ARG;
   memset(&op->d, 0, sizeof(op->d));
@@ -704,6 +714,31 @@ int dsea_cg_run(dsea_op_t op, dsea_ws_t ws, const double* shift, const double* b
   double* dP = w.aux;                            // partials of d.A'd (one per mat-vec block)
   double* rP = w.aux + DSEA_MAX_WAVE_TILES;      // partials of r.r   (one per update block)
   if (poll_every <= 0) poll_every = 16;
+
+  // Small halo-1 operators: the whole solve in ONE persistent launch (k_cg_persist_stencil), bit-identical iterates.
+  // Its granule buffer lives in w.aux (the streaming form's partial buffers, unused there).
+  if (w.persist_override != 0 && persist_comm_bytes(n) <= (size_t)4 * DSEA_MAX_WAVE_TILES * sizeof(double)) {
+    const int pr = launch_cg_persist(op->d, shift, b, x, state, eps, maxiter, w.aux,
+                                     w.persist_override > 0 ? w.persist_override : 0, st);
+    if (pr == -2) {
+      g_last_hip = (int)hipGetLastError();
+      return DSEA_ERR_HIP;
+    }
+    if (pr == 0) {
+      double hs[DSEA_CG_STATE_LEN];
+      if (hipMemcpyAsync(hs, state, sizeof(hs), hipMemcpyDeviceToHost, st) != hipSuccess ||
+          hipStreamSynchronize(st) != hipSuccess) {
+        g_last_hip = (int)hipGetLastError();
+        return DSEA_ERR_HIP;
+      }
+      if (iters_out) *iters_out = (int64_t)hs[DSEA_CG_ITERS];
+      if (resnorm_out) *resnorm_out = hs[DSEA_CG_RESNORM];
+      int rc0 = check_launch();
+      if (rc0 != DSEA_OK) return rc0;
+      if (hs[DSEA_CG_DONE] < 0.0) return DSEA_ERR_TIMEOUT;   // a workgroup of the persistent launch did not show up
+      return hs[DSEA_CG_DONE] != 0.0 ? DSEA_OK : DSEA_ERR_NOT_CONVERGED;
+    }
+  }
 
   // r = b - A'x0 ; early out ; d = r                            (CG.py:26-30)
   int nb = launch_spmv(op->d, x, Ad, shift, nullptr, nullptr, st);

@@ -11,6 +11,8 @@
 #define DSEA_MAX_WAVE_TILES 8192  /* cap on wave tiles (= partial sums per basis vector)      */
 #define DSEA_TFIM_TILE_LOG2 11    /* rows of x staged in LDS per block of the TFIM mat-vec    */
 #define DSEA_MAX_TFIM_BLOCKS 4096 /* grid cap of the TFIM mat-vec (<= DSEA_MAX_WAVE_TILES partial slots)   */
+#define DSEA_PERSIST_MAX_TILES 4096 /* canonical-tile regime of the CG kernels: n <= 2^21 rows               */
+#define DSEA_PERSIST_CG_MAX_TILES 1024 /* persistent single-launch CG: n <= 2^19 rows                       */
 #define DSEA_SCALARS 64
 #define DSEA_SCAL_BREAK 20    /* scal[20] = breakdown step, scal[21] = running scale (see broken())     */
 
@@ -84,6 +86,7 @@ struct Workspace {
   int kmax;
   int rpl_override;
   int split_override;  // -1 automatic, 0 off, 4/8/16 forced
+  int persist_override;  // persistent single-launch CG: -1 automatic, 0 off, 1/2/4 = row pairs per thread forced
   double* partials;  // DSEA_MAX_WAVE_TILES * max(kmax,1) doubles (also >= DSEA_MAX_EW_BLOCKS)
   double* aux;       // 4 * DSEA_MAX_WAVE_TILES doubles: small partial buffers that must not alias `partials`
   double* coef;      // kmax doubles
@@ -141,6 +144,9 @@ void launch_form_r(const double* u, const double* q1, const double* q2, const do
 void launch_hypercube_flipsum(const double* xT, double* zT, int P, int p, int64_t chunk, hipStream_t st);
 void launch_plz_finish(const double* r, const double* y, const double* pair, double* q, uint16_t* qs, double* u,
                        double* alpha_out, double* beta_out, int64_t n, hipStream_t st);
+size_t persist_comm_bytes(int64_t n);
+int launch_cg_persist(const OpDesc& op, const double* shift, const double* b, double* x, double* state, double eps,
+                      int64_t maxiter, void* comm, int ppt_override, hipStream_t st);
 int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shift, const double* skip,
                 double* P, hipStream_t st, EventPair* ev = nullptr);
 

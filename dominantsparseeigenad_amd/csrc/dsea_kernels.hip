@@ -1295,7 +1295,16 @@ __global__ __launch_bounds__(256) void k_spmv_sell(SellParams p, const double* _
   }
 }
 
-// 3-point stencil + diagonal (schrodinger1D.py:18-27)
+// 3-point stencil + diagonal (schrodinger1D.py:18-27).
+// Geometry ("canonical tile"): a block of 256 threads works on tiles of 512 consecutive rows, thread t on the row
+// pair (2t, 2t+1) of the tile -- 16-byte accesses; the two outer neighbours are scalar loads (L1 hits).  With
+// one tile per block (n <= 2^21, see ew_blocks) P[tile] is the x.y partial of exactly that tile: the geometry
+// the persistent single-launch CG (k_cg_persist_stencil) reproduces bit for bit.
+__device__ __forceinline__ double stencil_row(double coef, double Vi, double xi, double up, double dn) {
+  const double lap = __dadd_rn(__dadd_rn(__dmul_rn(-2.0, xi), up), dn);
+  return __dadd_rn(__dmul_rn(coef, lap), __dmul_rn(Vi, xi));
+}
+
 template <bool FUSED>
 __global__ __launch_bounds__(256) void k_spmv_stencil3(Stencil3Params p, const double* __restrict__ x,
                                                        double* __restrict__ y,
@@ -1308,27 +1317,315 @@ __global__ __launch_bounds__(256) void k_spmv_stencil3(Stencil3Params p, const d
   if (FUSED && !fused_beta(fa, sm5, beta)) return;
   const double s = shift ? shift[0] : 0.0;
   double acc = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * 256) {
-    double xi = x[i];
-    double up = (i + 1 < p.n) ? x[i + 1] : (p.halo_hi ? p.halo_hi[0] : 0.0);
+  const int64_t stride = (int64_t)gridDim.x * 512;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; i < p.n; i += stride) {
+    double2 xv = ld2<true>(x, i, p.n);
     double dn = (i > 0) ? x[i - 1] : (p.halo_lo ? p.halo_lo[0] : 0.0);
+    double up = (i + 2 < p.n) ? x[i + 2] : ((i + 2 == p.n && p.halo_hi) ? p.halo_hi[0] : 0.0);
+    if (i + 1 == p.n) up = 0.0;  // odd n: the pair's second row does not exist (its neighbour value is unused)
+    const bool has1 = i + 1 < p.n;
+    double up0 = has1 ? xv.y : (p.halo_hi ? p.halo_hi[0] : 0.0);  // upper neighbour of row i
     if (FUSED) {  // the same divisions the separate scale kernel would have done: bit-identical q, u
-      xi = xi / beta;
-      if (i + 1 < p.n) up = up / beta;
+      xv.x = xv.x / beta;
+      if (has1) {
+        xv.y = xv.y / beta;
+        up0 = xv.y;
+      }
       if (i > 0) dn = dn / beta;
-      fa.q_out[i] = xi;
-      if (fa.qs_out) fa.qs_out[i] = f64_to_bf16(xi);
+      if (i + 2 < p.n) up = up / beta;
+      st2<true>(fa.q_out, i, p.n, xv);
+      if (fa.qs_out) st_bf16x2(fa.qs_out, i, p.n, xv);
     }
-    const double lap = __dadd_rn(__dadd_rn(__dmul_rn(-2.0, xi), up), dn);
-    double v = __dadd_rn(__dmul_rn(p.coef, lap), __dmul_rn(p.V[i], xi));
-    if (!FUSED && shift) v = __dsub_rn(v, __dmul_rn(s, xi));
-    y[i] = v;
-    acc = fma(xi, v, acc);
+    double2 v, Vv = ld2<true>(p.V, i, p.n);
+    v.x = stencil_row(p.coef, Vv.x, xv.x, up0, dn);
+    v.y = has1 ? stencil_row(p.coef, Vv.y, xv.y, up, xv.x) : 0.0;
+    if (!FUSED && shift) {
+      v.x = __dsub_rn(v.x, __dmul_rn(s, xv.x));
+      v.y = __dsub_rn(v.y, __dmul_rn(s, xv.y));
+    }
+    st2<true>(y, i, p.n, v);
+    acc = fma(xv.x, v.x, acc);
+    acc = fma(xv.y, v.y, acc);
   }
   if (P) {
     __syncthreads();
     double tot = block_sum(acc, sm5);
     if (threadIdx.x == 0) P[blockIdx.x] = tot;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Persistent single-launch CG for the 3-point stencil on SMALL vectors (BASELINE config 3: N = 1e5, 0.8 MB per
+// vector).  There the three launches per iteration of the streaming form cost ~13 us for ~1 us of memory
+// traffic.  Here the whole solve is ONE launch of G workgroups x 1024 threads that keep x, r, d and V in
+// REGISTERS for the entire solve (row pairs, the canonical tile geometry of the streaming kernels); per
+// iteration only
+//   * the per-tile partials of d.Ad and r.r                      (one 8-byte value per 512 rows)
+//   * the two edge elements of r of every workgroup              (halo of the next mat-vec: d' = r + beta d)
+// cross workgroups, as data-tagged granules (cdna_hip_programming.md Guideline 16, form R2: the data is the
+// flag -- {epoch tag, 32 payload bits} written by ONE relaxed agent-scope 8-byte store, polled with relaxed
+// agent-scope loads; no fences, no separate flags, state zeroed by the launcher before every launch).
+// Every workgroup reads ALL tile partials and sums them in exactly the order the streaming kernels use
+// (sum_partials_block / k_finalize1), all elementwise updates use the same rounded operations, and a tile
+// partial is the same function of the tile's rows: the iterates are BIT-IDENTICAL to the 3-launch form
+// (tests/test_gpu_persistent.py) and identical on every workgroup, so all take the same exit.
+// Reference: CG.py:24-41 with A' = A - shift (CG.py:120).
+// ------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+#define DSEA_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#define DSEA_PERSIST_TIMEOUT_TICKS 300000000ll /* 3 s of the 100 MHz wall clock: a lost peer must not hang the GPU */
+
+__device__ __forceinline__ void put_f64(gu64* g, unsigned epoch, double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned long long tag = (unsigned long long)epoch << 32;
+  __hip_atomic_store(g, tag | (b & 0xffffffffull), DSEA_RLX_AGENT);
+  __hip_atomic_store(g + 1, tag | (b >> 32), DSEA_RLX_AGENT);
+}
+__device__ __forceinline__ bool try_get_f64(gu64* g, unsigned epoch, double& v) {
+  const unsigned long long lo = __hip_atomic_load(g, DSEA_RLX_AGENT);
+  const unsigned long long hi = __hip_atomic_load(g + 1, DSEA_RLX_AGENT);
+  v = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+  return (unsigned)(lo >> 32) == epoch && (unsigned)(hi >> 32) == epoch;
+}
+
+struct PersistArgs {
+  Stencil3Params p;
+  const double* shift;
+  const double* b;
+  double* x;        // in: start vector, out: solution
+  double* state;    // DSEA_CG_* (written by workgroup 0 at the end)
+  double eps;
+  long long maxiter;
+  unsigned long long* comm;  // granules: [2*ntiles] phase A | [2*ntiles] phase C | [4*G] edges ; zeroed per launch
+  int ntiles;
+};
+
+// shared scratch behind the d-with-halo array: wave partials of up to 4 sub-rounds, the broadcast slots
+struct PersistSm {
+  double red[4][16];
+  double bcast[8];   // [0] total  [1] left edge  [2] right edge  [3] fail flag
+};
+
+// All 1024 threads call this.  Threads 0..255 fetch the `count` tile partials of phase `base` (spinning until every
+// granule carries `epoch`) and sum them in the order of sum_partials_block (two_acc) or k_finalize1 (!two_acc);
+// thread 256 / 320 fetch the neighbour workgroups' edge values when `edges`.  Returns the total in every thread;
+// el / er receive the edges.  `fail` is set (in every thread) if a peer did not show up in time.
+__device__ __forceinline__ double persist_gather(gu64* base, int count, unsigned epoch, bool two_acc, gu64* edge_base,
+                                                 bool edges, int g, int G, PersistSm* sm, double& el, double& er,
+                                                 bool& fail) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long t0 = wall_clock64();
+  if (tid < 256) {
+    double pv[4] = {0.0, 0.0, 0.0, 0.0};
+    bool ok;
+    do {
+      ok = true;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int idx = tid + 256 * m;
+        if (idx < count) ok &= try_get_f64(base + 2 * idx, epoch, pv[m]);
+      }
+      if (!ok) {
+        __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t0 > DSEA_PERSIST_TIMEOUT_TICKS) break;
+      }
+    } while (!ok);
+    if (!ok) sm->bcast[3] = 1.0;
+    double acc;
+    if (two_acc) {
+      const double a0 = (0.0 + pv[0]) + pv[2], a1 = (0.0 + pv[1]) + pv[3];
+      acc = a0 + a1;
+    } else {
+      acc = (((0.0 + pv[0]) + pv[1]) + pv[2]) + pv[3];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) sm->red[0][wave] = acc;
+  } else if (edges && (tid == 256 || tid == 320)) {
+    const bool left = tid == 256;
+    const int peer = left ? g - 1 : g + 1;
+    double v = 0.0;
+    if (peer >= 0 && peer < G) {
+      gu64* src = edge_base + (peer * 2 + (left ? 1 : 0)) * 2;   // left neighbour's LAST row / right one's FIRST
+      bool ok;
+      do {
+        ok = try_get_f64(src, epoch, v);
+        if (!ok) {
+          __builtin_amdgcn_s_sleep(1);
+          if (wall_clock64() - t0 > DSEA_PERSIST_TIMEOUT_TICKS) break;
+        }
+      } while (!ok);
+      if (!ok) sm->bcast[3] = 1.0;
+    }
+    sm->bcast[left ? 1 : 2] = v;
+  }
+  __syncthreads();
+  const double tot = ((sm->red[0][0] + sm->red[0][1]) + sm->red[0][2]) + sm->red[0][3];
+  el = sm->bcast[1];
+  er = sm->bcast[2];
+  fail = sm->bcast[3] != 0.0;
+  __syncthreads();   // red / bcast may be rewritten by the next phase
+  return tot;
+}
+
+template <int PPT>
+__global__ __launch_bounds__(1024) void k_cg_persist_stencil(PersistArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  constexpr int TPW = 4 * PPT;          // tiles per workgroup
+  constexpr int ROWS = TPW * 512;
+  double* dsm = lds;                    // dsm[1] left halo, dsm[2 + local row] (pairs 16-byte aligned), dsm[2 + ROWS] right halo
+  PersistSm* sm = reinterpret_cast<PersistSm*>(lds + ROWS + 4);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, vb = tid >> 8, t = tid & 255;
+  const int g = blockIdx.x, G = gridDim.x;
+  const int64_t n = a.p.n;
+  gu64* commA = (gu64*)a.comm;
+  gu64* commC = commA + 2 * (int64_t)a.ntiles;
+  gu64* commE = commC + 2 * (int64_t)a.ntiles;
+  const double coef = a.p.coef;
+  const bool has_shift = a.shift != nullptr;
+  const double s = has_shift ? a.shift[0] : 0.0;
+  if (tid == 0) sm->bcast[3] = 0.0;
+  __syncthreads();
+
+  // my row pairs: sub-round q -> tile g*TPW + 4 q + vb, rows (tile*512 + 2t, +1)
+  int lrow[PPT];
+  int tile[PPT];
+  bool v0[PPT], v1[PPT];   // row exists
+  double2 xv[PPT], rv[PPT], dv[PPT], Vv[PPT];
+#pragma unroll
+  for (int q = 0; q < PPT; ++q) {
+    tile[q] = g * TPW + 4 * q + vb;
+    lrow[q] = (4 * q + vb) * 512 + 2 * t;
+    const int64_t i = (int64_t)tile[q] * 512 + 2 * t;
+    v0[q] = i < n;
+    v1[q] = i + 1 < n;
+    xv[q] = ld2<true>(a.x, i, n);
+    Vv[q] = ld2<true>(a.p.V, i, n);
+  }
+  // y = A' w for the vector currently in dsm (halos included); returns the pair of my sub-round q
+  auto apply = [&](int q, double2 w) -> double2 {
+    const double dn = dsm[lrow[q] + 1];       // element before the pair
+    const double up = dsm[lrow[q] + 4];       // element after the pair
+    double2 y;
+    y.x = v0[q] ? stencil_row(coef, Vv[q].x, w.x, v1[q] ? w.y : 0.0, dn) : 0.0;
+    y.y = v1[q] ? stencil_row(coef, Vv[q].y, w.y, up, w.x) : 0.0;
+    if (has_shift) {
+      y.x = __dsub_rn(y.x, __dmul_rn(s, w.x));
+      y.y = __dsub_rn(y.y, __dmul_rn(s, w.y));
+    }
+    return y;
+  };
+  auto stage = [&](const double2* w, double hl, double hr) {   // w with halos -> dsm
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) *reinterpret_cast<double2*>(dsm + 2 + lrow[q]) = w[q];
+    if (tid == 0) {
+      dsm[1] = hl;
+      dsm[2 + ROWS] = hr;
+    }
+    __syncthreads();
+  };
+  // per-tile partial sum_t (a.x b.x + a.y b.y) of sub-round q published under `epoch` in `dst`
+  auto publish_tiles = [&](gu64* dst, unsigned epoch, const double2* u, const double2* w) {
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+      double acc = 0.0;
+      acc = fma(u[q].x, w[q].x, acc);
+      acc = fma(u[q].y, w[q].y, acc);
+      acc = wave_sum(acc);
+      if (lane == 0) sm->red[q][wave] = acc;
+    }
+    __syncthreads();
+    if (t == 0) {
+#pragma unroll
+      for (int q = 0; q < PPT; ++q)
+        if (tile[q] < a.ntiles) {
+          const double tot = ((sm->red[q][4 * vb] + sm->red[q][4 * vb + 1]) + sm->red[q][4 * vb + 2]) + sm->red[q][4 * vb + 3];
+          put_f64(dst + 2 * tile[q], epoch, tot);
+        }
+    }
+    __syncthreads();
+  };
+  auto publish_edges = [&](unsigned epoch, const double2* w) {
+    if (tid == 0) put_f64(commE + (g * 2 + 0) * 2, epoch, w[0].x);
+    if (tid == 1023) put_f64(commE + (g * 2 + 1) * 2, epoch, w[PPT - 1].y);
+  };
+
+  double el, er;
+  bool fail;
+  unsigned epoch = 1;
+  // ---- r = b - A' x0 ; d = r ; rr = r.r                                          (CG.py:26-30)
+  publish_edges(epoch, xv);
+  {
+    double dummy = persist_gather(commA, 0, epoch, true, commE, true, g, G, sm, el, er, fail);
+    (void)dummy;
+  }
+  if (fail) {
+    if (g == 0 && tid == 0) a.state[DSEA_CG_DONE] = -1.0;
+    return;
+  }
+  stage(xv, el, er);
+#pragma unroll
+  for (int q = 0; q < PPT; ++q) {
+    const double2 Ax = apply(q, xv[q]);
+    const double2 bv = ld2<true>(a.b, (int64_t)tile[q] * 512 + 2 * t, n);
+    rv[q].x = __dsub_rn(bv.x, Ax.x);
+    rv[q].y = __dsub_rn(bv.y, Ax.y);
+    dv[q] = rv[q];
+  }
+  epoch = 2;
+  publish_edges(epoch, rv);
+  publish_tiles(commC, epoch, rv, rv);
+  double rr = persist_gather(commC, a.ntiles, epoch, false, commE, true, g, G, sm, el, er, fail);
+  double dL = el, dR = er;   // d = r: the neighbours' edge d values
+  double rn = sqrt(rr);
+  long long iters = 0;
+  bool done = rn < a.eps;
+  // ---- iterations                                                                  (CG.py:31-40)
+  while (!done && !fail && iters < a.maxiter) {
+    stage(dv, dL, dR);
+    double2 Ad[PPT];
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) Ad[q] = apply(q, dv[q]);
+    ++epoch;
+    publish_tiles(commA, epoch, dv, Ad);
+    const double dAd = persist_gather(commA, a.ntiles, epoch, true, commE, false, g, G, sm, el, er, fail);
+    if (fail) break;
+    const double alpha = rr / dAd;
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+      xv[q].x = __dadd_rn(xv[q].x, __dmul_rn(alpha, dv[q].x));
+      xv[q].y = __dadd_rn(xv[q].y, __dmul_rn(alpha, dv[q].y));
+      rv[q].x = __dsub_rn(rv[q].x, __dmul_rn(alpha, Ad[q].x));
+      rv[q].y = __dsub_rn(rv[q].y, __dmul_rn(alpha, Ad[q].y));
+    }
+    ++epoch;
+    publish_edges(epoch, rv);
+    publish_tiles(commC, epoch, rv, rv);
+    const double rr_new = persist_gather(commC, a.ntiles, epoch, true, commE, true, g, G, sm, el, er, fail);
+    if (fail) break;
+    ++iters;
+    rn = sqrt(rr_new);
+    if (rn < a.eps) {
+      done = true;
+      break;
+    }
+    const double beta = rr_new / rr;
+    rr = rr_new;
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+      dv[q].x = __dadd_rn(rv[q].x, __dmul_rn(beta, dv[q].x));
+      dv[q].y = __dadd_rn(rv[q].y, __dmul_rn(beta, dv[q].y));
+    }
+    dL = __dadd_rn(el, __dmul_rn(beta, dL));   // the neighbours' edge elements of d, updated as they update them
+    dR = __dadd_rn(er, __dmul_rn(beta, dR));
+  }
+#pragma unroll
+  for (int q = 0; q < PPT; ++q) st2<true>(a.x, (int64_t)tile[q] * 512 + 2 * t, n, xv[q]);
+  if (g == 0 && tid == 0) {
+    a.state[DSEA_CG_RR] = rr;
+    a.state[DSEA_CG_RESNORM] = rn;
+    a.state[DSEA_CG_ITERS] = (double)iters;
+    a.state[DSEA_CG_DONE] = fail ? -1.0 : (done ? 1.0 : 0.0);
   }
 }
 
@@ -1342,6 +1639,13 @@ static inline int ew_blocks(int64_t n) {
   if (nb < 1) nb = 1;
   if (nb > DSEA_MAX_EW_BLOCKS) nb = DSEA_MAX_EW_BLOCKS;
   return (int)nb;
+}
+// Kernels with a fused reduction in the CG loop: up to DSEA_PERSIST_MAX_TILES tiles of 512 rows (n <= 2^21) one
+// block per tile, so that P[tile] is a function of the tile alone (the "canonical tile" partial the persistent CG
+// kernel reproduces); beyond that the capped grid-stride form.
+static inline int tile_blocks(int64_t n) {
+  const int64_t nt = (n + 511) / 512;
+  return nt <= DSEA_PERSIST_MAX_TILES ? (int)(nt < 1 ? 1 : nt) : ew_blocks(n);
 }
 
 // Launch, optionally with a start/stop event pair attached to the dispatch itself (hipExtLaunchKernelGGL):
@@ -1484,7 +1788,7 @@ void launch_project_apply(const double* v, const double* a, const double* dot, d
 
 void launch_cg_init(const double* b, const double* Ax0, double* r, double* d, double* state, int64_t n,
                     double* P, hipStream_t st) {
-  const int nb = ew_blocks(n);
+  const int nb = tile_blocks(n);
   hipLaunchKernelGGL(k_cg_state_clear, dim3(1), dim3(64), 0, st, state);
   hipLaunchKernelGGL(k_cg_init, dim3(nb), dim3(256), 0, st, b, Ax0, r, d, n, P);
   launch_finalize1(P, nb, state + DSEA_CG_RR, st);
@@ -1570,9 +1874,7 @@ int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shif
     }
     case OP_STENCIL3: {
       const Stencil3Params& p = op.st3;
-      int64_t nb = (p.n + 255) / 256;
-      if (nb > DSEA_MAX_EW_BLOCKS) nb = DSEA_MAX_EW_BLOCKS;
-      if (nb < 1) nb = 1;
+      const int64_t nb = tile_blocks(p.n);
       TfimFusedArgs fa0 = {nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
       KLAUNCH(ev, (k_spmv_stencil3<false>), (unsigned)nb, 256, st, p, x, y, shift, skip, P, fa0);
       return (int)nb;
@@ -1598,8 +1900,7 @@ int launch_tfim_fused(const OpDesc& op, const double* r, const double* nP, int n
   }
   if (op.kind == OP_STENCIL3) {
     const Stencil3Params& p = op.st3;
-    int64_t nb = (p.n + 255) / 256;
-    if (nb > DSEA_MAX_EW_BLOCKS) nb = DSEA_MAX_EW_BLOCKS;
+    const int64_t nb = tile_blocks(p.n);
     KLAUNCH(ev, (k_spmv_stencil3<true>), (unsigned)nb, 256, st, p, r, y, nullc, nullc, P, fa);
     return (int)nb;
   }
@@ -1622,14 +1923,14 @@ int launch_tfim_fused(const OpDesc& op, const double* r, const double* nP, int n
 
 int launch_cg_update_fused(double* x, double* r, const double* d, const double* Ad, const double* state,
                            int parity, const double* dP, int dCount, int64_t n, double* P, hipStream_t st) {
-  const int nb = ew_blocks(n);
+  const int nb = tile_blocks(n);
   hipLaunchKernelGGL(k_cg_update_fused, dim3(nb), dim3(256), 0, st, x, r, d, Ad, state, parity, dP, dCount, n, P);
   return nb;
 }
 
 void launch_cg_direction_fused(const double* r, double* d, double* state, int parity, const double* rP,
                                int rCount, double eps, int64_t n, hipStream_t st) {
-  hipLaunchKernelGGL(k_cg_direction_fused, dim3(ew_blocks(n)), dim3(256), 0, st, r, d, state, parity, rP, rCount,
+  hipLaunchKernelGGL(k_cg_direction_fused, dim3(tile_blocks(n)), dim3(256), 0, st, r, d, state, parity, rP, rCount,
                      eps, n);
 }
 
@@ -1664,6 +1965,54 @@ void launch_plz_finish(const double* r, const double* y, const double* pair, dou
 
 void launch_finalize_slot(const double* P, int count, double* out, const double* skip, hipStream_t st) {
   hipLaunchKernelGGL(k_cg_finalize_slot, dim3(1), dim3(256), 0, st, P, count, out, skip);
+}
+
+// Persistent CG (see k_cg_persist_stencil).  Returns 0 if launched, -1 if the problem is outside its envelope
+// (then the caller runs the streaming 3-launch form), -2 on a HIP error.  `comm` must hold persist_comm_bytes().
+size_t persist_comm_bytes(int64_t n) {
+  const int64_t nt = (n + 511) / 512;
+  return (size_t)(4 * nt + 4 * 256) * sizeof(unsigned long long);
+}
+int launch_cg_persist(const OpDesc& op, const double* shift, const double* b, double* x, double* state, double eps,
+                      int64_t maxiter, void* comm, int ppt_override, hipStream_t st) {
+  if (op.kind != OP_STENCIL3 || op.st3.halo_lo || op.st3.halo_hi) return -1;
+  const int64_t n = op.st3.n;
+  const int64_t nt = (n + 511) / 512;
+  if (nt > DSEA_PERSIST_CG_MAX_TILES) return -1;
+  int ppt = ppt_override;
+  if (ppt != 1 && ppt != 2 && ppt != 4) ppt = nt <= 64 ? 1 : (nt <= 512 ? 2 : 4);
+  const int tpw = 4 * ppt;
+  const int G = (int)((nt + tpw - 1) / tpw);
+  if (G > 256) return -1;
+  const size_t cbytes = (size_t)(4 * nt + 4 * G) * sizeof(unsigned long long);
+  if (hipMemsetAsync(comm, 0, cbytes, st) != hipSuccess) return -2;
+  PersistArgs a;
+  a.p = op.st3;
+  a.shift = shift;
+  a.b = b;
+  a.x = x;
+  a.state = state;
+  a.eps = eps;
+  a.maxiter = (long long)maxiter;
+  a.comm = static_cast<unsigned long long*>(comm);
+  a.ntiles = (int)nt;
+  const size_t lds = (size_t)(tpw * 512 + 4) * sizeof(double) + sizeof(PersistSm);
+  hipError_t e = hipSuccess;
+  switch (ppt) {
+    case 1:
+      hipLaunchKernelGGL((k_cg_persist_stencil<1>), dim3(G), dim3(1024), lds, st, a);
+      break;
+    case 2:
+      hipLaunchKernelGGL((k_cg_persist_stencil<2>), dim3(G), dim3(1024), lds, st, a);
+      break;
+    default:
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cg_persist_stencil<4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return -2;
+      hipLaunchKernelGGL((k_cg_persist_stencil<4>), dim3(G), dim3(1024), lds, st, a);
+      break;
+  }
+  return 0;
 }
 
 }  // namespace dsea

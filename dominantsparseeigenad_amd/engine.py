@@ -101,6 +101,9 @@ class Workspace:
     def set_rows_per_lane(self, rpl):
         check(self.lib.dsea_ws_set_rows_per_lane(self.handle, int(rpl)), "dsea_ws_set_rows_per_lane")
 
+    def set_persist(self, mode):
+        check(self.lib.dsea_ws_set_persist(self.handle, int(mode)), "dsea_ws_set_persist")
+
     def set_split(self, waves):
         check(self.lib.dsea_ws_set_split(self.handle, int(waves)), "dsea_ws_set_split")
 

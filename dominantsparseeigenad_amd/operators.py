@@ -197,7 +197,7 @@ class Stencil3Operator:
         if value.device.type != "cuda" or value.dtype != F64 or value.numel() != self.n:
             raise ValueError("potential must be a float64 CUDA tensor of %d elements" % self.n)
         self._V = value
-        self._Vdata = value.detach().contiguous()
+        self._Vdata = engine.as_vector(value.detach(), self.n)     # contiguous, 16-byte aligned (pair loads)
         raw = c_void_p()
         check(_lib.load().dsea_op_create_stencil3(self.n, self.coef, c_void_p(self._Vdata.data_ptr()), None, None,
                                                   byref(raw)), "dsea_op_create_stencil3")

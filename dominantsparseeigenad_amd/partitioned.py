@@ -668,7 +668,7 @@ class PartitionedStencil3Operator(PartitionedOperator):
         self.h = float(h)
         self.coef = -0.5 / self.h ** 2
         self._V = potential_slab
-        self._Vdata = potential_slab.detach().to(F64).contiguous()
+        self._Vdata = _vec(potential_slab)          # contiguous, 16-byte aligned on the device (pair loads)
         self.has_lo, self.has_hi = comm.rank > 0, comm.rank < comm.world - 1
         if backend is None:
             backend = HipBackend(rows, device)

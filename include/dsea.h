@@ -48,6 +48,7 @@ extern "C" {
 #define DSEA_ERR_HIP (-4)       /* a HIP runtime call failed (see dsea_last_hip_error) */
 #define DSEA_ERR_NOT_CONVERGED (-5) /* dsea_cg_run hit maxiter                   */
 #define DSEA_ERR_UNSUPPORTED (-6)
+#define DSEA_ERR_TIMEOUT (-8)   /* persistent single-launch solver: a peer workgroup did not arrive (bounded spin) */
 #define DSEA_ERR_BREAKDOWN (-7) /* dsea_lanczos_status: the run met beta ~ 0 and stopped itself */
 
 typedef struct dsea_op_s *dsea_op_t; /* operator descriptor (host struct, device pointers inside) */
@@ -69,6 +70,11 @@ int dsea_ws_set_rows_per_lane(dsea_ws_t ws, int rpl);
  * 128-row tile and splits the basis vectors between its waves.  -1 = automatic (on below ~1.3e5 rows),
  * 0 = off, 4 / 8 / 16 = forced.                                                                          */
 int dsea_ws_set_split(dsea_ws_t ws, int waves);
+/* tuning knob: persistent single-launch CG of dsea_cg_run (3-point stencil without halo pointers, n <= 2^19): the
+ * whole solve is ONE launch whose workgroups keep x, r, d in registers and exchange only per-tile partial sums and
+ * edge elements; iterates are bit-identical to the streaming 3-launches-per-iteration form.
+ * -1 = automatic (on where it applies), 0 = off (streaming form), 1 / 2 / 4 = on with that many row pairs per thread. */
+int dsea_ws_set_persist(dsea_ws_t ws, int mode);
 
 /* Optional bf16 SHADOW of the Krylov basis (caller-owned, `rows` x `ld` uint16, ld % 8 == 0, 16-byte
  * aligned; null = off).  When registered, dsea_lanczos_run also stores every new basis vector rounded to

@@ -77,9 +77,9 @@ def test_full_size_curves_against_reference_data(N, k, idxs):
         e, de, d2e = E0.E0_sparseAD(model, k)
         assert abs(e - curE["E0s"][idx]) < 1e-6 * abs(curE["E0s"][idx]), (N, g, e, curE["E0s"][idx])
         assert abs(de - curE["dE0s"][idx]) < 1e-5 * abs(curE["dE0s"][idx]), (N, g, de, curE["dE0s"][idx])
-        assert abs(d2e - curE["d2E0s"][idx]) < 2e-3 * abs(curE["d2E0s"][idx]), (N, g, d2e, curE["d2E0s"][idx])
+        assert abs(d2e - curE["d2E0s"][idx]) < 1e-5 * abs(curE["d2E0s"][idx]), (N, g, d2e, curE["d2E0s"][idx])
         _, _, c = chi.chiF_sparseAD(model, k)
-        assert abs(c - curC["chiFs"][idx]) < 2e-3 * abs(curC["chiFs"][idx]), (N, g, c, curC["chiFs"][idx])
+        assert abs(c - curC["chiFs"][idx]) < 1e-5 * abs(curC["chiFs"][idx]), (N, g, c, curC["chiFs"][idx])
 
 
 def test_vumps_example_on_device():

@@ -1,0 +1,78 @@
+"""Persistent single-launch CG (k_cg_persist_stencil, BASELINE config 3 regime) against the streaming
+3-launches-per-iteration form: BIT-IDENTICAL iterates (torch.equal), same iteration counts, same residual norms --
+on ragged sizes, with and without shift, fixed-iteration and converged runs -- and against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle  # noqa: E402
+from dominantsparseeigenad_amd import engine  # noqa: E402
+from dominantsparseeigenad_amd.operators import Stencil3Operator  # noqa: E402
+from dominantsparseeigenad_amd.synthetic import normal_vector  # noqa: E402
+
+F64 = torch.float64
+cuda = torch.device("cuda:0")
+
+
+def _problem(N, seed=50):
+    h = 2.0 / N
+    xmesh = torch.from_numpy(np.linspace(-1.0, 1.0, num=N, endpoint=False))
+    V = 0.5 * xmesh ** 2
+    op = Stencil3Operator(N, h, V.to(cuda))
+    b = torch.from_numpy(normal_vector(N, seed)).to(cuda)
+    x0 = torch.from_numpy(normal_vector(N, seed + 1)).to(cuda)
+    return op, V, h, b, x0
+
+
+def _solve(op, b, x0, shift, mode, **kw):
+    ws = engine.Workspace.get(op.n, 8, cuda)
+    ws.set_persist(mode)
+    try:
+        x = engine.cg(b, x0, native=op, shift=shift, **kw)
+    finally:
+        ws.set_persist(-1)
+    return x, engine.last_cg.iters, engine.last_cg.resnorm, engine.last_cg.converged
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 511, 512, 513, 1000, 4097, 100000, 131072, 300001])
+def test_persistent_cg_is_bit_identical_to_streaming_form(N):
+    op, V, h, b, x0 = _problem(N)
+    shift = torch.tensor(-1.0, dtype=F64, device=cuda)
+    iters = 40 if N > 3 else 3
+    ref = _solve(op, b, x0, shift, 0, eps=0.0, maxiter=iters)
+    for mode in (-1, 1, 2, 4):
+        if mode == 1 and N > 64 * 4 * 512:
+            continue      # 1 pair per thread: at most 256 workgroups x 2048 rows
+        got = _solve(op, b, x0, shift, mode, eps=0.0, maxiter=iters)
+        assert got[1] == ref[1] == iters and got[2] == ref[2], (mode, got[1:], ref[1:])
+        assert torch.equal(got[0], ref[0]), (mode, float((got[0] - ref[0]).abs().max()))
+
+
+def test_persistent_cg_converged_run_and_no_shift():
+    N = 20000
+    op, V, h, b, x0 = _problem(N, seed=60)
+    for shift in (None, torch.tensor(-3.5e5, dtype=F64, device=cuda)):
+        ref = _solve(op, b, x0, shift, 0, eps=1e-3, maxiter=N)
+        got = _solve(op, b, x0, shift, -1, eps=1e-3, maxiter=N)
+        assert ref[3] and got[3] and got[1] == ref[1] and got[2] == ref[2]
+        assert torch.equal(got[0], ref[0])
+    # early out: a start vector that already solves the system
+    xs = got[0]
+    bb = op(xs) - shift * xs
+    again = _solve(op, bb, xs, shift, -1, eps=1e30, maxiter=N)
+    assert again[1] == 0 and again[3] and torch.equal(again[0], xs)
+
+
+def test_persistent_cg_first_50_iterates_against_oracle():
+    """parity on the first 50 CG iterates of the shifted SPD system at N = 1e5"""
+    N = 100000
+    op, V, h, b, x0 = _problem(N, seed=42)
+    ref = oracle.Stencil3(N, h, V)
+    theta = torch.tensor(-1.0, dtype=F64)
+    st = {}
+    xo = oracle.cg_solve(lambda v: ref.H(v) - theta * v, b.cpu(), x0.cpu(), sparse=True, maxiter=50, stats=st)
+    x, it, rn, _ = _solve(op, b, x0, theta.to(cuda), -1, eps=1e-7, maxiter=50)
+    assert it == st["iters"] == 50
+    assert float((x.cpu() - xo).abs().max()) <= 1e-10 * float(xo.abs().max())

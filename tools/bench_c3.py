@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE configs[2] in its well-posed restatement: 1-D Schroedinger stencil, N = 100000.
 Lanczos k = 300 forward time, and CG on the shifted SPD system over a FIXED 1000 iterations (us / iteration and
-algorithmic GB/s = 11 vectors per iteration)."""
+algorithmic GB/s = 11 vectors per iteration) -- persistent single-launch form vs streaming 3-launch form."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -24,9 +24,17 @@ print("Lanczos N=%d k=%d: %.2f ms  (%.1f us/step; algorithmic %.0f GB/s)  theta=
     N, k, (t1 - t0) * 1e3, (t1 - t0) / k * 1e6, 8.0 * N * (k * k + 12 * k) / (t1 - t0) / 1e9, lam.item()))
 b = torch.from_numpy(normal_vector(N, 2)).to(dev); x0 = torch.from_numpy(normal_vector(N, 3)).to(dev)
 shift = torch.tensor(-1.0, dtype=torch.float64, device=dev)
-for it in range(3):
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    xs = engine.cg(b, x0, native=op, shift=shift, eps=0.0, maxiter=1000, poll_every=64)
-    torch.cuda.synchronize(); t1 = time.perf_counter()
-print("CG fixed %d iterations: %.2f ms  %.2f us/iteration  %.0f GB/s algorithmic" % (
-    engine.last_cg.iters, (t1 - t0) * 1e3, (t1 - t0) / 1000 * 1e6, 11 * 8.0 * N * 1000 / (t1 - t0) / 1e9))
+ws = engine.Workspace.get(N, 8, dev)
+for mode, name in ((0, "streaming 3-launch"), (-1, "persistent auto"), (1, "persistent ppt=1"), (2, "persistent ppt=2"), (4, "persistent ppt=4")):
+    ws.set_persist(mode)
+    best = 1e30
+    try:
+        for it in range(4):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            xs = engine.cg(b, x0, native=op, shift=shift, eps=0.0, maxiter=1000, poll_every=1000)
+            torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+        print("CG %-20s fixed %d iterations: %.2f ms  %.2f us/iteration  %.0f GB/s algorithmic" % (
+            name, engine.last_cg.iters, best * 1e3, best / 1000 * 1e6, 11 * 8.0 * N * 1000 / best / 1e9))
+    except Exception as exc:
+        print("CG %-20s failed: %s" % (name, exc))
+ws.set_persist(-1)
