@@ -45,6 +45,9 @@ _SIGNATURES = {
     "dsea_op_create_csr": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
     "dsea_op_create_sell": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
     "dsea_op_create_stencil3": (c_int, [c_int64, c_double, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
+    "dsea_op_create_dense": (c_int, [c_int64, c_void_p, c_int64, c_int, POINTER(c_void_p)]),
+    "dsea_op_transfer_work_bytes": (c_size_t, [c_int, c_int]),
+    "dsea_op_create_transfer": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, POINTER(c_void_p)]),
     "dsea_op_destroy": (c_int, [c_void_p]),
     "dsea_op_dim": (c_int, [c_void_p, POINTER(c_int64)]),
     "dsea_spmv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -80,6 +83,18 @@ _SIGNATURES = {
                                 c_void_p, c_int64, c_void_p]),
     "dsea_lanczos_run": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                  c_void_p]),
+    "dsea_arnoldi_extend": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int,
+                                    c_void_p]),
+    "dsea_arnoldi_orth": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int,
+                                  c_void_p]),
+    "dsea_gmres_work_doubles": (c_size_t, [c_int]),
+    "dsea_gmres_begin": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_double,
+                                 c_void_p, c_void_p]),
+    "dsea_gmres_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
+                                c_void_p, c_double, c_void_p, c_void_p]),
+    "dsea_gmres_end": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dsea_gmres_cycle": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p,
+                                 c_double, c_void_p, c_int, c_void_p]),
     "dsea_lanczos_status": (c_int, [c_void_p, POINTER(c_int), c_void_p]),
     "dsea_cg_run": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int64,
                             c_int, POINTER(c_int64), POINTER(c_double), c_void_p]),

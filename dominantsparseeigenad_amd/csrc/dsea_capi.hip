@@ -48,7 +48,7 @@ WsLayout ws_layout(int64_t n, int kmax) {
   L.aux_off = off;
   off += (size_t)4 * DSEA_MAX_WAVE_TILES * sizeof(double);
   L.coef_off = off;
-  off += (size_t)round_up(kk + 2, 32) * sizeof(double);
+  off += (size_t)2 * round_up(kk + 2, 32) * sizeof(double);   // two coefficient vectors (Arnoldi: DGKS second pass)
   L.scal_off = off;
   off += (size_t)DSEA_SCALARS * sizeof(double);
   off = (size_t)round_up((int64_t)off, 256);
@@ -159,7 +159,14 @@ int dsea_ws_create(void* device_buffer, size_t bytes, int64_t n, int kmax, dsea_
   ws->w.partials = reinterpret_cast<double*>(base + L.partials_off);
   ws->w.aux = reinterpret_cast<double*>(base + L.aux_off);
   ws->w.coef = reinterpret_cast<double*>(base + L.coef_off);
+  ws->w.coef2 = ws->w.coef + round_up((kmax < 1 ? 1 : kmax) + 2, 32);
   ws->w.scal = reinterpret_cast<double*>(base + L.scal_off);
+  ws->w.zero = ws->w.scal + 30;
+  if (hipMemset(ws->w.scal, 0, DSEA_SCALARS * sizeof(double)) != hipSuccess) {   // scal[30] stays 0 for good
+    g_last_hip = (int)hipGetLastError();
+    delete ws;
+    return DSEA_ERR_HIP;
+  }
   for (int v = 0; v < 4; ++v)
     ws->w.vec[v] = reinterpret_cast<double*>(base + L.vec_off) + (size_t)v * (size_t)L.npad;
   *out = ws;
@@ -259,7 +266,7 @@ int dsea_ws_set_rows_per_lane(dsea_ws_t ws, int rpl) {
 
 int dsea_ws_set_persist(dsea_ws_t ws, int mode) {
   if (!ws) return DSEA_ERR_ARG;
-  if (mode != -1 && mode != 0 && mode != 1 && mode != 2 && mode != 4) return DSEA_ERR_ARG;
+  if (mode != -1 && mode != 0 && mode != 1 && mode != 2) return DSEA_ERR_ARG;
   ws->w.persist_override = mode;
   return DSEA_OK;
 }
@@ -328,6 +335,42 @@ int dsea_op_create_stencil3(int64_t n, double coef, const double* V_dev, const d
   op->d.st3 = Stencil3Params{n, coef, V_dev, halo_lo, halo_hi};
   *out = op;
   return DSEA_OK;
+}
+
+int dsea_op_create_dense(int64_t n, const double* A_dev, int64_t lda, int transpose, dsea_op_t* out) {
+  if (!out || n < 1 || !A_dev || lda < n || n > 2147483647ll || lda > 2147483647ll) return DSEA_ERR_ARG;
+  if (!blas_available()) return DSEA_ERR_UNSUPPORTED;
+  dsea_op_s* op = new (std::nothrow) dsea_op_s;
+  if (!op) return DSEA_ERR_ARG;
+  memset(&op->d, 0, sizeof(op->d));
+  op->d.tune_tile_log2 = DSEA_TFIM_TILE_LOG2;
+  op->d.kind = OP_DENSE;
+  op->d.n = n;
+  op->d.dense = DenseParams{n, lda, A_dev, transpose ? 1 : 0};
+  *out = op;
+  return DSEA_OK;
+}
+
+size_t dsea_op_transfer_work_bytes(int D, int d) {
+  return D < 1 || d < 1 ? 0 : (size_t)2 * (size_t)d * (size_t)D * (size_t)D * sizeof(double);
+}
+
+int dsea_op_create_transfer(int D, int d, const double* A_dev, int transpose, double* work, void* stream,
+                            dsea_op_t* out) {
+  if (!out || D < 1 || d < 1 || !A_dev || !work || (int64_t)d * D > 2147483647ll) return DSEA_ERR_ARG;
+  if (!aligned16(A_dev) || !aligned16(work)) return DSEA_ERR_ALIGN;
+  if (!blas_available()) return DSEA_ERR_UNSUPPORTED;
+  dsea_op_s* op = new (std::nothrow) dsea_op_s;
+  if (!op) return DSEA_ERR_ARG;
+  memset(&op->d, 0, sizeof(op->d));
+  op->d.tune_tile_log2 = DSEA_TFIM_TILE_LOG2;
+  op->d.kind = OP_TRANSFER;
+  op->d.n = (int64_t)D * D;
+  const size_t half = (size_t)d * D * D;
+  op->d.transfer = TransferParams{D, d, A_dev, transpose ? nullptr : work + half, work, transpose ? 1 : 0};
+  if (!transpose) launch_permute_kmn(A_dev, work + half, d, D, static_cast<hipStream_t>(stream));
+  *out = op;
+  return check_launch();
 }
 
 int dsea_op_destroy(dsea_op_t op) {
@@ -682,6 +725,143 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
     launch_finalize_slot(P, nb, alphas + i, brk, st);
   }
   return check_launch();
+}
+
+int dsea_arnoldi_extend(dsea_op_t op, dsea_ws_t ws, const double* shift, double* V, int64_t ldv, int j0, int j1,
+                        double* H, int ldh, void* stream) {
+  REQUIRE(op && ws && V && H && j0 >= 0 && j1 > j0 && ldh >= j1 + 1, DSEA_ERR_ARG);
+  const int64_t n = op->d.n;
+  REQUIRE(ldv >= n && ws->w.n >= n, DSEA_ERR_ARG);
+  REQUIRE(j1 + 1 <= ws->w.kmax, DSEA_ERR_WORKSPACE);
+  REQUIRE(aligned16(V) && (ldv % 2 == 0), DSEA_ERR_ALIGN);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Workspace& w = ws->w;
+  double* brk = w.scal + DSEA_SCAL_BREAK;
+  if (j0 == 0) {   // a new factorisation: clear the break record (a continued one keeps it)
+    if (hipMemsetAsync(brk, 0, 2 * sizeof(double), st) != hipSuccess) {
+      g_last_hip = (int)hipGetLastError();
+      return DSEA_ERR_HIP;
+    }
+  }
+  for (int j = j0; j < j1; ++j) {
+    if (arnoldi_step(op->d, w, shift ? shift : w.zero, V, ldv, j, H + (int64_t)j * ldh, brk, w.scal + 24, w.scal + 26,
+                     w.scal + 27, st) != 0)
+      return DSEA_ERR_UNSUPPORTED;
+  }
+  return check_launch();
+}
+
+int dsea_arnoldi_orth(dsea_ws_t ws, const double* u, const double* shift, double* V, int64_t ldv, int64_t n, int j,
+                      double* H, int ldh, void* stream) {
+  REQUIRE(ws && u && V && H && j >= 0 && ldh >= j + 2 && n >= 1 && ldv >= n && ws->w.n >= n, DSEA_ERR_ARG);
+  REQUIRE(j + 2 <= ws->w.kmax, DSEA_ERR_WORKSPACE);
+  REQUIRE(aligned16(V) && aligned16(u) && (ldv % 2 == 0), DSEA_ERR_ALIGN);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Workspace& w = ws->w;
+  double* brk = w.scal + DSEA_SCAL_BREAK;
+  if (j == 0 && hipMemsetAsync(brk, 0, 2 * sizeof(double), st) != hipSuccess) {
+    g_last_hip = (int)hipGetLastError();
+    return DSEA_ERR_HIP;
+  }
+  arnoldi_orth(w, n, u, shift ? shift : w.zero, V, ldv, j, H + (int64_t)j * ldh, brk, w.scal + 24, w.scal + 26,
+               w.scal + 27, st);
+  return check_launch();
+}
+
+size_t dsea_gmres_work_doubles(int m) { return m < 1 ? 0 : (size_t)(m + 1) * m + 4 * (size_t)m + 8; }
+
+namespace {
+struct GmresWork {
+  double *H, *cs, *sn, *g, *y;
+  int ldh;
+};
+inline GmresWork gmres_carve(double* work, int m) {
+  GmresWork gw;
+  gw.ldh = m + 1;
+  gw.H = work;
+  gw.cs = gw.H + (size_t)gw.ldh * m;
+  gw.sn = gw.cs + m;
+  gw.g = gw.sn + m;
+  gw.y = gw.g + (m + 1);
+  return gw;
+}
+}  // namespace
+
+int dsea_gmres_begin(dsea_ws_t ws, const double* b, const double* Ax, double* V, int64_t ldv, int64_t n, int m,
+                     double* work, double target, double* state, void* stream) {
+  REQUIRE(ws && b && V && work && state && m >= 1 && m <= 64 && n >= 1 && ldv >= n && ws->w.n >= n, DSEA_ERR_ARG);
+  REQUIRE(m + 1 <= ws->w.kmax, DSEA_ERR_WORKSPACE);
+  REQUIRE(aligned16(V) && aligned16(b) && (!Ax || aligned16(Ax)) && (ldv % 2 == 0), DSEA_ERR_ALIGN);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Workspace& w = ws->w;
+  GmresWork gw = gmres_carve(work, m);
+  double* nrm0 = w.scal + 0;
+  double* r0 = w.vec[3];
+  launch_residual(b, Ax, r0, n, w.partials, nrm0, st);                 // r0 = b - (A - shift) x  (Ax null: x = 0)
+  launch_gmres_begin(nrm0, target, gw.g, m, state, w.scal + 28, st);
+  launch_scale_store(r0, nrm0, V, nullptr, n, st, nullptr, nullptr, 0);  // v0 = r0 / ||r0||
+  return check_launch();
+}
+
+int dsea_gmres_step(dsea_op_t op, dsea_ws_t ws, const double* shift, const double* u, double* V, int64_t ldv,
+                    int64_t n, int j, int m, double* work, double target, double* state, void* stream) {
+  REQUIRE(ws && V && work && state && m >= 1 && m <= 64 && j >= 0 && j < m && (op || u), DSEA_ERR_ARG);
+  if (op) n = op->d.n;
+  REQUIRE(n >= 1 && ldv >= n && ws->w.n >= n, DSEA_ERR_ARG);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Workspace& w = ws->w;
+  GmresWork gw = gmres_carve(work, m);
+  double* brk = w.scal + 28;          // skip / breakdown record of this cycle's Arnoldi steps
+  const double* sh = shift ? shift : w.zero;
+  if (op) {
+    if (arnoldi_step(op->d, w, sh, V, ldv, j, gw.H + (size_t)j * gw.ldh, brk, w.scal + 24, w.scal + 26, w.scal + 27,
+                     st) != 0)
+      return DSEA_ERR_UNSUPPORTED;
+  } else {
+    REQUIRE(aligned16(u), DSEA_ERR_ALIGN);
+    arnoldi_orth(w, n, u, sh, V, ldv, j, gw.H + (size_t)j * gw.ldh, brk, w.scal + 24, w.scal + 26, w.scal + 27, st);
+  }
+  launch_gmres_givens(gw.H, gw.ldh, j, gw.cs, gw.sn, gw.g, target, state, brk, st);
+  return check_launch();
+}
+
+int dsea_gmres_end(dsea_ws_t ws, const double* V, int64_t ldv, int64_t n, int m, double* work, const double* state,
+                   double* x, void* stream) {
+  REQUIRE(ws && V && work && state && x && m >= 1 && m <= 64 && n >= 1 && ldv >= n && ws->w.n >= n, DSEA_ERR_ARG);
+  REQUIRE(aligned16(V) && aligned16(x) && (ldv % 2 == 0), DSEA_ERR_ALIGN);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Workspace& w = ws->w;
+  GmresWork gw = gmres_carve(work, m);
+  launch_gmres_solve(gw.H, gw.ldh, m, gw.g, state, gw.y, st);
+  // x += V[0..m) y   (y is zero beyond the columns processed; V must hold finite values there: callers zero it once)
+  TileGeom tg = w.geom(n);
+  double* dx = w.vec[0];
+  launch_ritz(tg, V, ldv, n, m, gw.y, dx, st);
+  launch_axpy(1.0, nullptr, dx, x, n, st);
+  return check_launch();
+}
+
+int dsea_gmres_cycle(dsea_op_t op, dsea_ws_t ws, const double* shift, const double* b, double* x, double* V,
+                     int64_t ldv, int m, double* work, double target, double* state, int first, void* stream) {
+  REQUIRE(op && ws && b && x && V && work && state && m >= 1 && m <= 64, DSEA_ERR_ARG);
+  const int64_t n = op->d.n;
+  REQUIRE(aligned16(x), DSEA_ERR_ALIGN);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Workspace& w = ws->w;
+  const double* Ax = nullptr;
+  if (!first) {   // r0 = b - (A - shift) x
+    double* u = w.vec[0];
+    int nb = launch_spmv(op->d, x, u, shift, nullptr, w.partials, st);
+    if (nb < 0) return DSEA_ERR_UNSUPPORTED;
+    Ax = u;
+  }
+  int rc = dsea_gmres_begin(ws, b, Ax, V, ldv, n, m, work, target, state, stream);
+  if (rc != DSEA_OK) return rc;
+  for (int j = 0; j < m; ++j) {
+    rc = dsea_gmres_step(op, ws, shift, nullptr, V, ldv, n, j, m, work, target, state, stream);
+    if (rc != DSEA_OK) return rc;
+  }
+  return dsea_gmres_end(ws, V, ldv, n, m, work, state, x, stream);
 }
 
 int dsea_lanczos_status(dsea_ws_t ws, int* break_step, void* stream) {

@@ -1,0 +1,117 @@
+// dsea_device.h -- device-side helpers shared by the kernel translation units (dsea_kernels.hip, dsea_krylov.hip).
+#ifndef DSEA_DEVICE_H
+#define DSEA_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dsea {
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;  // butterfly: every lane holds the same, order-fixed total
+}
+
+// block of 256 threads = 4 waves; returns the total in thread 0 (fixed order w0+w1+w2+w3)
+__device__ __forceinline__ double block_sum(double v, double* sm4) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sm4[w] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0) t = ((sm4[0] + sm4[1]) + sm4[2]) + sm4[3];
+  return t;
+}
+
+template <bool GUARD>
+__device__ __forceinline__ double2 ld2(const double* __restrict__ p, int64_t row, int64_t n) {
+  if (!GUARD || row + 1 < n) return *reinterpret_cast<const double2*>(p + row);
+  double2 v = make_double2(0.0, 0.0);
+  if (row < n) v.x = p[row];
+  return v;
+}
+// streaming load of basis data that is read once per pass: non-temporal hint (does not displace r / partials
+// in L2)
+template <bool GUARD>
+__device__ __forceinline__ double2 ld2_stream(const double* __restrict__ p, int64_t row, int64_t n) {
+  // measured on MI355X (tools/kbench.py, n = 2^20, i = 199): dots pass 290 us -> 255 us with the nt hint
+  if (!GUARD || row + 1 < n) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    v2d t = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p + row));
+    return make_double2(t.x, t.y);
+  }
+  return ld2<GUARD>(p, row, n);
+}
+__device__ __forceinline__ uint4 ld_u4_stream(const uint16_t* __restrict__ p) {
+  typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+  v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(p));
+  return make_uint4(t.x, t.y, t.z, t.w);
+}
+
+template <bool GUARD>
+__device__ __forceinline__ void st2(double* __restrict__ p, int64_t row, int64_t n, double2 v) {
+  if (!GUARD || row + 1 < n) {
+    *reinterpret_cast<double2*>(p + row) = v;
+  } else if (row < n) {
+    p[row] = v.x;
+  }
+}
+
+// bf16 shadow of the basis (storage only, see k_axpy_norm_lp): fp64 -> bf16 round-to-nearest-even
+__device__ __forceinline__ uint16_t f64_to_bf16(double v) {
+  const uint32_t u = __float_as_uint((float)v);
+  return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ double bf16lo_to_f64(uint32_t packed) { return (double)__uint_as_float(packed << 16); }
+__device__ __forceinline__ double bf16hi_to_f64(uint32_t packed) {
+  return (double)__uint_as_float(packed & 0xFFFF0000u);
+}
+__device__ __forceinline__ void st_bf16x2(uint16_t* __restrict__ p, int64_t row, int64_t n, double2 v) {
+  if (row + 1 < n) {
+    *reinterpret_cast<uint32_t*>(p + row) = (uint32_t)f64_to_bf16(v.x) | ((uint32_t)f64_to_bf16(v.y) << 16);
+  } else if (row < n) {
+    p[row] = f64_to_bf16(v.x);
+  }
+}
+
+// Breakdown record of a native Lanczos run: brk[0] = step at which beta ~ 0 was found (0 = none),
+// brk[1] = running max of |alpha_j|, |beta_j| (the scale beta is compared with).  Every kernel of the loop
+// starts with broken(brk): once the record is set the remaining launches of the run are no-ops.
+#define DSEA_BREAK_TOL 1e-13
+__device__ __forceinline__ bool broken(const double* __restrict__ brk) { return brk && brk[0] != 0.0; }
+
+// Consumers that fold the second reduction stage into their prologue: every wave / block sums the same
+// partials in the same order, so all of them obtain the bit-identical scalar without a separate launch.
+__device__ __forceinline__ double sum_partials_wave(const double* __restrict__ P, int count, int lane) {
+  double a0 = 0.0, a1 = 0.0;
+  int b = lane;
+  for (; b + 64 < count; b += 128) {
+    a0 += P[b];
+    a1 += P[b + 64];
+  }
+  if (b < count) a0 += P[b];
+  return wave_sum(a0 + a1);
+}
+__device__ __forceinline__ double sum_partials_block(const double* __restrict__ P, int count, double* sm5) {
+  double a0 = 0.0, a1 = 0.0;
+  int b = threadIdx.x;
+  for (; b + 256 < count; b += 512) {
+    a0 += P[b];
+    a1 += P[b + 256];
+  }
+  if (b < count) a0 += P[b];
+  double v = wave_sum(a0 + a1);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sm5[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) sm5[4] = ((sm5[0] + sm5[1]) + sm5[2]) + sm5[3];
+  __syncthreads();
+  return sm5[4];
+}
+
+}  // namespace dsea
+#endif

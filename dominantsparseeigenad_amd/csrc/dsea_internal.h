@@ -44,7 +44,19 @@ struct Stencil3Params {
   const double* halo_lo;
   const double* halo_hi;
 };
-enum OpKind { OP_TFIM = 1, OP_CSR = 2, OP_STENCIL3 = 3, OP_SELL = 4 };
+struct DenseParams {
+  int64_t n, lda;
+  const double* A;  // row-major n x n
+  int transpose;
+};
+struct TransferParams {
+  int D, d;
+  const double* A;  // d x D x D row-major
+  double* A2;       // A permuted to (m, k, n) (non-transposed form only), inside the caller's work buffer
+  double* T;        // d * D * D doubles of scratch, inside the caller's work buffer
+  int transpose;
+};
+enum OpKind { OP_TFIM = 1, OP_CSR = 2, OP_STENCIL3 = 3, OP_SELL = 4, OP_DENSE = 5, OP_TRANSFER = 6 };
 struct OpDesc {
   OpKind kind;
   int64_t n;
@@ -54,6 +66,8 @@ struct OpDesc {
   CsrParams csr;
   Stencil3Params st3;
   SellParams sell;
+  DenseParams dense;
+  TransferParams transfer;
 };
 
 // how the rows of one vector are cut into wave tiles for the basis-streaming kernels
@@ -90,6 +104,8 @@ struct Workspace {
   double* partials;  // DSEA_MAX_WAVE_TILES * max(kmax,1) doubles (also >= DSEA_MAX_EW_BLOCKS)
   double* aux;       // 4 * DSEA_MAX_WAVE_TILES doubles: small partial buffers that must not alias `partials`
   double* coef;      // kmax doubles
+  double* coef2;     // second coefficient vector (Arnoldi: DGKS second pass)
+  double* zero;      // one device double that is always 0
   double* scal;      // DSEA_SCALARS doubles
   double* vec[4];    // four work vectors of npad doubles
   Profiler* prof;    // null unless dsea_profile_begin was called
@@ -144,6 +160,22 @@ void launch_form_r(const double* u, const double* q1, const double* q2, const do
 void launch_hypercube_flipsum(const double* xT, double* zT, int P, int p, int64_t chunk, hipStream_t st);
 void launch_plz_finish(const double* r, const double* y, const double* pair, double* q, uint16_t* qs, double* u,
                        double* alpha_out, double* beta_out, int64_t n, hipStream_t st);
+// dsea_krylov.hip
+bool blas_available();
+int blas_apply(const OpDesc& op, const double* x, double* y, hipStream_t st);
+void launch_permute_kmn(const double* A, double* A2, int d, int D, hipStream_t st);
+void arnoldi_orth(Workspace& w, int64_t n, const double* u, const double* shift_or_zero, double* V, int64_t ldv, int j,
+                  double* hcol, double* brk, double* skip, double* nrm1, double* nrm2, hipStream_t st);
+int arnoldi_step(const OpDesc& op, Workspace& w, const double* shift_or_zero, double* V, int64_t ldv, int j,
+                 double* hcol, double* brk, double* skip, double* nrm1, double* nrm2, hipStream_t st);
+void launch_residual(const double* b, const double* u, double* r, int64_t n, double* P, double* nrm2_out,
+                     hipStream_t st);
+void launch_gmres_begin(const double* nrm2, double target, double* g, int m, double* state, double* brk,
+                        hipStream_t st);
+void launch_gmres_givens(double* H, int ldh, int j, double* cs, double* sn, double* g, double target, double* state,
+                         double* brk, hipStream_t st);
+void launch_gmres_solve(const double* H, int ldh, int m, const double* g, const double* state, double* y,
+                        hipStream_t st);
 size_t persist_comm_bytes(int64_t n);
 int launch_cg_persist(const OpDesc& op, const double* shift, const double* b, double* x, double* state, double eps,
                       int64_t maxiter, void* comm, int ppt_override, hipStream_t st);

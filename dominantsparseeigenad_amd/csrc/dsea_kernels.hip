@@ -15,85 +15,9 @@
 #include <stdint.h>
 
 #include "dsea_internal.h"
+#include "dsea_device.h"
 
 namespace dsea {
-
-// ------------------------------------------------------------------------------------------
-// small device helpers
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;  // butterfly: every lane holds the same, order-fixed total
-}
-
-// block of 256 threads = 4 waves; returns the total in thread 0 (fixed order w0+w1+w2+w3)
-__device__ __forceinline__ double block_sum(double v, double* sm4) {
-  v = wave_sum(v);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (lane == 0) sm4[w] = v;
-  __syncthreads();
-  double t = 0.0;
-  if (threadIdx.x == 0) t = ((sm4[0] + sm4[1]) + sm4[2]) + sm4[3];
-  return t;
-}
-
-template <bool GUARD>
-__device__ __forceinline__ double2 ld2(const double* __restrict__ p, int64_t row, int64_t n) {
-  if (!GUARD || row + 1 < n) return *reinterpret_cast<const double2*>(p + row);
-  double2 v = make_double2(0.0, 0.0);
-  if (row < n) v.x = p[row];
-  return v;
-}
-// streaming load of basis data that is read once per pass: non-temporal hint (does not displace r / partials
-// in L2)
-template <bool GUARD>
-__device__ __forceinline__ double2 ld2_stream(const double* __restrict__ p, int64_t row, int64_t n) {
-  // measured on MI355X (tools/kbench.py, n = 2^20, i = 199): dots pass 290 us -> 255 us with the nt hint
-  if (!GUARD || row + 1 < n) {
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    v2d t = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p + row));
-    return make_double2(t.x, t.y);
-  }
-  return ld2<GUARD>(p, row, n);
-}
-__device__ __forceinline__ uint4 ld_u4_stream(const uint16_t* __restrict__ p) {
-  typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-  v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(p));
-  return make_uint4(t.x, t.y, t.z, t.w);
-}
-
-template <bool GUARD>
-__device__ __forceinline__ void st2(double* __restrict__ p, int64_t row, int64_t n, double2 v) {
-  if (!GUARD || row + 1 < n) {
-    *reinterpret_cast<double2*>(p + row) = v;
-  } else if (row < n) {
-    p[row] = v.x;
-  }
-}
-
-// bf16 shadow of the basis (storage only, see k_axpy_norm_lp): fp64 -> bf16 round-to-nearest-even
-__device__ __forceinline__ uint16_t f64_to_bf16(double v) {
-  const uint32_t u = __float_as_uint((float)v);
-  return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
-}
-__device__ __forceinline__ double bf16lo_to_f64(uint32_t packed) { return (double)__uint_as_float(packed << 16); }
-__device__ __forceinline__ double bf16hi_to_f64(uint32_t packed) {
-  return (double)__uint_as_float(packed & 0xFFFF0000u);
-}
-__device__ __forceinline__ void st_bf16x2(uint16_t* __restrict__ p, int64_t row, int64_t n, double2 v) {
-  if (row + 1 < n) {
-    *reinterpret_cast<uint32_t*>(p + row) = (uint32_t)f64_to_bf16(v.x) | ((uint32_t)f64_to_bf16(v.y) << 16);
-  } else if (row < n) {
-    p[row] = f64_to_bf16(v.x);
-  }
-}
-
-// Breakdown record of a native Lanczos run: brk[0] = step at which beta ~ 0 was found (0 = none),
-// brk[1] = running max of |alpha_j|, |beta_j| (the scale beta is compared with).  Every kernel of the loop
-// starts with broken(brk): once the record is set the remaining launches of the run are no-ops.
-#define DSEA_BREAK_TOL 1e-13
-__device__ __forceinline__ bool broken(const double* __restrict__ brk) { return brk && brk[0] != 0.0; }
 
 // ------------------------------------------------------------------------------------------
 // stage-2 reductions (deterministic)
@@ -127,35 +51,6 @@ __global__ __launch_bounds__(256) void k_finalize_multi(const double* __restrict
   for (; w < nw; w += 256) a0 += row[w];
   double t = block_sum((a0 + a1) + (a2 + a3), sm4);
   if (threadIdx.x == 0) c[j] = t;
-}
-
-// Consumers that fold the second reduction stage into their prologue: every wave / block sums the same
-// partials in the same order, so all of them obtain the bit-identical scalar without a separate launch.
-__device__ __forceinline__ double sum_partials_wave(const double* __restrict__ P, int count, int lane) {
-  double a0 = 0.0, a1 = 0.0;
-  int b = lane;
-  for (; b + 64 < count; b += 128) {
-    a0 += P[b];
-    a1 += P[b + 64];
-  }
-  if (b < count) a0 += P[b];
-  return wave_sum(a0 + a1);
-}
-__device__ __forceinline__ double sum_partials_block(const double* __restrict__ P, int count, double* sm5) {
-  double a0 = 0.0, a1 = 0.0;
-  int b = threadIdx.x;
-  for (; b + 256 < count; b += 512) {
-    a0 += P[b];
-    a1 += P[b + 256];
-  }
-  if (b < count) a0 += P[b];
-  double v = wave_sum(a0 + a1);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (lane == 0) sm5[w] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) sm5[4] = ((sm5[0] + sm5[1]) + sm5[2]) + sm5[3];
-  __syncthreads();
-  return sm5[4];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1872,6 +1767,17 @@ int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shif
       KLAUNCH(ev, (k_spmv_sell<false>), (unsigned)nb, 256, st, p, x, y, shift, skip, P, fa0);
       return (int)nb;
     }
+    case OP_DENSE:
+    case OP_TRANSFER: {
+      // GEMM-shaped operands: rocBLAS (dsea_krylov.hip); the shift / x.y tail is one streaming kernel
+      if (blas_apply(op, x, y, st) != 0) return -1;
+      if (!shift && !P) return 0;
+      const int nbk = ew_blocks(op.n);
+      double* Pk = P ? P : nullptr;
+      if (!Pk) return -1;   // a shift without a partial buffer: callers always provide ws
+      hipLaunchKernelGGL(k_shift_dot, dim3(nbk), dim3(256), 0, st, x, y, shift, skip, op.n, Pk);
+      return nbk;
+    }
     case OP_STENCIL3: {
       const Stencil3Params& p = op.st3;
       const int64_t nb = tile_blocks(p.n);
@@ -1979,11 +1885,16 @@ int launch_cg_persist(const OpDesc& op, const double* shift, const double* b, do
   const int64_t n = op.st3.n;
   const int64_t nt = (n + 511) / 512;
   if (nt > DSEA_PERSIST_CG_MAX_TILES) return -1;
+  // one row pair per thread wherever the workgroup count allows it (measured on MI355X, 1000 fixed iterations:
+  // N = 1e5: 6.3 us / iteration with 1 pair (49 workgroups), 7.6 with 2; N = 2e4: 5.3 vs 6.8; streaming form 11.3 / 9.8)
   int ppt = ppt_override;
-  if (ppt != 1 && ppt != 2 && ppt != 4) ppt = nt <= 64 ? 1 : (nt <= 512 ? 2 : 4);
+  if (ppt != 1 && ppt != 2) ppt = nt <= 512 ? 1 : 2;
   const int tpw = 4 * ppt;
   const int G = (int)((nt + tpw - 1) / tpw);
-  if (G > 256) return -1;
+  if (G > 256) {
+    if (ppt == 1 && (nt + 7) / 8 <= 256) return launch_cg_persist(op, shift, b, x, state, eps, maxiter, comm, 2, st);
+    return -1;
+  }
   const size_t cbytes = (size_t)(4 * nt + 4 * G) * sizeof(unsigned long long);
   if (hipMemsetAsync(comm, 0, cbytes, st) != hipSuccess) return -2;
   PersistArgs a;
@@ -1997,21 +1908,10 @@ int launch_cg_persist(const OpDesc& op, const double* shift, const double* b, do
   a.comm = static_cast<unsigned long long*>(comm);
   a.ntiles = (int)nt;
   const size_t lds = (size_t)(tpw * 512 + 4) * sizeof(double) + sizeof(PersistSm);
-  hipError_t e = hipSuccess;
-  switch (ppt) {
-    case 1:
-      hipLaunchKernelGGL((k_cg_persist_stencil<1>), dim3(G), dim3(1024), lds, st, a);
-      break;
-    case 2:
-      hipLaunchKernelGGL((k_cg_persist_stencil<2>), dim3(G), dim3(1024), lds, st, a);
-      break;
-    default:
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cg_persist_stencil<4>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return -2;
-      hipLaunchKernelGGL((k_cg_persist_stencil<4>), dim3(G), dim3(1024), lds, st, a);
-      break;
-  }
+  if (ppt == 1)
+    hipLaunchKernelGGL((k_cg_persist_stencil<1>), dim3(G), dim3(1024), lds, st, a);
+  else
+    hipLaunchKernelGGL((k_cg_persist_stencil<2>), dim3(G), dim3(1024), lds, st, a);
   return 0;
 }
 

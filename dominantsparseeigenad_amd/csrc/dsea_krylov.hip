@@ -1,0 +1,324 @@
+// dsea_krylov.hip -- the NON-symmetric side of the hot path (BASELINE config 4):
+//   * dense and MPS-transfer-matrix operands whose mat-vec is GEMM-shaped and goes to rocBLAS (the one place of
+//     this library where a matrix core is the right unit: reference examples/TFIM_vumps/general.py:59-66 applies
+//     sum_s A_s r A_s^T as einsums on the host);
+//   * the Arnoldi factorisation loop and the restarted-GMRES cycle ON THE DEVICE, without a host round trip per
+//     step: what reference eig.py:29-30,54-57,116-117,137-144 delegates to SciPy's ARPACK `eigs` / `gmres`.
+// The orthogonalisation reuses the basis-streaming kernels of the Lanczos path (dots pass + correction pass,
+// classical Gram-Schmidt); the second pass runs only when the DGKS test asks for it (ARPACK's rule), decided on
+// the device through the same "skip record" the Lanczos breakdown logic uses.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+#include <stdint.h>
+
+#include <mutex>
+
+#include "dsea_internal.h"
+#include "dsea_device.h"
+
+namespace dsea {
+
+// ------------------------------------------------------------------------------------------
+// rocBLAS, bound at run time: the process already holds the copy PyTorch-ROCm loaded; binding by dlopen keeps
+// libdsea.so free of a link-time dependency on one particular rocBLAS build.
+// ------------------------------------------------------------------------------------------
+namespace {
+struct Blas {
+  bool ok = false;
+  rocblas_handle h = nullptr;
+  decltype(&rocblas_create_handle) create = nullptr;
+  decltype(&rocblas_set_stream) set_stream = nullptr;
+  decltype(&rocblas_set_pointer_mode) set_pointer_mode = nullptr;
+  decltype(&rocblas_set_atomics_mode) set_atomics_mode = nullptr;
+  decltype(&rocblas_dgemv) dgemv = nullptr;
+  decltype(&rocblas_dgemm) dgemm = nullptr;
+  decltype(&rocblas_dgemm_strided_batched) dgemm_sb = nullptr;
+};
+Blas g_blas;
+std::once_flag g_blas_once;
+
+void blas_init() {
+  void* lib = dlopen("librocblas.so.5", RTLD_NOW | RTLD_NOLOAD);
+  if (!lib) lib = dlopen("librocblas.so", RTLD_NOW | RTLD_NOLOAD);
+  if (!lib) lib = dlopen("librocblas.so.5", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) lib = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) return;
+#define BIND(field, name)                                                   \
+  g_blas.field = reinterpret_cast<decltype(g_blas.field)>(dlsym(lib, name)); \
+  if (!g_blas.field) return;
+  BIND(create, "rocblas_create_handle")
+  BIND(set_stream, "rocblas_set_stream")
+  BIND(set_pointer_mode, "rocblas_set_pointer_mode")
+  BIND(set_atomics_mode, "rocblas_set_atomics_mode")
+  BIND(dgemv, "rocblas_dgemv")
+  BIND(dgemm, "rocblas_dgemm")
+  BIND(dgemm_sb, "rocblas_dgemm_strided_batched")
+#undef BIND
+  if (g_blas.create(&g_blas.h) != rocblas_status_success) return;
+  g_blas.set_pointer_mode(g_blas.h, rocblas_pointer_mode_host);
+  g_blas.set_atomics_mode(g_blas.h, rocblas_atomics_not_allowed);  // bit-repeatable runs, like the rest of the path
+  g_blas.ok = true;
+}
+std::mutex g_blas_mutex;  // one handle: set_stream + call must not interleave between threads
+}  // namespace
+
+bool blas_available() {
+  std::call_once(g_blas_once, blas_init);
+  return g_blas.ok;
+}
+
+// A2[m][k][n] = A[k][m][n]   (the (m,(k,n)) layout the second contraction of the transfer mat-vec needs)
+__global__ __launch_bounds__(256) void k_permute_kmn(const double* __restrict__ A, double* __restrict__ A2, int d,
+                                                     int D) {
+  const int64_t total = (int64_t)d * D * D;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int n = (int)(e % D);
+    const int m = (int)((e / D) % D);
+    const int k = (int)(e / ((int64_t)D * D));
+    A2[((int64_t)m * d + k) * D + n] = A[e];
+  }
+}
+
+void launch_permute_kmn(const double* A, double* A2, int d, int D, hipStream_t st) {
+  int64_t nb = ((int64_t)d * D * D + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(k_permute_kmn, dim3((unsigned)nb), dim3(256), 0, st, A, A2, d, D);
+}
+
+// y = op x for the GEMM-shaped operands (row-major data, rocBLAS is column-major: a row-major product C = A B
+// is the column-major product C^T = B^T A^T on the same memory).  Returns 0 or -1.
+int blas_apply(const OpDesc& op, const double* x, double* y, hipStream_t st) {
+  if (!blas_available()) return -1;
+  const double one = 1.0, zero = 0.0;
+  std::lock_guard<std::mutex> lock(g_blas_mutex);
+  if (g_blas.set_stream(g_blas.h, st) != rocblas_status_success) return -1;
+  rocblas_status rs = rocblas_status_success;
+  if (op.kind == OP_DENSE) {
+    const DenseParams& p = op.dense;
+    // row-major A (n x n, lda) is the column-major A^T: y = A x = op_T(mem) x ; y = A^T x = op_N(mem) x
+    rs = g_blas.dgemv(g_blas.h, p.transpose ? rocblas_operation_none : rocblas_operation_transpose, (rocblas_int)p.n,
+                      (rocblas_int)p.n, &one, p.A, (rocblas_int)p.lda, x, 1, &zero, y, 1);
+  } else if (op.kind == OP_TRANSFER) {
+    const TransferParams& p = op.transfer;
+    const rocblas_int D = p.D, dD = p.d * p.D;
+    const rocblas_stride DD = (rocblas_stride)p.D * p.D;
+    if (!p.transpose) {
+      // y = sum_k A_k x A_k^T (general.py:59-61 "fr").  T[i][k][n] = (A_k x)[i][n]: one strided-batched GEMM writing
+      // the (i,(k,n)) layout directly (ldc = dD, batch stride D); then y = T (D x dD) * A2^T in ONE GEMM of depth dD.
+      rs = g_blas.dgemm_sb(g_blas.h, rocblas_operation_none, rocblas_operation_none, D, D, D, &one, x, D, 0, p.A, D, DD,
+                           &zero, p.T, dD, (rocblas_stride)p.D, p.d);
+      if (rs == rocblas_status_success)
+        rs = g_blas.dgemm(g_blas.h, rocblas_operation_transpose, rocblas_operation_none, D, D, dD, &one, p.A2, dD, p.T,
+                          dD, &zero, y, D);
+    } else {
+      // y = sum_k A_k^T x A_k (general.py:62-64 "fl").  U[k] = x A_k (batched), then y = Aflat^T (D x dD) * Ustack.
+      rs = g_blas.dgemm_sb(g_blas.h, rocblas_operation_none, rocblas_operation_none, D, D, D, &one, p.A, D, DD, x, D, 0,
+                           &zero, p.T, D, DD, p.d);
+      if (rs == rocblas_status_success)
+        rs = g_blas.dgemm(g_blas.h, rocblas_operation_none, rocblas_operation_transpose, D, D, dD, &one, p.T, D, p.A, D,
+                          &zero, y, D);
+    }
+  } else {
+    return -1;
+  }
+  return rs == rocblas_status_success ? 0 : -1;
+}
+
+// ------------------------------------------------------------------------------------------
+// Arnoldi step scalars
+// ------------------------------------------------------------------------------------------
+// DGKS test after the first Gram-Schmidt pass: a second pass is needed iff ||w - V V^T w||^2 < 1/2 ||w||^2.
+// skip[0] = 1 -> the second pass kernels return at once.  (c1[i] = ||w||^2 from the dots pass.)
+__global__ void k_dgks_decide(const double* __restrict__ c1, int i, const double* __restrict__ nrm1,
+                              double* __restrict__ skip, const double* __restrict__ brk) {
+  if (broken(brk)) {
+    skip[0] = 1.0;
+    return;
+  }
+  skip[0] = (nrm1[0] >= 0.5 * c1[i]) ? 1.0 : 0.0;
+}
+
+// Column j of H and the next basis vector:  h = c1 (+ c2 if the second pass ran),  beta = ||w||,  v_{j+1} = w / beta.
+// An (exactly or numerically) invariant subspace -- beta <= 1e-13 ||A v_j|| -- is recorded in brk like a Lanczos
+// breakdown; the remaining launches of the run are no-ops and the host uses the leading block.
+__global__ __launch_bounds__(256) void k_arnoldi_finish(const double* __restrict__ c1, const double* __restrict__ c2,
+                                                        const double* __restrict__ skip,
+                                                        const double* __restrict__ nrm1,
+                                                        const double* __restrict__ nrm2, int j,
+                                                        double* __restrict__ hcol, const double* __restrict__ w1,
+                                                        const double* __restrict__ w2, double* __restrict__ v_out,
+                                                        int64_t n, double* __restrict__ brk) {
+  if (broken(brk)) return;
+  const bool second = skip[0] == 0.0;
+  const double beta = sqrt(second ? nrm2[0] : nrm1[0]);
+  const double scale = sqrt(c1[j + 1]);   // ||A v_j - shift v_j||
+  const bool dead = !(beta > DSEA_BREAK_TOL * scale);
+  if (blockIdx.x == 0) {
+    for (int t = threadIdx.x; t <= j; t += 256) hcol[t] = second ? c1[t] + c2[t] : c1[t];
+    if (threadIdx.x == 0) {
+      hcol[j + 1] = beta;
+      if (dead && brk) brk[0] = (double)(j + 1);
+    }
+  }
+  if (dead) return;
+  const double* __restrict__ w = second ? w2 : w1;
+  const int64_t stride = (int64_t)gridDim.x * 512;
+  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; row < n; row += stride) {
+    double2 v = ld2<true>(w, row, n);
+    v.x = v.x / beta;
+    v.y = v.y / beta;
+    st2<true>(v_out, row, n, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// GMRES cycle scalars (restart length m <= 64): one thread each, all on the stream
+// gw = device work: H (m+1) x m column-major | cs[m] | sn[m] | g[m+1] | y[m]
+// state: [0] residual estimate  [1] converged (0/1)  [2] columns processed in this cycle  [3] ||r0||
+//        [4] cycle finished early (converged, or the Krylov space is exhausted)
+// brk  : the skip / breakdown record handed to the Arnoldi step kernels of the cycle (non-zero = steps are no-ops)
+// ------------------------------------------------------------------------------------------
+__global__ void k_gmres_begin(const double* __restrict__ nrm2, double target, double* __restrict__ g, int m,
+                              double* __restrict__ state, double* __restrict__ brk) {
+  const double beta0 = sqrt(nrm2[0]);
+  for (int t = 0; t <= m; ++t) g[t] = 0.0;
+  g[0] = beta0;
+  state[0] = beta0;
+  state[3] = beta0;
+  state[2] = 0.0;
+  const bool conv = beta0 <= target;
+  state[1] = conv ? 1.0 : 0.0;
+  state[4] = conv ? 1.0 : 0.0;
+  brk[0] = conv ? 1.0 : 0.0;   // converged already: every step kernel of the cycle returns at once
+  brk[1] = 0.0;
+}
+
+// Givens update for column j (already written by the Arnoldi step unless the cycle had finished)
+__global__ void k_gmres_givens(double* __restrict__ H, int ldh, int j, double* __restrict__ cs,
+                               double* __restrict__ sn, double* __restrict__ g, double target,
+                               double* __restrict__ state, double* __restrict__ brk) {
+  if (state[4] != 0.0) return;
+  double* h = H + (int64_t)j * ldh;
+  for (int t = 0; t < j; ++t) {
+    const double a = h[t], b = h[t + 1];
+    h[t] = cs[t] * a + sn[t] * b;
+    h[t + 1] = -sn[t] * a + cs[t] * b;
+  }
+  const double rho = hypot(h[j], h[j + 1]);
+  const double c = rho == 0.0 ? 1.0 : h[j] / rho, s = rho == 0.0 ? 0.0 : h[j + 1] / rho;
+  cs[j] = c;
+  sn[j] = s;
+  h[j] = rho;
+  h[j + 1] = 0.0;
+  g[j + 1] = -s * g[j];
+  g[j] = c * g[j];
+  const double res = fabs(g[j + 1]);
+  state[0] = res;
+  state[2] = (double)(j + 1);
+  if (res <= target) {
+    state[1] = 1.0;
+    state[4] = 1.0;
+    brk[0] = 1.0;
+  } else if (brk[0] != 0.0) {
+    state[4] = 1.0;   // this step's finish kernel found the Krylov space exhausted: column j was the last one
+  }
+}
+
+// back-substitution R y = g over the `steps` columns done; y[t >= steps] = 0
+__global__ void k_gmres_solve(const double* __restrict__ H, int ldh, int m, const double* __restrict__ g,
+                              const double* __restrict__ state, double* __restrict__ y) {
+  const int steps = (int)state[2];
+  for (int t = 0; t < m; ++t) y[t] = 0.0;
+  for (int i = steps - 1; i >= 0; --i) {
+    double acc = g[i];
+    for (int t = i + 1; t < steps; ++t) acc -= H[(int64_t)t * ldh + i] * y[t];
+    y[i] = acc / H[(int64_t)i * ldh + i];
+  }
+}
+
+// r = b - u ; partial r.r
+__global__ __launch_bounds__(256) void k_residual(const double* __restrict__ b, const double* __restrict__ u,
+                                                  double* __restrict__ r, int64_t n, double* __restrict__ P) {
+  __shared__ double sm4[4];
+  double acc = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * 512;
+  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; row < n; row += stride) {
+    double2 bv = ld2<true>(b, row, n);
+    if (u) {
+      const double2 uv = ld2<true>(u, row, n);
+      bv.x -= uv.x;
+      bv.y -= uv.y;
+    }
+    st2<true>(r, row, n, bv);
+    acc = fma(bv.x, bv.x, acc);
+    acc = fma(bv.y, bv.y, acc);
+  }
+  double t = block_sum(acc, sm4);
+  if (threadIdx.x == 0) P[blockIdx.x] = t;
+}
+
+static inline int kr_blocks(int64_t n) {
+  int64_t nb = (n + 2047) / 2048;
+  if (nb < 1) nb = 1;
+  if (nb > DSEA_MAX_EW_BLOCKS) nb = DSEA_MAX_EW_BLOCKS;
+  return (int)nb;
+}
+
+// One Arnoldi step j -> j+1 on (A - shift I):  w = A v_j - shift v_j, orthogonalised against V[0..j] (CGS + DGKS
+// second pass), column j of H, v_{j+1}.  brk: break / skip record of the run (2 doubles), skip: DGKS flag (1 double).
+int arnoldi_step(const OpDesc& op, Workspace& w, const double* shift_or_zero, double* V, int64_t ldv, int j,
+                 double* hcol, double* brk, double* skip, double* nrm1, double* nrm2, hipStream_t st) {
+  double* u = w.vec[0];
+  const double* vj = V + (int64_t)j * ldv;
+  int nb = launch_spmv(op, vj, u, nullptr, brk, nullptr, st);
+  if (nb < 0) return -1;
+  arnoldi_orth(w, op.n, u, shift_or_zero, V, ldv, j, hcol, brk, skip, nrm1, nrm2, st);
+  return 0;
+}
+
+// the step without its mat-vec: u = A v_j is given (generic-callable mode: the mat-vec is the caller's code)
+void arnoldi_orth(Workspace& w, int64_t n, const double* u, const double* shift_or_zero, double* V, int64_t ldv, int j,
+                  double* hcol, double* brk, double* skip, double* nrm1, double* nrm2, hipStream_t st) {
+  double* w1 = w.vec[1];
+  double* w2 = w.vec[2];
+  double* c1 = w.coef;
+  double* c2 = w.coef2;
+  const TileGeom g = w.geom(n);
+  const int i = j + 1;
+  // pass 1: w1 = u - shift v_j ; c1 = V^T w1 ; c1[i] = ||w1||^2 ; w1 -= V c1 ; nrm1 = ||w1||^2
+  launch_rdots(g, V, ldv, n, i, u, shift_or_zero, nullptr, w1, w.partials, c1, st, nullptr, nullptr, 0, nullptr, true, brk);
+  launch_axpy_norm(g, V, ldv, n, i, c1, w1, w.partials, nullptr, st, nullptr, brk);
+  launch_finalize_slot(w.partials, g.nw, nrm1, brk, st);
+  hipLaunchKernelGGL(k_dgks_decide, dim3(1), dim3(1), 0, st, (const double*)c1, i, (const double*)nrm1, skip,
+                     (const double*)brk);
+  // pass 2 (skipped on the device unless the DGKS test failed): w2 = w1 - V (V^T w1)
+  launch_rdots(g, V, ldv, n, i, w1, w.zero, nullptr, w2, w.partials, c2, st, nullptr, nullptr, 0, nullptr, false, skip);
+  launch_axpy_norm(g, V, ldv, n, i, c2, w2, w.partials, nullptr, st, nullptr, skip);
+  launch_finalize_slot(w.partials, g.nw, nrm2, skip, st);
+  hipLaunchKernelGGL(k_arnoldi_finish, dim3(kr_blocks(n)), dim3(256), 0, st, (const double*)c1, (const double*)c2,
+                     (const double*)skip, (const double*)nrm1, (const double*)nrm2, j, hcol, (const double*)w1,
+                     (const double*)w2, V + (int64_t)(j + 1) * ldv, n, brk);
+}
+
+void launch_residual(const double* b, const double* u, double* r, int64_t n, double* P, double* nrm2_out,
+                     hipStream_t st) {
+  const int nb = kr_blocks(n);
+  hipLaunchKernelGGL(k_residual, dim3(nb), dim3(256), 0, st, b, u, r, n, P);
+  launch_finalize1(P, nb, nrm2_out, st);
+}
+
+void launch_gmres_begin(const double* nrm2, double target, double* g, int m, double* state, double* brk,
+                        hipStream_t st) {
+  hipLaunchKernelGGL(k_gmres_begin, dim3(1), dim3(1), 0, st, nrm2, target, g, m, state, brk);
+}
+void launch_gmres_givens(double* H, int ldh, int j, double* cs, double* sn, double* g, double target, double* state,
+                         double* brk, hipStream_t st) {
+  hipLaunchKernelGGL(k_gmres_givens, dim3(1), dim3(1), 0, st, H, ldh, j, cs, sn, g, target, state, brk);
+}
+void launch_gmres_solve(const double* H, int ldh, int m, const double* g, const double* state, double* y,
+                        hipStream_t st) {
+  hipLaunchKernelGGL(k_gmres_solve, dim3(1), dim3(1), 0, st, H, ldh, m, g, state, y);
+}
+
+}  // namespace dsea

@@ -42,23 +42,23 @@ def _dominant_pair(A, AT, k, which):
     return lam, l, r
 
 
-def _dominant_pair_device(mv, mvT, n, k, which, device):
+def _dominant_pair_device(opA, opAT, n, k, which, device):
+    """opA / opAT: native operators (``.handle``) or mat-vec callables on device vectors"""
     from . import krylov
-    lam, r = krylov.arnoldi_dominant(mv, n, k, device, which)
-    lam_l, l = krylov.arnoldi_dominant(mvT, n, k, device, which)
+    lam, r = krylov.arnoldi_dominant(opA, n, k, device, which)
+    lam_l, l = krylov.arnoldi_dominant(opAT, n, k, device, which)
     if abs(lam - lam_l) > 1e-8 * max(abs(lam), 1e-300):
         raise RuntimeError("left / right eigenvalues disagree: %.15e vs %.15e" % (lam, lam_l))
     l = l / torch.dot(l, r)
     return torch.tensor([lam], dtype=torch.float64, device=device), l, r
 
 
-def _adjoint_solves_device(mv, mvT, lam, l, r, g_l, g_r):
+def _adjoint_solves_device(opA, opAT, lam, l, r, g_l, g_r):
     from . import krylov
-    lam_s = lam.reshape(())
     rhs = g_l - r * torch.dot(l, g_l)                                            # eig.py:53
-    lam_l = krylov.gmres(lambda v: mv(v) - lam_s * v, rhs, rtol=_GMRES_TOL, atol=_GMRES_TOL)
+    lam_l = krylov.gmres(opA, rhs, shift=lam, rtol=_GMRES_TOL, atol=_GMRES_TOL)  # (A - lam I) x = rhs, eig.py:54
     rhs = g_r - l * torch.dot(r, g_r)                                            # eig.py:56
-    lam_r = krylov.gmres(lambda v: mvT(v) - lam_s * v, rhs, rtol=_GMRES_TOL, atol=_GMRES_TOL)
+    lam_r = krylov.gmres(opAT, rhs, shift=lam, rtol=_GMRES_TOL, atol=_GMRES_TOL)
     return lam_l, lam_r
 
 
@@ -68,9 +68,11 @@ class DominantEig(torch.autograd.Function):
     @staticmethod
     def forward(ctx, A, k, which="LM"):
         if A.is_cuda:
-            Ad = A.detach().to(torch.float64)
-            lam, l, r = _dominant_pair_device(lambda v: Ad @ v, lambda v: Ad.T @ v, Ad.shape[0], k, which, A.device)
-            ctx.device_path, ctx.Ad, ctx.trip = True, Ad, (lam, l, r)
+            from .operators import DenseOperator
+            Ad = A.detach().to(torch.float64).contiguous()
+            ops = (DenseOperator(Ad), DenseOperator(Ad, transpose=True))     # rocBLAS GEMV inside the library loops
+            lam, l, r = _dominant_pair_device(ops[0], ops[1], Ad.shape[0], k, which, A.device)
+            ctx.device_path, ctx.ops, ctx.trip = True, ops, (lam, l, r)
             return lam, l, r
         ctx.device_path = False
         M = A.detach().cpu().numpy()
@@ -81,8 +83,8 @@ class DominantEig(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_lam, g_l, g_r):
         if ctx.device_path:
-            Ad, (lam, l, r) = ctx.Ad, ctx.trip
-            lam_l, lam_r = _adjoint_solves_device(lambda v: Ad @ v, lambda v: Ad.T @ v, lam, l, r, g_l, g_r)
+            ops, (lam, l, r) = ctx.ops, ctx.trip
+            lam_l, lam_r = _adjoint_solves_device(ops[0], ops[1], lam, l, r, g_l, g_r)
             gA = g_lam * l[:, None] * r - l[:, None] * lam_l - lam_r[:, None] * r        # eig.py:58-60
             return gA, None, None
         M, lam, l, r = ctx.M, ctx.lam, ctx.l, ctx.r
@@ -97,8 +99,10 @@ class DominantEig(torch.autograd.Function):
 
 
 def _on_device(op):
+    """device operand: a ``krylov.TorchLinearOperator`` or a native operator (``operators.TransferOperator`` ...)"""
     from .krylov import TorchLinearOperator
-    return isinstance(op, TorchLinearOperator) and op.device.type == "cuda"
+    dev = getattr(op, "device", None)
+    return (isinstance(op, TorchLinearOperator) or hasattr(op, "handle")) and dev is not None and dev.type == "cuda"
 
 
 def _make_sparse_eig(A, AT, Aadjoint_to_gadjoint):
@@ -109,7 +113,7 @@ def _make_sparse_eig(A, AT, Aadjoint_to_gadjoint):
         def forward(ctx, g, k):
             ctx.device_path = _on_device(A)
             if ctx.device_path:
-                lam, l, r = _dominant_pair_device(A.matvec, AT.matvec, A.shape[0], k, "LM", A.device)
+                lam, l, r = _dominant_pair_device(A, AT, A.shape[0], k, "LM", A.device)
                 ctx.trip = (lam, l, r)
                 return lam, l, r
             lam, l, r = _dominant_pair(A, AT, k, "LM")
@@ -120,7 +124,7 @@ def _make_sparse_eig(A, AT, Aadjoint_to_gadjoint):
         def backward(ctx, g_lam, g_l, g_r):
             if ctx.device_path:
                 lam, l, r = ctx.trip
-                lam_l, lam_r = _adjoint_solves_device(A.matvec, AT.matvec, lam, l, r, g_l, g_r)
+                lam_l, lam_r = _adjoint_solves_device(A, AT, lam, l, r, g_l, g_r)
                 pieces = ((g_lam * l, r), (-l, lam_l), (-lam_r, r))                      # eig.py:145-147
                 return Aadjoint_to_gadjoint(pieces), None
             lam, l, r = ctx.lam, ctx.l, ctx.r

@@ -1,24 +1,34 @@
 """Device-side Krylov solvers for the NON-symmetric primitives: what the
 reference delegates to SciPy on the host -- ARPACK ``eigs(A, k=1, which, ncv=k)`` (reference eig.py:29-30,
-116-117) and ``gmres(A - lambda I, b, tol=1e-12, atol=1e-12)`` (eig.py:52-57,137-144) -- restated on GPU
-vectors with the same HIP phase kernels the Lanczos path uses for its orthogonalisation:
+116-117) and ``gmres(A - lambda I, b, tol=1e-12, atol=1e-12)`` (eig.py:52-57,137-144).
 
-    arnoldi_dominant   explicitly restarted Arnoldi, ncv basis vectors, classical Gram-Schmidt on the dots /
-                       correction kernel pair with a second round when the DGKS test asks for it (ARPACK's
-                       rule), Hessenberg eigen-solve on the host (ncv x ncv), restart from the wanted Ritz
-                       vector until the residual estimate |h_{m+1,m} e_m^T y| is at rounding level
-    gmres              restarted GMRES(20) with the same orthogonalisation, Givens rotations on the host
+The loops run in libdsea (include/dsea.h "non-symmetric Krylov loops"):
 
-ARPACK's implicitly restarted method and this explicitly restarted one converge to the same eigenpair
-(ARPACK is called with tol = 0 = machine precision); eigenvectors are compared up to the gauge the
+    arnoldi_dominant   Krylov-Schur (thick-restart Arnoldi) with ncv basis vectors.  One cycle = ONE library call
+                       (``dsea_arnoldi_extend``) for native operands -- classical Gram-Schmidt on the basis-streaming
+                       kernels of the Lanczos path, second pass only when the DGKS test asks for it (ARPACK's rule),
+                       decided on the device, no host sync per step.  The host sees the small Hessenberg matrix once per
+                       cycle: ordered real Schur form, residual test |h_{m+1,m} e_m^T y| <= tol |theta|, and -- if not
+                       converged -- a restart that KEEPS the leading Schur vectors.
+    gmres              restarted GMRES(20): residual, Arnoldi steps, Givens rotations, back-substitution and the
+                       update on the device; the host reads 8 doubles per cycle.
+
+An operand is either a native operator (``operators.DenseOperator`` / ``TransferOperator`` / any object exposing
+``.handle``) or a Python callable / ``TorchLinearOperator`` (then the mat-vec is the caller's torch code and every
+other stage is a library call).  ARPACK's implicitly restarted method and Krylov-Schur converge to the same
+eigenpair (ARPACK is called with tol = 0 = machine precision); eigenvectors are compared up to the gauge the
 primitives fix afterwards (l.r = 1, r.r = 1, sign of r free).
 """
 from __future__ import annotations
 
+import ctypes
+from ctypes import byref, c_void_p
+
 import numpy as np
 import torch
 
-from . import engine
+from . import _lib, engine
+from ._lib import check
 
 F64 = torch.float64
 
@@ -43,152 +53,205 @@ def _select(evals, which):
     raise ValueError("which must be one of LM, SM, LR, SR")
 
 
-def _cgs2(ph, V, ldq, n, j, w, zero, bufs):
-    """orthogonalise w against V[0..j] twice; returns (h (j+1,) device, w_orth, ||w_orth||^2 (1,) device)"""
-    w1, w2, h1, h2, nrm2 = bufs
-    i = j + 1
-    ph.rdots(V, ldq, n, i, w, zero, None, w1, h1)        # w1 = w, h1 = V^T w    (alpha = 0: no three-term part)
-    ph.axpy_norm(V, ldq, n, i, h1, w1, nrm2)             # w1 -= V h1
-    ph.rdots(V, ldq, n, i, w1, zero, None, w2, h2)       # second round on the corrected vector
-    ph.axpy_norm(V, ldq, n, i, h2, w2, nrm2)
-    return h1[:i] + h2[:i], w2, nrm2
+def _rank_key(evals, which):
+    """larger = more wanted"""
+    return {"LM": np.abs(evals), "SM": -np.abs(evals), "LR": evals.real, "SR": -evals.real}[which]
 
 
-def _cgs_dgks(ph, V, ldq, n, j, w, zero, bufs):
-    """Classical Gram-Schmidt with the second round only when the DGKS test asks for it (what ARPACK does):
-    re-orthogonalise iff ||w - V V^T w||^2 < 1/2 ||w||^2.  The test needs two scalars on the host (one small
-    D2H copy per step); for long bases it saves a full dots + correction pass on almost every step."""
-    w1, w2, h1, h2, nrm2 = bufs
-    i = j + 1
-    ph.rdots(V, ldq, n, i, w, zero, None, w1, h1)        # w1 = w, h1 = V^T w, h1[i] = w.w
-    ph.axpy_norm(V, ldq, n, i, h1, w1, nrm2)             # w1 -= V h1, nrm2 = ||w1||^2
-    before, after = torch.stack((h1[i], nrm2[0])).tolist()
-    if after >= 0.5 * before:
-        return h1[:i], w1, nrm2
-    ph.rdots(V, ldq, n, i, w1, zero, None, w2, h2)
-    ph.axpy_norm(V, ldq, n, i, h2, w2, nrm2)
-    return h1[:i] + h2[:i], w2, nrm2
+class _one_thread:
+    """Small dense LAPACK calls (a 200 x 200 Hessenberg matrix) are faster on ONE thread than on a thread pool
+    (measured: eig 19 ms vs 41-190 ms, LU-based inverse iteration 1.5 vs 27 ms)."""
+
+    def __enter__(self):
+        try:
+            from threadpoolctl import threadpool_limits
+            self._ctx = threadpool_limits(limits=1)
+            self._ctx.__enter__()
+        except Exception:           # threadpoolctl not installed: run as is
+            self._ctx = None
+        return self
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            self._ctx.__exit__(*exc)
 
 
-def arnoldi_dominant(matvec, n, ncv, device, which="LM", v0=None, tol=1e-13, max_restarts=60):
-    """Wanted eigenvalue (real, asserted as in eig.py:31-32) and unit-norm eigenvector of a real matrix
-    given by ``matvec`` (torch device vector -> torch device vector)."""
-    device = torch.device(device)
-    ncv = int(min(ncv, n))
-    ph = engine.Phases(n, device, kmax=ncv + 1)
-    ldq = engine.round_up(n, 32)
-    V = ph.empty(ncv + 1, ldq)
-    H = ph.zeros(ncv + 1, ncv)
-    zero = ph.zeros(1)
-    bufs = (ph.empty(n), ph.empty(n), ph.zeros(ncv + 2), ph.zeros(ncv + 2), ph.zeros(1))
-    v = torch.randn(n, dtype=F64, device=device) if v0 is None else engine.as_vector(v0, n).clone()
-    nrm2 = ph.zeros(1)
-    last_res, theta, x, res, converged = None, None, None, float("inf"), False
-    for _ in range(max_restarts):
-        ph.dot(v, v, nrm2)
-        ph.scale_store(v, nrm2, V[0], None)
-        H.zero_()
-        for j in range(ncv):
-            w = engine.as_vector(matvec(V[j, :n]), n)
-            h, w_orth, wn2 = _cgs_dgks(ph, V, ldq, n, j, w, zero, bufs)
-            H[: j + 1, j] = h
-            ph.scale_store(w_orth, wn2, V[j + 1], H[j + 1, j: j + 1])
-        Hh = H.cpu().numpy()
-        # invariant subspace reached (n <= ncv or lucky breakdown): use the leading block only
-        m = ncv
-        scale = np.abs(Hh[:ncv, :ncv]).max()
-        sub = np.array([abs(Hh[j + 1, j]) for j in range(ncv)])
-        bad = np.where(~np.isfinite(sub) | (sub <= 1e-13 * scale))[0]
-        if bad.size:
-            m = int(bad[0]) + 1
-        evals, evecs = np.linalg.eig(Hh[:m, :m])
+def _wanted_pair(B, which):
+    """wanted eigenvalue of the small matrix B and its unit eigenvector: eigenvalues only (LAPACK hseqr without the
+    eigenvector back-transformation, which costs as much again) + two steps of inverse iteration"""
+    from scipy.linalg import lu_factor, lu_solve
+    with _one_thread():
+        evals = np.linalg.eigvals(B)
         idx = _select(evals, which)
-        theta, y = evals[idx], evecs[:, idx]
+        theta = evals[idx]
         if abs(theta.imag) > 1e-9 * max(abs(theta), 1e-300):
             raise ValueError("The desired eigenvalue of the matrix must be real")      # eig.py:31-32
-        y = (y / y[np.argmax(np.abs(y))]).real
-        y = y / np.linalg.norm(y)
-        sub_m = 0.0 if m < ncv or not np.isfinite(sub[m - 1]) else sub[m - 1]
-        res = abs(sub_m * y[-1]) if m == ncv else 0.0
-        x = ph.empty(n)
-        ph.ritz(V, ldq, n, m, torch.from_numpy(np.ascontiguousarray(y)).to(device), x)
-        x = x / x.norm()
-        if res <= tol * abs(theta.real) or (last_res is not None and res >= 0.5 * last_res and res <= 1e-10 * abs(theta.real)):
-            converged = True
+        th = float(theta.real)
+        mm = B.shape[0]
+        if mm == 1:
+            return th, np.ones(1), evals
+        lu = lu_factor(B - (th + 1e-10 * max(abs(th), 1e-300)) * np.eye(mm))
+        y = np.ones(mm) / np.sqrt(mm)
+        for _ in range(3):
+            y = lu_solve(lu, y)
+            y = y / np.linalg.norm(y)
+    return th, y, evals
+
+
+def _ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(None)
+
+
+def _native(A):
+    """operator object with a C-ABI handle behind ``A`` (the object itself or its bound mat-vec), or None"""
+    if hasattr(A, "handle") and hasattr(A, "n"):
+        return A
+    owner = getattr(A, "__self__", None)
+    if owner is not None and hasattr(owner, "handle") and hasattr(owner, "n"):
+        return owner
+    return None
+
+
+class _Loop:
+    """shared plumbing of the two solvers: workspace, stream, the operand in either form"""
+
+    def __init__(self, A, n, device, kmax):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.n = int(n)
+        self.native = _native(A)
+        self.callable = None if self.native is not None else (A.matvec if hasattr(A, "matvec") else A)
+        self.ws = engine.Workspace.get(self.n, kmax, self.device)
+        self.ldv = engine.round_up(self.n, 32)
+
+    def st(self):
+        return engine._stream(self.device)
+
+    def apply(self, v):
+        """A v as a library-ready vector"""
+        if self.native is not None:
+            return engine.spmv(self.native, v)
+        return engine.as_vector(self.callable(v), self.n)
+
+
+def arnoldi_dominant(A, n, ncv, device, which="LM", v0=None, tol=1e-13, max_restarts=60):
+    """Wanted eigenvalue (real, checked as in eig.py:31-32) and unit-norm eigenvector of a real matrix given as a
+    native operator or a mat-vec callable."""
+    from scipy.linalg import schur
+
+    device = torch.device(device)
+    m = int(min(ncv, n))
+    lp = _Loop(A, n, device, m + 2)
+    lib, ws, ldv, st = lp.lib, lp.ws, lp.ldv, lp.st
+    V = torch.zeros((m + 1, ldv), dtype=F64, device=device)
+    ldh = m + 1
+    Hd = torch.zeros((m, ldh), dtype=F64, device=device)       # row j = column j of H (column-major, ld = m + 1)
+    v = torch.randn(n, dtype=F64, device=device) if v0 is None else engine.as_vector(v0, n).clone()
+    nrm2 = torch.zeros(1, dtype=F64, device=device)
+    check(lib.dsea_nrm2sq(ws.handle, _ptr(v), n, _ptr(nrm2), st()), "dsea_nrm2sq")
+    check(lib.dsea_scale_store(ws.handle, _ptr(v), _ptr(nrm2), _ptr(V), None, n, st()), "dsea_scale_store")
+    p = 0                      # vectors kept from the previous cycle (Krylov-Schur block)
+    theta, x, res = None, None, float("inf")
+    for cycle in range(max_restarts + 1):
+        # ---- extend the factorisation to m columns: one library call (native) / one orthogonalisation call per
+        # step (callable); nothing returns to the host in between
+        if lp.native is not None:
+            check(lib.dsea_arnoldi_extend(lp.native.handle, ws.handle, None, _ptr(V), ldv, p, m, _ptr(Hd), ldh, st()),
+                  "dsea_arnoldi_extend")
+        else:
+            for j in range(p, m):
+                u = lp.apply(V[j, :n])
+                check(lib.dsea_arnoldi_orth(ws.handle, _ptr(u), None, _ptr(V), ldv, n, j, _ptr(Hd), ldh, st()),
+                      "dsea_arnoldi_orth")
+        brk = ctypes.c_int(0)
+        check(lib.dsea_lanczos_status(ws.handle, byref(brk), st()), "dsea_lanczos_status", allow=(_lib.ERR_BREAKDOWN,))
+        Hh = Hd.cpu().numpy()                     # (m, m+1): Hh[j, i] = H[i, j]
+        me = m if brk.value == 0 else int(brk.value)          # invariant subspace reached at step me
+        B = Hh[:me, :me].T.copy()
+        coupling = 0.0 if me < m or brk.value else float(Hh[m - 1, m])
+        theta, y, evals = _wanted_pair(B, which)
+        res = abs(coupling * y[-1])
+        if res <= tol * abs(theta) or me < m:
             break
-        last_res = res
-        v = x
-    if not converged:
-        # ARPACK raises ArpackNoConvergence here (eig.py:29-30 would propagate it); an unconverged pair must not
-        # reach the backward pass, whose solves of (A - theta I) assume an exact eigenvalue
-        raise ArnoldiNoConvergence("Arnoldi did not converge in %d restarts of %d vectors: residual estimate %.3e "
-                                   "relative to |theta| = %.3e" % (max_restarts, ncv, res, abs(theta.real)),
-                                   float(theta.real), x, res)
-    return float(theta.real), x
+        if cycle == max_restarts:
+            break
+        # ---- thick restart: keep the p most wanted Schur vectors (never splitting a complex pair)
+        order = np.argsort(-_rank_key(evals, which))
+        p_new = max(1, min(me - 2, m // 3))
+        cut = _rank_key(evals, which)[order[p_new - 1]]
+        keep = lambda re, im: _rank_key(np.array([complex(re, im)]), which)[0] >= cut - 1e-14 * abs(cut)  # noqa: E731
+        with _one_thread():
+            T, Z, sdim = schur(B, output="real", sort=keep)
+            p_new = int(sdim)
+            if p_new < 1 or p_new >= me:
+                T, Z, sdim = schur(B, output="real",
+                                   sort=lambda re, im: abs(complex(re, im) - theta) <= 1e-12 * abs(theta))
+                p_new = max(int(sdim), 1)
+        Zp = torch.from_numpy(np.ascontiguousarray(Z[:, :p_new].T)).to(device)          # (p, m)
+        Vnew = torch.matmul(Zp, V[:me])                                                   # rocBLAS GEMM, once per restart
+        last = V[me].clone()
+        V[:p_new] = Vnew
+        V[p_new] = last
+        V[p_new + 1:] = 0.0
+        Hn = np.zeros((m, ldh))
+        Hn[:p_new, :p_new] = T[:p_new, :p_new].T
+        Hn[:p_new, p_new] = coupling * Z[me - 1, :p_new]
+        Hd.copy_(torch.from_numpy(Hn))
+        p = p_new
+    xv = torch.empty(n, dtype=F64, device=device)
+    ys = torch.from_numpy(np.ascontiguousarray(y)).to(device)
+    check(lib.dsea_ritz_combine(ws.handle, _ptr(V), ldv, n, int(ys.numel()), _ptr(ys), _ptr(xv), st()), "dsea_ritz_combine")
+    x = xv / xv.norm()
+    if not (res <= tol * abs(theta) or me < m):
+        # the residual estimate stalls at the rounding level of the factorisation for ill-conditioned eigenvalues:
+        # accept a measured residual at that level, otherwise report (ARPACK raises ArpackNoConvergence, eig.py:29)
+        true_res = float((lp.apply(x) - theta * x).norm())
+        if true_res > 1e-10 * abs(theta):
+            raise ArnoldiNoConvergence("Arnoldi did not converge in %d restarts of %d vectors: residual %.3e relative to "
+                                       "|theta| = %.3e" % (max_restarts, m, true_res, abs(theta)), theta, x, true_res)
+    return theta, x
 
 
-def gmres(matvec, b, rtol=1e-12, atol=1e-12, restart=20, maxiter=None, check_every=5):
-    """Restarted GMRES from x0 = 0; stops when ||b - A x|| <= max(rtol ||b||, atol) (scipy's rule).
-
-    The Hessenberg columns stay on the device; the host pulls them (one small D2H copy = one sync) only every
-    ``check_every`` inner steps to advance the Givens rotations and test the residual, instead of after every
-    step -- the vectors here are small (2 MB at D = 512) and each step is latency-bound."""
+def gmres(A, b, shift=None, rtol=1e-12, atol=1e-12, restart=20, maxiter=None):
+    """Restarted GMRES from x0 = 0 for (A - shift I) x = b; stops when the residual is <= max(rtol ||b||, atol)
+    (scipy's rule, eig.py:54).  ``shift``: 0-dim / 1-element device tensor or None."""
     device, n = b.device, b.numel()
     b = engine.as_vector(b, n)
-    restart = int(min(restart, n))
-    ph = engine.Phases(n, device, kmax=restart + 1)
-    ldq = engine.round_up(n, 32)
-    V = ph.empty(restart + 1, ldq)
-    zero, nrm2 = ph.zeros(1), ph.zeros(1)
-    bufs = (ph.empty(n), ph.empty(n), ph.zeros(restart + 2), ph.zeros(restart + 2), ph.zeros(1))
-    Hdev = ph.zeros(restart, restart + 1)          # row j = column j of the Hessenberg matrix
-    x = ph.zeros(n)
+    m = int(min(restart, n, 64))
+    lp = _Loop(A, n, device, m + 2)
+    lib, ws, ldv, st = lp.lib, lp.ws, lp.ldv, lp.st
+    V = torch.zeros((m + 1, ldv), dtype=F64, device=device)
+    work = torch.zeros(int(lib.dsea_gmres_work_doubles(m)), dtype=F64, device=device)
+    state = torch.zeros(8, dtype=F64, device=device)
+    x = torch.zeros(n, dtype=F64, device=device)
+    sh = None if shift is None else shift.detach().reshape(-1)[:1].to(device=device, dtype=F64).contiguous()
     target = max(rtol * float(b.norm()), atol)
     cycles = 10 * n if maxiter is None else int(maxiter)
-    first = True
-    for _ in range(cycles):
-        r = b.clone() if first else b - engine.as_vector(matvec(x), n)
-        first = False
-        beta = float(r.norm())
-        if beta <= target:
+    info = None
+    for c in range(cycles):
+        if lp.native is not None:
+            check(lib.dsea_gmres_cycle(lp.native.handle, ws.handle, _ptr(sh), _ptr(b), _ptr(x), _ptr(V), ldv, m,
+                                       _ptr(work), float(target), _ptr(state), int(c == 0), st()), "dsea_gmres_cycle")
+        else:
+            Ax = None
+            if c > 0:
+                Ax = lp.apply(x)
+                if sh is not None:
+                    Ax = Ax - sh * x
+                Ax = engine.as_vector(Ax, n)
+            check(lib.dsea_gmres_begin(ws.handle, _ptr(b), _ptr(Ax), _ptr(V), ldv, n, m, _ptr(work), float(target),
+                                       _ptr(state), st()), "dsea_gmres_begin")
+            for j in range(m):
+                u = lp.apply(V[j, :n])
+                check(lib.dsea_gmres_step(None, ws.handle, _ptr(sh), _ptr(u), _ptr(V), ldv, n, j, m, _ptr(work),
+                                          float(target), _ptr(state), st()), "dsea_gmres_step")
+            check(lib.dsea_gmres_end(ws.handle, _ptr(V), ldv, n, m, _ptr(work), _ptr(state), _ptr(x), st()),
+                  "dsea_gmres_end")
+        info = state.cpu()
+        if info[1].item() != 0.0:
             break
-        ph.dot(r, r, nrm2)
-        ph.scale_store(r, nrm2, V[0], None)
-        Hm = np.zeros((restart + 1, restart))
-        cs, sn = np.zeros(restart), np.zeros(restart)
-        gvec = np.zeros(restart + 1)
-        gvec[0] = beta
-        m, done_cols, converged = 0, 0, False
-        Hdev.zero_()
-        for j in range(restart):
-            w = engine.as_vector(matvec(V[j, :n]), n)
-            h, w_orth, wn2 = _cgs2(ph, V, ldq, n, j, w, zero, bufs)
-            Hdev[j, : j + 1] = h
-            ph.scale_store(w_orth, wn2, V[j + 1], Hdev[j, j + 1: j + 2])
-            m = j + 1
-            if m % check_every == 0 or m == restart:
-                cols = Hdev[done_cols:m].cpu().numpy()                  # the host round trip
-                for jj in range(done_cols, m):
-                    col = cols[jj - done_cols, : jj + 2].copy()
-                    for t in range(jj):                                  # previous rotations
-                        a, c2 = col[t], col[t + 1]
-                        col[t], col[t + 1] = cs[t] * a + sn[t] * c2, -sn[t] * a + cs[t] * c2
-                    rho = np.hypot(col[jj], col[jj + 1])
-                    cs[jj], sn[jj] = (1.0, 0.0) if rho == 0.0 else (col[jj] / rho, col[jj + 1] / rho)
-                    col[jj], col[jj + 1] = rho, 0.0
-                    Hm[: jj + 2, jj] = col
-                    gvec[jj + 1] = -sn[jj] * gvec[jj]
-                    gvec[jj] = cs[jj] * gvec[jj]
-                    if abs(gvec[jj + 1]) <= target:
-                        m, converged = jj + 1, True
-                        break
-                done_cols = m
-                if converged:
-                    break
-        yv = np.linalg.solve(np.triu(Hm[:m, :m]), gvec[:m])
-        dx = ph.empty(n)
-        ph.ritz(V, ldq, n, m, torch.from_numpy(np.ascontiguousarray(yv)).to(device), dx)
-        x = x + dx
+    gmres.last_cycles = c + 1
+    gmres.last_residual = float(info[0].item()) if info is not None else float("nan")
     return x
 
 

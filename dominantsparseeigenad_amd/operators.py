@@ -305,3 +305,74 @@ class CSROperator:
 
     def __call__(self, v):
         return _SymmetricApply.apply(v, self._H)
+
+
+# ------------------------------------------------------------------------------------------ GEMM-shaped operands
+class DenseOperator:
+    """A dense real matrix (row-major device tensor) as a library operand of the NON-symmetric primitives
+    (reference eig.py:28-30 hands the matrix to ARPACK); ``transpose=True`` applies A^T.  The mat-vec is a rocBLAS
+    GEMV issued by libdsea (include/dsea.h: dsea_op_create_dense)."""
+
+    _native_methods = ("__call__", "matvec")
+
+    def __init__(self, A, transpose=False):
+        if A.device.type != "cuda" or A.dim() != 2 or A.shape[0] != A.shape[1]:
+            raise ValueError("DenseOperator takes a square CUDA matrix")
+        self.A = A.detach().to(F64).contiguous()
+        self.n = int(A.shape[0])
+        self.shape = (self.n, self.n)
+        self.device = self.A.device
+        self.transpose = bool(transpose)
+        raw = c_void_p()
+        check(_lib.load().dsea_op_create_dense(self.n, c_void_p(self.A.data_ptr()), self.n, int(self.transpose),
+                                               byref(raw)), "dsea_op_create_dense")
+        self._H = _NativeView(_Handle(raw, self.n, self.A))
+
+    @property
+    def handle(self):
+        return self._H.handle
+
+    def matvec(self, v):
+        return engine.spmv(self._H, v)
+
+    __call__ = matvec
+
+
+class TransferOperator:
+    """MPS transfer matrix of a real rank-3 tensor A (d, D, D) acting on D x D matrices stored as D^2-vectors
+    (reference examples/TFIM_vumps/general.py:59-66):
+
+        transpose=False:  r -> sum_s A_s r A_s^T      ("Gong",  the reference's ``fr``)
+        transpose=True :  l -> sum_s A_s^T l A_s      ("GongT", the reference's ``fl``)
+
+    applied by libdsea as one strided-batched fp64 GEMM + one GEMM of depth d*D (rocBLAS) -- the explicit D^2 x D^2
+    matrix of ``matrix_forward`` (general.py:47-49) would be 550 GB at D = 512."""
+
+    _native_methods = ("__call__", "matvec")
+
+    def __init__(self, A, transpose=False):
+        if A.device.type != "cuda" or A.dim() != 3 or A.shape[1] != A.shape[2]:
+            raise ValueError("TransferOperator takes a CUDA tensor of shape (d, D, D)")
+        self.A = A.detach().to(F64).contiguous()
+        self.d, self.D = int(A.shape[0]), int(A.shape[1])
+        self.n = self.D * self.D
+        self.shape = (self.n, self.n)
+        self.device = self.A.device
+        self.transpose = bool(transpose)
+        lib = _lib.load()
+        nbytes = lib.dsea_op_transfer_work_bytes(self.D, self.d)
+        self._work = torch.empty(nbytes // 8, dtype=F64, device=self.device)
+        raw = c_void_p()
+        check(lib.dsea_op_create_transfer(self.D, self.d, c_void_p(self.A.data_ptr()), int(self.transpose),
+                                          c_void_p(self._work.data_ptr()), engine._stream(self.device), byref(raw)),
+              "dsea_op_create_transfer")
+        self._H = _NativeView(_Handle(raw, self.n, (self.A, self._work)))
+
+    @property
+    def handle(self):
+        return self._H.handle
+
+    def matvec(self, v):
+        return engine.spmv(self._H, v)
+
+    __call__ = matvec

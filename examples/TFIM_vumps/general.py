@@ -60,11 +60,10 @@ class TFIM(torch.nn.Module):
         D, dev = self.D, self.device
         Ad = self.A.detach()
         if dev.type == "cuda":
-            from dominantsparseeigenad_amd.krylov import TorchLinearOperator
-            AdT = Ad.transpose(1, 2).contiguous()
-            fr = lambda v: torch.matmul(torch.matmul(Ad, v.reshape(D, D)), AdT).sum(0).reshape(-1)   # noqa: E731
-            fl = lambda v: torch.matmul(torch.matmul(AdT, v.reshape(D, D)), Ad).sum(0).reshape(-1)   # noqa: E731
-            G, GT = TorchLinearOperator((D * D, D * D), fr, dev), TorchLinearOperator((D * D, D * D), fl, dev)
+            # the transfer matrix as a NATIVE operand: Arnoldi / GMRES loops and the batched-GEMM mat-vec all
+            # inside libdsea (reference :59-66 builds scipy LinearOperators around numpy einsums)
+            from dominantsparseeigenad_amd.operators import TransferOperator
+            G, GT = TransferOperator(Ad), TransferOperator(Ad, transpose=True)
 
             def hook(pieces):
                 gA = torch.zeros_like(Ad)

@@ -73,7 +73,7 @@ int dsea_ws_set_split(dsea_ws_t ws, int waves);
 /* tuning knob: persistent single-launch CG of dsea_cg_run (3-point stencil without halo pointers, n <= 2^19): the
  * whole solve is ONE launch whose workgroups keep x, r, d in registers and exchange only per-tile partial sums and
  * edge elements; iterates are bit-identical to the streaming 3-launches-per-iteration form.
- * -1 = automatic (on where it applies), 0 = off (streaming form), 1 / 2 / 4 = on with that many row pairs per thread. */
+ * -1 = automatic (on where it applies), 0 = off (streaming form), 1 / 2 = on with that many row pairs per thread. */
 int dsea_ws_set_persist(dsea_ws_t ws, int mode);
 
 /* Optional bf16 SHADOW of the Krylov basis (caller-owned, `rows` x `ld` uint16, ld % 8 == 0, 16-byte
@@ -132,6 +132,21 @@ int dsea_op_create_stencil3(int64_t n, double coef, const double *V_dev, const d
 #define DSEA_TUNE_TFIM_TILE_LOG2 1
 #define DSEA_TUNE_CSR_GROUP 2
 int dsea_op_set_tuning(dsea_op_t op, int key, int value);
+
+/* GEMM-shaped operands of the NON-symmetric primitives (reference eig.py).  Their mat-vec goes to rocBLAS (bound at
+ * run time from the copy already in the process; DSEA_ERR_UNSUPPORTED if there is none) -- the one place on this path
+ * where a matrix core is the right unit -- and rocBLAS may keep device memory of its own.
+ *   dense   : row-major n x n matrix (eig.py:28-30, DominantEig); transpose != 0 applies A^T.
+ *   transfer: MPS transfer matrix of a rank-3 tensor A (d x D x D row-major), dimension D^2, vectors are D x D
+ *             row-major (reference examples/TFIM_vumps/general.py:59-66):
+ *                 transpose == 0:  y = sum_s A_s x A_s^T        ("Gong",  general.py:59-61)
+ *                 transpose != 0:  y = sum_s A_s^T x A_s        ("GongT", general.py:62-64)
+ *             as one strided-batched GEMM + one GEMM of depth d*D.  `work`: caller-owned scratch of
+ *             dsea_op_transfer_work_bytes(D, d); dsea_op_create_transfer fills part of it on `stream`.        */
+int dsea_op_create_dense(int64_t n, const double *A_dev, int64_t lda, int transpose, dsea_op_t *out);
+size_t dsea_op_transfer_work_bytes(int D, int d);
+int dsea_op_create_transfer(int D, int d, const double *A_dev, int transpose, double *work, void *stream,
+                            dsea_op_t *out);
 
 int dsea_op_destroy(dsea_op_t op);
 int dsea_op_dim(dsea_op_t op, int64_t *n);
@@ -270,6 +285,41 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double *q0, double
  * SYNCHRONISES the stream and returns DSEA_OK, or DSEA_ERR_BREAKDOWN with *break_step = i: the Krylov space of q0
  * has dimension i and the leading i x i block of T holds exact eigenpairs of the operator.                      */
 int dsea_lanczos_status(dsea_ws_t ws, int *break_step, void *stream);
+
+/* ------------------------------------------------------------------ non-symmetric Krylov loops (row f-1)
+ * What reference eig.py:29-30,116-117 (ARPACK eigs) and :54-57,137-144 (gmres) do inside SciPy on the host.
+ *
+ * dsea_arnoldi_extend: Arnoldi factorisation (A - (*shift) I) V_m = V_{m+1} H extended from column j0 to j1
+ * (exclusive), entirely on the stream, no host sync:  V = rows of a (>= j1+1) x ldv buffer with V[0..j0] given
+ * (orthonormal), H column-major with leading dimension ldh >= j1+1 (columns j0..j1-1 are written in full: h_0..h_j
+ * by classical Gram-Schmidt against ALL previous vectors -- so a restarted, non-Hessenberg start block is fine --
+ * and h_{j+1,j} = ||w||).  A second Gram-Schmidt pass runs only when the DGKS test asks for it, decided on the
+ * device.  An invariant subspace (||w|| <= 1e-13 ||A v_j||) is recorded; dsea_lanczos_status reports the step.  */
+int dsea_arnoldi_extend(dsea_op_t op, dsea_ws_t ws, const double *shift, double *V, int64_t ldv, int j0, int j1,
+                        double *H, int ldh, void *stream);
+
+/* the orthogonalisation of ONE Arnoldi step when the mat-vec is the caller's code: u = A v_j given, writes column j
+ * of H (entries 0..j+1) and V[j+1]; (*shift) v_j is subtracted from u inside the first pass.                    */
+int dsea_arnoldi_orth(dsea_ws_t ws, const double *u, const double *shift, double *V, int64_t ldv, int64_t n, int j,
+                      double *H, int ldh, void *stream);
+
+/* dsea_gmres_cycle: ONE cycle of restarted GMRES(m) for (A - (*shift) I) x = b (m <= 64): residual, m Arnoldi steps,
+ * Givens rotations, back-substitution and the update x += V y -- all on the stream, no host sync inside.  `first`
+ * != 0: x is taken as 0 (r0 = b).  `target` = absolute residual bound max(rtol ||b||, atol) (scipy's rule,
+ * eig.py:54).  work: dsea_gmres_work_doubles(m) device doubles; V: (m+1) x ldv, zero-initialised once by the caller.
+ * state (8 device doubles): [0] residual estimate  [1] converged  [2] columns used  [3] ||r0||  [4] finished early.
+ * The caller reads `state` after the cycle (its one sync) and issues the next cycle if [1] == 0.                 */
+size_t dsea_gmres_work_doubles(int m);
+/* the three stages of a cycle, for operands whose mat-vec is the caller's code (op == NULL, u = A v_j supplied per
+ * step; Ax = (A - shift) x supplied to begin, NULL for x = 0); dsea_gmres_cycle composes them for native operators */
+int dsea_gmres_begin(dsea_ws_t ws, const double *b, const double *Ax, double *V, int64_t ldv, int64_t n, int m,
+                     double *work, double target, double *state, void *stream);
+int dsea_gmres_step(dsea_op_t op, dsea_ws_t ws, const double *shift, const double *u, double *V, int64_t ldv,
+                    int64_t n, int j, int m, double *work, double target, double *state, void *stream);
+int dsea_gmres_end(dsea_ws_t ws, const double *V, int64_t ldv, int64_t n, int m, double *work, const double *state,
+                   double *x, void *stream);
+int dsea_gmres_cycle(dsea_op_t op, dsea_ws_t ws, const double *shift, const double *b, double *x, double *V,
+                     int64_t ldv, int m, double *work, double target, double *state, int first, void *stream);
 
 /* CG on (A - (*shift) I) x = b from x (in: start vector, out: solution).  Stops when ||r|| < eps
  * (absolute, CG.py:25) or after maxiter iterations.  The loop runs on the device; the host polls the

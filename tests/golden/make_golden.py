@@ -254,6 +254,70 @@ def case_schrodinger(N, k):
     save("schrodinger", N=N, k=k, h=h, seed_draw=7610, ndraw=ndraw, target=target, E=E, psi=psi, loss=loss, grad=gp)
 
 
+def _gauge(l, r):
+    """the primitives fix l.r = 1, r.r = 1 (eig.py:36); the sign of r is free: make its largest component positive"""
+    sgn = 1.0 if r[np.argmax(np.abs(r))] > 0 else -1.0
+    return l * sgn, r * sgn
+
+
+def case_dominant_eig(D=5, d=2, k=25):
+    """reference tests/test_gradient.py:5-22 (the gradcheck case of DominantEig) with seeded inputs: the dominant
+    eigen-triple of the D^2 x D^2 transfer matrix of a random rank-3 tensor and the gradient of a gauge-invariant
+    loss, computed by reference eig.py:27-62 (ARPACK eigs + scipy gmres on the host)."""
+    import DominantSparseEigenAD.eig as ref_eig
+    n = D * D
+    A = normal_vector(d * D * D, 7701).reshape(d, D, D)
+    Gong = np.einsum("kij,kmn->imjn", A, A).reshape(n, n)
+    a = float(normal_vector(1, 7702)[0])
+    M = normal_vector(n * n, 7703).reshape(n, n)
+    G = torch.from_numpy(Gong).requires_grad_(True)
+    lam, l, r = ref_eig.DominantEig.apply(G, k)
+    loss = a * lam + l.matmul(torch.from_numpy(M)).matmul(r)
+    (gG,) = torch.autograd.grad(loss.sum(), G)
+    lg, rg = _gauge(l.detach().numpy(), r.detach().numpy())
+    save("dominant_eig_D%d" % D, D=D, d=d, k=k, seed_A=7701, seed_a=7702, seed_M=7703, A=A, eigval=lam, l=lg, r=rg,
+         loss=loss.sum(), grad_Gong=gG)
+
+
+def case_dominant_sparse_eig(D=10, d=2, k=50):
+    """reference eig.py:64-152 (DominantSparseEig) on the transfer matrix given as scipy LinearOperators, the operand
+    form of reference examples/TFIM_vumps/general.py:59-74 (r -> sum_s A_s r A_s^T, l -> sum_s A_s^T l A_s, and the map
+    of the adjoint pieces (u, v) to A-bar), with seeded inputs."""
+    import DominantSparseEigenAD.eig as ref_eig
+    from scipy.sparse.linalg import LinearOperator
+    n = D * D
+    A0 = normal_vector(d * D * D, 7711).reshape(d, D, D)
+    M = normal_vector(n * n, 7713).reshape(n, n)
+    a = float(normal_vector(1, 7712)[0])
+
+    def right(v):
+        r = v.reshape(D, D)
+        return sum(A0[s] @ r @ A0[s].T for s in range(d)).reshape(-1)
+
+    def left(v):
+        lm = v.reshape(D, D)
+        return sum(A0[s].T @ lm @ A0[s] for s in range(d)).reshape(-1)
+
+    def pieces_to_Abar(pieces):
+        # Gong-bar = sum u v^T with Gong[(i,m),(j,n)] = sum_s A[s,i,j] A[s,m,n]
+        gA = np.zeros_like(A0)
+        for u, v in pieces:
+            U, Vm = u.reshape(D, D), v.reshape(D, D)
+            for s in range(d):
+                gA[s] += U @ A0[s] @ Vm.T + U.T @ A0[s] @ Vm
+        return torch.from_numpy(gA)
+
+    ref_eig.setDominantSparseEig(LinearOperator((n, n), matvec=right), LinearOperator((n, n), matvec=left),
+                                 pieces_to_Abar)
+    At = torch.from_numpy(A0).requires_grad_(True)
+    lam, l, r = ref_eig.DominantSparseEig.apply(At, k)
+    loss = a * lam + l.matmul(torch.from_numpy(M)).matmul(r)
+    (gA,) = torch.autograd.grad(loss.sum(), At)
+    lg, rg = _gauge(l.detach().numpy(), r.detach().numpy())
+    save("dominant_sparse_eig_D%d" % D, D=D, d=d, k=k, seed_A=7711, seed_a=7712, seed_M=7713, A=A0, eigval=lam, l=lg,
+         r=rg, loss=loss.sum(), grad_A=gA)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true")
@@ -270,6 +334,8 @@ def main():
         "tfim10b": lambda: case_tfim(10, 300, 1.5, "L10_k300_g1.5"),
         "tfim12": lambda: case_tfim(12, 200, 1.0, "L12_k200_g1.0"),
         "schrodinger": lambda: case_schrodinger(300, 300),
+        "eig": case_dominant_eig,
+        "sparse_eig": case_dominant_sparse_eig,
     }
     big = {
         "tfim16": lambda: case_tfim(16, 200, 1.0, "L16_k200_g1.0", second_order=False, store_psi=False, seed=12345),

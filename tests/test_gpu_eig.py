@@ -101,3 +101,173 @@ def test_gmres_device_matches_scipy():
     assert info == 0
     assert float((Md @ x - torch.from_numpy(b).to(cuda)).norm()) <= 1.01e-12 * np.linalg.norm(b) + 1e-12
     assert float((x.cpu() - torch.from_numpy(xs)).abs().max()) < 1e-9
+
+
+# ------------------------------------------------------------------ native operands + library loops
+GOLDEN = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden")
+
+
+def _gauge(l, r):
+    sgn = 1.0 if r[np.argmax(np.abs(r))] > 0 else -1.0
+    return l * sgn, r * sgn
+
+
+@pytest.mark.parametrize("D,d", [(3, 2), (16, 2), (33, 3), (64, 2)])
+def test_transfer_and_dense_operators_match_einsum(D, d):
+    """the batched-GEMM transfer mat-vec (both orientations) and the GEMV dense operand against torch einsums"""
+    from dominantsparseeigenad_amd.operators import DenseOperator, TransferOperator
+    rng = np.random.RandomState(D)
+    A = torch.from_numpy(rng.randn(d, D, D)).to(cuda)
+    v = torch.from_numpy(rng.randn(D * D)).to(cuda)
+    fr = torch.einsum("kij,kmn,jn->im", A, A, v.reshape(D, D)).reshape(-1)     # general.py:59-61
+    fl = torch.einsum("kij,kmn,im->jn", A, A, v.reshape(D, D)).reshape(-1)     # general.py:62-64
+    scale = float(fr.abs().max())
+    assert float((TransferOperator(A)(v) - fr).abs().max()) < 1e-13 * scale * D
+    assert float((TransferOperator(A, transpose=True)(v) - fl).abs().max()) < 1e-13 * scale * D
+    G = torch.einsum("kij,kmn->imjn", A, A).reshape(D * D, D * D)
+    assert float((DenseOperator(G)(v) - G @ v).abs().max()) < 1e-13 * scale * D
+    assert float((DenseOperator(G, transpose=True)(v) - G.T @ v).abs().max()) < 1e-13 * scale * D
+
+
+def test_dominant_eig_device_matches_reference_fixture():
+    """reference tests/test_gradient.py:5-22 case: outputs of the REFERENCE's DominantEig (ARPACK + scipy gmres,
+    eig.py:27-62) stored by tests/golden/make_golden.py, reproduced by the library Arnoldi / GMRES on the GPU."""
+    gd = np.load(__import__("os").path.join(GOLDEN, "dominant_eig_D5.npz"))
+    D, k = int(gd["D"]), int(gd["k"])
+    n = D * D
+    from dominantsparseeigenad_amd.synthetic import normal_vector
+    A = gd["A"]
+    Gong = np.einsum("kij,kmn->imjn", A, A).reshape(n, n)
+    a = float(normal_vector(1, int(gd["seed_a"]))[0])
+    M = torch.from_numpy(normal_vector(n * n, int(gd["seed_M"])).reshape(n, n)).to(cuda)
+    G = torch.from_numpy(Gong).to(cuda).requires_grad_(True)
+    lam, l, r = DominantEig.apply(G, k)
+    loss = a * lam + l.matmul(M).matmul(r)
+    (gG,) = torch.autograd.grad(loss.sum(), G)
+    lg, rg = _gauge(l.detach().cpu().numpy(), r.detach().cpu().numpy())
+    assert abs(lam.item() - float(gd["eigval"][0])) < 1e-11 * abs(float(gd["eigval"][0]))
+    assert np.max(np.abs(rg - gd["r"])) < 1e-9 and np.max(np.abs(lg - gd["l"])) < 1e-8 * np.max(np.abs(gd["l"]))
+    assert abs(loss.item() - float(gd["loss"])) < 1e-9 * abs(float(gd["loss"]))
+    assert float(np.max(np.abs(gG.cpu().numpy() - gd["grad_Gong"]))) < 1e-7 * float(np.max(np.abs(gd["grad_Gong"])))
+
+
+@pytest.mark.parametrize("native", [True, False])
+def test_dominant_sparse_eig_device_matches_reference_fixture(native):
+    """the REFERENCE's DominantSparseEig on the D = 10 transfer matrix (eig.py:115-149, operand form of
+    examples/TFIM_vumps/general.py:59-74) vs the device path: native TransferOperator (loops and batched-GEMM
+    mat-vec inside libdsea) and an opaque torch callable (mat-vec = user code, everything else library calls)."""
+    from dominantsparseeigenad_amd.operators import TransferOperator
+    from dominantsparseeigenad_amd.synthetic import normal_vector
+    gd = np.load(__import__("os").path.join(GOLDEN, "dominant_sparse_eig_D10.npz"))
+    D, d, k = int(gd["D"]), int(gd["d"]), int(gd["k"])
+    n = D * D
+    A = torch.from_numpy(gd["A"]).to(cuda).requires_grad_(True)
+    Ad = A.detach()
+    a = float(normal_vector(1, int(gd["seed_a"]))[0])
+    M = torch.from_numpy(normal_vector(n * n, int(gd["seed_M"])).reshape(n, n)).to(cuda)
+
+    def hook(pieces):
+        gA = torch.zeros_like(Ad)
+        for u, v in pieces:
+            um, vm = u.reshape(D, D), v.reshape(D, D)
+            gA = gA + torch.matmul(torch.matmul(um, Ad), vm.T) + torch.matmul(torch.matmul(um.T, Ad), vm)
+        return gA
+
+    if native:
+        op, opT = TransferOperator(Ad), TransferOperator(Ad, transpose=True)
+    else:
+        fr = lambda v: torch.einsum("kij,kmn,jn->im", Ad, Ad, v.reshape(D, D)).reshape(-1)   # noqa: E731
+        fl = lambda v: torch.einsum("kij,kmn,im->jn", Ad, Ad, v.reshape(D, D)).reshape(-1)   # noqa: E731
+        op, opT = krylov.TorchLinearOperator((n, n), fr, cuda), krylov.TorchLinearOperator((n, n), fl, cuda)
+    eig.setDominantSparseEig(op, opT, hook)
+    lam, l, r = eig.DominantSparseEig.apply(A, k)
+    loss = a * lam + l.matmul(M).matmul(r)
+    (gA,) = torch.autograd.grad(loss.sum(), A)
+    lg, rg = _gauge(l.detach().cpu().numpy(), r.detach().cpu().numpy())
+    assert abs(lam.item() - float(gd["eigval"][0])) < 1e-11 * abs(float(gd["eigval"][0]))
+    assert np.max(np.abs(rg - gd["r"])) < 1e-9 and np.max(np.abs(lg - gd["l"])) < 1e-8 * np.max(np.abs(gd["l"]))
+    assert abs(loss.item() - float(gd["loss"])) < 1e-9 * abs(float(gd["loss"]))
+    assert float(np.max(np.abs(gA.cpu().numpy() - gd["grad_A"]))) < 1e-7 * float(np.max(np.abs(gd["grad_A"])))
+
+
+def test_config4_transfer_matrix_D512_k200():
+    """BASELINE configs[3]: non-symmetric dominant eigen-triple of the D = 512 transfer matrix (n = 262144; the dense
+    matrix would be 550 GB), k = 200 -- size-independent properties: eigen-residuals of r and l, the gauge
+    l.r = 1 / r.r = 1, GMRES solves of the adjoint to 1e-12, and the gradient against a directional finite
+    difference of lambda."""
+    import time
+    from dominantsparseeigenad_amd.operators import TransferOperator
+    D, d, k = 512, 2, 200
+    n = D * D
+    gen = torch.Generator(device="cpu").manual_seed(1234)
+    A = (torch.randn(d, D, D, dtype=F64, generator=gen) / np.sqrt(D)).to(cuda).requires_grad_(True)
+    Ad = A.detach()
+
+    def hook(pieces):
+        gA = torch.zeros_like(Ad)
+        for u, v in pieces:
+            um, vm = u.reshape(D, D), v.reshape(D, D)
+            gA = gA + torch.matmul(torch.matmul(um, Ad), vm.T) + torch.matmul(torch.matmul(um.T, Ad), vm)
+        return gA
+
+    op, opT = TransferOperator(Ad), TransferOperator(Ad, transpose=True)
+    eig.setDominantSparseEig(op, opT, hook)
+    torch.manual_seed(3)
+    lam, l, r = eig.DominantSparseEig.apply(A, k)      # warm-up (rocBLAS start-up)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    lam, l, r = eig.DominantSparseEig.apply(A, k)
+    torch.cuda.synchronize()
+    t_fwd = time.perf_counter() - t0
+    lv, ld_, rd = lam.item(), l.detach(), r.detach()
+    assert float((op(rd) - lv * rd).norm()) <= 1e-12 * abs(lv)
+    assert float((opT(ld_) - lv * ld_).norm()) <= 1e-12 * abs(lv) * float(ld_.norm())
+    assert abs(float(ld_ @ rd) - 1.0) < 1e-12 and abs(float(rd.norm()) - 1.0) < 1e-12
+    t0 = time.perf_counter()
+    (gA,) = torch.autograd.grad(lam.sum(), A)
+    torch.cuda.synchronize()
+    t_bwd = time.perf_counter() - t0
+    # d lambda / dA = l r^T contracted with dGong/dA: check along a random direction by central differences
+    dirn = torch.randn(d, D, D, dtype=F64, generator=gen).to(cuda)
+    dirn = dirn / dirn.norm()
+    eps = 1e-5
+    lams = []
+    for sgn in (+1.0, -1.0):
+        Ap = (Ad + sgn * eps * dirn).contiguous()
+        lp, _ = krylov.arnoldi_dominant(TransferOperator(Ap), n, k, cuda, "LM", v0=rd)
+        lams.append(lp)
+    fd = (lams[0] - lams[1]) / (2 * eps)
+    assert abs(float((gA * dirn).sum()) - fd) < 1e-6 * max(abs(fd), 1.0), (float((gA * dirn).sum()), fd)
+    print("config 4: D=512 k=200 forward %.1f ms, backward %.1f ms" % (t_fwd * 1e3, t_bwd * 1e3))
+
+
+def test_gmres_native_operator_and_shift():
+    from dominantsparseeigenad_amd.operators import DenseOperator
+    rng = np.random.RandomState(19)
+    n = 500
+    Mh = rng.randn(n, n) / np.sqrt(n) + 3.0 * np.eye(n)
+    b = torch.from_numpy(rng.randn(n)).to(cuda)
+    Md = torch.from_numpy(Mh).to(cuda)
+    shift = torch.tensor(0.7, dtype=F64, device=cuda)
+    x = krylov.gmres(DenseOperator(Md), b, shift=shift)
+    assert float((Md @ x - 0.7 * x - b).norm()) <= 1.01e-12 * float(b.norm()) + 1e-12
+    xT = krylov.gmres(DenseOperator(Md, transpose=True), b, shift=shift)
+    assert float((Md.T @ xT - 0.7 * xT - b).norm()) <= 1.01e-12 * float(b.norm()) + 1e-12
+    # already solved: zero right-hand side
+    assert float(krylov.gmres(DenseOperator(Md), torch.zeros(n, dtype=F64, device=cuda)).abs().max()) == 0.0
+
+
+def test_arnoldi_restarts_and_reports_non_convergence():
+    """a small basis forces thick restarts; an impossible budget raises instead of returning an unconverged pair"""
+    from dominantsparseeigenad_amd.operators import DenseOperator
+    rng = np.random.RandomState(2)
+    n = 400
+    Mh = rng.randn(n, n) / np.sqrt(n) + np.diag(np.linspace(0.0, 3.0, n))
+    w = np.linalg.eigvals(Mh)
+    lam_ref = w[np.argmax(np.abs(w))].real
+    op = DenseOperator(torch.from_numpy(Mh).to(cuda))
+    torch.manual_seed(5)
+    lam, x = krylov.arnoldi_dominant(op, n, 12, cuda, "LM")          # ncv = 12: many restarts
+    assert abs(lam - lam_ref) < 1e-9 * abs(lam_ref)
+    with pytest.raises(krylov.ArnoldiNoConvergence):
+        krylov.arnoldi_dominant(op, n, 4, cuda, "LM", max_restarts=1)

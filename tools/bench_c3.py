@@ -25,7 +25,7 @@ print("Lanczos N=%d k=%d: %.2f ms  (%.1f us/step; algorithmic %.0f GB/s)  theta=
 b = torch.from_numpy(normal_vector(N, 2)).to(dev); x0 = torch.from_numpy(normal_vector(N, 3)).to(dev)
 shift = torch.tensor(-1.0, dtype=torch.float64, device=dev)
 ws = engine.Workspace.get(N, 8, dev)
-for mode, name in ((0, "streaming 3-launch"), (-1, "persistent auto"), (1, "persistent ppt=1"), (2, "persistent ppt=2"), (4, "persistent ppt=4")):
+for mode, name in ((0, "streaming 3-launch"), (-1, "persistent auto"), (1, "persistent ppt=1"), (2, "persistent ppt=2")):
     ws.set_persist(mode)
     best = 1e30
     try:

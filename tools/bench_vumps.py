@@ -27,7 +27,13 @@ def hook(pieces):
         um, vm = u.reshape(D, D), v.reshape(D, D)
         gA = gA + torch.matmul(torch.matmul(um, Ad), vm.T) + torch.matmul(torch.matmul(um.T, Ad), vm)
     return gA
-op, opT = krylov.TorchLinearOperator((n, n), fr, dev), krylov.TorchLinearOperator((n, n), fl, dev)
+NATIVE = os.environ.get("DSEA_VUMPS_CALLABLE", "0") != "1"
+if NATIVE:   # loops + batched-GEMM mat-vec inside libdsea
+    from dominantsparseeigenad_amd.operators import TransferOperator
+    op, opT = TransferOperator(Ad), TransferOperator(Ad, transpose=True)
+else:        # opaque torch callables: mat-vec = user code, every other stage a library call
+    op, opT = krylov.TorchLinearOperator((n, n), fr, dev), krylov.TorchLinearOperator((n, n), fl, dev)
+print("operand form:", "native TransferOperator" if NATIVE else "torch callable")
 eig.setDominantSparseEig(op, opT, hook)
 tv1 = torch.randn(n, dtype=torch.float64, device=dev); tv2 = torch.randn(n, dtype=torch.float64, device=dev)
 for it in range(3):
