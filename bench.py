@@ -220,6 +220,9 @@ def main():
     ap.add_argument("--operator", choices=["matrix-free", "sell", "csr"], default="matrix-free",
                     help="operand form of the TFIM operator at N=1: native matrix-free kernel (headline) or the "
                          "explicit 21-nnz/row matrix in SELL-64 / CSR layout")
+    ap.add_argument("--reorth", choices=["full", "none"], default="full",
+                    help="'none': basis-free two-pass Lanczos (no stored basis, no re-orthogonalisation) -- NOT the "
+                         "reference's algorithm, reported for what it is; lets k = 200 at L = 28 fit one GPU")
     ap.add_argument("--force-partitioned", action="store_true",
                     help="run the row-partitioned driver even with one rank (measures its host overhead)")
     args = ap.parse_args()
@@ -237,7 +240,9 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from dominantsparseeigenad_amd import _lib, engine
+    from dominantsparseeigenad_amd import Lanczos as _LZ
     import dominantsparseeigenad_amd.symeig as symeig
+    _LZ.REORTH_DEFAULT = args.reorth
     from dominantsparseeigenad_amd.synthetic import normal_vector
     lib = _lib.load()
 
@@ -263,7 +268,7 @@ def main():
     # one GPU cannot hold the fp64 basis AND its bf16 shadow at L = 28, k = 100 (215 + 54 GB of 288 GB)
     free_b, total_b = torch.cuda.mem_get_info(dev)
     need_shadow = 10.0 * nloc * k + 16 * 8.0 * nloc
-    if need_shadow > 0.92 * total_b:
+    if need_shadow > 0.92 * total_b or args.reorth == "none":
         engine.USE_SHADOW = False
 
     def slab(seed):
@@ -377,7 +382,7 @@ def main():
     # ---- per-launch durations of the dominant kernels: the same K steps again, this time with a HIP event
     # pair recorded on the launch stream around every reorth / mat-vec launch (the event records cost ~4 %
     # of a step, which is why they are kept out of the timed region above)
-    use_events = not args.no_kernel_events   # rank 0 reports its local kernels also in the partitioned run
+    use_events = not args.no_kernel_events and args.reorth == "full"   # rank 0's local kernels, also when partitioned
     launches = (c_int64 * 3)()
     total_ms = (c_double * 3)()
     dt_instr = None
@@ -393,7 +398,22 @@ def main():
     lp_stats = engine.lanczos_lp_stats(nloc, dev) if not partitioned_path else None
     # ---- the same step with the all-fp64 correction pass (no bf16 shadow of the basis): the figure to hold
     # against real HBM traffic
-    ms_fp64 = None
+    ms_fp64 = ms_basisfree = None
+    if not args.no_extras and not partitioned_path and args.reorth == "full" and not big:
+        # the same workload with the basis-free two-pass Lanczos (reorth='none'): a DIFFERENT forward algorithm (no
+        # full re-orthogonalisation, Lanczos.py:66), same eigenpair and gradient to rounding -- reported beside the
+        # headline, never as the headline
+        _LZ.REORTH_DEFAULT = "none"
+        step()
+        barrier()
+        t3 = time.perf_counter()
+        nb2 = min(steps, 5)
+        for _ in range(nb2):
+            E0bf, glbf = step()
+        barrier()
+        ms_basisfree = (time.perf_counter() - t3) / nb2 * 1e3
+        bf_dev = (abs(E0bf.item() - E0.item()) / abs(E0.item()), abs(float(glbf.reshape(-1)[0]) - float(gl.reshape(-1)[0])) / abs(float(gl.reshape(-1)[0])))
+        _LZ.REORTH_DEFAULT = "full"
     if not args.no_extras and engine.USE_SHADOW and not partitioned_path:
         engine.USE_SHADOW = False
         step()
@@ -426,7 +446,7 @@ def main():
                                    "loss=E0+psi.t, operand=%s, %s" % (L, L, nloc, k, args.operator, mode),
                        "cg_iterations": int(m), "algorithmic_bytes_per_step": total_bytes,
                        "frac_of_hbm_peak_whole_step": round(value / (HBM_PEAK_GBS * world), 4),
-                       "bf16_shadow_of_basis": bool(engine.USE_SHADOW),
+                       "bf16_shadow_of_basis": bool(engine.USE_SHADOW), "lanczos_reorthogonalisation": args.reorth,
                        "E0_per_site": E0.item() / L, "E0_per_site_closed_form": analytic_E0_per_site(L, 1.0),
                        "dloss_dg": float(gl.reshape(-1)[0].item()),
                        "adjoint_vs_reference_at_eps1e-7": ADJOINT_DEV_EPS7},
@@ -448,6 +468,11 @@ def main():
                 out["config"]["real_hbm_bytes_source"] = "rocprofv3 PMC FETCH_SIZE/WRITE_SIZE at commit %s" % pmc.get("_commit", "?")
                 out["value_real_traffic"] = round(real / (ms_per_step * 1e-3) / 1e9, 2)
                 out["config"]["frac_of_hbm_peak_real_traffic"] = round(real / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        if ms_basisfree is not None:
+            out["config"]["basisfree_two_pass_lanczos"] = {
+                "ms_per_step": round(ms_basisfree, 4), "E0_rel_dev_vs_full_reorth": bf_dev[0],
+                "dloss_dg_rel_dev_vs_full_reorth": bf_dev[1],
+                "note": "reorth='none' option: no stored basis, no re-orthogonalisation; not the reference's algorithm"}
         if ms_fp64 is not None:
             out["config"]["ms_per_step_fp64_basis"] = round(ms_fp64, 4)
             out["config"]["GBs_fp64_basis"] = round(total_bytes / (ms_fp64 * 1e-3) / 1e9, 2)

@@ -79,10 +79,36 @@ def Lanczos(A, k, device=torch.device("cpu"), *, sparse=False, dim=None, q0=None
     return Qk.to(dtype), T.to(dtype)
 
 
-def symeigLanczos(A, k, device=torch.device("cpu"), extreme="both", *, sparse=False, dim=None, q0=None):
-    """Extreme eigenvalue(s)/eigenvector(s); outputs as in Lanczos.py:88-105 (all torch tensors)."""
+# Module-level default of the ``reorth`` extension below (the autograd primitives' ``apply`` signatures are fixed by
+# the reference API, so they read it here): "full" = the reference's full re-orthogonalisation with a stored basis.
+REORTH_DEFAULT = "full"
+
+
+def symeigLanczos(A, k, device=torch.device("cpu"), extreme="both", *, sparse=False, dim=None, q0=None, reorth=None):
+    """Extreme eigenvalue(s)/eigenvector(s); outputs as in Lanczos.py:88-105 (all torch tensors).
+
+    Keyword-only extension ``reorth``: "full" (default, reference Lanczos.py:66) or "none" -- basis-free two-pass
+    Lanczos for native device operators: three rotating vectors instead of the k-vector basis (so k = 200 at
+    n = 2^28 fits ONE GPU) and no k^2 n re-orthogonalisation traffic; the extreme Ritz pair is the same to rounding,
+    interior Ritz values may appear more than once (not returned here)."""
     if extreme not in ("both", "min", "max"):
         raise ValueError("extreme must be 'both', 'min' or 'max'")
+    reorth = REORTH_DEFAULT if reorth is None else reorth
+    if reorth not in ("full", "none"):
+        raise ValueError("reorth must be 'full' or 'none'")
+    if reorth == "none":
+        native = engine.native_of(A) if sparse else None
+        if native is None or getattr(native, "partitioned", False) or torch.device(device).type != "cuda":
+            raise NotImplementedError("reorth='none' (basis-free two-pass Lanczos) needs a native single-GPU operator")
+        n = int(dim)
+        dev = torch.device(device)
+        if q0 is None:
+            q0 = torch.randn(n, dtype=torch.float64, device=dev)           # Lanczos.py:52
+        torch.randn(n, dtype=torch.float64, device=dev)                    # Lanczos.py:59: same RNG consumption
+        out = []
+        for val, vec in engine.lanczos_basisfree(native, k, n, dev, q0, extreme):
+            out += [torch.tensor(val, dtype=torch.float64, device=dev), vec]
+        return tuple(out)
     # the basis is transient here (only Ritz vectors are returned): it lives in the persistent arena
     where, Q, ldq, n, alphas, betas, dtype = _lanczos_core(A, k, device, sparse, dim, q0, arena=True)
     pairs = engine.tridiag_extreme(alphas, betas, extreme)

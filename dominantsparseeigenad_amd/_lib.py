@@ -83,8 +83,11 @@ _SIGNATURES = {
                                 c_void_p, c_int64, c_void_p]),
     "dsea_lanczos_run": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                  c_void_p]),
+    "dsea_lanczos_run_basisfree": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p]),
     "dsea_arnoldi_extend": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int,
                                     c_void_p]),
+    "dsea_arnoldi_second_passes": (c_int, [c_void_p, POINTER(c_int64), c_void_p]),
     "dsea_arnoldi_orth": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int,
                                   c_void_p]),
     "dsea_gmres_work_doubles": (c_size_t, [c_int]),

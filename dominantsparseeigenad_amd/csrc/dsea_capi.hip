@@ -727,6 +727,48 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
   return check_launch();
 }
 
+int dsea_lanczos_run_basisfree(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double* Qrot, int64_t ldq,
+                               double* alphas, double* betas, const double* s, double* psi, void* stream) {
+  REQUIRE(op && ws && q0 && Qrot && alphas && betas && k >= 1 && ((s == nullptr) == (psi == nullptr)), DSEA_ERR_ARG);
+  const int64_t n = op->d.n;
+  REQUIRE(ldq >= n && ws->w.n >= n, DSEA_ERR_ARG);
+  REQUIRE(aligned16(q0) && aligned16(Qrot) && (!psi || aligned16(psi)) && (ldq % 2 == 0), DSEA_ERR_ALIGN);
+  const bool has_fused_tail = (op->d.kind == OP_TFIM && op->d.tfim.L_local >= 1) || op->d.kind == OP_SELL ||
+                              op->d.kind == OP_STENCIL3;
+  REQUIRE(has_fused_tail, DSEA_ERR_UNSUPPORTED);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Workspace& w = ws->w;
+  double* u = w.vec[0];
+  double* r = w.vec[1];
+  double* nrm2 = w.scal + 0;
+  double* aP = w.aux;
+  double* nP = w.aux + DSEA_MAX_WAVE_TILES;
+  double* brk = w.scal + DSEA_SCAL_BREAK;
+  if (hipMemsetAsync(brk, 0, 2 * sizeof(double), st) != hipSuccess) {
+    g_last_hip = (int)hipGetLastError();
+    return DSEA_ERR_HIP;
+  }
+  if (psi && hipMemsetAsync(psi, 0, (size_t)n * sizeof(double), st) != hipSuccess) {
+    g_last_hip = (int)hipGetLastError();
+    return DSEA_ERR_HIP;
+  }
+  auto slot = [&](int i) { return Qrot + (int64_t)(i % 3) * ldq; };
+  launch_dot(q0, q0, n, w.partials, nrm2, st);
+  launch_scale_store(q0, nrm2, slot(0), nullptr, n, st, nullptr);
+  int na = launch_spmv(op->d, slot(0), u, nullptr, nullptr, aP, st);
+  if (na < 0) return DSEA_ERR_UNSUPPORTED;
+  for (int i = 1; i < k; ++i) {
+    // psi += s[i-1] q_{i-1} rides on the pass that reads q_{i-1} anyway
+    const int nn = launch_three_term(u, slot(i - 1), i >= 2 ? slot(i - 2) : nullptr, aP, na, alphas + (i - 1),
+                                     i >= 2 ? betas + (i - 2) : nullptr, r, nP, psi, s ? s + (i - 1) : nullptr, n, brk,
+                                     st);
+    na = launch_tfim_fused(op->d, r, nP, nn, slot(i), u, betas + (i - 1), aP, st, nullptr, nullptr, brk, i);
+  }
+  launch_finalize_slot(aP, na, alphas + (k - 1), brk, st);
+  if (psi) launch_axpy(1.0, s + (k - 1), slot(k - 1), psi, n, st);
+  return check_launch();
+}
+
 int dsea_arnoldi_extend(dsea_op_t op, dsea_ws_t ws, const double* shift, double* V, int64_t ldv, int j0, int j1,
                         double* H, int ldh, void* stream) {
   REQUIRE(op && ws && V && H && j0 >= 0 && j1 > j0 && ldh >= j1 + 1, DSEA_ERR_ARG);
@@ -738,6 +780,7 @@ int dsea_arnoldi_extend(dsea_op_t op, dsea_ws_t ws, const double* shift, double*
   Workspace& w = ws->w;
   double* brk = w.scal + DSEA_SCAL_BREAK;
   if (j0 == 0) {   // a new factorisation: clear the break record (a continued one keeps it)
+    hipMemsetAsync(w.scal + 31, 0, sizeof(double), st);   // second-pass counter (dsea_arnoldi_second_passes)
     if (hipMemsetAsync(brk, 0, 2 * sizeof(double), st) != hipSuccess) {
       g_last_hip = (int)hipGetLastError();
       return DSEA_ERR_HIP;
@@ -766,6 +809,19 @@ int dsea_arnoldi_orth(dsea_ws_t ws, const double* u, const double* shift, double
   arnoldi_orth(w, n, u, shift ? shift : w.zero, V, ldv, j, H + (int64_t)j * ldh, brk, w.scal + 24, w.scal + 26,
                w.scal + 27, st);
   return check_launch();
+}
+
+int dsea_arnoldi_second_passes(dsea_ws_t ws, int64_t* count, void* stream) {
+  if (!ws || !count) return DSEA_ERR_ARG;
+  double h = 0.0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemcpyAsync(&h, ws->w.scal + 31, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess) {
+    g_last_hip = (int)hipGetLastError();
+    return DSEA_ERR_HIP;
+  }
+  *count = (int64_t)h;
+  return DSEA_OK;
 }
 
 size_t dsea_gmres_work_doubles(int m) { return m < 1 ? 0 : (size_t)(m + 1) * m + 4 * (size_t)m + 8; }
@@ -799,7 +855,8 @@ int dsea_gmres_begin(dsea_ws_t ws, const double* b, const double* Ax, double* V,
   double* r0 = w.vec[3];
   launch_residual(b, Ax, r0, n, w.partials, nrm0, st);                 // r0 = b - (A - shift) x  (Ax null: x = 0)
   launch_gmres_begin(nrm0, target, gw.g, m, state, w.scal + 28, st);
-  launch_scale_store(r0, nrm0, V, nullptr, n, st, nullptr, nullptr, 0);  // v0 = r0 / ||r0||
+  // v0 = r0 / ||r0|| -- skipped on the device when the cycle starts converged (r0 = 0 would give 0/0)
+  launch_scale_store(r0, nrm0, V, nullptr, n, st, nullptr, w.scal + 28, 0);
   return check_launch();
 }
 

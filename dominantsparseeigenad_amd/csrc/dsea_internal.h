@@ -117,6 +117,9 @@ struct Workspace {
 };
 
 void launch_finalize1(const double* P, int count, double* out, hipStream_t st);
+int launch_three_term(const double* u, const double* q1, const double* q2, const double* aP, int aCount,
+                      double* a_store, const double* beta, double* r, double* P, double* psi, const double* s1,
+                      int64_t n, double* brk, hipStream_t st);
 void launch_finalize_slot(const double* P, int count, double* out, const double* skip, hipStream_t st);
 void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* u,
                   const double* alpha, const double* beta, double* r, double* P, double* c_out,

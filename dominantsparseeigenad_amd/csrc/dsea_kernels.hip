@@ -701,6 +701,53 @@ __global__ __launch_bounds__(256) void k_plz_finish(const double* __restrict__ r
 }
 
 // ------------------------------------------------------------------------------------------
+// Basis-free ("two-pass") Lanczos: the three-term recurrence WITHOUT re-orthogonalisation and without a stored
+// basis (an option the reference lacks; it keeps all k vectors and re-orthogonalises against them, Lanczos.py:49,66).
+//   r = u - alpha q1 - beta q2 ; partial ||r||^2 ; second pass only: psi += s1 * q1  (Ritz vector accumulated
+//   while the recurrence is replayed -- same kernels, same order, hence bit-identical q_j in both passes)
+// alpha arrives as the mat-vec's per-block partials (summed here, stored once), as in k_rdots.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_three_term(const double* __restrict__ u, const double* __restrict__ q1,
+                                                    const double* __restrict__ q2, const double* __restrict__ aP,
+                                                    int aCount, double* __restrict__ a_store,
+                                                    const double* __restrict__ beta, double* __restrict__ r,
+                                                    double* __restrict__ P, double* __restrict__ psi,
+                                                    const double* __restrict__ s1, int64_t n,
+                                                    double* __restrict__ brk) {
+  __shared__ double sm5[5];
+  if (broken(brk)) return;
+  const double a = sum_partials_block(aP, aCount, sm5);
+  const double b = (beta && q2) ? beta[0] : 0.0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    a_store[0] = a;
+    if (brk) brk[1] = fmax(brk[1], fmax(fabs(a), fabs(b)));
+  }
+  const double sc = s1 ? s1[0] : 0.0;
+  double acc = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * 512;
+  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; row < n; row += stride) {
+    const double2 uu = ld2<true>(u, row, n), qa = ld2<true>(q1, row, n);
+    double2 qb = make_double2(0.0, 0.0);
+    if (q2) qb = ld2<true>(q2, row, n);
+    double2 rv;
+    rv.x = __dsub_rn(__dsub_rn(uu.x, __dmul_rn(a, qa.x)), __dmul_rn(b, qb.x));
+    rv.y = __dsub_rn(__dsub_rn(uu.y, __dmul_rn(a, qa.y)), __dmul_rn(b, qb.y));
+    st2<true>(r, row, n, rv);
+    acc = fma(rv.x, rv.x, acc);
+    acc = fma(rv.y, rv.y, acc);
+    if (psi) {
+      double2 pv = ld2<true>(psi, row, n);
+      pv.x = fma(sc, qa.x, pv.x);
+      pv.y = fma(sc, qa.y, pv.y);
+      st2<true>(psi, row, n, pv);
+    }
+  }
+  __syncthreads();
+  const double t = block_sum(acc, sm5);
+  if (threadIdx.x == 0) P[blockIdx.x] = t;
+}
+
+// ------------------------------------------------------------------------------------------
 // CG kernels (CG.py:24-41)
 // ------------------------------------------------------------------------------------------
 // r = b - Ax0 ; d = r ; partial r.r
@@ -864,25 +911,58 @@ __global__ __launch_bounds__(256) void k_spmv_tfim(TfimParams p, const double* _
   constexpr int TILE = 1 << T;
   constexpr int NPAIR = TILE / 2;                       // T >= 1
   constexpr int PER = (NPAIR + 255) / 256;              // pairs per thread
+  // far bits whose loads are issued up front: as many as registers allow (L = 20: all of them either way)
+// (measured on MI355X at L = 20, average over the fused + plain launches of a bench step: FB_FUSED 1 / 3 / 5 / 7 / 9
+//  -> 14.5 / 13.8 / 13.3 / 13.1 / 17.9 us -- at 9 the fused kernel needs 254 VGPRs and only one block fits a CU.
+//  The kernel is NOT latency-bound after all: it sits on the fabric traffic of its cross-XCD reads)
+#ifndef DSEA_FB_FUSED
+#define DSEA_FB_FUSED 7
+#endif
+#ifndef DSEA_FB_PLAIN
+#define DSEA_FB_PLAIN 9
+#endif
+  constexpr int FB = PER >= 4 ? (FUSED ? DSEA_FB_FUSED : DSEA_FB_PLAIN) : (PER == 2 ? 12 : 14);
   __shared__ double2 tile2[NPAIR];
   __shared__ double sm5[5];
   if (!FUSED && skip && skip[0] != 0.0) return;
-  double beta = 1.0;
-  if (FUSED && !fused_beta(fa, sm5, beta)) return;
-  const double g = p.g_dev ? p.g_dev[0] : p.g_const;
-  const double s = shift ? shift[0] : 0.0;
+  if (FUSED && broken(fa.brk)) return;
   const uint64_t maskL = (p.L >= 64) ? ~0ull : ((1ull << p.L) - 1ull);
   const int64_t ntiles = ((int64_t)1 << p.L_local) >> T;
   double acc = 0.0;
+  double beta = 1.0, g = 0.0, s = 0.0;
+  bool first = true;
   // a block walks tiles blockIdx.x, +gridDim.x, ... (the grid is capped so that the per-block partials fit)
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t base = tile * TILE;
+    // 1. everything that does not depend on a scalar is put in flight first: the block's own rows and the
+    //    out-of-tile neighbours of the first FB far bits (they are scaled by 1/beta afterwards -- linearity).  The
+    //    kernel is latency-bound (~5 dependent memory round trips of 1.5-2 us when issued one after the other);
+    //    issued together they overlap each other, the beta reduction and the LDS staging.
+    double2 own[PER];
+    double2 fb[PER][FB];
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+      const int lp = t * 256 + threadIdx.x;
+      const int64_t i0 = base + 2 * (int64_t)(lp < NPAIR ? lp : 0);
+      own[t] = *reinterpret_cast<const double2*>(x + i0);
+#pragma unroll
+      for (int e = 0; e < FB; ++e) {
+        fb[t][e] = make_double2(0.0, 0.0);
+        if (T + e < p.L_local) fb[t][e] = *reinterpret_cast<const double2*>(x + (i0 ^ ((int64_t)1 << (T + e))));
+      }
+    }
+    if (first) {
+      if (FUSED && !fused_beta(fa, sm5, beta)) return;   // the same decision in every block
+      g = p.g_dev ? p.g_dev[0] : p.g_const;
+      s = shift ? shift[0] : 0.0;
+      first = false;
+    }
     __syncthreads();  // previous tile's LDS reads are done
 #pragma unroll
     for (int t = 0; t < PER; ++t) {
       const int lp = t * 256 + threadIdx.x;
       if (lp < NPAIR) {
-        double2 v = *reinterpret_cast<const double2*>(x + base + 2 * lp);
+        double2 v = own[t];
         if (FUSED) {
           v.x = v.x / beta;
           v.y = v.y / beta;
@@ -895,11 +975,18 @@ __global__ __launch_bounds__(256) void k_spmv_tfim(TfimParams p, const double* _
       }
     }
     __syncthreads();
-    // out-of-tile neighbours: all pairs of this thread, four bits per trip, loads first
     double2 far[PER];
 #pragma unroll
-    for (int t = 0; t < PER; ++t) far[t] = make_double2(0.0, 0.0);
-    int j = T;
+    for (int t = 0; t < PER; ++t) {
+      far[t] = make_double2(0.0, 0.0);
+#pragma unroll
+      for (int e = 0; e < FB; ++e) {   // zero for bits beyond L_local
+        far[t].x += fb[t][e].x;
+        far[t].y += fb[t][e].y;
+      }
+    }
+    // remaining far bits (L_local > T + FB): four bits per trip, loads first
+    int j = T + FB;
     for (; j + 4 <= p.L_local; j += 4) {
       double2 nb[PER][4];
 #pragma unroll
@@ -1867,6 +1954,15 @@ void launch_plz_finish(const double* r, const double* y, const double* pair, dou
                        double* alpha_out, double* beta_out, int64_t n, hipStream_t st) {
   hipLaunchKernelGGL(k_plz_finish, dim3(ew_blocks(n)), dim3(256), 0, st, r, y, pair, q, qs, u, alpha_out,
                      beta_out, n);
+}
+
+int launch_three_term(const double* u, const double* q1, const double* q2, const double* aP, int aCount,
+                      double* a_store, const double* beta, double* r, double* P, double* psi, const double* s1,
+                      int64_t n, double* brk, hipStream_t st) {
+  const int nb = ew_blocks(n);
+  hipLaunchKernelGGL(k_three_term, dim3(nb), dim3(256), 0, st, u, q1, q2, aP, aCount, a_store, beta, r, P, psi, s1, n,
+                     brk);
+  return nb;
 }
 
 void launch_finalize_slot(const double* P, int count, double* out, const double* skip, hipStream_t st) {

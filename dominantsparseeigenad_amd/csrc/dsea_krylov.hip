@@ -131,12 +131,15 @@ int blas_apply(const OpDesc& op, const double* x, double* y, hipStream_t st) {
 // DGKS test after the first Gram-Schmidt pass: a second pass is needed iff ||w - V V^T w||^2 < 1/2 ||w||^2.
 // skip[0] = 1 -> the second pass kernels return at once.  (c1[i] = ||w||^2 from the dots pass.)
 __global__ void k_dgks_decide(const double* __restrict__ c1, int i, const double* __restrict__ nrm1,
-                              double* __restrict__ skip, const double* __restrict__ brk) {
+                              double* __restrict__ skip, const double* __restrict__ brk,
+                              double* __restrict__ counter) {
   if (broken(brk)) {
     skip[0] = 1.0;
     return;
   }
-  skip[0] = (nrm1[0] >= 0.5 * c1[i]) ? 1.0 : 0.0;
+  const bool enough = nrm1[0] >= 0.5 * c1[i];
+  skip[0] = enough ? 1.0 : 0.0;
+  if (!enough && counter) counter[0] += 1.0;
 }
 
 // Column j of H and the next basis vector:  h = c1 (+ c2 if the second pass ran),  beta = ||w||,  v_{j+1} = w / beta.
@@ -291,7 +294,7 @@ void arnoldi_orth(Workspace& w, int64_t n, const double* u, const double* shift_
   launch_axpy_norm(g, V, ldv, n, i, c1, w1, w.partials, nullptr, st, nullptr, brk);
   launch_finalize_slot(w.partials, g.nw, nrm1, brk, st);
   hipLaunchKernelGGL(k_dgks_decide, dim3(1), dim3(1), 0, st, (const double*)c1, i, (const double*)nrm1, skip,
-                     (const double*)brk);
+                     (const double*)brk, w.scal + 31);
   // pass 2 (skipped on the device unless the DGKS test failed): w2 = w1 - V (V^T w1)
   launch_rdots(g, V, ldv, n, i, w1, w.zero, nullptr, w2, w.partials, c2, st, nullptr, nullptr, 0, nullptr, false, skip);
   launch_axpy_norm(g, V, ldv, n, i, c2, w2, w.partials, nullptr, st, nullptr, skip);

@@ -198,6 +198,7 @@ def arnoldi_dominant(A, n, ncv, device, which="LM", v0=None, tol=1e-13, max_rest
         Hn[:p_new, p_new] = coupling * Z[me - 1, :p_new]
         Hd.copy_(torch.from_numpy(Hn))
         p = p_new
+    arnoldi_dominant.last_cycles = cycle + 1
     xv = torch.empty(n, dtype=F64, device=device)
     ys = torch.from_numpy(np.ascontiguousarray(y)).to(device)
     check(lib.dsea_ritz_combine(ws.handle, _ptr(V), ldv, n, int(ys.numel()), _ptr(ys), _ptr(xv), st()), "dsea_ritz_combine")
@@ -225,7 +226,11 @@ def gmres(A, b, shift=None, rtol=1e-12, atol=1e-12, restart=20, maxiter=None):
     state = torch.zeros(8, dtype=F64, device=device)
     x = torch.zeros(n, dtype=F64, device=device)
     sh = None if shift is None else shift.detach().reshape(-1)[:1].to(device=device, dtype=F64).contiguous()
-    target = max(rtol * float(b.norm()), atol)
+    bnorm = float(b.norm())
+    gmres.last_cycles, gmres.last_residual = 0, 0.0
+    if bnorm == 0.0:
+        return x                       # scipy returns x0 = 0 for a zero right-hand side
+    target = max(rtol * bnorm, atol)
     cycles = 10 * n if maxiter is None else int(maxiter)
     info = None
     for c in range(cycles):

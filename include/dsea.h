@@ -279,6 +279,16 @@ int dsea_plz_finish(dsea_ws_t ws, const double *r, const double *y, const double
  *   Q       : k x ldq basis (output), alphas[k], betas[max(k-1,1)] (outputs, device)            */
 int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double *q0, double *Q, int64_t ldq,
                      double *alphas, double *betas, void *stream);
+/* BASIS-FREE Lanczos (an option the reference lacks; it stores all k vectors -- 8 n k bytes, 429 GB at n = 2^28,
+ * k = 200 -- and re-orthogonalises against them, Lanczos.py:49,66): the plain three-term recurrence with three
+ * rotating vectors Qrot (3 x ldq, caller-owned), NO re-orthogonalisation.  Call once with s = psi = NULL for the
+ * tridiagonal (alphas[k], betas[k-1]); after the host has the Ritz coefficients s[k] (device), call again with the
+ * same q0: the recurrence is replayed bit-identically and psi = sum_j s[j] q_j is accumulated on the way.  Without
+ * re-orthogonalisation converged Ritz values reappear as copies ("ghosts"); the EXTREME eigenpair -- the one the
+ * primitives want -- and its residual beta_k |s_k| are unaffected, psi must be normalised by the caller.
+ * Operators with a fused Lanczos tail only (matrix-free TFIM, SELL, 3-point stencil).                        */
+int dsea_lanczos_run_basisfree(dsea_op_t op, dsea_ws_t ws, int k, const double *q0, double *Qrot, int64_t ldq,
+                               double *alphas, double *betas, const double *s, double *psi, void *stream);
 /* Breakdown (the reference has no test: Lanczos.py:69-70 divides by beta whatever it is): the run compares every
  * beta_{i-1} ON THE DEVICE with 1e-13 * max_j(|alpha_j|, |beta_j|); at the first one below it records step i,
  * leaves Q[i..], alphas[i..], betas[i..] untouched and turns its remaining launches into no-ops.  This call
@@ -297,6 +307,9 @@ int dsea_lanczos_status(dsea_ws_t ws, int *break_step, void *stream);
  * device.  An invariant subspace (||w|| <= 1e-13 ||A v_j||) is recorded; dsea_lanczos_status reports the step.  */
 int dsea_arnoldi_extend(dsea_op_t op, dsea_ws_t ws, const double *shift, double *V, int64_t ldv, int j0, int j1,
                         double *H, int ldh, void *stream);
+
+/* diagnostics (synchronises): how many steps since the last j0 == 0 call needed the second Gram-Schmidt pass */
+int dsea_arnoldi_second_passes(dsea_ws_t ws, int64_t *count, void *stream);
 
 /* the orthogonalisation of ONE Arnoldi step when the mat-vec is the caller's code: u = A v_j given, writes column j
  * of H (entries 0..j+1) and V[j+1]; (*shift) v_j is subtracted from u inside the first pass.                    */

@@ -103,3 +103,51 @@ def test_basis_arena_is_reused_and_not_handed_to_users():
     Qk, T = Lanczos(op, k, dev(), sparse=True, dim=n, q0=q0)                                 # user-visible basis
     assert Qk.untyped_storage().data_ptr() not in bufs.values()
     assert float((Qk.T @ Qk - torch.eye(k, dtype=F64, device=dev())).abs().max()) < 1e-13
+
+
+@pytest.mark.parametrize("kind", ["tfim", "stencil"])
+def test_basisfree_two_pass_lanczos_matches_full_reorthogonalisation(kind):
+    """reorth='none': no stored basis, no re-orthogonalisation, Ritz vector from a replayed recurrence.  The extreme
+    pair agrees with the full-reorthogonalisation path (the reference's algorithm, Lanczos.py:66) to rounding --
+    stated tolerance: eigenvalue 1e-12 relative, eigenvector 1e-8 -- and satisfies the eigen-equation."""
+    from dominantsparseeigenad_amd import Lanczos as LZ
+    import dominantsparseeigenad_amd.symeig as symeig
+    if kind == "tfim":
+        n, k = 1 << 14, 200
+        op = TFIMOperator(14, dev(), g=torch.tensor([1.0], dtype=F64, device=dev(), requires_grad=True))
+        A, hook, g = op.H, op.Hadjoint_to_gadjoint, op.g
+    else:
+        n, k = 3000, 600
+        xm = torch.from_numpy(np.linspace(-1.0, 1.0, num=n, endpoint=False)).to(dev())
+        V = (0.5 * xm ** 2).requires_grad_(True)
+        op = Stencil3Operator(n, 2.0 / n, V)
+        A, hook, g = op.H, op.Hadjoint_to_padjoint, V
+    q0 = unit(n, 21).to(dev())
+    lo_f, v_f = symeigLanczos(A, k, dev(), extreme="min", sparse=True, dim=n, q0=q0)
+    lo_n, v_n = symeigLanczos(A, k, dev(), extreme="min", sparse=True, dim=n, q0=q0, reorth="none")
+    assert abs(lo_f.item() - lo_n.item()) < 1e-12 * abs(lo_f.item())
+    sgn = 1.0 if float(v_f @ v_n) > 0 else -1.0
+    assert float((v_f - sgn * v_n).abs().max()) < 1e-8
+    assert abs(float(v_n.norm()) - 1.0) < 1e-13
+    res_f = float((op(v_f) - lo_f * v_f).norm())
+    res_n = float((op(v_n) - lo_n * v_n).norm())
+    assert res_n < 10 * res_f + 1e-9 * abs(lo_f.item())
+    both = symeigLanczos(A, k, dev(), extreme="both", sparse=True, dim=n, q0=q0, reorth="none")
+    hi_f = symeigLanczos(A, k, dev(), extreme="max", sparse=True, dim=n, q0=q0)[0]
+    assert abs(both[0].item() - lo_f.item()) < 1e-12 * abs(lo_f.item())
+    assert abs(both[2].item() - hi_f.item()) < 1e-10 * abs(hi_f.item())
+    # through the primitive: module-level switch (the apply signature is the reference's), gradient unchanged
+    symeig.setDominantSparseSymeig(A, hook)
+    tvec = unit(n, 22).to(dev())
+    grads = []
+    for mode in ("full", "none"):
+        LZ.REORTH_DEFAULT = mode
+        try:
+            torch.manual_seed(4)
+            E, psi = symeig.DominantSparseSymeig.apply(g, k, n, dev())
+            s2 = 1.0 if float(psi.detach() @ v_f) > 0 else -1.0
+            (gr,) = torch.autograd.grad(E + s2 * psi.matmul(tvec), g)
+            grads.append(gr)
+        finally:
+            LZ.REORTH_DEFAULT = "full"
+    assert float((grads[0] - grads[1]).abs().max()) < 1e-6 * float(grads[0].abs().max())
