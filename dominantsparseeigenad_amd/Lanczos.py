@@ -59,6 +59,11 @@ def _lanczos_core(A, k, device, sparse, dim, q0, arena=False):
             amap = lambda v: torch.matmul(A64, v)              # noqa: E731
             q0 = q0.to(torch.float64)
         native = engine.native_of(A) if sparse else None
+        if not sparse and engine.DENSE_SYMMETRIC_KERNEL:
+            # dense symmetric tensor (Lanczos.py:46-49): the hand-written upper-triangle mat-vec as a native operand,
+            # so the whole loop runs inside the library
+            from .operators import SymmetricDenseOperator
+            native = SymmetricDenseOperator(A)
         if native is not None:
             Q, ldq, alphas, betas = engine.lanczos(A, k, n, device, q0, native=native, arena=arena)
         else:

@@ -351,6 +351,27 @@ int dsea_op_create_dense(int64_t n, const double* A_dev, int64_t lda, int transp
   return DSEA_OK;
 }
 
+size_t dsea_op_symdense_work_bytes(int64_t n) {
+  if (n < 1) return 0;
+  const int64_t nb = (n + 63) / 64;
+  return (size_t)nb * (size_t)(nb * 64) * sizeof(double);
+}
+
+int dsea_op_create_symdense(int64_t n, const double* A_dev, int64_t lda, double* work, dsea_op_t* out) {
+  if (!out || n < 1 || !A_dev || !work || lda < n || (n + 63) / 64 > 65535) return DSEA_ERR_ARG;
+  if (!aligned16(A_dev) || (lda % 2) != 0) return DSEA_ERR_ALIGN;   // rows are read as 16-byte pairs
+  dsea_op_s* op = new (std::nothrow) dsea_op_s;
+  if (!op) return DSEA_ERR_ARG;
+  memset(&op->d, 0, sizeof(op->d));
+  op->d.tune_tile_log2 = DSEA_TFIM_TILE_LOG2;
+  op->d.kind = OP_SYMDENSE;
+  op->d.n = n;
+  const int64_t nb = (n + 63) / 64;
+  op->d.symdense = SymDenseParams{n, lda, nb * 64, A_dev, work, (int)nb};
+  *out = op;
+  return DSEA_OK;
+}
+
 size_t dsea_op_transfer_work_bytes(int D, int d) {
   return D < 1 || d < 1 ? 0 : (size_t)2 * (size_t)d * (size_t)D * (size_t)D * sizeof(double);
 }
@@ -659,8 +680,10 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
   // optional bf16 shadow of the basis for the correction pass (see k_axpy_norm_lp)
   uint16_t* Qs = nullptr;
   int64_t lds = 0;
-  if (w.shadow && w.shadow_rows >= k && w.shadow_ld >= n && !w.geom(n).split_w) {
-    Qs = w.shadow;   // (small slabs are latency-bound, not bandwidth-bound: they keep the fp64 split kernels)
+  if (w.shadow && w.shadow_rows >= k && w.shadow_ld >= n && (!w.geom(n).split_w || n >= 32768)) {
+    // small slabs (split geometry) use the split form of the shadow pass; below 2^15 rows the basis is a few MB, the
+    // step is launch-bound and the 128-row fp64 split kernels expose more parallelism
+    Qs = w.shadow;
     lds = w.shadow_ld;
   }
   double* lp_count = w.scal + 16;
@@ -672,7 +695,7 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
       return DSEA_ERR_HIP;
     }
   }
-  const int rps = n >= 512 * 2 * 512 ? 2 : 1;
+  const int rps = g.split_w ? 0 : (n >= 512 * 2 * 512 ? 2 : 1);   // 0 = split form (small n)
   launch_dot(q0, q0, n, P, nrm2, st);
   launch_scale_store(q0, nrm2, Q, nullptr, n, st, Qs);
   const bool has_fused_tail = (op->d.kind == OP_TFIM && op->d.tfim.L_local >= 1) || op->d.kind == OP_SELL ||

@@ -56,7 +56,13 @@ struct TransferParams {
   double* T;        // d * D * D doubles of scratch, inside the caller's work buffer
   int transpose;
 };
-enum OpKind { OP_TFIM = 1, OP_CSR = 2, OP_STENCIL3 = 3, OP_SELL = 4, OP_DENSE = 5, OP_TRANSFER = 6 };
+struct SymDenseParams {
+  int64_t n, lda, npad;
+  const double* A;  // row-major, symmetric; only the upper triangle is read
+  double* work;     // nb x npad doubles of per-tile partial results
+  int nb;           // 64-row blocks
+};
+enum OpKind { OP_TFIM = 1, OP_CSR = 2, OP_STENCIL3 = 3, OP_SELL = 4, OP_DENSE = 5, OP_TRANSFER = 6, OP_SYMDENSE = 7 };
 struct OpDesc {
   OpKind kind;
   int64_t n;
@@ -68,6 +74,7 @@ struct OpDesc {
   SellParams sell;
   DenseParams dense;
   TransferParams transfer;
+  SymDenseParams symdense;
 };
 
 // how the rows of one vector are cut into wave tiles for the basis-streaming kernels

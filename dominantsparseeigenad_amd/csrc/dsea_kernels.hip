@@ -498,6 +498,108 @@ __global__ __launch_bounds__(256) void k_axpy_norm_lp(const double* __restrict__
   if (lane == 0) P[widx] = acc;
 }
 
+// Small-n ("split") form of the shadow pass: a block of W waves shares ONE tile of 512 rows (a lane owns 8 rows =
+// one 16-byte shadow load) and splits the basis vectors between its waves in chunks of four; the W partial sums are
+// combined through LDS in wave order (deterministic), wave 0 applies them.  Same premise check and fp64 fallback
+// as k_axpy_norm_lp.  BASELINE config 3 (N = 1e5, k = 300): the correction pass streams 60 MB instead of 240 MB.
+template <int W>
+__global__ __launch_bounds__(W * 64) void k_axpy_norm_lp_split(const double* __restrict__ Q, int64_t ldq,
+                                                               const uint16_t* __restrict__ Qs, int64_t lds, int i,
+                                                               int64_t n, const double* __restrict__ c, double tau2,
+                                                               double* __restrict__ r, double* __restrict__ P,
+                                                               double* __restrict__ lp_count,
+                                                               const double* __restrict__ brk) {
+  __shared__ double part[W][8][64];
+  if (broken(brk)) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t tile = blockIdx.x;
+  const int64_t row = tile * 512 + lane * 8;
+  double m = 0.0;
+  for (int b = lane; b < i; b += 64) {
+    const double v = c[b];
+    m = fmax(m, v * v);
+  }
+#pragma unroll
+  for (int sft = 32; sft >= 1; sft >>= 1) m = fmax(m, __shfl_xor(m, sft, 64));
+  const bool use_lp = m <= tau2 * c[i];
+  if (tile == 0 && threadIdx.x == 0 && lp_count) lp_count[use_lp ? 0 : 1] += 1.0;
+  const bool full = row + 8 <= n;
+  double w[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) w[e] = 0.0;
+  const int nchunks = (i + 3) / 4;
+  for (int cc = wv; cc < nchunks; cc += W) {
+    const int j0 = 4 * cc;
+    if (use_lp) {
+      uint4 h[4];
+      double cj[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        h[v] = make_uint4(0u, 0u, 0u, 0u);
+        cj[v] = 0.0;
+        if (j0 + v < i) {
+          cj[v] = c[j0 + v];
+          const uint16_t* __restrict__ qj = Qs + (int64_t)(j0 + v) * lds;
+          if (full) {
+            h[v] = ld_u4_stream(qj + row);
+          } else {
+            uint32_t t4[4] = {0u, 0u, 0u, 0u};
+            for (int e = 0; e < 8; ++e)
+              if (row + e < n) t4[e >> 1] |= (uint32_t)qj[row + e] << ((e & 1) * 16);
+            h[v] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+          }
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        w[0] = fma(cj[v], bf16lo_to_f64(h[v].x), w[0]);
+        w[1] = fma(cj[v], bf16hi_to_f64(h[v].x), w[1]);
+        w[2] = fma(cj[v], bf16lo_to_f64(h[v].y), w[2]);
+        w[3] = fma(cj[v], bf16hi_to_f64(h[v].y), w[3]);
+        w[4] = fma(cj[v], bf16lo_to_f64(h[v].z), w[4]);
+        w[5] = fma(cj[v], bf16hi_to_f64(h[v].z), w[5]);
+        w[6] = fma(cj[v], bf16lo_to_f64(h[v].w), w[6]);
+        w[7] = fma(cj[v], bf16hi_to_f64(h[v].w), w[7]);
+      }
+    } else {
+      for (int v = 0; v < 4; ++v) {
+        if (j0 + v >= i) break;
+        const double* __restrict__ qj = Q + (int64_t)(j0 + v) * ldq;
+        const double cj = c[j0 + v];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const double2 q = ld2_stream<true>(qj, row + 2 * t, n);
+          w[2 * t] = fma(cj, q.x, w[2 * t]);
+          w[2 * t + 1] = fma(cj, q.y, w[2 * t + 1]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) part[wv][e][lane] = w[e];
+  __syncthreads();
+  if (wv == 0) {
+    double acc = 0.0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      double tx = part[0][2 * t][lane], ty = part[0][2 * t + 1][lane];
+#pragma unroll
+      for (int k2 = 1; k2 < W; ++k2) {
+        tx += part[k2][2 * t][lane];
+        ty += part[k2][2 * t + 1][lane];
+      }
+      double2 rv = ld2<true>(r, row + 2 * t, n);
+      rv.x -= tx;
+      rv.y -= ty;
+      st2<true>(r, row + 2 * t, n, rv);
+      acc = fma(rv.x, rv.x, acc);
+      acc = fma(rv.y, rv.y, acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) P[tile] = acc;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // streaming elementwise kernels with a fused reduction (grid-stride, double2)
 // ------------------------------------------------------------------------------------------
@@ -1337,6 +1439,90 @@ __global__ __launch_bounds__(256) void k_spmv_stencil3(Stencil3Params p, const d
 }
 
 // ------------------------------------------------------------------------------------------
+// Dense SYMMETRIC operand (DominantSymeig, reference symeig.py:15-31 / Lanczos.py:46-49 applies torch.matmul(A, v):
+// a GEMV that streams all n^2 elements).  y = A x reading only the UPPER triangle: the matrix is cut into 64 x 64
+// tiles, tile (I, J), I <= J, is loaded once (coalesced 16-byte loads along its rows, staged in LDS) and used twice:
+//     y_I += A_IJ x_J            (row part)              y_J += A_IJ^T x_I   (column part, I < J)
+// Every tile writes its two 64-element results to their own slots of a partial buffer, P2[a][b-block]: slot
+// (J, I-block) <- row part, slot (I, J-block) <- column part -- each slot is written exactly once per call, so there
+// are no atomics and no zero-fill; k_symv_reduce adds the nb slots of a row in fixed order (deterministic), applies
+// the optional shift and leaves the x.y partials.  Bytes: n^2/2 * 8 matrix + 2 * n^2/64 * 8 partials (3 %).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_symv_upper(SymDenseParams p, const double* __restrict__ x,
+                                                    const double* __restrict__ skip) {
+  __shared__ double tileA[64][65];
+  __shared__ double xsI[64], xsJ[64];
+  if (skip && skip[0] != 0.0) return;
+  const int I = blockIdx.y, J = blockIdx.x;
+  if (J < I) return;
+  const int t = threadIdx.x;
+  const int64_t r0 = (int64_t)I * 64, c0 = (int64_t)J * 64;
+  const int c2 = t & 31;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int r = (t >> 5) + 8 * m;
+    const int64_t gr = r0 + r, gc = c0 + 2 * c2;
+    double2 v = make_double2(0.0, 0.0);
+    if (gr < p.n) {
+      const double* __restrict__ src = p.A + gr * p.lda + gc;
+      if (gc + 1 < p.n) v = *reinterpret_cast<const double2*>(src);
+      else if (gc < p.n) v.x = src[0];
+    }
+    tileA[r][2 * c2] = v.x;
+    tileA[r][2 * c2 + 1] = v.y;
+  }
+  if (t < 64) {
+    xsI[t] = (r0 + t < p.n) ? x[r0 + t] : 0.0;
+    xsJ[t] = (c0 + t < p.n) ? x[c0 + t] : 0.0;
+  }
+  __syncthreads();
+  if (I == J) {   // diagonal tile: only its upper part is data; mirror it
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const int e = t + 256 * m;
+      const int r = e >> 6, c = e & 63;
+      if (r > c) tileA[r][c] = tileA[c][r];
+    }
+    __syncthreads();
+  }
+  const int rr = t >> 2, q = t & 3;
+  double s1 = 0.0;
+#pragma unroll
+  for (int k2 = 0; k2 < 16; ++k2) s1 = fma(tileA[rr][16 * q + k2], xsJ[16 * q + k2], s1);
+  s1 += __shfl_xor(s1, 1, 64);
+  s1 += __shfl_xor(s1, 2, 64);
+  if (q == 0) p.work[(int64_t)J * p.npad + r0 + rr] = s1;
+  if (I < J) {
+    double s2 = 0.0;
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) s2 = fma(tileA[16 * q + k2][rr], xsI[16 * q + k2], s2);
+    s2 += __shfl_xor(s2, 1, 64);
+    s2 += __shfl_xor(s2, 2, 64);
+    if (q == 0) p.work[(int64_t)I * p.npad + c0 + rr] = s2;
+  }
+}
+
+// y = sum_a P2[a][:] - shift x ; partial x.y
+__global__ __launch_bounds__(256) void k_symv_reduce(SymDenseParams p, const double* __restrict__ x,
+                                                     double* __restrict__ y, const double* __restrict__ shift,
+                                                     const double* __restrict__ skip, double* __restrict__ P) {
+  __shared__ double sm4[4];
+  if (skip && skip[0] != 0.0) return;
+  const double s = shift ? shift[0] : 0.0;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * 256) {
+    double v = 0.0;
+    for (int a = 0; a < p.nb; ++a) v += p.work[(int64_t)a * p.npad + i];
+    const double xi = x[i];
+    if (shift) v = __dsub_rn(v, __dmul_rn(s, xi));
+    y[i] = v;
+    acc = fma(xi, v, acc);
+  }
+  const double tot = block_sum(acc, sm4);
+  if (P && threadIdx.x == 0) P[blockIdx.x] = tot;
+}
+
+// ------------------------------------------------------------------------------------------
 // Persistent single-launch CG for the 3-point stencil on SMALL vectors (BASELINE config 3: N = 1e5, 0.8 MB per
 // vector).  There the three launches per iteration of the streaming form cost ~13 us for ~1 us of memory
 // traffic.  Here the whole solve is ONE launch of G workgroups x 1024 threads that keep x, r, d and V in
@@ -1704,6 +1890,11 @@ void launch_axpy_norm(const TileGeom& g, const double* Q, int64_t ldq, int64_t n
 int launch_axpy_norm_lp(int64_t n, int rps, const double* Q, int64_t ldq, const uint16_t* Qs, int64_t lds, int i,
                         const double* c, double tau, double* r, double* P, double* lp_count, hipStream_t st,
                         EventPair* ev, const double* brk) {
+  if (rps == 0) {   // small-n split form: one block of 8 waves per 512-row tile
+    const int64_t nt = (n + 511) / 512;
+    KLAUNCH(ev, (k_axpy_norm_lp_split<8>), (unsigned)nt, 512, st, Q, ldq, Qs, lds, i, n, c, tau * tau, r, P, lp_count, brk);
+    return (int)nt;
+  }
   const int64_t tile = 512 * (int64_t)rps;
   int64_t ntiles = (n + tile - 1) / tile;
   if (ntiles < 1) ntiles = 1;
@@ -1853,6 +2044,14 @@ int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shif
       TfimFusedArgs fa0 = {nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
       KLAUNCH(ev, (k_spmv_sell<false>), (unsigned)nb, 256, st, p, x, y, shift, skip, P, fa0);
       return (int)nb;
+    }
+    case OP_SYMDENSE: {
+      const SymDenseParams& p = op.symdense;
+      KLAUNCH(ev, k_symv_upper, dim3(p.nb, p.nb), 256, st, p, x, skip);
+      int64_t nbr = (p.n + 255) / 256;
+      if (nbr > DSEA_MAX_EW_BLOCKS) nbr = DSEA_MAX_EW_BLOCKS;
+      hipLaunchKernelGGL(k_symv_reduce, dim3((unsigned)nbr), dim3(256), 0, st, p, x, y, shift, skip, P);
+      return (int)nbr;
     }
     case OP_DENSE:
     case OP_TRANSFER: {

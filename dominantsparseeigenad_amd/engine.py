@@ -21,6 +21,10 @@ F64 = torch.float64
 # dsea_ws_set_shadow).  SHADOW_TAU is the device-side premise bound max|c_j| <= tau ||r||.
 USE_SHADOW = True
 SHADOW_TAU = 1e-12
+# Dense tensors handed to the SYMMETRIC primitives (DominantSymeig, CGSubspace) are applied by the hand-written
+# upper-triangle mat-vec (operators.SymmetricDenseOperator): only the upper triangle of the tensor is read.  Set to
+# False to apply them with torch.matmul (rocBLAS GEMV on the full matrix) instead.
+DENSE_SYMMETRIC_KERNEL = True
 last_lp_steps = (0, 0)
 last_break = 0
 

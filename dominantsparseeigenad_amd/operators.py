@@ -338,6 +338,44 @@ class DenseOperator:
     __call__ = matvec
 
 
+class SymmetricDenseOperator:
+    """A dense real SYMMETRIC matrix as a native operand of the symmetric primitives (reference symeig.py:15-31,
+    CG.py:43-71 apply ``torch.matmul(A, v)``): hand-written HIP mat-vec that reads only the UPPER triangle, each
+    64 x 64 tile once for both its row and its column block -- half the bytes of a GEMV -- and lets the dense
+    primitive run its Lanczos / CG loops inside libdsea like the sparse ones (no Python per iteration)."""
+
+    _native_methods = ("__call__", "matvec")
+
+    def __init__(self, A):
+        if A.device.type != "cuda" or A.dim() != 2 or A.shape[0] != A.shape[1]:
+            raise ValueError("SymmetricDenseOperator takes a square CUDA matrix")
+        self.n = int(A.shape[0])
+        A = A.detach().to(F64)
+        if self.n % 2:   # rows are read as 16-byte pairs: pad the leading dimension to an even number
+            Ap = torch.zeros((self.n, self.n + 1), dtype=F64, device=A.device)
+            Ap[:, : self.n] = A
+            self.A, lda = Ap, self.n + 1
+        else:
+            self.A, lda = A.contiguous(), self.n
+        self.shape = (self.n, self.n)
+        self.device = self.A.device
+        lib = _lib.load()
+        self._work = torch.empty(lib.dsea_op_symdense_work_bytes(self.n) // 8, dtype=F64, device=self.device)
+        raw = c_void_p()
+        check(lib.dsea_op_create_symdense(self.n, c_void_p(self.A.data_ptr()), lda, c_void_p(self._work.data_ptr()),
+                                          byref(raw)), "dsea_op_create_symdense")
+        self._H = _NativeView(_Handle(raw, self.n, (self.A, self._work)))
+
+    @property
+    def handle(self):
+        return self._H.handle
+
+    def matvec(self, v):
+        return engine.spmv(self._H, v)
+
+    __call__ = matvec
+
+
 class TransferOperator:
     """MPS transfer matrix of a real rank-3 tensor A (d, D, D) acting on D x D matrices stored as D^2-vectors
     (reference examples/TFIM_vumps/general.py:59-66):

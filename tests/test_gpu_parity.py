@@ -359,14 +359,16 @@ def test_adjoint_tight_eps_headline_size(monkeypatch):
 
 
 # ------------------------------------------------------------------ bf16 shadow of the basis (correction pass)
-def test_shadow_basis_pass_is_exact_to_working_precision(monkeypatch):
+@pytest.mark.parametrize("L", [18, 16])
+def test_shadow_basis_pass_is_exact_to_working_precision(monkeypatch, L):
     """The correction pass may stream a bf16 shadow of the basis (include/dsea.h, dsea_ws_set_shadow).
     Compared with the all-fp64 run: the well-conditioned outputs -- extreme Ritz pair, the leading part of
     the tridiagonal, orthonormality of the basis -- agree to rounding level; every step takes the shadow path
     on a healthy run; tau = 0 forces the in-kernel fp64 fallback on every step.  (Late Lanczos coefficients
     are ill-conditioned functions of the data -- any two rounding-different fp64 runs disagree there too --
-    so they are not compared.)  n = 2^18: above the small-n regime, where the split kernels keep the fp64 basis."""
-    L, k = 18, 120
+    so they are not compared.)  n = 2^18: wave-per-tile kernels; n = 2^16: the small-n split form of the shadow pass
+    (k_axpy_norm_lp_split)."""
+    k = 120
     n = 1 << L
     g = torch.tensor([1.0], dtype=F64, device=dev())
     op = TFIMOperator(L, dev(), g=g)
