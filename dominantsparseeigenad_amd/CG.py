@@ -47,8 +47,8 @@ def _solve(A, b, initialx, sparse, shift=None, eps=None, maxiter=None):
             raise NotImplementedError("the HIP CG kernels are fp64; got %s" % b.dtype)
         native = engine.native_of(A) if sparse else None
         if not sparse and engine.DENSE_SYMMETRIC_KERNEL:
-            from .operators import SymmetricDenseOperator
-            native = SymmetricDenseOperator(A)        # upper-triangle mat-vec, loop inside the library
+            from .operators import dense_symmetric_operand
+            native = dense_symmetric_operand(A)        # upper-triangle mat-vec, loop inside the library
         if native is not None:
             return engine.cg(b, initialx, native=native, shift=shift, eps=eps, maxiter=cap)
         amap = A if sparse else (lambda v: torch.matmul(A, v))

@@ -62,8 +62,8 @@ def _lanczos_core(A, k, device, sparse, dim, q0, arena=False):
         if not sparse and engine.DENSE_SYMMETRIC_KERNEL:
             # dense symmetric tensor (Lanczos.py:46-49): the hand-written upper-triangle mat-vec as a native operand,
             # so the whole loop runs inside the library
-            from .operators import SymmetricDenseOperator
-            native = SymmetricDenseOperator(A)
+            from .operators import dense_symmetric_operand
+            native = dense_symmetric_operand(A)
         if native is not None:
             Q, ldq, alphas, betas = engine.lanczos(A, k, n, device, q0, native=native, arena=arena)
         else:

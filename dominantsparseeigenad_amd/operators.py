@@ -376,6 +376,16 @@ class SymmetricDenseOperator:
     __call__ = matvec
 
 
+def dense_symmetric_operand(A):
+    """native operand for a dense symmetric tensor: the upper-triangle kernel where it wins (measured on MI355X:
+    n = 8192: 115 vs 124 us, n = 16384: 400 vs 439 us for the rocBLAS GEMV), the library's rocBLAS GEMV operand below
+    (n = 4096: 39 vs 21 us -- two launches and 64 x 64 tiles do not fill the chip there).  Either way the Lanczos / CG
+    loops run inside libdsea."""
+    if A.shape[0] >= 8192:
+        return SymmetricDenseOperator(A)
+    return DenseOperator(A)
+
+
 class TransferOperator:
     """MPS transfer matrix of a real rank-3 tensor A (d, D, D) acting on D x D matrices stored as D^2-vectors
     (reference examples/TFIM_vumps/general.py:59-66):
