@@ -33,7 +33,11 @@ def _resolve(A, device, sparse, dim):
 
 
 def _lanczos_core(A, k, device, sparse, dim, q0, arena=False):
+    global WARM_START
     device = torch.device(device)
+    warm = None
+    if q0 is None and WARM_START is not None:
+        warm, WARM_START = WARM_START, None
     part = engine.native_of(A) if sparse else None
     if part is not None and getattr(part, "partitioned", False):
         # row-partitioned operator (partitioned.py): ``dim`` is the global dimension, every vector is this rank's
@@ -41,12 +45,16 @@ def _lanczos_core(A, k, device, sparse, dim, q0, arena=False):
         nloc, dev = part.nloc, part.device
         if q0 is None:
             q0 = torch.randn(nloc, dtype=torch.float64, device=dev)
+            if warm is not None:
+                q0 = warm.detach().to(device=dev, dtype=torch.float64)
         torch.randn(nloc, dtype=torch.float64, device=dev)
         Q, ldq, alphas, betas = part.lanczos(k, q0, arena=arena)
         return (part, Q, ldq, nloc, alphas, betas, torch.float64)
     n, dtype, amap = _resolve(A, device, sparse, dim)
     if q0 is None:
         q0 = torch.randn(n, dtype=dtype, device=device)        # Lanczos.py:52
+        if warm is not None:
+            q0 = warm.detach().to(device=device, dtype=dtype)
     torch.randn(n, dtype=dtype, device=device)                 # Lanczos.py:59 (value multiplies beta = 0)
     if device.type == "cuda":
         if dtype not in (torch.float64, torch.float32):
@@ -84,6 +92,12 @@ def Lanczos(A, k, device=torch.device("cpu"), *, sparse=False, dim=None, q0=None
     return Qk.to(dtype), T.to(dtype)
 
 
+# Warm start (an extension the reference lacks): when set to a tensor, the NEXT Lanczos run takes it as
+# its start vector instead of the ``torch.randn`` draw of Lanczos.py:52 (the draw is still made, so the RNG advances
+# as in the reference) and the attribute is cleared.  In a parameter sweep the previous point's eigenvector is an
+# excellent start: far fewer Lanczos vectors reach the same residual (examples/TFIM/sweep.py --warm).
+WARM_START = None
+
 # Module-level default of the ``reorth`` extension below (the autograd primitives' ``apply`` signatures are fixed by
 # the reference API, so they read it here): "full" = the reference's full re-orthogonalisation with a stored basis.
 REORTH_DEFAULT = "full"
@@ -105,10 +119,13 @@ def symeigLanczos(A, k, device=torch.device("cpu"), extreme="both", *, sparse=Fa
         native = engine.native_of(A) if sparse else None
         if native is None or getattr(native, "partitioned", False) or torch.device(device).type != "cuda":
             raise NotImplementedError("reorth='none' (basis-free two-pass Lanczos) needs a native single-GPU operator")
+        global WARM_START
         n = int(dim)
         dev = torch.device(device)
         if q0 is None:
             q0 = torch.randn(n, dtype=torch.float64, device=dev)           # Lanczos.py:52
+            if WARM_START is not None:
+                q0, WARM_START = WARM_START.detach().to(device=dev, dtype=torch.float64), None
         torch.randn(n, dtype=torch.float64, device=dev)                    # Lanczos.py:59: same RNG consumption
         out = []
         for val, vec in engine.lanczos_basisfree(native, k, n, dev, q0, extreme):

@@ -45,8 +45,8 @@ def _dominant_pair(A, AT, k, which):
 def _dominant_pair_device(opA, opAT, n, k, which, device):
     """opA / opAT: native operators (``.handle``) or mat-vec callables on device vectors"""
     from . import krylov
-    lam, r = krylov.arnoldi_dominant(opA, n, k, device, which)
-    lam_l, l = krylov.arnoldi_dominant(opAT, n, k, device, which)
+    lam, r, lam_l, l = _two_sides(lambda: krylov.arnoldi_dominant(opA, n, k, device, which),
+                                  lambda: krylov.arnoldi_dominant(opAT, n, k, device, which), device)
     if abs(lam - lam_l) > 1e-8 * max(abs(lam), 1e-300):
         raise RuntimeError("left / right eigenvalues disagree: %.15e vs %.15e" % (lam, lam_l))
     l = l / torch.dot(l, r)
@@ -55,11 +55,56 @@ def _dominant_pair_device(opA, opAT, n, k, which, device):
 
 def _adjoint_solves_device(opA, opAT, lam, l, r, g_l, g_r):
     from . import krylov
-    rhs = g_l - r * torch.dot(l, g_l)                                            # eig.py:53
-    lam_l = krylov.gmres(opA, rhs, shift=lam, rtol=_GMRES_TOL, atol=_GMRES_TOL)  # (A - lam I) x = rhs, eig.py:54
-    rhs = g_r - l * torch.dot(r, g_r)                                            # eig.py:56
-    lam_r = krylov.gmres(opAT, rhs, shift=lam, rtol=_GMRES_TOL, atol=_GMRES_TOL)
+    rhs_l = g_l - r * torch.dot(l, g_l)                                          # eig.py:53
+    rhs_r = g_r - l * torch.dot(r, g_r)                                          # eig.py:56
+    lam_l, lam_r = _two_sides(
+        lambda: (krylov.gmres(opA, rhs_l, shift=lam, rtol=_GMRES_TOL, atol=_GMRES_TOL),),    # eig.py:54
+        lambda: (krylov.gmres(opAT, rhs_r, shift=lam, rtol=_GMRES_TOL, atol=_GMRES_TOL),), rhs_l.device)
     return lam_l, lam_r
+
+
+CONCURRENT_SIDES = True
+
+
+def _two_sides(right, left, device):
+    """The right- and left-eigenvector problems (eig.py:29-30; the two adjoint solves, eig.py:54,57) are independent:
+    the second one runs on a worker thread with its own HIP stream, so that one side's host work -- the small
+    Hessenberg eigen-solve of a Krylov-Schur cycle, the per-cycle state read of GMRES -- overlaps the other side's
+    device loop.  Workspaces and the basis arena are per stream (engine.Workspace / BasisArena), ctypes and LAPACK
+    release the GIL.  Returns the concatenated results (right..., left...)."""
+    if not CONCURRENT_SIDES or torch.device(device).type != "cuda":
+        return tuple(right()) + tuple(left())
+    import threading
+    main = torch.cuda.current_stream(device)
+    side = torch.cuda.Stream(device=device)
+    ready = torch.cuda.Event()
+    ready.record(main)
+    box = {}
+
+    def work():
+        try:
+            with torch.cuda.device(device), torch.cuda.stream(side):
+                side.wait_event(ready)          # the operands were produced on the caller's stream
+                box["out"] = tuple(left())
+                done = torch.cuda.Event()
+                done.record(side)
+                box["done"] = done
+        except BaseException as exc:            # noqa: BLE001 -- re-raised on the caller's thread
+            box["exc"] = exc
+
+    th = threading.Thread(target=work)
+    th.start()
+    try:
+        out_r = tuple(right())
+    finally:
+        th.join()
+    if "exc" in box:
+        raise box["exc"]
+    main.wait_event(box["done"])
+    for t in box["out"]:
+        if torch.is_tensor(t):
+            t.record_stream(main)
+    return out_r + box["out"]
 
 
 class DominantEig(torch.autograd.Function):

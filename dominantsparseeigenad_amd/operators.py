@@ -295,6 +295,12 @@ class CSROperator:
                    torch.from_numpy(M.data.astype("float64")).to(device), M.shape[0], layout=layout)
 
     @classmethod
+    def from_npz(cls, path, device="cuda", layout="sell"):
+        """on-disk sparse symmetric operand: a file written by ``scipy.sparse.save_npz`` (any scipy sparse format)"""
+        import scipy.sparse as sp
+        return cls.from_scipy(sp.load_npz(path), device, layout=layout)
+
+    @classmethod
     def from_dense(cls, A, device="cuda", layout="sell"):
         import scipy.sparse as sp
         return cls.from_scipy(sp.csr_matrix(A.detach().cpu().numpy()), device, layout=layout)

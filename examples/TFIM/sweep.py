@@ -28,7 +28,11 @@ def main():
     ap.add_argument("--points", type=int, default=100)
     ap.add_argument("--data", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "datas"))
     ap.add_argument("--device", default="cuda")
+    ap.add_argument("--warm", type=int, default=0,
+                    help="Lanczos vectors per forward pass from the second coupling on, with the previous coupling's "
+                         "eigenvector as start vector (Lanczos.WARM_START; an extension the reference lacks)")
     args = ap.parse_args()
+    import DominantSparseEigenAD.Lanczos as LZ
     curE = np.load(os.path.join(args.data, "E0_N_%d.npz" % args.N))
     curC = np.load(os.path.join(args.data, "chiF_N_%d.npz" % args.N))
     dev = torch.device(args.device)
@@ -36,14 +40,22 @@ def main():
     idxs = np.linspace(0, len(curE["gs"]) - 1, args.points).round().astype(int)
     dev_E = dev_d = dev_d2 = dev_c = 0.0
     torch.manual_seed(0)
+    prev = None
     if dev.type == "cuda":
         torch.cuda.synchronize()
     t0 = time.time()
     for idx in idxs:
         g = float(curE["gs"][idx])
         model.g = torch.tensor([g], dtype=torch.float64, device=dev, requires_grad=True)
-        e, de, d2e = E0_sparseAD(model, args.k)
-        _, _, c = chiF_sparseAD(model, args.k)
+        k = args.k
+        if args.warm and prev is not None:
+            k = args.warm
+            LZ.WARM_START = prev
+        e, de, d2e = E0_sparseAD(model, k)
+        if args.warm and prev is not None:
+            LZ.WARM_START = prev
+        _, psi, c = chiF_sparseAD(model, k)
+        prev = psi.detach()
         dev_E = max(dev_E, abs(e - curE["E0s"][idx]) / abs(curE["E0s"][idx]))
         dev_d = max(dev_d, abs(de - curE["dE0s"][idx]) / abs(curE["dE0s"][idx]))
         dev_d2 = max(dev_d2, abs(d2e - curE["d2E0s"][idx]) / abs(curE["d2E0s"][idx]))
