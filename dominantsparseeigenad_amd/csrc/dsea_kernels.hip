@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256) void k_shift_dot(const double* __restrict__ x,
     acc = fma(a.y, b.y, acc);
   }
   double t = block_sum(acc, sm4);
-  if (threadIdx.x == 0) P[blockIdx.x] = t;
+  if (P && threadIdx.x == 0) P[blockIdx.x] = t;
 }
 
 // y += (a_host * a_dev) x
@@ -2059,10 +2059,8 @@ int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shif
       if (blas_apply(op, x, y, st) != 0) return -1;
       if (!shift && !P) return 0;
       const int nbk = ew_blocks(op.n);
-      double* Pk = P ? P : nullptr;
-      if (!Pk) return -1;   // a shift without a partial buffer: callers always provide ws
-      hipLaunchKernelGGL(k_shift_dot, dim3(nbk), dim3(256), 0, st, x, y, shift, skip, op.n, Pk);
-      return nbk;
+      hipLaunchKernelGGL(k_shift_dot, dim3(nbk), dim3(256), 0, st, x, y, shift, skip, op.n, P);   // P may be null
+      return P ? nbk : 0;
     }
     case OP_STENCIL3: {
       const Stencil3Params& p = op.st3;
