@@ -39,8 +39,10 @@ def _solve(A, b, initialx, sparse, shift=None, eps=None, maxiter=None):
     cap = n if maxiter is None else int(maxiter)
     if b.is_cuda:
         if b.dtype == torch.float32 and not sparse:
-            # dense fp32 system: promoted to fp64 for the fp64 kernels, result rounded back (see Lanczos.py)
-            x = _solve(A.to(torch.float64), b.to(torch.float64), initialx.to(torch.float64), False,
+            # dense fp32 system: vectors promoted to fp64 for the fp64 kernels, result rounded back (see Lanczos.py);
+            # the matrix stays fp32 when it goes to the native symmetric operand
+            A_use = A if engine.DENSE_SYMMETRIC_KERNEL else A.to(torch.float64)
+            x = _solve(A_use, b.to(torch.float64), initialx.to(torch.float64), False,
                        None if shift is None else shift.to(torch.float64), eps, maxiter)
             return x.to(torch.float32)
         if b.dtype != torch.float64:
@@ -51,7 +53,7 @@ def _solve(A, b, initialx, sparse, shift=None, eps=None, maxiter=None):
             native = dense_symmetric_operand(A)        # upper-triangle mat-vec, loop inside the library
         if native is not None:
             return engine.cg(b, initialx, native=native, shift=shift, eps=eps, maxiter=cap)
-        amap = A if sparse else (lambda v: torch.matmul(A, v))
+        amap = A if sparse else (lambda v: torch.matmul(A.to(v.dtype), v))
         return engine.cg(b, initialx, callable_A=amap, shift=shift, eps=eps, maxiter=cap)
     base = A if sparse else (lambda v: torch.matmul(A, v))
     amap = base if shift is None else (lambda v: base(v) - shift * v)   # CG.py:120

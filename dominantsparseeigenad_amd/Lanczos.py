@@ -63,8 +63,10 @@ def _lanczos_core(A, k, device, sparse, dim, q0, arena=False):
             # dense fp32 input (reference Lanczos.py:47: the dense path follows A.dtype): the kernels are fp64, so
             # the loop runs in fp64 on promoted operands and the outputs are rounded back to fp32 by the callers --
             # at least as accurate as fp32 arithmetic, same dtypes in and out
-            A64 = A.to(torch.float64)
-            amap = lambda v: torch.matmul(A64, v)              # noqa: E731
+            # The MATRIX itself is not promoted when it goes to the native symmetric operand (read as fp32).
+            if not engine.DENSE_SYMMETRIC_KERNEL:
+                A64 = A.to(torch.float64)
+                amap = lambda v: torch.matmul(A64, v)          # noqa: E731
             q0 = q0.to(torch.float64)
         native = engine.native_of(A) if sparse else None
         if not sparse and engine.DENSE_SYMMETRIC_KERNEL:

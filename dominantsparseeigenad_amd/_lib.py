@@ -47,7 +47,7 @@ _SIGNATURES = {
     "dsea_op_create_stencil3": (c_int, [c_int64, c_double, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
     "dsea_op_create_dense": (c_int, [c_int64, c_void_p, c_int64, c_int, POINTER(c_void_p)]),
     "dsea_op_symdense_work_bytes": (c_size_t, [c_int64]),
-    "dsea_op_create_symdense": (c_int, [c_int64, c_void_p, c_int64, c_void_p, POINTER(c_void_p)]),
+    "dsea_op_create_symdense": (c_int, [c_int64, c_void_p, c_int, c_int64, c_void_p, POINTER(c_void_p)]),
     "dsea_op_transfer_work_bytes": (c_size_t, [c_int, c_int]),
     "dsea_op_create_transfer": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, POINTER(c_void_p)]),
     "dsea_op_destroy": (c_int, [c_void_p]),

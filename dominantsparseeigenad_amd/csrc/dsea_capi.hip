@@ -357,9 +357,10 @@ size_t dsea_op_symdense_work_bytes(int64_t n) {
   return (size_t)nb * (size_t)(nb * 64) * sizeof(double);
 }
 
-int dsea_op_create_symdense(int64_t n, const double* A_dev, int64_t lda, double* work, dsea_op_t* out) {
-  if (!out || n < 1 || !A_dev || !work || lda < n || (n + 63) / 64 > 65535) return DSEA_ERR_ARG;
-  if (!aligned16(A_dev) || (lda % 2) != 0) return DSEA_ERR_ALIGN;   // rows are read as 16-byte pairs
+int dsea_op_create_symdense(int64_t n, const void* A_dev, int elem_bytes, int64_t lda, double* work, dsea_op_t* out) {
+  if (!out || n < 1 || !A_dev || !work || lda < n || (n + 63) / 64 > 65535 || (elem_bytes != 8 && elem_bytes != 4))
+    return DSEA_ERR_ARG;
+  if (!aligned16(A_dev) || (lda % 2) != 0) return DSEA_ERR_ALIGN;   // rows are read as element pairs
   dsea_op_s* op = new (std::nothrow) dsea_op_s;
   if (!op) return DSEA_ERR_ARG;
   memset(&op->d, 0, sizeof(op->d));
@@ -367,7 +368,7 @@ int dsea_op_create_symdense(int64_t n, const double* A_dev, int64_t lda, double*
   op->d.kind = OP_SYMDENSE;
   op->d.n = n;
   const int64_t nb = (n + 63) / 64;
-  op->d.symdense = SymDenseParams{n, lda, nb * 64, A_dev, work, (int)nb};
+  op->d.symdense = SymDenseParams{n, lda, nb * 64, A_dev, work, (int)nb, elem_bytes};
   *out = op;
   return DSEA_OK;
 }

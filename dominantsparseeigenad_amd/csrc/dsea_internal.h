@@ -58,9 +58,10 @@ struct TransferParams {
 };
 struct SymDenseParams {
   int64_t n, lda, npad;
-  const double* A;  // row-major, symmetric; only the upper triangle is read
+  const void* A;    // row-major, symmetric, fp64 or fp32 (elem); only the upper triangle is read
   double* work;     // nb x npad doubles of per-tile partial results
   int nb;           // 64-row blocks
+  int elem;         // bytes per matrix element: 8 or 4
 };
 enum OpKind { OP_TFIM = 1, OP_CSR = 2, OP_STENCIL3 = 3, OP_SELL = 4, OP_DENSE = 5, OP_TRANSFER = 6, OP_SYMDENSE = 7 };
 struct OpDesc {

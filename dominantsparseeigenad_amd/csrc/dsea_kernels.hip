@@ -14,6 +14,8 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "dsea_internal.h"
 #include "dsea_device.h"
 
@@ -1448,8 +1450,13 @@ __global__ __launch_bounds__(256) void k_spmv_stencil3(Stencil3Params p, const d
 // are no atomics and no zero-fill; k_symv_reduce adds the nb slots of a row in fixed order (deterministic), applies
 // the optional shift and leaves the x.y partials.  Bytes: n^2/2 * 8 matrix + 2 * n^2/64 * 8 partials (3 %).
 // ------------------------------------------------------------------------------------------
+// T = double or float: the MATRIX may be stored in fp32 (reference Lanczos.py:47: the dense path follows A.dtype);
+// it is widened on load, vectors and all arithmetic stay fp64 -- no promoted fp64 copy of the matrix is ever made.
+template <typename T>
 __global__ __launch_bounds__(256) void k_symv_upper(SymDenseParams p, const double* __restrict__ x,
                                                     const double* __restrict__ skip) {
+  typedef typename std::conditional<sizeof(T) == 8, double2, float2>::type pair_t;
+  const T* __restrict__ Am = static_cast<const T*>(p.A);
   __shared__ double tileA[64][65];
   __shared__ double xsI[64], xsJ[64];
   if (skip && skip[0] != 0.0) return;
@@ -1462,14 +1469,19 @@ __global__ __launch_bounds__(256) void k_symv_upper(SymDenseParams p, const doub
   for (int m = 0; m < 8; ++m) {
     const int r = (t >> 5) + 8 * m;
     const int64_t gr = r0 + r, gc = c0 + 2 * c2;
-    double2 v = make_double2(0.0, 0.0);
+    double vx = 0.0, vy = 0.0;
     if (gr < p.n) {
-      const double* __restrict__ src = p.A + gr * p.lda + gc;
-      if (gc + 1 < p.n) v = *reinterpret_cast<const double2*>(src);
-      else if (gc < p.n) v.x = src[0];
+      const T* __restrict__ src = Am + gr * p.lda + gc;
+      if (gc + 1 < p.n) {
+        const pair_t pv = *reinterpret_cast<const pair_t*>(src);
+        vx = (double)pv.x;
+        vy = (double)pv.y;
+      } else if (gc < p.n) {
+        vx = (double)src[0];
+      }
     }
-    tileA[r][2 * c2] = v.x;
-    tileA[r][2 * c2 + 1] = v.y;
+    tileA[r][2 * c2] = vx;
+    tileA[r][2 * c2 + 1] = vy;
   }
   if (t < 64) {
     xsI[t] = (r0 + t < p.n) ? x[r0 + t] : 0.0;
@@ -2047,7 +2059,10 @@ int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shif
     }
     case OP_SYMDENSE: {
       const SymDenseParams& p = op.symdense;
-      KLAUNCH(ev, k_symv_upper, dim3(p.nb, p.nb), 256, st, p, x, skip);
+      if (p.elem == 4)
+        KLAUNCH(ev, k_symv_upper<float>, dim3(p.nb, p.nb), 256, st, p, x, skip);
+      else
+        KLAUNCH(ev, k_symv_upper<double>, dim3(p.nb, p.nb), 256, st, p, x, skip);
       int64_t nbr = (p.n + 255) / 256;
       if (nbr > DSEA_MAX_EW_BLOCKS) nbr = DSEA_MAX_EW_BLOCKS;
       hipLaunchKernelGGL(k_symv_reduce, dim3((unsigned)nbr), dim3(256), 0, st, p, x, y, shift, skip, P);

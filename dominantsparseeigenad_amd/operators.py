@@ -356,20 +356,24 @@ class SymmetricDenseOperator:
         if A.device.type != "cuda" or A.dim() != 2 or A.shape[0] != A.shape[1]:
             raise ValueError("SymmetricDenseOperator takes a square CUDA matrix")
         self.n = int(A.shape[0])
-        A = A.detach().to(F64)
-        if self.n % 2:   # rows are read as 16-byte pairs: pad the leading dimension to an even number
-            Ap = torch.zeros((self.n, self.n + 1), dtype=F64, device=A.device)
+        A = A.detach()
+        if A.dtype not in (F64, torch.float32):
+            A = A.to(F64)
+        if self.n % 2:   # rows are read as element pairs: pad the leading dimension to an even number
+            Ap = torch.zeros((self.n, self.n + 1), dtype=A.dtype, device=A.device)
             Ap[:, : self.n] = A
             self.A, lda = Ap, self.n + 1
         else:
             self.A, lda = A.contiguous(), self.n
+        if self.A.data_ptr() % 16:
+            self.A = self.A.clone()
         self.shape = (self.n, self.n)
         self.device = self.A.device
         lib = _lib.load()
         self._work = torch.empty(lib.dsea_op_symdense_work_bytes(self.n) // 8, dtype=F64, device=self.device)
         raw = c_void_p()
-        check(lib.dsea_op_create_symdense(self.n, c_void_p(self.A.data_ptr()), lda, c_void_p(self._work.data_ptr()),
-                                          byref(raw)), "dsea_op_create_symdense")
+        check(lib.dsea_op_create_symdense(self.n, c_void_p(self.A.data_ptr()), self.A.element_size(), lda,
+                                          c_void_p(self._work.data_ptr()), byref(raw)), "dsea_op_create_symdense")
         self._H = _NativeView(_Handle(raw, self.n, (self.A, self._work)))
 
     @property
@@ -387,8 +391,8 @@ def dense_symmetric_operand(A):
     n = 8192: 115 vs 124 us, n = 16384: 400 vs 439 us for the rocBLAS GEMV), the library's rocBLAS GEMV operand below
     (n = 4096: 39 vs 21 us -- two launches and 64 x 64 tiles do not fill the chip there).  Either way the Lanczos / CG
     loops run inside libdsea."""
-    if A.shape[0] >= 8192:
-        return SymmetricDenseOperator(A)
+    if A.shape[0] >= 8192 or (A.dtype == torch.float32 and A.shape[0] >= 2048):
+        return SymmetricDenseOperator(A)      # fp32 matrices are read as fp32: no promoted copy (Lanczos.py:47)
     return DenseOperator(A)
 
 

@@ -586,7 +586,9 @@ class PartitionedTFIMOperator(PartitionedOperator):
             token = self.comm.start_flip_exchange(be, S.r_send, self._xT, self._zT, self._z)
             premise_ok = True
             if i >= 1:
-                be.plz_dots(S.Q, S.ldq, n, i, S.r, S.zero, None, S.r, S.c)    # alpha = 0: r stays, c = Q^T r, c[i] = r.r
+                # alpha = 0: r is rewritten with its own values (read from the snapshot copy, so that input and
+                # output of the kernel do not alias), c = Q^T r, c[i] = r.r
+                be.plz_dots(S.Q, S.ldq, n, i, S.r_send, S.zero, None, S.r, S.c)
                 self.comm.allreduce(S.c[:i + 1])
                 tau = _engine_mod.SHADOW_TAU
                 premise_ok = bool((S.c[:i].abs().max() <= tau * S.c[i].sqrt()).item())

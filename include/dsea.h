@@ -147,9 +147,11 @@ int dsea_op_create_dense(int64_t n, const double *A_dev, int64_t lda, int transp
 /* dense SYMMETRIC operand (reference symeig.py:15-31 DominantSymeig; Lanczos.py:46-49 applies torch.matmul(A, v)):
  * hand-written mat-vec that reads only the UPPER triangle of the row-major matrix -- every 64 x 64 tile is loaded
  * once and used for both its row block and its column block (half the bytes of a GEMV; deterministic, no atomics).
+ * The matrix may be fp64 (elem_bytes = 8) or fp32 (elem_bytes = 4: the reference's dense path follows A.dtype,
+ * Lanczos.py:47) -- fp32 elements are widened on load, vectors and arithmetic stay fp64, no promoted copy is made.
  * `work`: caller-owned scratch of dsea_op_symdense_work_bytes(n) (per-tile partial results, n^2/8 bytes).  lda even. */
 size_t dsea_op_symdense_work_bytes(int64_t n);
-int dsea_op_create_symdense(int64_t n, const double *A_dev, int64_t lda, double *work, dsea_op_t *out);
+int dsea_op_create_symdense(int64_t n, const void *A_dev, int elem_bytes, int64_t lda, double *work, dsea_op_t *out);
 size_t dsea_op_transfer_work_bytes(int D, int d);
 int dsea_op_create_transfer(int D, int d, const double *A_dev, int transpose, double *work, void *stream,
                             dsea_op_t *out);

@@ -173,6 +173,19 @@ def test_symmetric_dense_matvec_reads_upper_triangle_only(n):
     assert float((ys - (ref - 0.37 * x)).abs().max()) <= 1e-12 * max(float(ref.abs().max()), 1.0)
 
 
+def test_symmetric_matvec_reads_fp32_matrices_without_promotion():
+    from dominantsparseeigenad_amd.operators import SymmetricDenseOperator, dense_symmetric_operand
+    n = 2500
+    rng = np.random.RandomState(1)
+    M = rng.randn(n, n).astype(np.float32)
+    A = torch.from_numpy(M + M.T).to(dev())
+    x = torch.from_numpy(rng.randn(n)).to(dev())
+    op = dense_symmetric_operand(A)
+    assert isinstance(op, SymmetricDenseOperator) and op.A.dtype == torch.float32       # the matrix stays fp32
+    ref = A.double() @ x
+    assert float((op(x) - ref).abs().max()) <= 1e-12 * float(ref.abs().max())          # fp64 arithmetic on fp32 data
+
+
 def test_dense_primitive_runs_native_loops_and_matches_gemv_path(monkeypatch):
     """DominantSymeig on a dense CUDA tensor: native in-library loops on the upper-triangle operator vs the generic
     path with torch.matmul (rocBLAS GEMV) as mat-vec"""
