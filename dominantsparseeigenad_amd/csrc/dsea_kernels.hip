@@ -1452,6 +1452,9 @@ __global__ __launch_bounds__(256) void k_spmv_stencil3(Stencil3Params p, const d
 // ------------------------------------------------------------------------------------------
 // T = double or float: the MATRIX may be stored in fp32 (reference Lanczos.py:47: the dense path follows A.dtype);
 // it is widened on load, vectors and all arithmetic stay fp64 -- no promoted fp64 copy of the matrix is ever made.
+// (Two row-streaming variants without the LDS tile -- a block owning 64 rows x 512 columns, waves streaming 16 rows
+//  each, 1-2 KB contiguous runs -- were measured at 1.5-2.4 TB/s, i.e. SLOWER than this one-tile-per-block form:
+//  many small independent blocks keep more loads in flight than a few long-running ones.)
 template <typename T>
 __global__ __launch_bounds__(256) void k_symv_upper(SymDenseParams p, const double* __restrict__ x,
                                                     const double* __restrict__ skip) {
@@ -1514,22 +1517,41 @@ __global__ __launch_bounds__(256) void k_symv_upper(SymDenseParams p, const doub
   }
 }
 
-// y = sum_a P2[a][:] - shift x ; partial x.y
+// y = sum_a P2[a][:] - shift x ; partial x.y.  One block per 64-row block-row: lane = row, the four waves split the
+// nb slots (independent loads, four accumulators each: the slot reads are pipelined instead of forming one serial
+// chain) and are combined in fixed order through LDS.
 __global__ __launch_bounds__(256) void k_symv_reduce(SymDenseParams p, const double* __restrict__ x,
                                                      double* __restrict__ y, const double* __restrict__ shift,
                                                      const double* __restrict__ skip, double* __restrict__ P) {
+  __shared__ double part[4][64];
   __shared__ double sm4[4];
   if (skip && skip[0] != 0.0) return;
   const double s = shift ? shift[0] : 0.0;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double acc = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * 256) {
-    double v = 0.0;
-    for (int a = 0; a < p.nb; ++a) v += p.work[(int64_t)a * p.npad + i];
-    const double xi = x[i];
-    if (shift) v = __dsub_rn(v, __dmul_rn(s, xi));
-    y[i] = v;
-    acc = fma(xi, v, acc);
+  for (int Ib = blockIdx.x; Ib < p.nb; Ib += gridDim.x) {
+    const int64_t i = (int64_t)Ib * 64 + lane;
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+    int a = wv;
+    for (; a + 12 < p.nb; a += 16) {
+      v0 += p.work[(int64_t)a * p.npad + i];
+      v1 += p.work[(int64_t)(a + 4) * p.npad + i];
+      v2 += p.work[(int64_t)(a + 8) * p.npad + i];
+      v3 += p.work[(int64_t)(a + 12) * p.npad + i];
+    }
+    for (; a < p.nb; a += 4) v0 += p.work[(int64_t)a * p.npad + i];
+    __syncthreads();
+    part[wv][lane] = (v0 + v1) + (v2 + v3);
+    __syncthreads();
+    if (wv == 0 && i < p.n) {
+      double v = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+      const double xi = x[i];
+      if (shift) v = __dsub_rn(v, __dmul_rn(s, xi));
+      y[i] = v;
+      acc = fma(xi, v, acc);
+    }
   }
+  __syncthreads();
   const double tot = block_sum(acc, sm4);
   if (P && threadIdx.x == 0) P[blockIdx.x] = tot;
 }
@@ -2063,7 +2085,7 @@ int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shif
         KLAUNCH(ev, k_symv_upper<float>, dim3(p.nb, p.nb), 256, st, p, x, skip);
       else
         KLAUNCH(ev, k_symv_upper<double>, dim3(p.nb, p.nb), 256, st, p, x, skip);
-      int64_t nbr = (p.n + 255) / 256;
+      int64_t nbr = p.nb;
       if (nbr > DSEA_MAX_EW_BLOCKS) nbr = DSEA_MAX_EW_BLOCKS;
       hipLaunchKernelGGL(k_symv_reduce, dim3((unsigned)nbr), dim3(256), 0, st, p, x, y, shift, skip, P);
       return (int)nbr;

@@ -14,7 +14,7 @@ def timeit(fn, reps=50):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-for n in (256, 1024, 4096, 8192, 16384):
+for n in [int(a) for a in sys.argv[1:]] or (256, 1024, 4096, 8192, 16384):
     A = torch.randn(n, n, dtype=torch.float64, device=dev); A = A + A.T
     x = torch.randn(n, dtype=torch.float64, device=dev)
     op = SymmetricDenseOperator(A)
