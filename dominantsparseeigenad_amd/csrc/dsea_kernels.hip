@@ -1575,6 +1575,9 @@ __global__ __launch_bounds__(256) void k_symv_reduce(SymDenseParams p, const dou
 // ------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 #define DSEA_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#ifndef DSEA_PERSIST_SLEEP
+#define DSEA_PERSIST_SLEEP 1
+#endif
 #define DSEA_PERSIST_TIMEOUT_TICKS 300000000ll /* 3 s of the 100 MHz wall clock: a lost peer must not hang the GPU */
 
 __device__ __forceinline__ void put_f64(gu64* g, unsigned epoch, double v) {
@@ -1598,7 +1601,7 @@ struct PersistArgs {
   double* state;    // DSEA_CG_* (written by workgroup 0 at the end)
   double eps;
   long long maxiter;
-  unsigned long long* comm;  // granules: [2*ntiles] phase A | [2*ntiles] phase C | [4*G] edges ; zeroed per launch
+  unsigned long long* comm;  // granules: [2*ntiles] phase A | [2*ntiles] phase C | [4*G] r edges | [4*G] x edges ; zeroed per launch
   int ntiles;
 };
 
@@ -1628,7 +1631,7 @@ __device__ __forceinline__ double persist_gather(gu64* base, int count, unsigned
         if (idx < count) ok &= try_get_f64(base + 2 * idx, epoch, pv[m]);
       }
       if (!ok) {
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(DSEA_PERSIST_SLEEP);
         if (wall_clock64() - t0 > DSEA_PERSIST_TIMEOUT_TICKS) break;
       }
     } while (!ok);
@@ -1652,7 +1655,7 @@ __device__ __forceinline__ double persist_gather(gu64* base, int count, unsigned
       do {
         ok = try_get_f64(src, epoch, v);
         if (!ok) {
-          __builtin_amdgcn_s_sleep(1);
+          __builtin_amdgcn_s_sleep(DSEA_PERSIST_SLEEP);
           if (wall_clock64() - t0 > DSEA_PERSIST_TIMEOUT_TICKS) break;
         }
       } while (!ok);
@@ -1682,6 +1685,12 @@ __global__ __launch_bounds__(1024) void k_cg_persist_stencil(PersistArgs a) {
   gu64* commA = (gu64*)a.comm;
   gu64* commC = commA + 2 * (int64_t)a.ntiles;
   gu64* commE = commC + 2 * (int64_t)a.ntiles;
+  // The start-up exchange of the x edges has its OWN slots: that phase waits for the two neighbours only, so a fast
+  // workgroup may be a whole phase ahead of a neighbour that has not read its x edge yet -- were the r edges of the
+  // next phase written to the same granules, that neighbour would wait for an epoch that is gone (seen as a timeout
+  // when the pollers' back-off sleep was lengthened in an experiment).  All later phases are separated by an
+  // all-to-all dependency (every workgroup needs every tile partial), which is what makes slot reuse safe there.
+  gu64* commX = commE + 4 * (int64_t)gridDim.x;
   const double coef = a.p.coef;
   const bool has_shift = a.shift != nullptr;
   const double s = has_shift ? a.shift[0] : 0.0;
@@ -1756,9 +1765,10 @@ __global__ __launch_bounds__(1024) void k_cg_persist_stencil(PersistArgs a) {
   bool fail;
   unsigned epoch = 1;
   // ---- r = b - A' x0 ; d = r ; rr = r.r                                          (CG.py:26-30)
-  publish_edges(epoch, xv);
+  if (tid == 0) put_f64(commX + (g * 2 + 0) * 2, epoch, xv[0].x);
+  if (tid == 1023) put_f64(commX + (g * 2 + 1) * 2, epoch, xv[PPT - 1].y);
   {
-    double dummy = persist_gather(commA, 0, epoch, true, commE, true, g, G, sm, el, er, fail);
+    double dummy = persist_gather(commA, 0, epoch, true, commX, true, g, G, sm, el, er, fail);
     (void)dummy;
   }
   if (fail) {
@@ -2207,7 +2217,7 @@ void launch_finalize_slot(const double* P, int count, double* out, const double*
 // (then the caller runs the streaming 3-launch form), -2 on a HIP error.  `comm` must hold persist_comm_bytes().
 size_t persist_comm_bytes(int64_t n) {
   const int64_t nt = (n + 511) / 512;
-  return (size_t)(4 * nt + 4 * 256) * sizeof(unsigned long long);
+  return (size_t)(4 * nt + 8 * 256) * sizeof(unsigned long long);
 }
 int launch_cg_persist(const OpDesc& op, const double* shift, const double* b, double* x, double* state, double eps,
                       int64_t maxiter, void* comm, int ppt_override, hipStream_t st) {
@@ -2225,7 +2235,7 @@ int launch_cg_persist(const OpDesc& op, const double* shift, const double* b, do
     if (ppt == 1 && (nt + 7) / 8 <= 256) return launch_cg_persist(op, shift, b, x, state, eps, maxiter, comm, 2, st);
     return -1;
   }
-  const size_t cbytes = (size_t)(4 * nt + 4 * G) * sizeof(unsigned long long);
+  const size_t cbytes = (size_t)(4 * nt + 8 * G) * sizeof(unsigned long long);
   if (hipMemsetAsync(comm, 0, cbytes, st) != hipSuccess) return -2;
   PersistArgs a;
   a.p = op.st3;

@@ -388,10 +388,10 @@ class SymmetricDenseOperator:
 
 def dense_symmetric_operand(A):
     """native operand for a dense symmetric tensor: the upper-triangle kernel where it wins (measured on MI355X:
-    n = 8192: 115 vs 124 us, n = 16384: 400 vs 439 us for the rocBLAS GEMV), the library's rocBLAS GEMV operand below
-    (n = 4096: 39 vs 21 us -- two launches and 64 x 64 tiles do not fill the chip there).  Either way the Lanczos / CG
+    n = 6144: 50 vs 74 us, n = 16384: 317 vs 439 us for the rocBLAS GEMV), the library's rocBLAS GEMV operand below
+    (n = 4096: 29 vs 21 us -- two launches do not pay off there).  Either way the Lanczos / CG
     loops run inside libdsea."""
-    if A.shape[0] >= 8192 or (A.dtype == torch.float32 and A.shape[0] >= 2048):
+    if A.shape[0] >= 6144 or (A.dtype == torch.float32 and A.shape[0] >= 2048):
         return SymmetricDenseOperator(A)      # fp32 matrices are read as fp32: no promoted copy (Lanczos.py:47)
     return DenseOperator(A)
 
