@@ -374,7 +374,7 @@ int dsea_op_create_symdense(int64_t n, const void* A_dev, int elem_bytes, int64_
 }
 
 size_t dsea_op_transfer_work_bytes(int D, int d) {
-  return D < 1 || d < 1 ? 0 : (size_t)2 * (size_t)d * (size_t)D * (size_t)D * sizeof(double);
+  return D < 1 || d < 1 ? 0 : (size_t)(1 + 3 * (size_t)d) * (size_t)D * (size_t)D * sizeof(double);
 }
 
 int dsea_op_create_transfer(int D, int d, const double* A_dev, int transpose, double* work, void* stream,
@@ -388,9 +388,13 @@ int dsea_op_create_transfer(int D, int d, const double* A_dev, int transpose, do
   op->d.tune_tile_log2 = DSEA_TFIM_TILE_LOG2;
   op->d.kind = OP_TRANSFER;
   op->d.n = (int64_t)D * D;
-  const size_t half = (size_t)d * D * D;
-  op->d.transfer = TransferParams{D, d, A_dev, transpose ? nullptr : work + half, work, transpose ? 1 : 0};
-  if (!transpose) launch_permute_kmn(A_dev, work + half, d, D, static_cast<hipStream_t>(stream));
+  const size_t DD = (size_t)D * D, slab = (size_t)d * DD;
+  double* xT = work;
+  double* T = work + DD;
+  double* Y = T + slab;
+  double* AT = Y + slab;
+  op->d.transfer = TransferParams{D, d, transpose ? AT : A_dev, xT, T, Y, transpose ? 1 : 0};
+  if (transpose) launch_transpose_sq(A_dev, AT, D, d, static_cast<hipStream_t>(stream));   // B_k = A_k^T, once
   *out = op;
   return check_launch();
 }

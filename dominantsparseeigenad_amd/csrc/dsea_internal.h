@@ -51,9 +51,10 @@ struct DenseParams {
 };
 struct TransferParams {
   int D, d;
-  const double* A;  // d x D x D row-major
-  double* A2;       // A permuted to (m, k, n) (non-transposed form only), inside the caller's work buffer
-  double* T;        // d * D * D doubles of scratch, inside the caller's work buffer
+  const double* B;  // d x D x D row-major: A itself, or its slice-wise transpose (inside the caller's work buffer)
+  double* xT;       // D * D      scratch: the transposed input
+  double* T;        // d * D * D  scratch: B_k x
+  double* Y;        // d * D * D  scratch: (B_k x) B_k^T
   int transpose;
 };
 struct SymDenseParams {
@@ -174,7 +175,7 @@ void launch_plz_finish(const double* r, const double* y, const double* pair, dou
 // dsea_krylov.hip
 bool blas_available();
 int blas_apply(const OpDesc& op, const double* x, double* y, hipStream_t st);
-void launch_permute_kmn(const double* A, double* A2, int d, int D, hipStream_t st);
+void launch_transpose_sq(const double* in, double* out, int D, int batch, hipStream_t st);
 void arnoldi_orth(Workspace& w, int64_t n, const double* u, const double* shift_or_zero, double* V, int64_t ldv, int j,
                   double* hcol, double* brk, double* skip, double* nrm1, double* nrm2, hipStream_t st);
 int arnoldi_step(const OpDesc& op, Workspace& w, const double* shift_or_zero, double* V, int64_t ldv, int j,

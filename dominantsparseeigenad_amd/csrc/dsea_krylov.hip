@@ -68,22 +68,43 @@ bool blas_available() {
   return g_blas.ok;
 }
 
-// A2[m][k][n] = A[k][m][n]   (the (m,(k,n)) layout the second contraction of the transfer mat-vec needs)
-__global__ __launch_bounds__(256) void k_permute_kmn(const double* __restrict__ A, double* __restrict__ A2, int d,
-                                                     int D) {
-  const int64_t total = (int64_t)d * D * D;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int n = (int)(e % D);
-    const int m = (int)((e / D) % D);
-    const int k = (int)(e / ((int64_t)D * D));
-    A2[((int64_t)m * d + k) * D + n] = A[e];
+// out[b] = in[b]^T for `batch` square D x D row-major matrices (32 x 32 tiles through LDS, coalesced both ways)
+__global__ __launch_bounds__(256) void k_transpose_sq(const double* __restrict__ in, double* __restrict__ out, int D) {
+  __shared__ double tile[32][33];
+  const int64_t base = (int64_t)blockIdx.z * D * D;
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = by + ty + 8 * k, c = bx + tx;
+    tile[ty + 8 * k][tx] = (r < D && c < D) ? in[base + (int64_t)r * D + c] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = bx + ty + 8 * k, c = by + tx;
+    if (r < D && c < D) out[base + (int64_t)r * D + c] = tile[tx][ty + 8 * k];
   }
 }
 
-void launch_permute_kmn(const double* A, double* A2, int d, int D, hipStream_t st) {
-  int64_t nb = ((int64_t)d * D * D + 255) / 256;
-  if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL(k_permute_kmn, dim3((unsigned)nb), dim3(256), 0, st, A, A2, d, D);
+void launch_transpose_sq(const double* in, double* out, int D, int batch, hipStream_t st) {
+  const unsigned g = (unsigned)((D + 31) / 32);
+  hipLaunchKernelGGL(k_transpose_sq, dim3(g, g, (unsigned)batch), dim3(256), 0, st, in, out, D);
+}
+
+// y = Y[0] + Y[1] + ... + Y[d-1]   (fixed order)
+__global__ __launch_bounds__(256) void k_sum_slices(const double* __restrict__ Y, int d, int64_t n,
+                                                    double* __restrict__ y) {
+  const int64_t stride = (int64_t)gridDim.x * 512;
+  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; row < n; row += stride) {
+    double2 acc = ld2<true>(Y, row, n);
+    for (int k = 1; k < d; ++k) {
+      const double2 v = ld2<true>(Y + (int64_t)k * n, row, n);
+      acc.x += v.x;
+      acc.y += v.y;
+    }
+    st2<true>(y, row, n, acc);
+  }
 }
 
 // y = op x for the GEMM-shaped operands (row-major data, rocBLAS is column-major: a row-major product C = A B
@@ -100,24 +121,25 @@ int blas_apply(const OpDesc& op, const double* x, double* y, hipStream_t st) {
     rs = g_blas.dgemv(g_blas.h, p.transpose ? rocblas_operation_none : rocblas_operation_transpose, (rocblas_int)p.n,
                       (rocblas_int)p.n, &one, p.A, (rocblas_int)p.lda, x, 1, &zero, y, 1);
   } else if (op.kind == OP_TRANSFER) {
+    // y = sum_k B_k x B_k^T with B = A (general.py:59-61 "fr") or B_k = A_k^T (general.py:62-64 "fl": the same form on
+    // the transposed tensor, copied once at creation).  Both contractions are issued in the row-major "X Y^T" shape,
+    // the one rocBLAS runs fastest for 512^3 fp64 (measured: X Y^T 12.6 us per pair of 512^3 products, X Y 18.8 us,
+    // one (D x dD)(dD x D) product 35 us): T_k = B_k (x^T)^T with x^T from a small transpose kernel, Y_k = T_k B_k^T,
+    // then y = sum_k Y_k in fixed order.  Row-major C = X Y^T is the column-major product C^T = Y X^T: gemm(T, N, ...)
+    // with Y's memory first.
     const TransferParams& p = op.transfer;
-    const rocblas_int D = p.D, dD = p.d * p.D;
+    const rocblas_int D = p.D;
     const rocblas_stride DD = (rocblas_stride)p.D * p.D;
-    if (!p.transpose) {
-      // y = sum_k A_k x A_k^T (general.py:59-61 "fr").  T[i][k][n] = (A_k x)[i][n]: one strided-batched GEMM writing
-      // the (i,(k,n)) layout directly (ldc = dD, batch stride D); then y = T (D x dD) * A2^T in ONE GEMM of depth dD.
-      rs = g_blas.dgemm_sb(g_blas.h, rocblas_operation_none, rocblas_operation_none, D, D, D, &one, x, D, 0, p.A, D, DD,
-                           &zero, p.T, dD, (rocblas_stride)p.D, p.d);
-      if (rs == rocblas_status_success)
-        rs = g_blas.dgemm(g_blas.h, rocblas_operation_transpose, rocblas_operation_none, D, D, dD, &one, p.A2, dD, p.T,
-                          dD, &zero, y, D);
-    } else {
-      // y = sum_k A_k^T x A_k (general.py:62-64 "fl").  U[k] = x A_k (batched), then y = Aflat^T (D x dD) * Ustack.
-      rs = g_blas.dgemm_sb(g_blas.h, rocblas_operation_none, rocblas_operation_none, D, D, D, &one, p.A, D, DD, x, D, 0,
-                           &zero, p.T, D, DD, p.d);
-      if (rs == rocblas_status_success)
-        rs = g_blas.dgemm(g_blas.h, rocblas_operation_none, rocblas_operation_transpose, D, D, dD, &one, p.T, D, p.A, D,
-                          &zero, y, D);
+    launch_transpose_sq(x, p.xT, p.D, 1, st);
+    rs = g_blas.dgemm_sb(g_blas.h, rocblas_operation_transpose, rocblas_operation_none, D, D, D, &one, p.xT, D, 0, p.B, D,
+                         DD, &zero, p.T, D, DD, p.d);
+    if (rs == rocblas_status_success)
+      rs = g_blas.dgemm_sb(g_blas.h, rocblas_operation_transpose, rocblas_operation_none, D, D, D, &one, p.B, D, DD, p.T,
+                           D, DD, &zero, p.Y, D, DD, p.d);
+    if (rs == rocblas_status_success) {
+      int64_t nb = ((int64_t)DD + 511) / 512;
+      if (nb > 2048) nb = 2048;
+      hipLaunchKernelGGL(k_sum_slices, dim3((unsigned)nb), dim3(256), 0, st, (const double*)p.Y, p.d, (int64_t)DD, y);
     }
   } else {
     return -1;

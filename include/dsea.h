@@ -141,8 +141,10 @@ int dsea_op_set_tuning(dsea_op_t op, int key, int value);
  *             row-major (reference examples/TFIM_vumps/general.py:59-66):
  *                 transpose == 0:  y = sum_s A_s x A_s^T        ("Gong",  general.py:59-61)
  *                 transpose != 0:  y = sum_s A_s^T x A_s        ("GongT", general.py:62-64)
- *             as one strided-batched GEMM + one GEMM of depth d*D.  `work`: caller-owned scratch of
- *             dsea_op_transfer_work_bytes(D, d); dsea_op_create_transfer fills part of it on `stream`.        */
+ *             as two strided-batched GEMMs in the "X Y^T" shape (the transposed form is the same contraction on
+ *             the slice-wise transposed tensor, copied once) + a transpose and a slice-sum kernel.  `work`:
+ *             caller-owned scratch of dsea_op_transfer_work_bytes(D, d); dsea_op_create_transfer fills part of it
+ *             on `stream`.                                                                                    */
 int dsea_op_create_dense(int64_t n, const double *A_dev, int64_t lda, int transpose, dsea_op_t *out);
 /* dense SYMMETRIC operand (reference symeig.py:15-31 DominantSymeig; Lanczos.py:46-49 applies torch.matmul(A, v)):
  * hand-written mat-vec that reads only the UPPER triangle of the row-major matrix -- every 64 x 64 tile is loaded
