@@ -529,14 +529,18 @@ __global__ __launch_bounds__(W * 64) void k_axpy_norm_lp_split(const double* __r
   double w[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) w[e] = 0.0;
-  const int nchunks = (i + 3) / 4;
+  // LPV basis vectors per trip: with W = 16 waves and 8 loads of 16 bytes in flight per lane a wave needs one or two
+  // trips for i <= 300 (the pass is a chain of dependent round trips, not a bandwidth problem, at these sizes:
+  // 4 vectors per trip on 8 waves measured 17.2 us at N = 1e5, i ~ 150, for 30 MB of shadow)
+  constexpr int LPV = 8;
+  const int nchunks = (i + LPV - 1) / LPV;
   for (int cc = wv; cc < nchunks; cc += W) {
-    const int j0 = 4 * cc;
+    const int j0 = LPV * cc;
     if (use_lp) {
-      uint4 h[4];
-      double cj[4];
+      uint4 h[LPV];
+      double cj[LPV];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
+      for (int v = 0; v < LPV; ++v) {
         h[v] = make_uint4(0u, 0u, 0u, 0u);
         cj[v] = 0.0;
         if (j0 + v < i) {
@@ -553,7 +557,7 @@ __global__ __launch_bounds__(W * 64) void k_axpy_norm_lp_split(const double* __r
         }
       }
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
+      for (int v = 0; v < LPV; ++v) {
         w[0] = fma(cj[v], bf16lo_to_f64(h[v].x), w[0]);
         w[1] = fma(cj[v], bf16hi_to_f64(h[v].x), w[1]);
         w[2] = fma(cj[v], bf16lo_to_f64(h[v].y), w[2]);
@@ -564,7 +568,7 @@ __global__ __launch_bounds__(W * 64) void k_axpy_norm_lp_split(const double* __r
         w[7] = fma(cj[v], bf16hi_to_f64(h[v].w), w[7]);
       }
     } else {
-      for (int v = 0; v < 4; ++v) {
+      for (int v = 0; v < LPV; ++v) {
         if (j0 + v >= i) break;
         const double* __restrict__ qj = Q + (int64_t)(j0 + v) * ldq;
         const double cj = c[j0 + v];
@@ -1934,9 +1938,9 @@ void launch_axpy_norm(const TileGeom& g, const double* Q, int64_t ldq, int64_t n
 int launch_axpy_norm_lp(int64_t n, int rps, const double* Q, int64_t ldq, const uint16_t* Qs, int64_t lds, int i,
                         const double* c, double tau, double* r, double* P, double* lp_count, hipStream_t st,
                         EventPair* ev, const double* brk) {
-  if (rps == 0) {   // small-n split form: one block of 8 waves per 512-row tile
+  if (rps == 0) {   // small-n split form: one block of 16 waves per 512-row tile
     const int64_t nt = (n + 511) / 512;
-    KLAUNCH(ev, (k_axpy_norm_lp_split<8>), (unsigned)nt, 512, st, Q, ldq, Qs, lds, i, n, c, tau * tau, r, P, lp_count, brk);
+    KLAUNCH(ev, (k_axpy_norm_lp_split<16>), (unsigned)nt, 1024, st, Q, ldq, Qs, lds, i, n, c, tau * tau, r, P, lp_count, brk);
     return (int)nt;
   }
   const int64_t tile = 512 * (int64_t)rps;
