@@ -266,7 +266,8 @@ int dsea_ws_set_rows_per_lane(dsea_ws_t ws, int rpl) {
 
 int dsea_ws_set_persist(dsea_ws_t ws, int mode) {
   if (!ws) return DSEA_ERR_ARG;
-  if (mode != -1 && mode != 0 && mode != 1 && mode != 2) return DSEA_ERR_ARG;
+  if (mode != -1 && mode != 0 && mode != 1 && mode != 2 && mode != 11 && mode != 12 && mode != 21 && mode != 22)
+    return DSEA_ERR_ARG;
   ws->w.persist_override = mode;
   return DSEA_OK;
 }

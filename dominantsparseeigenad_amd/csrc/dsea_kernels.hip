@@ -1619,11 +1619,32 @@ struct PersistSm {
 // granule carries `epoch`) and sum them in the order of sum_partials_block (two_acc) or k_finalize1 (!two_acc);
 // thread 256 / 320 fetch the neighbour workgroups' edge values when `edges`.  Returns the total in every thread;
 // el / er receive the edges.  `fail` is set (in every thread) if a peer did not show up in time.
+template <int NVB>
 __device__ __forceinline__ double persist_gather(gu64* base, int count, unsigned epoch, bool two_acc, gu64* edge_base,
                                                  bool edges, int g, int G, PersistSm* sm, double& el, double& er,
                                                  bool& fail) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long t0 = wall_clock64();
+  // edge pollers: two lanes of waves that do not poll tile partials (NVB >= 2), else two lanes of the polling waves
+  constexpr int EL = NVB >= 2 ? 256 : 0, ER = NVB >= 2 ? 320 : 64;
+  if (NVB == 1 && edges && (tid == EL || tid == ER)) {
+    const bool left = tid == EL;
+    const int peer = left ? g - 1 : g + 1;
+    double v = 0.0;
+    if (peer >= 0 && peer < G) {
+      gu64* src = edge_base + (peer * 2 + (left ? 1 : 0)) * 2;
+      bool ok;
+      do {
+        ok = try_get_f64(src, epoch, v);
+        if (!ok) {
+          __builtin_amdgcn_s_sleep(DSEA_PERSIST_SLEEP);
+          if (wall_clock64() - t0 > DSEA_PERSIST_TIMEOUT_TICKS) break;
+        }
+      } while (!ok);
+      if (!ok) sm->bcast[3] = 1.0;
+    }
+    sm->bcast[left ? 1 : 2] = v;
+  }
   if (tid < 256) {
     double pv[4] = {0.0, 0.0, 0.0, 0.0};
     bool ok;
@@ -1649,8 +1670,8 @@ __device__ __forceinline__ double persist_gather(gu64* base, int count, unsigned
     }
     acc = wave_sum(acc);
     if (lane == 0) sm->red[0][wave] = acc;
-  } else if (edges && (tid == 256 || tid == 320)) {
-    const bool left = tid == 256;
+  } else if (NVB >= 2 && edges && (tid == EL || tid == ER)) {
+    const bool left = tid == EL;
     const int peer = left ? g - 1 : g + 1;
     double v = 0.0;
     if (peer >= 0 && peer < G) {
@@ -1676,10 +1697,11 @@ __device__ __forceinline__ double persist_gather(gu64* base, int count, unsigned
   return tot;
 }
 
-template <int PPT>
-__global__ __launch_bounds__(1024) void k_cg_persist_stencil(PersistArgs a) {
+// NVB = "virtual blocks" of 256 threads per workgroup (a virtual block reproduces one block of the streaming kernels)
+template <int PPT, int NVB>
+__global__ __launch_bounds__(256 * NVB) void k_cg_persist_stencil(PersistArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  constexpr int TPW = 4 * PPT;          // tiles per workgroup
+  constexpr int TPW = NVB * PPT;        // tiles per workgroup
   constexpr int ROWS = TPW * 512;
   double* dsm = lds;                    // dsm[1] left halo, dsm[2 + local row] (pairs 16-byte aligned), dsm[2 + ROWS] right halo
   PersistSm* sm = reinterpret_cast<PersistSm*>(lds + ROWS + 4);
@@ -1701,15 +1723,15 @@ __global__ __launch_bounds__(1024) void k_cg_persist_stencil(PersistArgs a) {
   if (tid == 0) sm->bcast[3] = 0.0;
   __syncthreads();
 
-  // my row pairs: sub-round q -> tile g*TPW + 4 q + vb, rows (tile*512 + 2t, +1)
+  // my row pairs: sub-round q -> tile g*TPW + NVB q + vb, rows (tile*512 + 2t, +1)
   int lrow[PPT];
   int tile[PPT];
   bool v0[PPT], v1[PPT];   // row exists
   double2 xv[PPT], rv[PPT], dv[PPT], Vv[PPT];
 #pragma unroll
   for (int q = 0; q < PPT; ++q) {
-    tile[q] = g * TPW + 4 * q + vb;
-    lrow[q] = (4 * q + vb) * 512 + 2 * t;
+    tile[q] = g * TPW + NVB * q + vb;
+    lrow[q] = (NVB * q + vb) * 512 + 2 * t;
     const int64_t i = (int64_t)tile[q] * 512 + 2 * t;
     v0[q] = i < n;
     v1[q] = i + 1 < n;
@@ -1762,7 +1784,7 @@ __global__ __launch_bounds__(1024) void k_cg_persist_stencil(PersistArgs a) {
   };
   auto publish_edges = [&](unsigned epoch, const double2* w) {
     if (tid == 0) put_f64(commE + (g * 2 + 0) * 2, epoch, w[0].x);
-    if (tid == 1023) put_f64(commE + (g * 2 + 1) * 2, epoch, w[PPT - 1].y);
+    if (tid == 256 * NVB - 1) put_f64(commE + (g * 2 + 1) * 2, epoch, w[PPT - 1].y);
   };
 
   double el, er;
@@ -1770,9 +1792,9 @@ __global__ __launch_bounds__(1024) void k_cg_persist_stencil(PersistArgs a) {
   unsigned epoch = 1;
   // ---- r = b - A' x0 ; d = r ; rr = r.r                                          (CG.py:26-30)
   if (tid == 0) put_f64(commX + (g * 2 + 0) * 2, epoch, xv[0].x);
-  if (tid == 1023) put_f64(commX + (g * 2 + 1) * 2, epoch, xv[PPT - 1].y);
+  if (tid == 256 * NVB - 1) put_f64(commX + (g * 2 + 1) * 2, epoch, xv[PPT - 1].y);
   {
-    double dummy = persist_gather(commA, 0, epoch, true, commX, true, g, G, sm, el, er, fail);
+    double dummy = persist_gather<NVB>(commA, 0, epoch, true, commX, true, g, G, sm, el, er, fail);
     (void)dummy;
   }
   if (fail) {
@@ -1791,7 +1813,7 @@ __global__ __launch_bounds__(1024) void k_cg_persist_stencil(PersistArgs a) {
   epoch = 2;
   publish_edges(epoch, rv);
   publish_tiles(commC, epoch, rv, rv);
-  double rr = persist_gather(commC, a.ntiles, epoch, false, commE, true, g, G, sm, el, er, fail);
+  double rr = persist_gather<NVB>(commC, a.ntiles, epoch, false, commE, true, g, G, sm, el, er, fail);
   double dL = el, dR = er;   // d = r: the neighbours' edge d values
   double rn = sqrt(rr);
   long long iters = 0;
@@ -1804,7 +1826,7 @@ __global__ __launch_bounds__(1024) void k_cg_persist_stencil(PersistArgs a) {
     for (int q = 0; q < PPT; ++q) Ad[q] = apply(q, dv[q]);
     ++epoch;
     publish_tiles(commA, epoch, dv, Ad);
-    const double dAd = persist_gather(commA, a.ntiles, epoch, true, commE, false, g, G, sm, el, er, fail);
+    const double dAd = persist_gather<NVB>(commA, a.ntiles, epoch, true, commE, false, g, G, sm, el, er, fail);
     if (fail) break;
     const double alpha = rr / dAd;
 #pragma unroll
@@ -1817,7 +1839,7 @@ __global__ __launch_bounds__(1024) void k_cg_persist_stencil(PersistArgs a) {
     ++epoch;
     publish_edges(epoch, rv);
     publish_tiles(commC, epoch, rv, rv);
-    const double rr_new = persist_gather(commC, a.ntiles, epoch, true, commE, true, g, G, sm, el, er, fail);
+    const double rr_new = persist_gather<NVB>(commC, a.ntiles, epoch, true, commE, true, g, G, sm, el, er, fail);
     if (fail) break;
     ++iters;
     rn = sqrt(rr_new);
@@ -2229,14 +2251,24 @@ int launch_cg_persist(const OpDesc& op, const double* shift, const double* b, do
   const int64_t n = op.st3.n;
   const int64_t nt = (n + 511) / 512;
   if (nt > DSEA_PERSIST_CG_MAX_TILES) return -1;
-  // one row pair per thread wherever the workgroup count allows it (measured on MI355X, 1000 fixed iterations:
-  // N = 1e5: 6.3 us / iteration with 1 pair (49 workgroups), 7.6 with 2; N = 2e4: 5.3 vs 6.8; streaming form 11.3 / 9.8)
-  int ppt = ppt_override;
-  if (ppt != 1 && ppt != 2) ppt = nt <= 512 ? 1 : 2;
-  const int tpw = 4 * ppt;
+  // Geometry: ppt row pairs per thread, nvb virtual blocks of 256 threads per workgroup.  Override codes (tuning knob
+  // dsea_ws_set_persist): 1 / 2 = ppt with nvb = 4; 21 / 22 = ppt 1 / 2 with nvb = 2; 11 / 12 = ppt 1 / 2 with nvb = 1.
+  // Measured on MI355X, 1000 fixed iterations, nvb = 4: N = 1e5: 6.1 us / iteration with 1 pair (49 workgroups),
+  // 7.4 with 2; N = 2e4: 5.1 vs 6.8; streaming form 10.6 / 9.8.
+  int ppt, nvb = 4;
+  switch (ppt_override) {
+    case 1: case 2: ppt = ppt_override; break;
+    case 21: case 22: ppt = ppt_override - 20; nvb = 2; break;
+    case 11: case 12: ppt = ppt_override - 10; nvb = 1; break;
+    default:   // measured (N = 1e5 / 2e4, us per iteration): nvb 4: 6.2 / 5.2, nvb 2: 5.6 / 4.5, nvb 1: 5.8 / 4.2
+      if (nt <= 64) { ppt = 1; nvb = 1; }
+      else if (nt <= 512) { ppt = 1; nvb = 2; }
+      else { ppt = 2; nvb = 2; }
+      break;
+  }
+  const int tpw = nvb * ppt;
   const int G = (int)((nt + tpw - 1) / tpw);
   if (G > 256) {
-    if (ppt == 1 && (nt + 7) / 8 <= 256) return launch_cg_persist(op, shift, b, x, state, eps, maxiter, comm, 2, st);
     return -1;
   }
   const size_t cbytes = (size_t)(4 * nt + 8 * G) * sizeof(unsigned long long);
@@ -2252,10 +2284,10 @@ int launch_cg_persist(const OpDesc& op, const double* shift, const double* b, do
   a.comm = static_cast<unsigned long long*>(comm);
   a.ntiles = (int)nt;
   const size_t lds = (size_t)(tpw * 512 + 4) * sizeof(double) + sizeof(PersistSm);
-  if (ppt == 1)
-    hipLaunchKernelGGL((k_cg_persist_stencil<1>), dim3(G), dim3(1024), lds, st, a);
-  else
-    hipLaunchKernelGGL((k_cg_persist_stencil<2>), dim3(G), dim3(1024), lds, st, a);
+#define PERSIST_CASE(P, V) \
+  if (ppt == P && nvb == V) hipLaunchKernelGGL((k_cg_persist_stencil<P, V>), dim3(G), dim3(256 * V), lds, st, a);
+  PERSIST_CASE(1, 4) PERSIST_CASE(2, 4) PERSIST_CASE(1, 2) PERSIST_CASE(2, 2) PERSIST_CASE(1, 1) PERSIST_CASE(2, 1)
+#undef PERSIST_CASE
   return 0;
 }
 

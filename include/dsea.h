@@ -73,7 +73,8 @@ int dsea_ws_set_split(dsea_ws_t ws, int waves);
 /* tuning knob: persistent single-launch CG of dsea_cg_run (3-point stencil without halo pointers, n <= 2^19): the
  * whole solve is ONE launch whose workgroups keep x, r, d in registers and exchange only per-tile partial sums and
  * edge elements; iterates are bit-identical to the streaming 3-launches-per-iteration form.
- * -1 = automatic (on where it applies), 0 = off (streaming form), 1 / 2 = on with that many row pairs per thread. */
+ * -1 = automatic (on where it applies), 0 = off (streaming form); forced geometries: 1 / 2 = that many row pairs per
+ * thread in workgroups of 1024 threads, 21 / 22 = in workgroups of 512, 11 / 12 = in workgroups of 256.            */
 int dsea_ws_set_persist(dsea_ws_t ws, int mode);
 
 /* Optional bf16 SHADOW of the Krylov basis (caller-owned, `rows` x `ld` uint16, ld % 8 == 0, 16-byte

@@ -25,7 +25,7 @@ print("Lanczos N=%d k=%d: %.2f ms  (%.1f us/step; algorithmic %.0f GB/s)  theta=
 b = torch.from_numpy(normal_vector(N, 2)).to(dev); x0 = torch.from_numpy(normal_vector(N, 3)).to(dev)
 shift = torch.tensor(-1.0, dtype=torch.float64, device=dev)
 ws = engine.Workspace.get(N, 8, dev)
-for mode, name in ((0, "streaming 3-launch"), (-1, "persistent auto"), (1, "persistent ppt=1"), (2, "persistent ppt=2")):
+for mode, name in ((0, "streaming 3-launch"), (-1, "persistent auto"), (1, "persistent ppt=1 nvb=4"), (2, "persistent ppt=2 nvb=4"), (21, "persistent ppt=1 nvb=2"), (22, "persistent ppt=2 nvb=2"), (11, "persistent ppt=1 nvb=1"), (12, "persistent ppt=2 nvb=1")):
     ws.set_persist(mode)
     best = 1e30
     try:
@@ -33,8 +33,8 @@ for mode, name in ((0, "streaming 3-launch"), (-1, "persistent auto"), (1, "pers
             torch.cuda.synchronize(); t0 = time.perf_counter()
             xs = engine.cg(b, x0, native=op, shift=shift, eps=0.0, maxiter=1000, poll_every=1000)
             torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
-        print("CG %-20s fixed %d iterations: %.2f ms  %.2f us/iteration  %.0f GB/s algorithmic" % (
+        print("CG %-26s fixed %d iterations: %.2f ms  %.2f us/iteration  %.0f GB/s algorithmic" % (
             name, engine.last_cg.iters, best * 1e3, best / 1000 * 1e6, 11 * 8.0 * N * 1000 / best / 1e9))
     except Exception as exc:
-        print("CG %-20s failed: %s" % (name, exc))
+        print("CG %-26s failed: %s" % (name, exc))
 ws.set_persist(-1)
