@@ -348,7 +348,11 @@ class SymmetricDenseOperator:
     """A dense real SYMMETRIC matrix as a native operand of the symmetric primitives (reference symeig.py:15-31,
     CG.py:43-71 apply ``torch.matmul(A, v)``): hand-written HIP mat-vec that reads only the UPPER triangle, each
     64 x 64 tile once for both its row and its column block -- half the bytes of a GEMV -- and lets the dense
-    primitive run its Lanczos / CG loops inside libdsea like the sparse ones (no Python per iteration)."""
+    primitive run its Lanczos / CG loops inside libdsea like the sparse ones (no Python per iteration).
+
+    Handed to ``setDominantSparseSymeig(op, hook)`` it is also the way to get the adjoint of a LARGE dense matrix in
+    its lazy rank-1 form: the hook receives (v1, v2) with A-bar = v1 v2^T (reference symeig.py:56-64) and contracts
+    them with whatever produced A -- the n x n gradient of ``DominantSymeig`` (symeig.py:29) is never formed."""
 
     _native_methods = ("__call__", "matvec")
 
@@ -381,7 +385,8 @@ class SymmetricDenseOperator:
         return self._H.handle
 
     def matvec(self, v):
-        return engine.spmv(self._H, v)
+        """A v, differentiable in v (dy/dv^T g = A g: the same symmetric kernel, re-entrant)"""
+        return _SymmetricApply.apply(v, self._H)
 
     __call__ = matvec
 

@@ -240,3 +240,29 @@ def test_warm_start_reaches_the_same_pair_with_fewer_vectors(tmp_path):
     x = unit(500, 33).to(dev())
     y = CSROperator.from_npz(path, dev())(x)
     assert float((y.cpu() - torch.from_numpy(M @ x.cpu().numpy())).abs().max()) < 1e-13
+
+
+def test_lazy_rank_one_adjoint_of_a_dense_matrix_through_the_sparse_primitive():
+    """the rank-1 adjoint A-bar = v1 v2^T without the n x n gradient.  A(p) = A0 + p A1 dense symmetric:
+    the dense primitive materialises grad_A (symeig.py:29) and autograd contracts it with A1; the sparse primitive on
+    the SAME dense operand hands (v1, v2) to the hook, which returns v1^T A1 v2.  Same numbers."""
+    from dominantsparseeigenad_amd.operators import SymmetricDenseOperator
+    from dominantsparseeigenad_amd.symeig import DominantSymeig
+    import dominantsparseeigenad_amd.symeig as symeig
+    from helpers import sym_from_seed, PatchRandn
+    n, k = 700, 150
+    A0, A1 = sym_from_seed(n, 8201).to(dev()), sym_from_seed(n, 8202, scale=0.1).to(dev())
+    t = unit(n, 8203).to(dev())
+    p = torch.tensor([0.3], dtype=F64, device=dev(), requires_grad=True)
+    with PatchRandn(8210):
+        lam, psi = DominantSymeig.apply(A0 + p * A1, k, dev())
+        sgn = 1.0 if float(psi.detach()[:16].sum()) > 0 else -1.0
+        (g_dense,) = torch.autograd.grad(lam + sgn * psi.matmul(t), p)
+    op = SymmetricDenseOperator((A0 + p.detach() * A1))
+    symeig.setDominantSparseSymeig(op, lambda v1, v2: (v1.matmul(A1.matmul(v2)))[None])
+    with PatchRandn(8210):
+        lam2, psi2 = symeig.DominantSparseSymeig.apply(p, k, n, dev())
+        sgn2 = 1.0 if float(psi2.detach()[:16].sum()) > 0 else -1.0
+        (g_lazy,) = torch.autograd.grad(lam2 + sgn2 * psi2.matmul(t), p)
+    assert abs(lam.item() - lam2.item()) < 1e-12 * abs(lam.item())
+    assert abs(g_dense.item() - g_lazy.item()) < 1e-7 * abs(g_dense.item()), (g_dense.item(), g_lazy.item())
