@@ -562,9 +562,17 @@ class PartitionedTFIMOperator(PartitionedOperator):
                 self.be.axpy(-1.0, None, buf, y)                 # dH/dg: y -= x_partner (TFIM.py:64)
 
     def apply_shift_dot(self, x, y, shift, out, skip):
-        """y = (H - shift) x with the remote part, the shift and the local x.y in ONE kernel after the exchange"""
-        self.be.tfim_local(x, y, "H")
-        recv = self._exchange(x)
+        """y = (H - shift) x with the remote part, the shift and the local x.y in ONE kernel after the exchange.
+        Transposed exchange: it is started first (side stream) and runs behind the slab-local part of the mat-vec --
+        x is final here, so unlike the Lanczos overlap nothing is approximated."""
+        if self.transposed and self.p > 0:
+            token = self.comm.start_flip_exchange(self.be, x, self._xT, self._zT, self._z)
+            self.be.tfim_local(x, y, "H")
+            self.comm.finish_flip_exchange(token, self.device)
+            recv = [self._z]
+        else:
+            self.be.tfim_local(x, y, "H")
+            recv = self._exchange(x)
         if out is None:
             out = self.be.zeros(1)
         self.be.axpy_multi_dot(-1.0, self.g.detach(), recv, shift, skip, x, y, out)
