@@ -64,6 +64,7 @@ def _adjoint_solves_device(opA, opAT, lam, l, r, g_l, g_r):
 
 
 CONCURRENT_SIDES = True
+_SIDE_STREAMS = {}
 
 
 def _two_sides(right, left, device):
@@ -76,7 +77,9 @@ def _two_sides(right, left, device):
         return tuple(right()) + tuple(left())
     import threading
     main = torch.cuda.current_stream(device)
-    side = torch.cuda.Stream(device=device)
+    side = _SIDE_STREAMS.get(str(device))       # one side stream per device: its workspace / arena entries are reused
+    if side is None:
+        side = _SIDE_STREAMS[str(device)] = torch.cuda.Stream(device=device)
     ready = torch.cuda.Event()
     ready.record(main)
     box = {}
