@@ -37,6 +37,13 @@ struct Blas {
 };
 Blas g_blas;
 std::once_flag g_blas_once;
+// One rocBLAS handle PER STREAM (created on first use, bound to its stream once): switching the stream of a shared
+// handle while its earlier work may still be running is not safe for kernels that use the handle's device workspace,
+// and the left / right solves of the non-symmetric primitives run concurrently on two streams (eig._two_sides).
+constexpr int MAX_STREAM_HANDLES = 16;
+hipStream_t g_handle_stream[MAX_STREAM_HANDLES];
+rocblas_handle g_handle[MAX_STREAM_HANDLES];
+int g_handles = 0;
 
 void blas_init() {
   void* lib = dlopen("librocblas.so.5", RTLD_NOW | RTLD_NOLOAD);
@@ -55,12 +62,30 @@ void blas_init() {
   BIND(dgemm, "rocblas_dgemm")
   BIND(dgemm_sb, "rocblas_dgemm_strided_batched")
 #undef BIND
-  if (g_blas.create(&g_blas.h) != rocblas_status_success) return;
-  g_blas.set_pointer_mode(g_blas.h, rocblas_pointer_mode_host);
-  g_blas.set_atomics_mode(g_blas.h, rocblas_atomics_not_allowed);  // bit-repeatable runs, like the rest of the path
+  if (g_blas.create(&g_blas.h) != rocblas_status_success) return;   // probe: the library is usable
   g_blas.ok = true;
 }
-std::mutex g_blas_mutex;  // one handle: set_stream + call must not interleave between threads
+std::mutex g_blas_mutex;  // guards the handle table (calls on distinct handles run concurrently)
+
+// the handle of `st` (nullptr on failure)
+rocblas_handle handle_for(hipStream_t st) {
+  std::lock_guard<std::mutex> lock(g_blas_mutex);
+  for (int i = 0; i < g_handles; ++i)
+    if (g_handle_stream[i] == st) return g_handle[i];
+  rocblas_handle h = nullptr;
+  if (g_handles == 0) {
+    h = g_blas.h;   // reuse the probe handle for the first stream
+  } else if (g_handles >= MAX_STREAM_HANDLES || g_blas.create(&h) != rocblas_status_success) {
+    return nullptr;
+  }
+  if (g_blas.set_stream(h, st) != rocblas_status_success) return nullptr;
+  g_blas.set_pointer_mode(h, rocblas_pointer_mode_host);
+  g_blas.set_atomics_mode(h, rocblas_atomics_not_allowed);  // bit-repeatable runs, like the rest of the path
+  g_handle_stream[g_handles] = st;
+  g_handle[g_handles] = h;
+  ++g_handles;
+  return h;
+}
 }  // namespace
 
 bool blas_available() {
@@ -112,13 +137,13 @@ __global__ __launch_bounds__(256) void k_sum_slices(const double* __restrict__ Y
 int blas_apply(const OpDesc& op, const double* x, double* y, hipStream_t st) {
   if (!blas_available()) return -1;
   const double one = 1.0, zero = 0.0;
-  std::lock_guard<std::mutex> lock(g_blas_mutex);
-  if (g_blas.set_stream(g_blas.h, st) != rocblas_status_success) return -1;
+  rocblas_handle hd = handle_for(st);
+  if (!hd) return -1;
   rocblas_status rs = rocblas_status_success;
   if (op.kind == OP_DENSE) {
     const DenseParams& p = op.dense;
     // row-major A (n x n, lda) is the column-major A^T: y = A x = op_T(mem) x ; y = A^T x = op_N(mem) x
-    rs = g_blas.dgemv(g_blas.h, p.transpose ? rocblas_operation_none : rocblas_operation_transpose, (rocblas_int)p.n,
+    rs = g_blas.dgemv(hd, p.transpose ? rocblas_operation_none : rocblas_operation_transpose, (rocblas_int)p.n,
                       (rocblas_int)p.n, &one, p.A, (rocblas_int)p.lda, x, 1, &zero, y, 1);
   } else if (op.kind == OP_TRANSFER) {
     // y = sum_k B_k x B_k^T with B = A (general.py:59-61 "fr") or B_k = A_k^T (general.py:62-64 "fl": the same form on
@@ -131,10 +156,10 @@ int blas_apply(const OpDesc& op, const double* x, double* y, hipStream_t st) {
     const rocblas_int D = p.D;
     const rocblas_stride DD = (rocblas_stride)p.D * p.D;
     launch_transpose_sq(x, p.xT, p.D, 1, st);
-    rs = g_blas.dgemm_sb(g_blas.h, rocblas_operation_transpose, rocblas_operation_none, D, D, D, &one, p.xT, D, 0, p.B, D,
+    rs = g_blas.dgemm_sb(hd, rocblas_operation_transpose, rocblas_operation_none, D, D, D, &one, p.xT, D, 0, p.B, D,
                          DD, &zero, p.T, D, DD, p.d);
     if (rs == rocblas_status_success)
-      rs = g_blas.dgemm_sb(g_blas.h, rocblas_operation_transpose, rocblas_operation_none, D, D, D, &one, p.B, D, DD, p.T,
+      rs = g_blas.dgemm_sb(hd, rocblas_operation_transpose, rocblas_operation_none, D, D, D, &one, p.B, D, DD, p.T,
                            D, DD, &zero, p.Y, D, DD, p.d);
     if (rs == rocblas_status_success) {
       int64_t nb = ((int64_t)DD + 511) / 512;

@@ -45,8 +45,12 @@ def _dominant_pair(A, AT, k, which):
 def _dominant_pair_device(opA, opAT, n, k, which, device):
     """opA / opAT: native operators (``.handle``) or mat-vec callables on device vectors"""
     from . import krylov
-    lam, r, lam_l, l = _two_sides(lambda: krylov.arnoldi_dominant(opA, n, k, device, which),
-                                  lambda: krylov.arnoldi_dominant(opAT, n, k, device, which), device)
+    # both start vectors are drawn HERE, on the caller's thread and stream, in a fixed order: the two solves run
+    # concurrently and must not race for the global RNG (runs stay repeatable under torch.manual_seed)
+    v0r = torch.randn(n, dtype=torch.float64, device=device)
+    v0l = torch.randn(n, dtype=torch.float64, device=device)
+    lam, r, lam_l, l = _two_sides(lambda: krylov.arnoldi_dominant(opA, n, k, device, which, v0=v0r),
+                                  lambda: krylov.arnoldi_dominant(opAT, n, k, device, which, v0=v0l), device)
     if abs(lam - lam_l) > 1e-8 * max(abs(lam), 1e-300):
         raise RuntimeError("left / right eigenvalues disagree: %.15e vs %.15e" % (lam, lam_l))
     l = l / torch.dot(l, r)

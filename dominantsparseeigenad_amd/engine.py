@@ -7,6 +7,7 @@ The engine never falls back to torch arithmetic; a missing library raises (``_li
 from __future__ import annotations
 
 import ctypes
+import threading
 from ctypes import byref, c_double, c_int64, c_size_t, c_void_p
 
 import numpy as np
@@ -16,6 +17,7 @@ from . import _lib
 from ._lib import check
 
 F64 = torch.float64
+_CACHE_LOCK = threading.RLock()
 
 # bf16 shadow of the basis for the correction pass of the native Lanczos loop (include/dsea.h,
 # dsea_ws_set_shadow).  SHADOW_TAU is the device-side premise bound max|c_j| <= tau ||r||.
@@ -90,12 +92,13 @@ class Workspace:
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
         key = (int(n), str(device), int(torch.cuda.current_stream(device).cuda_stream))
-        ws = cls._cache.pop(key, None)
-        if ws is None or ws.kmax < kmax:
-            ws = cls(n, max(int(kmax), 8), device)
-        cls._cache[key] = ws            # re-insert: dict order = recency
-        while len(cls._cache) > cls._CACHE_LIMIT:
-            cls._cache.pop(next(iter(cls._cache)))
+        with _CACHE_LOCK:               # two host threads may drive two streams (eig._two_sides)
+            ws = cls._cache.pop(key, None)
+            if ws is None or ws.kmax < kmax:
+                ws = cls(n, max(int(kmax), 8), device)
+            cls._cache[key] = ws            # re-insert: dict order = recency
+            while len(cls._cache) > cls._CACHE_LIMIT:
+                cls._cache.pop(next(iter(cls._cache)))
         return ws
 
     @classmethod
@@ -132,14 +135,15 @@ class BasisArena:
     def get(cls, device, tag, nbytes):
         device = torch.device(device)
         key = (str(device), int(torch.cuda.current_stream(device).cuda_stream) if device.type == "cuda" else 0, tag)
-        buf = cls._bufs.get(key)
-        if buf is None or buf.numel() < nbytes:
-            if buf is not None:
-                del cls._bufs[key], buf
-                if device.type == "cuda":
-                    torch.cuda.empty_cache()
-            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-            cls._bufs[key] = buf
+        with _CACHE_LOCK:
+            buf = cls._bufs.get(key)
+            if buf is None or buf.numel() < nbytes:
+                if buf is not None:
+                    del cls._bufs[key], buf
+                    if device.type == "cuda":
+                        torch.cuda.empty_cache()
+                buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+                cls._bufs[key] = buf
         return buf
 
     @classmethod
