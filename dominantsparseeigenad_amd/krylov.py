@@ -98,6 +98,31 @@ def _wanted_pair(B, which):
     return th, y, evals
 
 
+# Convergence of the wanted Ritz pair is tested after STAGES of the factorisation, not only once all ncv columns exist
+# (0 = the latter, ARPACK's schedule).  STAGE_FIRST: columns before the first test; later stage ends are extrapolated
+# from the observed residual decay.
+STAGE_FIRST = 32
+STAGE_MIN = 8
+STAGE_MAX = 64
+
+
+def _next_stage_end(j, p, m, hist, tol):
+    """end column of the next stage of a cycle that has j columns (p of them kept from a restart)"""
+    if STAGE_FIRST <= 0 or m <= STAGE_FIRST + STAGE_MIN:
+        return m
+    if j == p:
+        return min(m, max(p + STAGE_MIN, STAGE_FIRST))
+    step = STAGE_FIRST // 2
+    if len(hist) >= 2:
+        (ja, ra), (jb, rb) = hist[-2], hist[-1]
+        if rb < ra and rb > 0.0 and jb > ja:
+            rate = np.log(rb / ra) / (jb - ja)                    # < 0: decades per column
+            step = int(np.ceil(np.log(0.3 * tol / rb) / rate)) + 2
+    step = max(STAGE_MIN, min(STAGE_MAX, step))
+    j1 = j + step
+    return m if j1 + STAGE_MIN > m else j1
+
+
 def _ptr(t):
     return c_void_p(t.data_ptr()) if t is not None else c_void_p(None)
 
@@ -152,26 +177,44 @@ def arnoldi_dominant(A, n, ncv, device, which="LM", v0=None, tol=1e-13, max_rest
     check(lib.dsea_scale_store(ws.handle, _ptr(v), _ptr(nrm2), _ptr(V), None, n, st()), "dsea_scale_store")
     p = 0                      # vectors kept from the previous cycle (Krylov-Schur block)
     theta, x, res = None, None, float("inf")
+    stages_run = 0
     for cycle in range(max_restarts + 1):
-        # ---- extend the factorisation to m columns: one library call (native) / one orthogonalisation call per
-        # step (callable); nothing returns to the host in between
-        if lp.native is not None:
-            check(lib.dsea_arnoldi_extend(lp.native.handle, ws.handle, None, _ptr(V), ldv, p, m, _ptr(Hd), ldh, st()),
-                  "dsea_arnoldi_extend")
-        else:
-            for j in range(p, m):
-                u = lp.apply(V[j, :n])
-                check(lib.dsea_arnoldi_orth(ws.handle, _ptr(u), None, _ptr(V), ldv, n, j, _ptr(Hd), ldh, st()),
-                      "dsea_arnoldi_orth")
-        brk = ctypes.c_int(0)
-        check(lib.dsea_lanczos_status(ws.handle, byref(brk), st()), "dsea_lanczos_status", allow=(_lib.ERR_BREAKDOWN,))
-        Hh = Hd.cpu().numpy()                     # (m, m+1): Hh[j, i] = H[i, j]
-        me = m if brk.value == 0 else int(brk.value)          # invariant subspace reached at step me
-        B = Hh[:me, :me].T.copy()
-        coupling = 0.0 if me < m or brk.value else float(Hh[m - 1, m])
-        theta, y, evals = _wanted_pair(B, which)
-        res = abs(coupling * y[-1])
-        if res <= tol * abs(theta) or me < m:
+        # ---- extend the factorisation towards m columns in STAGES: one library call per stage (native) / one
+        # orthogonalisation call per step (callable); nothing returns to the host inside a stage.  After each stage
+        # the host tests the wanted Ritz pair of the leading j x j block (ARPACK tests only once all ncv columns
+        # exist, eig.py:29; a converged pair is the same pair, found with fewer mat-vecs) and chooses the end of the
+        # next stage from the observed convergence rate.
+        j, hist = p, []
+        while True:
+            j1 = _next_stage_end(j, p, m, hist, tol)
+            if lp.native is not None:
+                check(lib.dsea_arnoldi_extend(lp.native.handle, ws.handle, None, _ptr(V), ldv, j, j1, _ptr(Hd), ldh,
+                                              st()), "dsea_arnoldi_extend")
+            else:
+                for jj in range(j, j1):
+                    u = lp.apply(V[jj, :n])
+                    check(lib.dsea_arnoldi_orth(ws.handle, _ptr(u), None, _ptr(V), ldv, n, jj, _ptr(Hd), ldh, st()),
+                          "dsea_arnoldi_orth")
+            stages_run += 1
+            brk = ctypes.c_int(0)
+            check(lib.dsea_lanczos_status(ws.handle, byref(brk), st()), "dsea_lanczos_status",
+                  allow=(_lib.ERR_BREAKDOWN,))
+            Hh = Hd[:j1, :j1 + 1].cpu().numpy()         # (j1, j1+1): Hh[j, i] = H[i, j]
+            me = j1 if brk.value == 0 else int(brk.value)         # invariant subspace reached at step me
+            B = Hh[:me, :me].T.copy()
+            coupling = 0.0 if me < j1 or brk.value else float(Hh[j1 - 1, j1])
+            j = j1
+            try:
+                theta, y, evals = _wanted_pair(B, which)
+            except ValueError:
+                if j1 >= m or me < j1:
+                    raise                      # the full factorisation says the wanted eigenvalue is complex: eig.py:31-32
+                continue                       # an early block may well have a complex wanted Ritz value: keep going
+            res = abs(coupling * y[-1])
+            if res <= tol * abs(theta) or me < j1 or j1 >= m:
+                break
+            hist.append((j1, res / max(abs(theta), 1e-300)))
+        if res <= tol * abs(theta) or me < j:
             break
         if cycle == max_restarts:
             break
@@ -199,11 +242,13 @@ def arnoldi_dominant(A, n, ncv, device, which="LM", v0=None, tol=1e-13, max_rest
         Hd.copy_(torch.from_numpy(Hn))
         p = p_new
     arnoldi_dominant.last_cycles = cycle + 1
+    arnoldi_dominant.last_columns = j              # columns of the last cycle's factorisation when it stopped
+    arnoldi_dominant.last_stages = stages_run
     xv = torch.empty(n, dtype=F64, device=device)
     ys = torch.from_numpy(np.ascontiguousarray(y)).to(device)
     check(lib.dsea_ritz_combine(ws.handle, _ptr(V), ldv, n, int(ys.numel()), _ptr(ys), _ptr(xv), st()), "dsea_ritz_combine")
     x = xv / xv.norm()
-    if not (res <= tol * abs(theta) or me < m):
+    if not (res <= tol * abs(theta) or me < j):
         # the residual estimate stalls at the rounding level of the factorisation for ill-conditioned eigenvalues:
         # accept a measured residual at that level, otherwise report (ARPACK raises ArpackNoConvergence, eig.py:29)
         true_res = float((lp.apply(x) - theta * x).norm())

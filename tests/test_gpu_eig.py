@@ -271,3 +271,36 @@ def test_arnoldi_restarts_and_reports_non_convergence():
     assert abs(lam - lam_ref) < 1e-9 * abs(lam_ref)
     with pytest.raises(krylov.ArnoldiNoConvergence):
         krylov.arnoldi_dominant(op, n, 4, cuda, "LM", max_restarts=1)
+
+
+def test_staged_convergence_test_finds_the_same_pair_with_fewer_columns():
+    """The wanted Ritz pair is tested after stages of the factorisation (krylov.STAGE_FIRST) instead of only once all
+    ncv columns exist (ARPACK's schedule, reference eig.py:29): same eigenpair, fewer mat-vecs; a callable operand
+    takes the same path; STAGE_FIRST = 0 restores the single full-length cycle."""
+    from dominantsparseeigenad_amd.operators import TransferOperator
+    D, d, k = 64, 2, 200
+    n = D * D
+    gen = torch.Generator().manual_seed(23)
+    Ad = (torch.randn(d, D, D, dtype=F64, generator=gen) / D ** 0.5).to(cuda)
+    v0 = torch.randn(n, dtype=F64, generator=gen).to(cuda)
+    op = TransferOperator(Ad)
+    saved = krylov.STAGE_FIRST
+    try:
+        krylov.STAGE_FIRST = 0
+        lam_full, x_full = krylov.arnoldi_dominant(op, n, k, cuda, "LM", v0=v0)
+        assert krylov.arnoldi_dominant.last_columns == k and krylov.arnoldi_dominant.last_stages == 1
+        krylov.STAGE_FIRST = saved
+        lam_st, x_st = krylov.arnoldi_dominant(op, n, k, cuda, "LM", v0=v0)
+        cols = krylov.arnoldi_dominant.last_columns
+        assert cols < k and krylov.arnoldi_dominant.last_stages >= 2, cols
+        AdT = Ad.transpose(1, 2).contiguous()
+        fr = lambda v: torch.matmul(torch.matmul(Ad, v.reshape(D, D)), AdT).sum(0).reshape(-1)  # noqa: E731
+        lam_cb, x_cb = krylov.arnoldi_dominant(krylov.TorchLinearOperator((n, n), fr, cuda), n, k, cuda, "LM", v0=v0)
+    finally:
+        krylov.STAGE_FIRST = saved
+    assert abs(lam_st - lam_full) <= 1e-12 * abs(lam_full) and abs(lam_cb - lam_full) <= 1e-12 * abs(lam_full)
+    for x in (x_st, x_cb):
+        s = 1.0 if float(x @ x_full) > 0 else -1.0
+        assert float((s * x - x_full).abs().max()) < 1e-10
+        assert float((op(x) - lam_st * x).norm()) <= 1e-12 * abs(lam_st)
+    print("staged Arnoldi: converged with %d of %d columns" % (cols, k))
