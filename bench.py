@@ -357,7 +357,10 @@ def main():
         if warmup == 0:
             E0, gl = step()
         resid = eigen_residual(E0, last["psi"])
-        if op.transposed and op.overlap:
+        notes["slab_exchange"] = ("none (one rank)" if op.p == 0 else
+                                  ("transposed all-to-all form" if op.transposed else "pairwise hypercube partners")
+                                  + (", overlapped with the dots / correction passes" if op.overlap else ""))
+        if op.p > 0 and op.overlap:
             op.overlap = False
             E0s, _ = step()
             resid_seq = eigen_residual(E0s, last["psi"])

@@ -217,6 +217,25 @@ class TorchDistComm:
         if token is not None:
             torch.cuda.current_stream(device).wait_event(token)
 
+    def start_pair_exchange(self, x_send, recv, peers):
+        """pairwise form of the same: the slab x_send goes to every hypercube partner, theirs arrive in recv[b];
+        started NOW on the side stream (device tensors) and joined by ``finish_flip_exchange``.  With P = 2 a
+        mat-vec moves one whole slab over the ONE xGMI link between the two GPUs (268 MB at 2^25 rows: about as long
+        as the dots pass of a Lanczos step), so hiding it matters most exactly there."""
+        if not x_send.is_cuda:
+            self.exchange(x_send, recv, peers)
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=x_send.device)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(x_send.device))
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ready)
+            self.exchange(x_send, recv, peers)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        return done
+
     def all_to_all(self, src, dst):
         """chunk j of src goes to rank j, chunk j of dst comes from rank j (equal chunks; own chunk copied).
         Over RCCL this is ``all_to_all_single``; elsewhere (gloo in the CPU tests) the same exchange is written
@@ -510,7 +529,7 @@ class PartitionedTFIMOperator(PartitionedOperator):
         backend.attach_tfim(self.L, self.Lloc, comm.rank * nloc, g)
         super().__init__(1 << self.L, nloc, comm.rank * nloc, device, comm, backend)
         self.g = g
-        # Overlap of the slab exchange with the dots / correction passes (transposed form only): the remote part
+        # Overlap of the slab exchange with the dots / correction passes (both exchange forms): the remote part
         # of u = A r' is then taken from the UN-corrected r (its exchange starts before the coefficients c are
         # known).  r - r' = Q c lies at the 1e-14 relative level per element while |c_j| <= ~1e-15 ||r||, the
         # level of the mat-vec's own rounding error.  That premise is CHECKED every step (max|c_j| <= tau ||r||,
@@ -551,6 +570,17 @@ class PartitionedTFIMOperator(PartitionedOperator):
         self.comm.exchange(x, self._recv, [self.rank ^ (1 << b) for b in range(self.p)])
         return self._recv
 
+    def _start_exchange(self, x):
+        """the same exchange started on the communicator's side stream; ``_finish_exchange`` joins it and returns the
+        buffers.  x must stay untouched until then."""
+        if self.transposed:
+            return self.comm.start_flip_exchange(self.be, x, self._xT, self._zT, self._z)
+        return self.comm.start_pair_exchange(x, self._recv, [self.rank ^ (1 << b) for b in range(self.p)])
+
+    def _finish_exchange(self, token):
+        self.comm.finish_flip_exchange(token, self.device)
+        return [self._z] if self.transposed else self._recv
+
     # ---- mat-vec on buffers
     def matvec(self, x, y, which="H"):
         """y = H x (or dH/dg x) on this slab: local low-bit part in HIP, top-bit flips from the partners"""
@@ -563,13 +593,12 @@ class PartitionedTFIMOperator(PartitionedOperator):
 
     def apply_shift_dot(self, x, y, shift, out, skip):
         """y = (H - shift) x with the remote part, the shift and the local x.y in ONE kernel after the exchange.
-        Transposed exchange: it is started first (side stream) and runs behind the slab-local part of the mat-vec --
-        x is final here, so unlike the Lanczos overlap nothing is approximated."""
-        if self.transposed and self.p > 0:
-            token = self.comm.start_flip_exchange(self.be, x, self._xT, self._zT, self._z)
+        The exchange is started first (side stream) and runs behind the slab-local part of the mat-vec -- x is final
+        here, so unlike the Lanczos overlap nothing is approximated."""
+        if self.p > 0 and hasattr(self.comm, "start_pair_exchange"):
+            token = self._start_exchange(x)
             self.be.tfim_local(x, y, "H")
-            self.comm.finish_flip_exchange(token, self.device)
-            recv = [self._z]
+            recv = self._finish_exchange(token)
         else:
             self.be.tfim_local(x, y, "H")
             recv = self._exchange(x)
@@ -580,7 +609,7 @@ class PartitionedTFIMOperator(PartitionedOperator):
     # ---- Lanczos step with the fused correction + local mat-vec and the overlapped exchange
     def lanczos_step(self, i, S):
         be, n = self.be, S.n
-        overlap = self.transposed and self.overlap and hasattr(be, "form_r")
+        overlap = self.p > 0 and self.overlap and hasattr(be, "form_r") and hasattr(self.comm, "start_pair_exchange")
         prev_a = S.alphas[i - 1:i] if i >= 1 else None
         prev_b = S.betas[i - 2:i - 1] if i >= 2 else None
         if overlap:
@@ -591,7 +620,7 @@ class PartitionedTFIMOperator(PartitionedOperator):
                 be.form_r(S.Q, S.ldq, n, i, S.u, prev_a, prev_b, S.r, S.r_send)
             else:
                 S.r_send.copy_(S.r)
-            token = self.comm.start_flip_exchange(be, S.r_send, self._xT, self._zT, self._z)
+            token = self._start_exchange(S.r_send)
             premise_ok = True
             if i >= 1:
                 # alpha = 0: r is rewritten with its own values (read from the snapshot copy, so that input and
@@ -601,10 +630,8 @@ class PartitionedTFIMOperator(PartitionedOperator):
                 tau = _engine_mod.SHADOW_TAU
                 premise_ok = bool((S.c[:i].abs().max() <= tau * S.c[i].sqrt()).item())
             be.plz_correct_matvec(S.Q, S.ldq, i, S.c, S.r, S.y, S.pair)
-            self.comm.finish_flip_exchange(token, self.device)
-            if premise_ok:
-                recv = [self._z]
-            else:   # identical decision on every rank (c is replicated): redo the exchange with the corrected r
+            recv = self._finish_exchange(token)
+            if not premise_ok:   # identical decision on every rank (c is replicated): redo the exchange with the corrected r
                 self.overlap_fallbacks += 1
                 recv = self._exchange(S.r)
         else:

@@ -64,13 +64,14 @@ def _comm(backend):
     return None if backend == "nccl" else _host_staged_comm()
 
 
-def _case_driver(rank, world, backend, dev):
+def _case_driver(rank, world, backend, dev, overlap=False):
     from dominantsparseeigenad_amd.partitioned import PartitionedTFIM
     p = world.bit_length() - 1
     nloc = 1 << (L - p)
     off = rank * nloc
     g = torch.tensor([G], dtype=torch.float64, device=dev)
     solver = PartitionedTFIM(L, g, dev, eps=1e-12, comm=_comm(backend))
+    solver.overlap = overlap
     q0 = torch.from_numpy(normal_vector(nloc, 5100, offset=off)).to(dev)
     x0 = torch.from_numpy(normal_vector(nloc, 5102, offset=off)).to(dev)
     t = torch.from_numpy(normal_vector(nloc, 5103, offset=off)).to(dev)
@@ -186,8 +187,12 @@ def _run(world, backend, case, *args):
     return [ret[r] for r in range(world)]
 
 
-@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (4, "gloo")])
-def test_partitioned_hip_backend(world, backend):
+@pytest.mark.parametrize("world,backend,overlap", [(1, "nccl", False), (2, "gloo", False), (4, "gloo", False),
+                                                   (2, "gloo", True), (4, "gloo", True)])
+def test_partitioned_hip_backend(world, backend, overlap):
+    """overlap: the step that starts the slab exchange of the un-corrected r on the side stream before the dots pass
+    (form_r snapshot, premise check, side-stream join) on the HIP slab kernels -- pairwise form at 2 ranks, transposed
+    form at 4 (at the config-5 slab size ``overlap="auto"`` turns it on by itself)."""
     assert torch.cuda.is_available()
     n = 1 << L
     model = oracle.TFIMTables(L)
@@ -195,7 +200,7 @@ def test_partitioned_hip_backend(world, backend):
     f = oracle.make_sparse_dominant_symeig(model.H, model.adjoint_hook, draw=SeedDraws(5100), eps=1e-12).apply
     t = torch.from_numpy(normal_vector(n, 5103))
     E_o, psi_o = f(model.g, K, n)
-    ret = _run(world, backend, "_case_driver")
+    ret = _run(world, backend, "_case_driver", overlap)
     psi = torch.cat([torch.from_numpy(ret[r][1]) for r in range(world)])
     sgn = 1.0 if float(psi @ psi_o.detach()) > 0 else -1.0
     (g_o,) = torch.autograd.grad(E_o + sgn * psi_o.matmul(t), model.g)

@@ -29,20 +29,24 @@ def _free_port():
     return port
 
 
-def _case_driver(rank, world):
+def _case_driver(rank, world, overlap=False, tau=None):
     """hand-written forward + backward of partitioned.PartitionedTFIM (no autograd)"""
     from cpu_backend import CpuBackend
+    from dominantsparseeigenad_amd import engine
     from dominantsparseeigenad_amd.partitioned import PartitionedTFIM
     p = world.bit_length() - 1
     nloc = 1 << (L - p)
     off = rank * nloc
     g = torch.tensor([G], dtype=torch.float64)
     solver = PartitionedTFIM(L, g, "cpu", backend=CpuBackend(nloc), eps=1e-12)
+    solver.overlap = overlap
+    if tau is not None:
+        engine.SHADOW_TAU = tau
     q0 = torch.from_numpy(normal_vector(nloc, 5000, offset=off))
     x0 = torch.from_numpy(normal_vector(nloc, 5002, offset=off))
     t = torch.from_numpy(normal_vector(nloc, 5003, offset=off))
     E0, psi, grad = solver.forward_backward(K, q0, x0, t)
-    return (E0.item(), psi.numpy().copy(), grad.item(), solver.last_cg_iters)
+    return (E0.item(), psi.numpy().copy(), grad.item(), solver.last_cg_iters, solver.op.overlap_fallbacks)
 
 
 def _case_api_tfim(rank, world, tag):
@@ -124,8 +128,12 @@ def _run(world, case, *args):
     return [ret[r] for r in range(world)]
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_partitioned_matches_single_process_oracle(world):
+@pytest.mark.parametrize("world,overlap,tau", [(2, False, None), (4, False, None), (8, False, None),
+                                               (2, True, None), (4, True, None), (4, True, 0.0)])
+def test_partitioned_matches_single_process_oracle(world, overlap, tau):
+    """overlap: the slab exchange of the un-corrected r is started before the dots pass (pairwise form at 2 ranks,
+    transposed form from 4) and its premise max|c_j| <= tau ||r|| is checked every step; tau = 0 makes every step
+    fail the premise, i.e. exercises the redo-with-the-corrected-r branch."""
     n = 1 << L
     model = oracle.TFIMTables(L)
     model.g = torch.tensor([G], dtype=torch.float64, requires_grad=True)
@@ -135,7 +143,11 @@ def test_partitioned_matches_single_process_oracle(world):
     E_o, psi_o = f(model.g, K, n)
     (g_o,) = torch.autograd.grad(E_o + psi_o.matmul(t), model.g)
 
-    ret = _run(world, "_case_driver")
+    ret = _run(world, "_case_driver", overlap, tau)
+    if overlap:
+        # n = 256, k = 120: close to the end the Krylov space of the start vector is nearly exhausted and a few steps
+        # fail the premise on their own (they take the redo branch, which is what the check is for)
+        assert (ret[0][4] == K - 1) if tau == 0.0 else (ret[0][4] < 10), ret[0][4]
     psi = torch.cat([torch.from_numpy(ret[r][1]) for r in range(world)])
     sgn = 1.0 if float(psi @ psi_o.detach()) > 0 else -1.0
     for r in range(world):
