@@ -266,8 +266,10 @@ int dsea_ws_set_rows_per_lane(dsea_ws_t ws, int rpl) {
 
 int dsea_ws_set_persist(dsea_ws_t ws, int mode) {
   if (!ws) return DSEA_ERR_ARG;
-  if (mode != -1 && mode != 0 && mode != 1 && mode != 2 && mode != 11 && mode != 12 && mode != 21 && mode != 22)
+  const int geo = mode >= 100 ? mode - 100 : mode;     // >= 100: merged-reduction form with geometry code mode - 100
+  if (geo != -1 && geo != 0 && geo != 1 && geo != 2 && geo != 11 && geo != 12 && geo != 21 && geo != 22)
     return DSEA_ERR_ARG;
+  if (mode >= 100 && geo == -1) return DSEA_ERR_ARG;
   ws->w.persist_override = mode;
   return DSEA_OK;
 }

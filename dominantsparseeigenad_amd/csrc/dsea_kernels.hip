@@ -1868,6 +1868,240 @@ __global__ __launch_bounds__(256 * NVB) void k_cg_persist_stencil(PersistArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
+// ONE grid-wide exchange per iteration: the same persistent solve with the two reductions of an iteration MERGED
+// (Chronopoulos & Gear's arrangement of CG: s = A p is carried by a recurrence, w = A r is the mat-vec, and
+// gamma = r.r, delta = r.Ar are reduced together).  The mat-vec's own neighbour exchange rides on the same
+// exchange: w = A r is first formed with zero halos, the missing cross terms of delta are added from the
+// published edge elements (2 coef r_last(g) r_first(g+1) per workgroup boundary), and the two edge rows of w are
+// completed once the neighbours' edges have arrived.
+//     p = r + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s ; w = A' r ;
+//     gamma' = r.r , delta = r.w   <- the ONE exchange ;  beta' = gamma'/gamma ; alpha' = gamma'/(delta - beta' gamma'/alpha)
+// Mathematically the iteration of CG.py:31-40; NOT its rounding sequence (the search direction's image is
+// updated by recurrence instead of being recomputed), so this form is an OPTION (dsea_ws_set_persist mode >= 100),
+// never the default: iterates agree with the reference's to rounding-error growth, not bit for bit.
+// Exchange: every workgroup publishes {gamma_g, delta_g, first r, last r} under the epoch into the slot set of the
+// epoch's PARITY -- with one exchange per iteration a fast workgroup may publish epoch e+1 while a slow one still
+// reads epoch e; it cannot reach e+2 before everyone has published e+1, i.e. has finished reading e.
+// Every workgroup reads all 4 G values and sums them in the same fixed order: identical scalars everywhere.
+// ------------------------------------------------------------------------------------------
+struct PersistSmM {
+  double red[2][16];
+  double bcast[8];      // [0] gamma [1] delta [2] left edge [3] right edge [4] fail
+  double vals[4 * 256];
+};
+
+template <int PPT, int NVB>
+__global__ __launch_bounds__(256 * NVB) void k_cg_persist_stencil_merged(PersistArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  constexpr int TPW = NVB * PPT;
+  constexpr int ROWS = TPW * 512;
+  constexpr int NWAVES = 4 * NVB;
+  double* dsm = lds;
+  PersistSmM* sm = reinterpret_cast<PersistSmM*>(lds + ROWS + 4);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, vb = tid >> 8, t = tid & 255;
+  const int g = blockIdx.x, G = gridDim.x;
+  const int64_t n = a.p.n;
+  gu64* commS = (gu64*)a.comm;                       // [2 parities][G][4 values][2 granules]
+  gu64* commX = commS + 16 * (int64_t)G;             // x edges of the start-up: [G][2][2]
+  const double coef = a.p.coef;
+  const bool has_shift = a.shift != nullptr;
+  const double sh = has_shift ? a.shift[0] : 0.0;
+  if (tid == 0) sm->bcast[4] = 0.0;
+  __syncthreads();
+
+  int lrow[PPT];
+  int tile[PPT];
+  bool v0[PPT], v1[PPT];
+  double2 xv[PPT], rv[PPT], pv[PPT], sv[PPT], wv[PPT], Vv[PPT];
+#pragma unroll
+  for (int q = 0; q < PPT; ++q) {
+    tile[q] = g * TPW + NVB * q + vb;
+    lrow[q] = (NVB * q + vb) * 512 + 2 * t;
+    const int64_t i = (int64_t)tile[q] * 512 + 2 * t;
+    v0[q] = i < n;
+    v1[q] = i + 1 < n;
+    xv[q] = ld2<true>(a.x, i, n);
+    Vv[q] = ld2<true>(a.p.V, i, n);
+    pv[q] = make_double2(0.0, 0.0);
+    sv[q] = make_double2(0.0, 0.0);
+  }
+  auto apply = [&](int q, double2 w) -> double2 {
+    const double dn = dsm[lrow[q] + 1];
+    const double up = dsm[lrow[q] + 4];
+    double2 y;
+    y.x = v0[q] ? stencil_row(coef, Vv[q].x, w.x, v1[q] ? w.y : 0.0, dn) : 0.0;
+    y.y = v1[q] ? stencil_row(coef, Vv[q].y, w.y, up, w.x) : 0.0;
+    if (has_shift) {
+      y.x = __dsub_rn(y.x, __dmul_rn(sh, w.x));
+      y.y = __dsub_rn(y.y, __dmul_rn(sh, w.y));
+    }
+    return y;
+  };
+  auto stage = [&](const double2* w, double hl, double hr) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) *reinterpret_cast<double2*>(dsm + 2 + lrow[q]) = w[q];
+    if (tid == 0) {
+      dsm[1] = hl;
+      dsm[2 + ROWS] = hr;
+    }
+    __syncthreads();
+  };
+  // bounded spin on one value
+  auto wait_f64 = [&](gu64* src, unsigned epoch, double& v, long long t0) -> bool {
+    bool ok;
+    do {
+      ok = try_get_f64(src, epoch, v);
+      if (!ok) {
+        __builtin_amdgcn_s_sleep(DSEA_PERSIST_SLEEP);
+        if (wall_clock64() - t0 > DSEA_PERSIST_TIMEOUT_TICKS) break;
+      }
+    } while (!ok);
+    return ok;
+  };
+
+  // ---- start-up: x edges to the two neighbours (slots of their own), r = b - A' x0           (CG.py:26-27)
+  if (tid == 0) put_f64(commX + (g * 2 + 0) * 2, 1u, xv[0].x);
+  if (tid == 256 * NVB - 1) put_f64(commX + (g * 2 + 1) * 2, 1u, xv[PPT - 1].y);
+  if (tid == 0 || tid == 64) {
+    const bool left = tid == 0;
+    const int peer = left ? g - 1 : g + 1;
+    double v = 0.0;
+    if (peer >= 0 && peer < G) {
+      if (!wait_f64(commX + (peer * 2 + (left ? 1 : 0)) * 2, 1u, v, wall_clock64())) sm->bcast[4] = 1.0;
+    }
+    sm->bcast[left ? 2 : 3] = v;
+  }
+  __syncthreads();
+  bool fail = sm->bcast[4] != 0.0;
+  if (fail) {
+    if (g == 0 && tid == 0) a.state[DSEA_CG_DONE] = -1.0;
+    return;
+  }
+  stage(xv, sm->bcast[2], sm->bcast[3]);
+#pragma unroll
+  for (int q = 0; q < PPT; ++q) {
+    const double2 Ax = apply(q, xv[q]);
+    const double2 bv = ld2<true>(a.b, (int64_t)tile[q] * 512 + 2 * t, n);
+    rv[q].x = __dsub_rn(bv.x, Ax.x);
+    rv[q].y = __dsub_rn(bv.y, Ax.y);
+  }
+
+  // w = A' r and the merged reduction of (gamma, delta): the ONE exchange of an iteration
+  unsigned epoch = 1;
+  double gamma = 0.0, delta = 0.0;
+  auto exchange = [&]() {
+    ++epoch;
+    stage(rv, 0.0, 0.0);                       // zero halos: the cross terms come from the published edges
+    double ga = 0.0, da = 0.0;
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+      wv[q] = apply(q, rv[q]);
+      ga = fma(rv[q].x, rv[q].x, ga);
+      ga = fma(rv[q].y, rv[q].y, ga);
+      da = fma(rv[q].x, wv[q].x, da);
+      da = fma(rv[q].y, wv[q].y, da);
+    }
+    ga = wave_sum(ga);
+    da = wave_sum(da);
+    if (lane == 0) {
+      sm->red[0][wave] = ga;
+      sm->red[1][wave] = da;
+    }
+    __syncthreads();
+    gu64* slot = commS + (int64_t)(epoch & 1u) * 8 * G;
+    if (tid < 4) {
+      double v;
+      if (tid < 2) {
+        v = 0.0;
+        for (int k2 = 0; k2 < NWAVES; ++k2) v += sm->red[tid][k2];
+      } else if (tid == 2) {
+        v = dsm[2];                // first row of this workgroup
+      } else {
+        v = dsm[2 + ROWS - 1];     // last row
+      }
+      put_f64(slot + ((int64_t)g * 4 + tid) * 2, epoch, v);
+    }
+    // gather all 4 G values (threads 0..255, up to four each)
+    if (tid < 256) {
+      const long long t0 = wall_clock64();
+      bool ok = true;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int idx = tid + 256 * m;
+        if (idx < 4 * G) {
+          double v = 0.0;
+          ok &= wait_f64(slot + (int64_t)idx * 2, epoch, v, t0);
+          sm->vals[idx] = v;
+        }
+      }
+      if (!ok) sm->bcast[4] = 1.0;
+    }
+    __syncthreads();
+    // wave 0: gamma ; wave 1: delta incl. the cross terms of the workgroup boundaries (fixed order)
+    if (wave < 2) {
+      double acc = 0.0;
+      for (int gg = lane; gg < G; gg += 64) {
+        double v = sm->vals[gg * 4 + wave];
+        if (wave == 1 && gg + 1 < G) v = fma(2.0 * coef * sm->vals[gg * 4 + 3], sm->vals[(gg + 1) * 4 + 2], v);
+        acc += v;
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) sm->bcast[wave] = acc;
+    }
+    if (tid == 128) {
+      sm->bcast[2] = g > 0 ? sm->vals[(g - 1) * 4 + 3] : 0.0;
+      sm->bcast[3] = g + 1 < G ? sm->vals[(g + 1) * 4 + 2] : 0.0;
+    }
+    __syncthreads();
+    gamma = sm->bcast[0];
+    delta = sm->bcast[1];
+    fail = sm->bcast[4] != 0.0;
+    // the two edge rows of w receive their neighbours
+    if (tid == 0 && v0[0]) wv[0].x = fma(coef, sm->bcast[2], wv[0].x);
+    if (tid == 256 * NVB - 1 && v1[PPT - 1]) wv[PPT - 1].y = fma(coef, sm->bcast[3], wv[PPT - 1].y);
+  };
+
+  exchange();
+  double rn = sqrt(gamma);
+  long long iters = 0;
+  bool done = rn < a.eps;
+  double alpha = gamma / delta, beta = 0.0;
+  while (!done && !fail && iters < a.maxiter) {
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+      pv[q].x = fma(beta, pv[q].x, rv[q].x);
+      pv[q].y = fma(beta, pv[q].y, rv[q].y);
+      sv[q].x = fma(beta, sv[q].x, wv[q].x);
+      sv[q].y = fma(beta, sv[q].y, wv[q].y);
+      xv[q].x = fma(alpha, pv[q].x, xv[q].x);
+      xv[q].y = fma(alpha, pv[q].y, xv[q].y);
+      rv[q].x = fma(-alpha, sv[q].x, rv[q].x);
+      rv[q].y = fma(-alpha, sv[q].y, rv[q].y);
+    }
+    const double gamma_old = gamma;
+    exchange();
+    if (fail) break;
+    ++iters;
+    rn = sqrt(gamma);
+    if (rn < a.eps) {
+      done = true;
+      break;
+    }
+    beta = gamma / gamma_old;
+    alpha = gamma / (delta - beta * gamma / alpha);
+  }
+#pragma unroll
+  for (int q = 0; q < PPT; ++q) st2<true>(a.x, (int64_t)tile[q] * 512 + 2 * t, n, xv[q]);
+  if (g == 0 && tid == 0) {
+    a.state[DSEA_CG_RR] = gamma;
+    a.state[DSEA_CG_RESNORM] = rn;
+    a.state[DSEA_CG_ITERS] = (double)iters;
+    a.state[DSEA_CG_DONE] = fail ? -1.0 : (done ? 1.0 : 0.0);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // host-side launch wrappers (called from dsea_capi.hip)
 // ------------------------------------------------------------------------------------------
 // (tuning knobs live in the operator descriptor: OpDesc::tune_tile_log2, OpDesc::tune_csr_group)
@@ -2243,10 +2477,14 @@ void launch_finalize_slot(const double* P, int count, double* out, const double*
 // (then the caller runs the streaming 3-launch form), -2 on a HIP error.  `comm` must hold persist_comm_bytes().
 size_t persist_comm_bytes(int64_t n) {
   const int64_t nt = (n + 511) / 512;
-  return (size_t)(4 * nt + 8 * 256) * sizeof(unsigned long long);
+  return (size_t)(4 * nt + 20 * 256) * sizeof(unsigned long long);   // (the merged form needs 20 G <= 20 * 256)
 }
 int launch_cg_persist(const OpDesc& op, const double* shift, const double* b, double* x, double* state, double eps,
                       int64_t maxiter, void* comm, int ppt_override, hipStream_t st) {
+  // mode >= 100: the merged-reduction form (one exchange per iteration, k_cg_persist_stencil_merged) with the
+  // geometry code mode - 100
+  const bool merged = ppt_override >= 100;
+  if (merged) ppt_override -= 100;
   if (op.kind != OP_STENCIL3 || op.st3.halo_lo || op.st3.halo_hi) return -1;
   const int64_t n = op.st3.n;
   const int64_t nt = (n + 511) / 512;
@@ -2264,6 +2502,9 @@ int launch_cg_persist(const OpDesc& op, const double* shift, const double* b, do
       if (nt <= 64) { ppt = 1; nvb = 1; }
       else if (nt <= 512) { ppt = 1; nvb = 2; }
       else { ppt = 2; nvb = 2; }
+      // merged form, measured (N = 1e5 / 2e4): (ppt, nvb) = (2,1): 3.26 / 2.92, (1,1): 3.87 / 2.60, (1,2): 3.49 / 2.90,
+      // (2,2): 3.48 / 2.97, (1,4): 3.87 / 3.65
+      if (merged && nt > 64 && nt <= 512) { ppt = 2; nvb = 1; }
       break;
   }
   const int tpw = nvb * ppt;
@@ -2271,7 +2512,8 @@ int launch_cg_persist(const OpDesc& op, const double* shift, const double* b, do
   if (G > 256) {
     return -1;
   }
-  const size_t cbytes = (size_t)(4 * nt + 8 * G) * sizeof(unsigned long long);
+  const size_t cbytes = merged ? (size_t)(16 + 4) * G * sizeof(unsigned long long)
+                               : (size_t)(4 * nt + 8 * G) * sizeof(unsigned long long);
   if (hipMemsetAsync(comm, 0, cbytes, st) != hipSuccess) return -2;
   PersistArgs a;
   a.p = op.st3;
@@ -2283,9 +2525,14 @@ int launch_cg_persist(const OpDesc& op, const double* shift, const double* b, do
   a.maxiter = (long long)maxiter;
   a.comm = static_cast<unsigned long long*>(comm);
   a.ntiles = (int)nt;
-  const size_t lds = (size_t)(tpw * 512 + 4) * sizeof(double) + sizeof(PersistSm);
-#define PERSIST_CASE(P, V) \
-  if (ppt == P && nvb == V) hipLaunchKernelGGL((k_cg_persist_stencil<P, V>), dim3(G), dim3(256 * V), lds, st, a);
+  const size_t lds = (size_t)(tpw * 512 + 4) * sizeof(double) + (merged ? sizeof(PersistSmM) : sizeof(PersistSm));
+#define PERSIST_CASE(P, V)                                                                                      \
+  if (ppt == P && nvb == V) {                                                                                   \
+    if (merged)                                                                                                 \
+      hipLaunchKernelGGL((k_cg_persist_stencil_merged<P, V>), dim3(G), dim3(256 * V), lds, st, a);              \
+    else                                                                                                        \
+      hipLaunchKernelGGL((k_cg_persist_stencil<P, V>), dim3(G), dim3(256 * V), lds, st, a);                     \
+  }
   PERSIST_CASE(1, 4) PERSIST_CASE(2, 4) PERSIST_CASE(1, 2) PERSIST_CASE(2, 2) PERSIST_CASE(1, 1) PERSIST_CASE(2, 1)
 #undef PERSIST_CASE
   return 0;

@@ -110,6 +110,7 @@ class Workspace:
 
     def set_persist(self, mode):
         check(self.lib.dsea_ws_set_persist(self.handle, int(mode)), "dsea_ws_set_persist")
+        self.persist_mode = int(mode)
 
     def set_split(self, waves):
         check(self.lib.dsea_ws_set_split(self.handle, int(waves)), "dsea_ws_set_split")
@@ -411,11 +412,21 @@ class CGInfo:
 last_cg = CGInfo()
 
 
-def cg(b, x0, *, native=None, callable_A=None, shift=None, eps=1e-7, maxiter=None, poll_every=8):
+# Latency-bound solves on small halo-1 operators (BASELINE config 3): run the persistent single-launch CG in its
+# MERGED-REDUCTION form -- one grid-wide exchange per iteration instead of two (3.3-3.5 instead of 5.4 us per
+# iteration at N = 1e5).  The same iteration in exact arithmetic, not the rounding sequence of reference
+# CG.py:31-40 (measured: 6e-14 relative after 40 iterations, same iteration counts on converged runs), hence off
+# by default; ``cg(..., merged_reductions=True)`` selects it per call.
+CG_MERGED_REDUCTIONS = False
+
+
+def cg(b, x0, *, native=None, callable_A=None, shift=None, eps=1e-7, maxiter=None, poll_every=8,
+       merged_reductions=None):
     """Conjugate gradients on the GPU (reference CG.py:24-41) for (A - shift I) x = b.
 
     ``shift`` is a 0-dim/1-element device tensor (the eigenvalue E0 of CG.py:120) or None.
     Returns x (new tensor).  The loop state lives on the device; the host polls a flag.
+    ``merged_reductions``: see CG_MERGED_REDUCTIONS (applies where the persistent form does; ignored elsewhere).
     """
     lib = _lib.load()
     device = b.device
@@ -431,8 +442,16 @@ def cg(b, x0, *, native=None, callable_A=None, shift=None, eps=1e-7, maxiter=Non
         shift_t = shift.detach().reshape(-1)[:1].to(device=device, dtype=F64).contiguous()
     if native is not None:
         iters, res = c_int64(0), c_double(0.0)
-        rc = lib.dsea_cg_run(native.handle, ws.handle, _ptr(shift_t), _ptr(b), _ptr(x), _ptr(state), float(eps),
-                             cap, int(poll_every), byref(iters), byref(res), st)
+        merged = CG_MERGED_REDUCTIONS if merged_reductions is None else bool(merged_reductions)
+        prev_mode = getattr(ws, "persist_mode", -1)
+        if merged and prev_mode == -1:
+            ws.set_persist(100)
+        try:
+            rc = lib.dsea_cg_run(native.handle, ws.handle, _ptr(shift_t), _ptr(b), _ptr(x), _ptr(state), float(eps),
+                                 cap, int(poll_every), byref(iters), byref(res), st)
+        finally:
+            if merged and prev_mode == -1:
+                ws.set_persist(-1)
         check(rc, "dsea_cg_run", allow=(_lib.ERR_NOT_CONVERGED,))
         last_cg.iters, last_cg.resnorm, last_cg.converged = iters.value, res.value, rc == 0
         return x

@@ -74,7 +74,11 @@ int dsea_ws_set_split(dsea_ws_t ws, int waves);
  * whole solve is ONE launch whose workgroups keep x, r, d in registers and exchange only per-tile partial sums and
  * edge elements; iterates are bit-identical to the streaming 3-launches-per-iteration form.
  * -1 = automatic (on where it applies), 0 = off (streaming form); forced geometries: 1 / 2 = that many row pairs per
- * thread in workgroups of 1024 threads, 21 / 22 = in workgroups of 512, 11 / 12 = in workgroups of 256.            */
+ * thread in workgroups of 1024 threads, 21 / 22 = in workgroups of 512, 11 / 12 = in workgroups of 256.
+ * 100 + g (g = 0 automatic geometry, or one of the codes above): the MERGED-REDUCTION form -- one grid-wide exchange
+ * per iteration instead of two (r.r and r.Ar reduced together, A p carried by a recurrence: Chronopoulos-Gear).  The
+ * same iteration in exact arithmetic, NOT the rounding sequence of reference CG.py:31-40: an option for
+ * latency-bound solves, never selected automatically.                                                           */
 int dsea_ws_set_persist(dsea_ws_t ws, int mode);
 
 /* Optional bf16 SHADOW of the Krylov basis (caller-owned, `rows` x `ld` uint16, ld % 8 == 0, 16-byte
