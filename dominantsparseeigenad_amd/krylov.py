@@ -60,20 +60,38 @@ def _rank_key(evals, which):
 
 class _one_thread:
     """Small dense LAPACK calls (a 200 x 200 Hessenberg matrix) are faster on ONE thread than on a thread pool
-    (measured: eig 19 ms vs 41-190 ms, LU-based inverse iteration 1.5 vs 27 ms)."""
+    (measured: eig 19 ms vs 41-190 ms, LU-based inverse iteration 1.5 vs 27 ms).  The limit is process-wide state and
+    the right / left solves of eig._two_sides enter it from two threads at once: it is reference-counted under a lock
+    (first entrant sets it, last one restores it) -- nested per-thread contexts would restore each other's value and
+    could leave the whole process single-threaded."""
+
+    _lock = None
+    _depth = 0
+    _ctx = None
 
     def __enter__(self):
-        try:
-            from threadpoolctl import threadpool_limits
-            self._ctx = threadpool_limits(limits=1)
-            self._ctx.__enter__()
-        except Exception:           # threadpoolctl not installed: run as is
-            self._ctx = None
+        import threading
+        cls = _one_thread
+        if cls._lock is None:
+            cls._lock = threading.Lock()
+        with cls._lock:
+            if cls._depth == 0:
+                try:
+                    from threadpoolctl import threadpool_limits
+                    cls._ctx = threadpool_limits(limits=1)
+                    cls._ctx.__enter__()
+                except Exception:           # threadpoolctl not installed: run as is
+                    cls._ctx = None
+            cls._depth += 1
         return self
 
     def __exit__(self, *exc):
-        if self._ctx is not None:
-            self._ctx.__exit__(*exc)
+        cls = _one_thread
+        with cls._lock:
+            cls._depth -= 1
+            if cls._depth == 0 and cls._ctx is not None:
+                ctx, cls._ctx = cls._ctx, None
+                ctx.__exit__(None, None, None)
 
 
 def _wanted_pair(B, which):

@@ -2,6 +2,7 @@
 CPU plumbing).  Mirrors reference DominantSparseEigenAD/tests/test_Lanczos.py, test_CG.py, test_symeig.py,
 test_gradient.py -- same sizes, same assertions -- through the drop-in import name."""
 import numpy as np
+import pytest
 import torch
 
 import DominantSparseEigenAD.symeig as symeig
@@ -244,3 +245,24 @@ def test_bench_self_launches_one_worker_per_gpu():
     else:
         assert out.returncode != 0
         assert out.stderr.count("bench.py needs the MI355X") >= 2 or "local_rank: 1" in out.stderr, out.stderr[-1500:]
+
+
+def test_one_thread_limit_is_restored_after_concurrent_use():
+    """krylov._one_thread (single-threaded LAPACK for the small Hessenberg problems) is entered from the two
+    concurrent sides of eig._two_sides: the process-wide pool sizes must come back."""
+    import threading
+    threadpoolctl = pytest.importorskip("threadpoolctl")
+    from dominantsparseeigenad_amd import krylov
+    rng = np.random.RandomState(0)
+    krylov._wanted_pair(rng.rand(8, 8) + 5 * np.eye(8), "LM")       # loads every BLAS the call needs
+    before = sorted((d["user_api"], d["num_threads"]) for d in threadpoolctl.threadpool_info())
+
+    def work():
+        for _ in range(10):
+            krylov._wanted_pair(rng.rand(40, 40) + 5 * np.eye(40), "LM")
+
+    threads = [threading.Thread(target=work) for _ in range(4)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    after = sorted((d["user_api"], d["num_threads"]) for d in threadpoolctl.threadpool_info())
+    assert after == before and krylov._one_thread._depth == 0
