@@ -22,6 +22,7 @@ primitives fix afterwards (l.r = 1, r.r = 1, sign of r free).
 from __future__ import annotations
 
 import ctypes
+import time
 from ctypes import byref, c_void_p
 
 import numpy as np
@@ -122,6 +123,7 @@ def _wanted_pair(B, which):
 STAGE_FIRST = 32
 STAGE_MIN = 8
 STAGE_MAX = 64
+STAGE_LOG = None        # set to a list to record [columns, ms until the stage's H is on the host, host ms, residual]
 
 
 def _next_stage_end(j, p, m, hist, tol):
@@ -214,6 +216,7 @@ def arnoldi_dominant(A, n, ncv, device, which="LM", v0=None, tol=1e-13, max_rest
                     check(lib.dsea_arnoldi_orth(ws.handle, _ptr(u), None, _ptr(V), ldv, n, jj, _ptr(Hd), ldh, st()),
                           "dsea_arnoldi_orth")
             stages_run += 1
+            t_issue = time.perf_counter()
             brk = ctypes.c_int(0)
             check(lib.dsea_lanczos_status(ws.handle, byref(brk), st()), "dsea_lanczos_status",
                   allow=(_lib.ERR_BREAKDOWN,))
@@ -222,6 +225,9 @@ def arnoldi_dominant(A, n, ncv, device, which="LM", v0=None, tol=1e-13, max_rest
             B = Hh[:me, :me].T.copy()
             coupling = 0.0 if me < j1 or brk.value else float(Hh[j1 - 1, j1])
             j = j1
+            t_dev = time.perf_counter()
+            if STAGE_LOG is not None:
+                STAGE_LOG.append([j1, (t_dev - t_issue) * 1e3, None])
             try:
                 theta, y, evals = _wanted_pair(B, which)
             except ValueError:
@@ -229,6 +235,9 @@ def arnoldi_dominant(A, n, ncv, device, which="LM", v0=None, tol=1e-13, max_rest
                     raise                      # the full factorisation says the wanted eigenvalue is complex: eig.py:31-32
                 continue                       # an early block may well have a complex wanted Ritz value: keep going
             res = abs(coupling * y[-1])
+            if STAGE_LOG is not None:
+                STAGE_LOG[-1][2] = (time.perf_counter() - t_dev) * 1e3
+                STAGE_LOG[-1].append(res / max(abs(theta), 1e-300))
             if res <= tol * abs(theta) or me < j1 or j1 >= m:
                 break
             hist.append((j1, res / max(abs(theta), 1e-300)))

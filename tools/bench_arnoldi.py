@@ -37,3 +37,9 @@ for rep in range(3):
     lam, xr = krylov.arnoldi_dominant(op, n, m, dev, "LM")
     torch.cuda.synchronize(); t1 = time.perf_counter()
 print("arnoldi_dominant: %.2f ms, %d cycle(s), lambda=%.12f" % ((t1 - t0) * 1e3, krylov.arnoldi_dominant.last_cycles, lam))
+krylov.STAGE_LOG = []
+torch.cuda.synchronize(); t0 = time.perf_counter()
+lam, xr = krylov.arnoldi_dominant(op, n, m, dev, "LM")
+torch.cuda.synchronize(); t1 = time.perf_counter()
+print("one more run, %.2f ms, stages [columns, ms to H on host, host ms, relative residual]:" % ((t1 - t0) * 1e3))
+for row in krylov.STAGE_LOG: print("   ", ["%.3g" % v if v is not None else None for v in row])
