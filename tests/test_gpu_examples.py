@@ -106,6 +106,30 @@ def test_vumps_example_on_device():
     assert exact - 1e-9 <= E0 < -1.2730, (E0, exact, stored_D5)
 
 
+def test_symmetric_vumps_example_on_device():
+    """The caller of the DENSE primitive (reference examples/TFIM_vumps/symmetric.py:40-48): energy
+    and gradient of the symmetric-tensor ansatz on the device equal the host path on the same tensor, and a short LBFGS
+    run moves the variational energy towards the exact value of datas/E0_sum.npz from above."""
+    ex = _load(os.path.join(ROOT, "examples", "TFIM_vumps", "symmetric.py"), "ex_vumps_sym")
+    exact = float(np.load(os.path.join(GOLDEN, "ref_datas", "vumps_E0_sum.npz"))["E0s"][4])
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(11)
+    A0 = torch.randn(2, 8, 8, dtype=torch.float64, generator=gen)
+    out = {}
+    for name, device in (("cpu", torch.device("cpu")), ("gpu", dev)):
+        model = ex.TFIM(8, 64, device)           # k = n = 64: the Krylov process is exact, start vectors drop out
+        model.seth(1.0)
+        model.setparameters(A0.clone())
+        E = model()
+        (gA,) = torch.autograd.grad(E, model.A)
+        out[name] = (E.item(), gA.detach().cpu())
+    assert abs(out["gpu"][0] - out["cpu"][0]) < 1e-10 * abs(out["cpu"][0])
+    assert float((out["gpu"][1] - out["cpu"][1]).abs().max()) < 1e-6 * float(out["cpu"][1].abs().max())
+    torch.manual_seed(42)
+    E0, _ = ex.optimise(1.0, 6, 30, 12, dev, verbose=False)
+    assert exact - 1e-9 <= E0 < -1.2730, (E0, exact)
+
+
 def test_dense_primitive_second_order_on_device():
     """DominantSymeig on the dense Hamiltonian tensor on the GPU (reference E0.py:38-51, E0_matrixAD): first and
     second derivative through the shift-in-kernel projected CG (no A - lambda*I copy) against the closed form."""
