@@ -31,8 +31,13 @@ def main():
     ap.add_argument("--warm", type=int, default=0,
                     help="Lanczos vectors per forward pass from the second coupling on, with the previous coupling's "
                          "eigenvector as start vector (Lanczos.WARM_START; an extension the reference lacks)")
+    ap.add_argument("--skip-zero-rhs", type=int, default=0,
+                    help="1: symeig.SKIP_ZERO_RHS -- the first backward of every point (a loss that ignores the "
+                         "eigenvector) skips its CG solve of (A - E0) x = 0: two solves per E0 point instead of three")
     args = ap.parse_args()
     import DominantSparseEigenAD.Lanczos as LZ
+    import DominantSparseEigenAD.symeig as SE
+    SE.SKIP_ZERO_RHS = bool(args.skip_zero_rhs)
     curE = np.load(os.path.join(args.data, "E0_N_%d.npz" % args.N))
     curC = np.load(os.path.join(args.data, "chiF_N_%d.npz" % args.N))
     dev = torch.device(args.device)

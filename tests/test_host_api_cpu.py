@@ -266,3 +266,41 @@ def test_one_thread_limit_is_restored_after_concurrent_use():
     [t.join() for t in threads]
     after = sorted((d["user_api"], d["num_threads"]) for d in threadpoolctl.threadpool_info())
     assert after == before and krylov._one_thread._depth == 0
+
+
+def test_skip_zero_rhs_option(golden):
+    """symeig.SKIP_ZERO_RHS: a loss that ignores the eigenvector skips the CG solve of (A - E0) x = 0 -- the
+    first derivative becomes the exact Hellmann-Feynman value, the second derivative is unchanged to the CG tolerance,
+    and the default (off) stays draw-for-draw with the reference."""
+    import oracle
+    gd = golden("tfim_L10_k300_g1.0")
+    model = oracle.TFIMTables(10)
+    model.g = torch.tensor([1.0], dtype=torch.float64, requires_grad=True)
+    symeig.setDominantSparseSymeig(model.H, model.adjoint_hook)
+    calls = [0]
+    inner = model.H
+
+    def counting(v):
+        calls[0] += 1
+        return inner(v)
+
+    out = {}
+    for flag in (False, True):
+        symeig.SKIP_ZERO_RHS = flag
+        try:
+            symeig.setDominantSparseSymeig(counting, model.adjoint_hook)
+            with PatchRandn(int(gd["seed_draw_E"])) as draws:
+                E0, psi = symeig.DominantSparseSymeig.apply(model.g, 300, model.dim)
+                c0 = calls[0]
+                (dE0,) = torch.autograd.grad(E0, model.g, create_graph=True)
+                c1 = calls[0]
+                (d2E0,) = torch.autograd.grad(dE0, model.g)
+                out[flag] = (dE0.item(), d2E0.item(), c1 - c0, draws.count)
+        finally:
+            symeig.SKIP_ZERO_RHS = False
+    assert out[False][3] == int(gd["ndraw_E"]) and out[True][3] == int(gd["ndraw_E"]) - 1
+    assert out[False][2] > 20 and out[True][2] == 0          # the first backward makes no mat-vec at all
+    hf = (psi.detach() @ model.dHdg(psi.detach())).item()    # Hellmann-Feynman: dE0/dg = <psi| dH/dg |psi>
+    assert abs(out[True][0] - hf) < 1e-13 * abs(hf)
+    assert abs(out[True][0] - float(gd["dE0"][0])) < 1e-9 * abs(float(gd["dE0"][0]))
+    assert abs(out[True][1] - float(gd["d2E0"][0])) < 1e-8 * abs(float(gd["d2E0"][0]))
