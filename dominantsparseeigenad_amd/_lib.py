@@ -19,6 +19,7 @@ CG_RR, CG_DAD, CG_RRNEW, CG_ALPHA, CG_BETA, CG_RESNORM, CG_DONE, CG_ITERS = rang
 CG_STATE_LEN = 8
 ERR_NOT_CONVERGED = -5
 ERR_BREAKDOWN = -7
+ERR_TIMEOUT = -8
 
 
 class DseaError(RuntimeError):

@@ -449,6 +449,20 @@ def cg(b, x0, *, native=None, callable_A=None, shift=None, eps=1e-7, maxiter=Non
         try:
             rc = lib.dsea_cg_run(native.handle, ws.handle, _ptr(shift_t), _ptr(b), _ptr(x), _ptr(state), float(eps),
                                  cap, int(poll_every), byref(iters), byref(res), st)
+            if rc == _lib.ERR_TIMEOUT:
+                # The persistent single-launch form needs all of its workgroups resident at the same time; if other
+                # work holds compute units (e.g. a second persistent solve on another stream) its bounded spins give
+                # up and report instead of hanging.  The solve is then repeated in the streaming form.
+                import warnings
+                warnings.warn("persistent CG launch timed out waiting for a peer workgroup (device shared with other "
+                              "work?): repeating the solve with the streaming kernels", RuntimeWarning)
+                x.copy_(as_vector(x0, n))
+                ws.set_persist(0)
+                try:
+                    rc = lib.dsea_cg_run(native.handle, ws.handle, _ptr(shift_t), _ptr(b), _ptr(x), _ptr(state),
+                                         float(eps), cap, int(poll_every), byref(iters), byref(res), st)
+                finally:
+                    ws.set_persist(prev_mode)
         finally:
             if merged and prev_mode == -1:
                 ws.set_persist(-1)
