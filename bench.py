@@ -338,6 +338,8 @@ def main():
         res = op.H(psi) - E0.detach() * psi
         return float(dot(res, res).sqrt())
 
+    if os.environ.get("DSEA_PLACEMENT_TRIES"):
+        engine.BasisArena.PLACEMENT_TRIES = int(os.environ["DSEA_PLACEMENT_TRIES"])
     ws = engine.Workspace.get(nloc, k, dev)
     if args.rpl:
         ws.set_rows_per_lane(args.rpl)
@@ -471,7 +473,8 @@ def main():
                        "bf16_shadow_of_basis": bool(engine.USE_SHADOW), "lanczos_reorthogonalisation": args.reorth,
                        "E0_per_site": E0.item() / L, "E0_per_site_closed_form": analytic_E0_per_site(L, 1.0),
                        "dloss_dg": float(gl.reshape(-1)[0].item()),
-                       "adjoint_vs_reference_at_eps1e-7": ADJOINT_DEV_EPS7},
+                       "adjoint_vs_reference_at_eps1e-7": ADJOINT_DEV_EPS7,
+                       "basis_placement_probe_us": [round(t, 1) for t in (engine.BasisArena.last_placement or [])]},
         }
         out["config"].update(notes)
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")

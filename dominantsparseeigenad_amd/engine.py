@@ -131,9 +131,22 @@ class BasisArena:
     use it.  ``release()`` gives the memory back."""
 
     _bufs = {}
+    # PLACEMENT.  The dots pass runs in one of two modes (256 vs 272 us per pass at n = 2^20, i = 199: 6.67 vs
+    # 6.28 TB/s) that are a property of WHERE the basis lives, not of the code: on one MI355X box the first large
+    # allocation of a process was slow and every one of seven later allocations of the same shape fast, reproducibly
+    # per buffer while all were alive; on another box all nine candidates of a process were slow; bench processes on
+    # one box alternate (tools/placement_probe.py, profiles/r02_placement_probe.txt).  Initialised or untouched
+    # memory, random or zero data make no difference.  Physical placement is not visible from user space, so it is
+    # MEASURED: when the arena has to allocate a large fp64 basis it takes up to PLACEMENT_TRIES candidates that are
+    # alive at the same time, times the real dots pass on each (three launches on whatever bytes the memory holds)
+    # and keeps the fastest.  Costs a few ms once per arena allocation and helps only where candidates differ; skipped
+    # when the candidates would not fit beside each other (L = 28 on one GPU); two candidates above 8 GB.  0 / 1 = off.
+    PLACEMENT_TRIES = 3
+    PLACEMENT_MIN_BYTES = 128 << 20
+    last_placement = None           # [us per probe pass of each candidate], for the curious
 
     @classmethod
-    def get(cls, device, tag, nbytes):
+    def get(cls, device, tag, nbytes, probe=None):
         device = torch.device(device)
         key = (str(device), int(torch.cuda.current_stream(device).cuda_stream) if device.type == "cuda" else 0, tag)
         with _CACHE_LOCK:
@@ -143,19 +156,67 @@ class BasisArena:
                     del cls._bufs[key], buf
                     if device.type == "cuda":
                         torch.cuda.empty_cache()
+                tries = 1
+                if probe is not None and device.type == "cuda" and nbytes >= cls.PLACEMENT_MIN_BYTES:
+                    free_b, _ = torch.cuda.mem_get_info(device)
+                    tries = max(1, min(int(cls.PLACEMENT_TRIES), 2 if nbytes > (8 << 30) else 99,
+                                       int(0.7 * free_b // max(int(nbytes), 1))))
                 buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+                if tries > 1:
+                    cands, nxt = [(probe(buf), buf)], None
+                    for _ in range(tries - 1):
+                        try:
+                            nxt = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+                        except RuntimeError:          # out of memory after all: keep what we have
+                            break
+                        cands.append((probe(nxt), nxt))
+                    cls.last_placement = [t for t, _ in cands]
+                    buf = min(cands, key=lambda tb: tb[0])[1]
+                    del cands, nxt
+                    torch.cuda.empty_cache()          # the losing candidates go back to the driver
                 cls._bufs[key] = buf
         return buf
 
     @classmethod
-    def matrix(cls, device, tag, rows, cols, dtype):
+    def matrix(cls, device, tag, rows, cols, dtype, n_hint=None):
+        """(rows, cols) view of the arena buffer ``tag``.  ``n_hint`` (fp64 bases): the vector length of the solver
+        that will stream it -- enables the placement selection above."""
         esz = torch.empty(0, dtype=dtype).element_size()
-        buf = cls.get(device, tag, rows * cols * esz)
+        probe = None
+        if n_hint is not None and dtype == F64 and rows >= 8:
+            probe = lambda b: _dots_probe_us(b, int(rows), int(cols), int(n_hint), torch.device(device))  # noqa: E731
+        buf = cls.get(device, tag, rows * cols * esz, probe)
         return buf[: rows * cols * esz].view(dtype).view(rows, cols)
 
     @classmethod
     def release(cls):
         cls._bufs.clear()
+
+
+def _dots_probe_us(buf, rows, ldq, n, device):
+    """microseconds per dots pass (dsea_lanczos_rdots, all rows - 1 vectors) over the candidate basis buffer ``buf``;
+    the values in the buffer are whatever the memory holds (the results are scratch)"""
+    lib = _lib.load()
+    ws = Workspace.get(n, rows, device)
+    st = _stream(device)
+    i = rows - 1
+    u = torch.zeros(n, dtype=F64, device=device)
+    r = torch.empty(n, dtype=F64, device=device)
+    c = torch.zeros(rows + 2, dtype=F64, device=device)
+    ab = torch.zeros(2, dtype=F64, device=device)
+
+    def launch():
+        check(lib.dsea_lanczos_rdots(ws.handle, _ptr(buf), int(ldq), int(n), int(i), _ptr(u), _ptr(ab),
+                                     c_void_p(ab.data_ptr() + 8), _ptr(r), _ptr(c), st), "dsea_lanczos_rdots")
+
+    launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        launch()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / 3 * 1e3
 
 
 def native_of(A):
@@ -233,7 +294,7 @@ def lanczos(A, k, n, device, q0, native=None, callable_A=None, arena=False):
     st = _stream(device)
     ldq = round_up(n, 32)
     # arena: the caller does not keep the basis (symeigLanczos) -> persistent buffer instead of a fresh allocation
-    Q = BasisArena.matrix(device, "Q", k, ldq, F64) if arena else torch.empty((k, ldq), dtype=F64, device=device)
+    Q = BasisArena.matrix(device, "Q", k, ldq, F64, n_hint=n) if arena else torch.empty((k, ldq), dtype=F64, device=device)
     new_shadow = (lambda: BasisArena.matrix(device, "Qs", k, ldq, torch.bfloat16)) if arena else \
         (lambda: torch.empty((k, ldq), dtype=torch.bfloat16, device=device))
     alphas = torch.empty(k, dtype=F64, device=device)

@@ -95,7 +95,7 @@ class HipBackend(_engine_mod.Phases):
     # -- macro phases of the partitioned Lanczos step (include/dsea.h "row-partitioned macro phases")
     def basis(self, k, ldq, arena):
         if arena:
-            return self.engine.BasisArena.matrix(self.device, "Q", k, ldq, F64)
+            return self.engine.BasisArena.matrix(self.device, "Q", k, ldq, F64, n_hint=self.n)
         return self.empty(k, ldq)
 
     def set_shadow(self, k, ldq, arena=False):

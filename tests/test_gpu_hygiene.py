@@ -266,3 +266,32 @@ def test_lazy_rank_one_adjoint_of_a_dense_matrix_through_the_sparse_primitive():
         (g_lazy,) = torch.autograd.grad(lam2 + sgn2 * psi2.matmul(t), p)
     assert abs(lam.item() - lam2.item()) < 1e-12 * abs(lam.item())
     assert abs(g_dense.item() - g_lazy.item()) < 1e-7 * abs(g_dense.item()), (g_dense.item(), g_lazy.item())
+
+
+def test_basis_arena_measures_the_placement_of_a_new_basis(monkeypatch):
+    """A new arena basis above PLACEMENT_MIN_BYTES is chosen among PLACEMENT_TRIES simultaneously alive candidates by
+    timing the dots pass on each (engine.BasisArena); results do not depend on which candidate wins."""
+    L, k = 14, 64
+    n = 1 << L
+    op = TFIMOperator(L, dev())
+    op.g = torch.tensor([1.0], dtype=F64, device=dev())
+    q0 = unit(n, 77).to(dev())
+    out = []
+    for tries in (1, 3):
+        engine.BasisArena.release()
+        torch.cuda.empty_cache()
+        monkeypatch.setattr(engine.BasisArena, "PLACEMENT_MIN_BYTES", 1 << 20)
+        monkeypatch.setattr(engine.BasisArena, "PLACEMENT_TRIES", tries)
+        engine.BasisArena.last_placement = None
+        lo, v = symeigLanczos(op, k, dev(), extreme="min", sparse=True, dim=n, q0=q0)
+        out.append((lo.item(), v.clone()))
+        if tries == 1:
+            assert engine.BasisArena.last_placement is None
+        else:
+            assert len(engine.BasisArena.last_placement) == 3 and min(engine.BasisArena.last_placement) > 0.0
+            # the arena is reused: no new measurement on the second call
+            engine.BasisArena.last_placement = None
+            symeigLanczos(op, k, dev(), extreme="min", sparse=True, dim=n, q0=q0)
+            assert engine.BasisArena.last_placement is None
+    assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1])
+    engine.BasisArena.release()

@@ -1,10 +1,13 @@
 #!/bin/bash
-# A/B of two builds of the library on the SAME box: libdsea_A.so (baseline) vs libdsea.so, alternating
+# A/B/... of several builds of the library on the SAME box, alternating processes (the dots pass is bimodal per
+# process, so every variant is sampled several times):  bash tools/ab.sh "R0 R1 R2" [reps] [bench args...]
+# (variants are dominantsparseeigenad_amd/csrc/libdsea_<name>.so; "-" = the in-tree libdsea.so)
 cd "$GRAFT_REPO_ROOT" || exit 1
+VARS=${1:-"A -"}; REPS=${2:-3}; shift; shift
 O=gpurun_out/ab; mkdir -p $O
-for rep in 1 2 3; do
-  for v in A B; do
-    if [ $v = A ]; then export DSEA_LIB=$PWD/dominantsparseeigenad_amd/csrc/libdsea_A.so; else unset DSEA_LIB; fi
+for rep in $(seq 1 $REPS); do
+  for v in $VARS; do
+    if [ "$v" = "-" ]; then unset DSEA_LIB; else export DSEA_LIB=$PWD/dominantsparseeigenad_amd/csrc/libdsea_$v.so; fi
     python bench.py --no-cpu-baseline --no-extras "$@" > $O/$v$rep.log 2>$O/$v$rep.err
     python - "$v$rep" $O/$v$rep.log <<'PY'
 import json,sys
