@@ -132,13 +132,13 @@ int dsea_op_set_tuning(dsea_op_t op, int key, int value) {
 
 // ---------------------------------------------------------------------------- workspace
 int dsea_ws_bytes(int64_t n, int kmax, size_t* bytes) {
-  if (!bytes || n < 1 || kmax < 0) return DSEA_ERR_ARG;
+  if (!bytes || n < 1 || kmax < 0 || kmax > DSEA_MAX_KRYLOV) return DSEA_ERR_ARG;
   *bytes = ws_layout(n, kmax).total;
   return DSEA_OK;
 }
 
 int dsea_ws_create(void* device_buffer, size_t bytes, int64_t n, int kmax, dsea_ws_t* out) {
-  if (!device_buffer || !out || n < 1 || kmax < 0) return DSEA_ERR_ARG;
+  if (!device_buffer || !out || n < 1 || kmax < 0 || kmax > DSEA_MAX_KRYLOV) return DSEA_ERR_ARG;
   if (!aligned16(device_buffer)) return DSEA_ERR_ALIGN;
   WsLayout L = ws_layout(n, kmax);
   if (bytes < L.total) return DSEA_ERR_WORKSPACE;

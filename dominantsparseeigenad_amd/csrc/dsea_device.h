@@ -16,6 +16,46 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;  // butterfly: every lane holds the same, order-fixed total
 }
 
+// Four wave-wide sums at once without the LDS crossbar: on gfx950 ``__shfl_xor`` is a ds_bpermute (a round trip
+// through the LDS pipeline, ~100+ cycles, seven of them in a dependent chain for the transposed butterfly the dots
+// pass used) during which a wave that is alone on its SIMD has no loads in flight.  v_permlane32_swap / v_permlane16_swap
+// (new in gfx950) exchange half-waves / alternate 16-lane rows of two registers in one VALU instruction, which is
+// exactly the "transposed" step: after swap32(a0, a2) the sum a0 + a2 holds the 32-lane partial sums of a0 in its lower
+// half and those of a2 in its upper half (likewise a1, a3); after swap16 of the two results, row v (lanes 16v..16v+15)
+// of their sum holds 16 partial sums of a_v; four DPP row shifts finish inside the rows.
+// Returns the total of a_v in lane 16 v + 15 (other lanes hold partial sums).  Fixed order: deterministic.
+typedef unsigned dsea_v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void permlane32_swap_f64(double& d, double& s) {
+  const dsea_v2u lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(d), (unsigned)__double2loint(s), false, false);
+  const dsea_v2u hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(d), (unsigned)__double2hiint(s), false, false);
+  d = __hiloint2double((int)hi.x, (int)lo.x);
+  s = __hiloint2double((int)hi.y, (int)lo.y);
+}
+__device__ __forceinline__ void permlane16_swap_f64(double& d, double& s) {
+  const dsea_v2u lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(d), (unsigned)__double2loint(s), false, false);
+  const dsea_v2u hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(d), (unsigned)__double2hiint(s), false, false);
+  d = __hiloint2double((int)hi.x, (int)lo.x);
+  s = __hiloint2double((int)hi.y, (int)lo.y);
+}
+template <int CTRL>   // DPP row_shr:n = 0x110 + n ; lanes without a source read 0
+__device__ __forceinline__ double dpp_row_shr_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum4_rows(double a0, double a1, double a2, double a3) {
+  permlane32_swap_f64(a0, a2);
+  permlane32_swap_f64(a1, a3);
+  double A = a0 + a2, B = a1 + a3;
+  permlane16_swap_f64(A, B);
+  double v = A + B;
+  v += dpp_row_shr_f64<0x118>(v);
+  v += dpp_row_shr_f64<0x114>(v);
+  v += dpp_row_shr_f64<0x112>(v);
+  v += dpp_row_shr_f64<0x111>(v);
+  return v;
+}
+
 // block of 256 threads = 4 waves; returns the total in thread 0 (fixed order w0+w1+w2+w3)
 __device__ __forceinline__ double block_sum(double v, double* sm4) {
   v = wave_sum(v);

@@ -12,6 +12,7 @@
 #define DSEA_TFIM_TILE_LOG2 11    /* rows of x staged in LDS per block of the TFIM mat-vec    */
 #define DSEA_MAX_TFIM_BLOCKS 4096 /* grid cap of the TFIM mat-vec (<= DSEA_MAX_WAVE_TILES partial slots)   */
 #define DSEA_PERSIST_MAX_TILES 4096 /* canonical-tile regime of the CG kernels: n <= 2^21 rows               */
+#define DSEA_MAX_KRYLOV 8000       /* cap on kmax: the dots pass keeps one LDS row of k partial sums per wave      */
 #define DSEA_PERSIST_CG_MAX_TILES 1024 /* persistent single-launch CG: n <= 2^19 rows                       */
 #define DSEA_SCALARS 64
 #define DSEA_SCAL_BREAK 20    /* scal[20] = breakdown step, scal[21] = running scale (see broken())     */

@@ -62,8 +62,12 @@ template <int RPL, bool GUARD>
 __device__ __forceinline__ void rdots_tile(const double* __restrict__ Q, int64_t ldq, int i, int64_t n,
                                            int64_t base, int lane, const double* __restrict__ u,
                                            double a, double b, double* __restrict__ r,
-                                           double* __restrict__ P, int64_t pstride, int64_t widx,
-                                           bool accumulate, bool want_rr) {
+                                           double* __restrict__ sP, bool accumulate, bool want_rr) {
+  // sP: this wave's row of i + 1 partial sums in LDS.  They are NOT stored to global memory inside the loop: on
+  // gfx9 loads and stores share the in-order vmcnt counter, so a store issued between two trips makes the next
+  // trip's loads wait for the store's acknowledgement from L2 (measured: 12.6 us of a 273 us pass at i = 199 for the
+  // 200 eight-byte stores of a wave).  LDS traffic is counted separately (lgkmcnt); the row is flushed once, after the
+  // last tile, by k_rdots.
   constexpr int NP = RPL / 2;
   double2 rv[NP];
   const double* __restrict__ q1 = Q + (int64_t)(i - 1) * ldq;
@@ -88,10 +92,7 @@ __device__ __forceinline__ void rdots_tile(const double* __restrict__ Q, int64_t
       acc = fma(rv[t].y, rv[t].y, acc);
     }
     acc = wave_sum(acc);
-    if (lane == 0) {
-      double* dst = P + (int64_t)i * pstride + widx;
-      *dst = accumulate ? (*dst + acc) : acc;
-    }
+    if (lane == 0) sP[i] = accumulate ? (sP[i] + acc) : acc;
   }
   // four basis vectors per trip: 4*NP independent 16-byte loads in flight per lane, and one
   // transposed butterfly (7 shuffles instead of 24) leaves the four totals in lanes 0/16/32/48.
@@ -110,10 +111,7 @@ __device__ __forceinline__ void rdots_tile(const double* __restrict__ Q, int64_t
       acc = fma(q.y, rv[t].y, acc);
     }
     acc = wave_sum(acc);
-    if (lane == 0) {
-      double* dst = P + (int64_t)j * pstride + widx;
-      *dst = accumulate ? (*dst + acc) : acc;
-    }
+    if (lane == 0) sP[j] = accumulate ? (sP[j] + acc) : acc;
   };
   if (rev)
     for (int j = i - 1; j >= 4 * nchunks; --j) single(j);
@@ -135,18 +133,11 @@ __device__ __forceinline__ void rdots_tile(const double* __restrict__ Q, int64_t
         acc[v] = fma(q[v][t].y, rv[t].y, acc[v]);
       }
     }
-    const bool hi32 = (lane & 32) != 0, hi16 = (lane & 16) != 0;
-    double a0 = hi32 ? acc[2] : acc[0], s0 = hi32 ? acc[0] : acc[2];
-    double a1 = hi32 ? acc[3] : acc[1], s1 = hi32 ? acc[1] : acc[3];
-    a0 += __shfl_xor(s0, 32, 64);
-    a1 += __shfl_xor(s1, 32, 64);
-    double bsum = hi16 ? a1 : a0, bs = hi16 ? a0 : a1;
-    bsum += __shfl_xor(bs, 16, 64);
-#pragma unroll
-    for (int m = 8; m >= 1; m >>= 1) bsum += __shfl_xor(bsum, m, 64);
-    if ((lane & 15) == 0) {
-      double* dst = P + (int64_t)(j + (lane >> 4)) * pstride + widx;
-      *dst = accumulate ? (*dst + bsum) : bsum;
+    // (four totals without the LDS crossbar: wave_sum4_rows leaves the total of vector j + v in lane 16 v + 15)
+    const double bsum = wave_sum4_rows(acc[0], acc[1], acc[2], acc[3]);
+    if ((lane & 15) == 15) {
+      const int idx = j + (lane >> 4);
+      sP[idx] = accumulate ? (sP[idx] + bsum) : bsum;
     }
   }
   if (!rev)
@@ -163,29 +154,45 @@ __global__ __launch_bounds__(256) void k_rdots(const double* __restrict__ Q, int
                                                double* __restrict__ a_store, int want_rr,
                                                double* __restrict__ brk) {
   const int lane = threadIdx.x & 63;
-  const int64_t widx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (widx >= nw) return;
-  if (broken(brk)) return;
-  // alpha_{i-1}: either finalised already (phase API) or still as the mat-vec's per-block partials
-  double a;
-  if (aCount > 0) {
-    a = sum_partials_wave(aP, aCount, lane);
-    if (widx == 0 && lane == 0) a_store[0] = a;
-  } else {
-    a = alpha[0];
-  }
-  const double b = beta ? beta[0] : 0.0;
-  // (read by the tail kernel of this step -- a later launch -- only)
-  if (brk && widx == 0 && lane == 0) brk[1] = fmax(brk[1], fmax(fabs(a), fabs(b)));
+  const int wpb = blockDim.x >> 6;                                                     // 4, 2 or 1 waves per block
+  const int64_t widx = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6);
+  if (broken(brk)) return;                                                             // (uniform over the block)
   constexpr int64_t TILE = 64 * RPL;
-  bool first = true;
-  for (int64_t tile = widx; tile < ntiles; tile += nw) {
-    const int64_t base = tile * TILE;
-    if (base + TILE <= n)
-      rdots_tile<RPL, false>(Q, ldq, i, n, base, lane, u, a, b, r, P, pstride, widx, !first, want_rr != 0);
-    else
-      rdots_tile<RPL, true>(Q, ldq, i, n, base, lane, u, a, b, r, P, pstride, widx, !first, want_rr != 0);
-    first = false;
+  extern __shared__ double rdots_lds[];                                                // [wpb waves][i + 1]
+  double* __restrict__ sP = rdots_lds + (threadIdx.x >> 6) * (i + 1);
+  const int cnt = i + (want_rr ? 1 : 0);
+  if (widx < nw) {
+    // alpha_{i-1}: either finalised already (phase API) or still as the mat-vec's per-block partials
+    double a;
+    if (aCount > 0) {
+      a = sum_partials_wave(aP, aCount, lane);
+      if (widx == 0 && lane == 0) a_store[0] = a;
+    } else {
+      a = alpha[0];
+    }
+    const double b = beta ? beta[0] : 0.0;
+    // (read by the tail kernel of this step -- a later launch -- only)
+    if (brk && widx == 0 && lane == 0) brk[1] = fmax(brk[1], fmax(fabs(a), fabs(b)));
+    bool first = true;
+    for (int64_t tile = widx; tile < ntiles; tile += nw) {
+      const int64_t base = tile * TILE;
+      if (base + TILE <= n)
+        rdots_tile<RPL, false>(Q, ldq, i, n, base, lane, u, a, b, r, sP, !first, want_rr != 0);
+      else
+        rdots_tile<RPL, true>(Q, ldq, i, n, base, lane, u, a, b, r, sP, !first, want_rr != 0);
+      first = false;
+    }
+  } else {
+    for (int idx = lane; idx < cnt; idx += 64) sP[idx] = 0.0;                          // a wave without tiles adds zeros
+  }
+  // The block's waves are combined in LDS (fixed order w0 + w1 + ...) and ONE partial per block and basis vector is
+  // stored: a quarter of the scattered 8-byte stores at the end of the kernel and a quarter of the values the
+  // second stage (k_finalize_multi) has to sum.
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < cnt; idx += blockDim.x) {
+    double t = rdots_lds[idx];
+    for (int w = 1; w < wpb; ++w) t += rdots_lds[w * (i + 1) + idx];
+    P[(int64_t)idx * pstride + blockIdx.x] = t;
   }
 }
 
@@ -312,17 +319,9 @@ __global__ __launch_bounds__(W * 64) void k_rdots_split(const double* __restrict
       if (j + v < i) q = ld2_stream<true>(Q + (int64_t)(j + v) * ldq, row, n);
       acc[v] = fma(q.x, rv.x, q.y * rv.y);
     }
-    const bool hi32 = (lane & 32) != 0, hi16 = (lane & 16) != 0;
-    double a0 = hi32 ? acc[2] : acc[0], s0 = hi32 ? acc[0] : acc[2];
-    double a1 = hi32 ? acc[3] : acc[1], s1 = hi32 ? acc[1] : acc[3];
-    a0 += __shfl_xor(s0, 32, 64);
-    a1 += __shfl_xor(s1, 32, 64);
-    double bsum = hi16 ? a1 : a0, bs = hi16 ? a0 : a1;
-    bsum += __shfl_xor(bs, 16, 64);
-#pragma unroll
-    for (int m = 8; m >= 1; m >>= 1) bsum += __shfl_xor(bsum, m, 64);
+    const double bsum = wave_sum4_rows(acc[0], acc[1], acc[2], acc[3]);
     const int jj = j + (lane >> 4);
-    if ((lane & 15) == 0 && jj < i) P[(int64_t)jj * pstride + tile] = bsum;
+    if ((lane & 15) == 15 && jj < i) P[(int64_t)jj * pstride + tile] = bsum;
   }
 }
 
@@ -2130,14 +2129,22 @@ static inline int tile_blocks(int64_t n) {
       hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(block), 0, stream, __VA_ARGS__);                 \
   } while (0)
 
-#define LAUNCH_RPL(ev, KERNEL, rpl, grid, stream, ...)                                \
-  do {                                                                                \
-    switch (rpl) {                                                                    \
-      case 2: KLAUNCH(ev, (KERNEL<2>), grid, 256, stream, __VA_ARGS__); break;        \
-      case 4: KLAUNCH(ev, (KERNEL<4>), grid, 256, stream, __VA_ARGS__); break;        \
-      case 8: KLAUNCH(ev, (KERNEL<8>), grid, 256, stream, __VA_ARGS__); break;        \
-      default: KLAUNCH(ev, (KERNEL<16>), grid, 256, stream, __VA_ARGS__); break;      \
-    }                                                                                 \
+#define KLAUNCH_LDS(ev, KERNEL, grid, block, lds, stream, ...)                                     \
+  do {                                                                                             \
+    if (ev)                                                                                        \
+      hipExtLaunchKernelGGL(KERNEL, dim3(grid), dim3(block), lds, stream, (ev)->a, (ev)->b, 0, __VA_ARGS__); \
+    else                                                                                           \
+      hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(block), lds, stream, __VA_ARGS__);               \
+  } while (0)
+
+#define LAUNCH_RPL(ev, KERNEL, rpl, grid, block, lds, stream, ...)                                \
+  do {                                                                                            \
+    switch (rpl) {                                                                                \
+      case 2: KLAUNCH_LDS(ev, (KERNEL<2>), grid, block, lds, stream, __VA_ARGS__); break;         \
+      case 4: KLAUNCH_LDS(ev, (KERNEL<4>), grid, block, lds, stream, __VA_ARGS__); break;         \
+      case 8: KLAUNCH_LDS(ev, (KERNEL<8>), grid, block, lds, stream, __VA_ARGS__); break;         \
+      default: KLAUNCH_LDS(ev, (KERNEL<16>), grid, block, lds, stream, __VA_ARGS__); break;       \
+    }                                                                                             \
   } while (0)
 
 void launch_finalize1(const double* P, int count, double* out, hipStream_t st) {
@@ -2160,12 +2167,16 @@ void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, in
                        (int64_t)g.pstride, g.nw, c_out, (const double*)brk);
     return;
   }
-  const int grid = (g.nw + 3) / 4;
-  LAUNCH_RPL(ev, k_rdots, g.rpl, grid, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, g.nw,
+  // one row of i + 1 partial sums per wave in LDS (see rdots_tile); 64 KiB of dynamic LDS hold 4 waves up to
+  // i = 2047, 2 waves up to 4095, 1 wave up to 8191 (dsea_ws_create caps kmax at DSEA_MAX_KRYLOV = 8000)
+  const int wpb = (i + 1) <= 2048 ? 4 : ((i + 1) <= 4096 ? 2 : 1);
+  const int grid = (g.nw + wpb - 1) / wpb;
+  const size_t lds = (size_t)wpb * (i + 1) * sizeof(double);
+  LAUNCH_RPL(ev, k_rdots, g.rpl, grid, 64 * wpb, lds, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, g.nw,
              g.ntiles, aP, aCount, a_store, want_rr ? 1 : 0, brk);
   // want_rr: one more row of partials (||r||^2) -> c_out[i]
   hipLaunchKernelGGL(k_finalize_multi, dim3(want_rr ? i + 1 : i), dim3(256), 0, st, (const double*)P,
-                     (int64_t)g.pstride, g.nw, c_out, (const double*)brk);
+                     (int64_t)g.pstride, grid, c_out, (const double*)brk);
 }
 
 void launch_axpy_norm(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* c,

@@ -60,7 +60,8 @@ int dsea_last_hip_error(void);
 
 /* ------------------------------------------------------------------ workspace
  * Scratch for partial sums, reorthogonalisation coefficients and four work vectors.
- * dsea_ws_bytes tells the caller how much device memory to provide.                 */
+ * dsea_ws_bytes tells the caller how much device memory to provide.  kmax (Krylov vectors the
+ * workspace can serve) is capped at 8000: DSEA_ERR_ARG beyond.                                  */
 int dsea_ws_bytes(int64_t n, int kmax, size_t *bytes);
 int dsea_ws_create(void *device_buffer, size_t bytes, int64_t n, int kmax, dsea_ws_t *out);
 int dsea_ws_destroy(dsea_ws_t ws);
