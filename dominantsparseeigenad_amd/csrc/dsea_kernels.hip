@@ -82,8 +82,9 @@ __device__ __forceinline__ void rdots_tile(const double* __restrict__ Q, int64_t
     // (u - alpha*q) - beta*q' with each product rounded on its own, as the torch expression does
     rv[t].x = __dsub_rn(__dsub_rn(uu.x, __dmul_rn(a, qa.x)), __dmul_rn(b, qb.x));
     rv[t].y = __dsub_rn(__dsub_rn(uu.y, __dmul_rn(a, qa.y)), __dmul_rn(b, qb.y));
-    st2<GUARD>(r, row, n, rv[t]);
   }
+  // (r is written at the END of the tile, from the registers it stays in: stores issued here would sit in front of
+  // the first basis loads in the in-order vmcnt accounting and delay them by a store acknowledgement)
   if (want_rr) {  // ||r||^2 before the correction, as pseudo-vector i (scale for the low-precision test)
     double acc = 0.0;
 #pragma unroll
@@ -142,6 +143,8 @@ __device__ __forceinline__ void rdots_tile(const double* __restrict__ Q, int64_t
   }
   if (!rev)
     for (int j = 4 * nchunks; j < i; ++j) single(j);
+#pragma unroll
+  for (int t = 0; t < NP; ++t) st2<GUARD>(r, base + t * 128 + lane * 2, n, rv[t]);
 }
 
 template <int RPL>
