@@ -305,12 +305,12 @@ __global__ __launch_bounds__(W * 64) void k_rdots_split(const double* __restrict
   double2 rv;
   rv.x = __dsub_rn(__dsub_rn(uu.x, __dmul_rn(a, qa.x)), __dmul_rn(b, qb.x));
   rv.y = __dsub_rn(__dsub_rn(uu.y, __dmul_rn(a, qa.y)), __dmul_rn(b, qb.y));
-  if (wv == 0) {
-    st2<true>(r, row, n, rv);
-    if (want_rr) {
-      double acc = wave_sum(fma(rv.x, rv.x, rv.y * rv.y));
-      if (lane == 0) P[(int64_t)i * pstride + tile] = acc;
-    }
+  // The tile's i (+1) partial sums are collected in LDS and flushed once, r is written at the end from its
+  // registers: no global store sits between the trips of a wave (see rdots_tile).
+  extern __shared__ double split_lds[];     // [i + 1]
+  if (wv == 0 && want_rr) {
+    const double acc = wave_sum(fma(rv.x, rv.x, rv.y * rv.y));
+    if (lane == 0) split_lds[i] = acc;
   }
   const int nchunks = (i + 3) / 4;
   for (int cc = wv; cc < nchunks; cc += W) {
@@ -324,8 +324,12 @@ __global__ __launch_bounds__(W * 64) void k_rdots_split(const double* __restrict
     }
     const double bsum = wave_sum4_rows(acc[0], acc[1], acc[2], acc[3]);
     const int jj = j + (lane >> 4);
-    if ((lane & 15) == 15 && jj < i) P[(int64_t)jj * pstride + tile] = bsum;
+    if ((lane & 15) == 15 && jj < i) split_lds[jj] = bsum;
   }
+  if (wv == 0) st2<true>(r, row, n, rv);
+  __syncthreads();
+  const int cnt = i + (want_rr ? 1 : 0);
+  for (int idx = threadIdx.x; idx < cnt; idx += W * 64) P[(int64_t)idx * pstride + tile] = split_lds[idx];
 }
 
 // MODE 0: r -= sum_j c_j Q_j, partial ||r||^2 ; MODE 1: out = sum_j c_j Q_j (Ritz vector)
@@ -2161,10 +2165,11 @@ void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, in
   if (g.split_w) {
     const unsigned tiles = (unsigned)g.ntiles;
     const int wr = want_rr ? 1 : 0;
+    const size_t slds = (size_t)(i + 1) * sizeof(double);     // the tile's partial sums (see k_rdots_split)
     switch (g.split_w) {
-      case 4: KLAUNCH(ev, (k_rdots_split<4>), tiles, 256, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, aP, aCount, a_store, wr, brk); break;
-      case 8: KLAUNCH(ev, (k_rdots_split<8>), tiles, 512, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, aP, aCount, a_store, wr, brk); break;
-      default: KLAUNCH(ev, (k_rdots_split<16>), tiles, 1024, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, aP, aCount, a_store, wr, brk); break;
+      case 4: KLAUNCH_LDS(ev, (k_rdots_split<4>), tiles, 256, slds, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, aP, aCount, a_store, wr, brk); break;
+      case 8: KLAUNCH_LDS(ev, (k_rdots_split<8>), tiles, 512, slds, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, aP, aCount, a_store, wr, brk); break;
+      default: KLAUNCH_LDS(ev, (k_rdots_split<16>), tiles, 1024, slds, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, aP, aCount, a_store, wr, brk); break;
     }
     hipLaunchKernelGGL(k_finalize_multi, dim3(want_rr ? i + 1 : i), dim3(256), 0, st, (const double*)P,
                        (int64_t)g.pstride, g.nw, c_out, (const double*)brk);
