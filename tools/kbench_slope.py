@@ -26,14 +26,28 @@ def timeit(fn, reps=40):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
+# the shadow pass: a bf16 copy of the basis, coefficients at rounding level so that the premise holds
+Qs = Q.to(torch.bfloat16)
+c_small = torch.full((imax + 2,), 1e-17, dtype=torch.float64, device=dev); c_small[-2:] = 1.0
+
+
+def shadow_pass(i):
+    cc = c_small.clone(); cc[i] = 1.0          # c[i] = ||r||^2 (scale of the premise test)
+    _lib.check(lib.dsea_ws_set_shadow(ws.handle, _ptr(Qs), n, imax + 1, 1e-12), "shadow")
+    t = timeit(lambda: lib.dsea_lanczos_axpy_norm(ws.handle, _ptr(Q), n, n, i, _ptr(cc), _ptr(r), _ptr(nrm2), st))
+    _lib.check(lib.dsea_ws_set_shadow(ws.handle, None, 0, 0, 0.0), "shadow off")
+    return t
+
+
 rows = []
 for i in (4, 8, 20, 52, 100, 148, 200):
     t1 = timeit(lambda: lib.dsea_lanczos_rdots(ws.handle, _ptr(Q), n, n, i, _ptr(u), _ptr(ab), c_void_p(ab.data_ptr() + 8), _ptr(r), _ptr(c), st))
     t2 = timeit(lambda: lib.dsea_lanczos_axpy_norm(ws.handle, _ptr(Q), n, n, i, _ptr(c), _ptr(r), _ptr(nrm2), st))
-    rows.append((i, t1, t2))
-    print("i=%3d  dots pass + finalize %.1f us   fp64 correction pass + finalize %.1f us" % (i, t1, t2))
+    t3 = shadow_pass(i)
+    rows.append((i, t1, t2, t3))
+    print("i=%3d  dots pass + finalize %.1f us   fp64 correction pass + finalize %.1f us   bf16-shadow correction pass + finalize %.1f us" % (i, t1, t2, t3))
 A = np.array([[1.0, r_[0]] for r_ in rows[2:]])
-for name, col in (("dots", 1), ("correction", 2)):
+for name, col, esz in (("dots", 1, 8.0), ("correction", 2, 8.0), ("shadow", 3, 2.0)):
     y = np.array([r_[col] for r_ in rows[2:]])
     (a, b), *_ = np.linalg.lstsq(A, y, rcond=None)
-    print("%-10s fixed %.1f us + %.3f us per basis vector  (%.0f GB/s streaming rate)" % (name, a, b, 8.0 * n / b / 1e3))
+    print("%-10s fixed %.1f us + %.3f us per basis vector  (%.0f GB/s streaming rate)" % (name, a, b, esz * n / b / 1e3))
