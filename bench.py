@@ -237,7 +237,14 @@ def main():
                          "reference's algorithm, reported for what it is; lets k = 200 at L = 28 fit one GPU")
     ap.add_argument("--force-partitioned", action="store_true",
                     help="run the row-partitioned driver even with one rank (measures its host overhead)")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="CONTROL-FLOW CHECK ONLY, no measurement: the multi-rank path of this script (self-launch, "
+                         "row-partitioned operator behind the reference API, collective fallback decision, exchange "
+                         "self-check, max-over-ranks timing, rank-0 JSON) on CPU processes over gloo with the torch test "
+                         "double of the slab kernels (tests/cpu_backend.py).  Use a small --L / --k.  The line it prints "
+                         "is labelled as a dry run and carries no roofline / cpu_baseline.")
     args = ap.parse_args()
+    dry = args.dry_run_cpu
 
     env_world = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and env_world is None:
@@ -247,20 +254,24 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU fallback for the product path"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if dry:
+        dev = torch.device("cpu")
+        torch.set_num_threads(1)
+    else:
+        assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU fallback for the product path"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
 
     from dominantsparseeigenad_amd import _lib, engine
     from dominantsparseeigenad_amd import Lanczos as _LZ
     import dominantsparseeigenad_amd.symeig as symeig
     _LZ.REORTH_DEFAULT = args.reorth
     from dominantsparseeigenad_amd.synthetic import normal_vector
-    lib = _lib.load()
+    lib = None if dry else _lib.load()
 
     p = int(np.log2(world))
     assert (1 << p) == world, "world size must be a power of two"
-    partitioned_path = world > 1 or args.force_partitioned
+    partitioned_path = world > 1 or args.force_partitioned or dry
     strong = args.scaling == "strong"
     if args.L is not None:
         L = args.L
@@ -278,7 +289,7 @@ def main():
     steps = args.steps if args.steps is not None else (3 if big else 10)
     warmup = args.warmup if args.warmup is not None else (1 if big else 2)
     # one GPU cannot hold the fp64 basis AND its bf16 shadow at L = 28, k = 100 (215 + 54 GB of 288 GB)
-    free_b, total_b = torch.cuda.mem_get_info(dev)
+    free_b, total_b = (0, 1 << 62) if dry else torch.cuda.mem_get_info(dev)
     need_shadow = 10.0 * nloc * k + 16 * 8.0 * nloc
     if need_shadow > 0.92 * total_b or args.reorth == "none":
         engine.USE_SHADOW = False
@@ -309,17 +320,27 @@ def main():
             if world == 1:
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
                 os.environ.setdefault("MASTER_PORT", str(_free_port()))
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        op = partitioned.PartitionedTFIMOperator(L, g, dev)
+            if dry:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = None
+        if dry:   # the torch test double of the slab kernels (test infrastructure; never on the product path)
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from cpu_backend import CpuBackend
+            backend = CpuBackend(nloc)
+        op = partitioned.PartitionedTFIMOperator(L, g, dev, backend=backend, overlap=True if dry else "auto")
         op.force_driver = True
         A_operand = op.H
         dot = op.dot
         tvec = tvec / op.dot(tvec, tvec).sqrt()
 
         def barrier():
-            torch.cuda.synchronize()
+            if not dry:
+                torch.cuda.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
+            if not dry:
+                torch.cuda.synchronize()
 
     symeig.setDominantSparseSymeig(A_operand, op.Hadjoint_to_gadjoint)
     f = symeig.DominantSparseSymeig.apply
@@ -340,8 +361,8 @@ def main():
 
     if os.environ.get("DSEA_PLACEMENT_TRIES"):
         engine.BasisArena.PLACEMENT_TRIES = int(os.environ["DSEA_PLACEMENT_TRIES"])
-    ws = engine.Workspace.get(nloc, k, dev)
-    if args.rpl:
+    ws = None if dry else engine.Workspace.get(nloc, k, dev)
+    if args.rpl and ws is not None:
         ws.set_rows_per_lane(args.rpl)
 
     notes = {}
@@ -353,7 +374,8 @@ def main():
         try:
             probe = torch.zeros(world * 8, dtype=torch.float64, device=dev)
             op.comm.all_to_all(probe, torch.empty_like(probe))
-            torch.cuda.synchronize()
+            if not dry:
+                torch.cuda.synchronize()
         except Exception as exc:  # noqa: BLE001
             failed[0] = 1.0
             notes["distributed_fallback_reason"] = "%s: %s" % (type(exc).__name__, str(exc)[:120])
@@ -399,7 +421,7 @@ def main():
     # ---- per-launch durations of the dominant kernels: the same K steps again, this time with a HIP event
     # pair recorded on the launch stream around every reorth / mat-vec launch (the event records cost ~4 %
     # of a step, which is why they are kept out of the timed region above)
-    use_events = not args.no_kernel_events and args.reorth == "full"   # rank 0's local kernels, also when partitioned
+    use_events = not args.no_kernel_events and args.reorth == "full" and not dry   # rank 0's local kernels, also when partitioned
     launches = (c_int64 * 3)()
     total_ms = (c_double * 3)()
     dt_instr = None
@@ -460,7 +482,9 @@ def main():
     if rank == 0:
         mode = "row-partitioned over %d GPUs, %s scaling" % (world, args.scaling) if partitioned_path else "one GPU"
         out = {
-            "metric": "DominantSparseSymeig fwd+bwd algorithmic HBM GB/s (TFIM, fp64)" if args.reorth == "full" else
+            "metric": "DRY RUN on CPU processes (gloo, torch test double of the slab kernels): control flow of the "
+                      "multi-rank bench only, not a measurement" if dry else
+                      "DominantSparseSymeig fwd+bwd algorithmic HBM GB/s (TFIM, fp64)" if args.reorth == "full" else
                       "DominantSparseSymeig fwd+bwd GB/s, basis-free two-pass Lanczos option (TFIM, fp64; not the "
                       "reference's full-reorthogonalisation algorithm)",
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": steps, "warmup": warmup,

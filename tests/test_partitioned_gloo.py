@@ -193,3 +193,34 @@ def test_reference_api_on_partitioned_stencil_matches_reference_fixture(world):
     assert signed_close(psi, gd["psi"], 1e-9)[0]
     assert abs(ret[0]["loss"] - float(gd["loss"])) < 1e-9
     assert np.max(np.abs(grad - gd["grad"])) < 1e-5 * np.max(np.abs(gd["grad"]))   # CG hits the n-iteration cap
+
+
+@pytest.mark.parametrize("world,launcher", [(2, "self"), (4, "torchrun")])
+def test_bench_multi_rank_control_flow_dry_run(world, launcher):
+    """bench.py's multi-rank path end to end on CPU processes (``--dry-run-cpu``: gloo + the torch test double of the
+    slab kernels): self-launch of one worker per rank, or under the driver's own launcher line (python -m
+    torch.distributed.run ... bench.py --gpus N --steps K --warmup W); row-partitioned operator behind the reference
+    API, collective decision on the exchange form, overlapped-exchange self-check, max-over-ranks timing, ONE JSON line
+    from rank 0 as the last line of stdout.  No measurement is taken from it."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    tail = [os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--dry-run-cpu",
+            "--L", "10", "--k", "60"]
+    if launcher == "self":
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + tail
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and out.stdout.strip().splitlines()[-1] == lines[0]       # one JSON line, and it is the last
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["steps"] == 2 and d["warmup"] == 1 and d["metric"].startswith("DRY RUN")
+    cfg = d["config"]
+    assert ("transposed" if world >= 4 else "pairwise") in cfg["slab_exchange"] and "overlapped" in cfg["slab_exchange"]
+    assert cfg["distributed_self_check"].startswith("overlapped exchange verified")
+    assert abs(cfg["E0_per_site"] - cfg["E0_per_site_closed_form"]) < 1e-9
+    assert "roofline" not in d and "cpu_baseline" not in d
