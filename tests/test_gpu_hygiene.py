@@ -295,3 +295,31 @@ def test_basis_arena_measures_the_placement_of_a_new_basis(monkeypatch):
             assert engine.BasisArena.last_placement is None
     assert out[0][0] == out[1][0] and torch.equal(out[0][1], out[1][1])
     engine.BasisArena.release()
+
+
+def test_more_than_2048_krylov_vectors():
+    """The dots pass keeps one LDS row of i + 1 partial sums per wave: beyond 2048 vectors a block carries two waves
+    instead of four (beyond 4096 one), and kmax is capped at 8000 (include/dsea.h)."""
+    from ctypes import byref, c_size_t
+    L, k = 18, 2100
+    n = 1 << L
+    op = TFIMOperator(L, dev(), g=torch.tensor([1.0], dtype=F64, device=dev()))
+    q0 = unit(n, 5).to(dev())
+    engine.BasisArena.release()
+    Qk, T = Lanczos(op, k, dev(), sparse=True, dim=n, q0=q0)
+    # orthonormality of a sample of the basis, early / middle / late vectors alike
+    idx = torch.tensor([0, 1, 2, 500, 1023, 1024, 2047, 2048, 2049, 2098, 2099], device=dev())
+    S = Qk[:, idx]
+    G = S.T @ Qk
+    G[torch.arange(idx.numel(), device=dev()), idx] -= 1.0
+    assert float(G.abs().max()) < 1e-12
+    lo = torch.linalg.eigvalsh(T)[0].item()
+    ks = (2 * np.arange(L) + 1) * np.pi / L
+    exact = float(-0.5 * (2 * np.sqrt(2 - 2 * np.cos(ks))).sum())
+    assert abs(lo - exact) < 1e-11 * abs(exact)
+    nbytes = c_size_t()
+    lib = _lib.load()
+    assert lib.dsea_ws_bytes(1 << 12, 8000, byref(nbytes)) == 0
+    assert lib.dsea_ws_bytes(1 << 12, 8001, byref(nbytes)) == -1
+    del Qk
+    torch.cuda.empty_cache()
