@@ -177,16 +177,26 @@ int blas_apply(const OpDesc& op, const double* x, double* y, hipStream_t st) {
 // ------------------------------------------------------------------------------------------
 // DGKS test after the first Gram-Schmidt pass: a second pass is needed iff ||w - V V^T w||^2 < 1/2 ||w||^2.
 // skip[0] = 1 -> the second pass kernels return at once.  (c1[i] = ||w||^2 from the dots pass.)
-__global__ void k_dgks_decide(const double* __restrict__ c1, int i, const double* __restrict__ nrm1,
-                              double* __restrict__ skip, const double* __restrict__ brk,
-                              double* __restrict__ counter) {
+// (The second stage of ||w1||^2 -- the sum of the correction pass's `count` partials, in the order of
+//  k_cg_finalize_slot -- is done here as well: one launch instead of two small dependent ones per step.)
+__global__ __launch_bounds__(256) void k_dgks_decide(const double* __restrict__ c1, int i,
+                                                     const double* __restrict__ P, int count,
+                                                     double* __restrict__ nrm1, double* __restrict__ skip,
+                                                     const double* __restrict__ brk, double* __restrict__ counter) {
+  __shared__ double sm4[4];
   if (broken(brk)) {
-    skip[0] = 1.0;
+    if (threadIdx.x == 0) skip[0] = 1.0;
     return;
   }
-  const bool enough = nrm1[0] >= 0.5 * c1[i];
-  skip[0] = enough ? 1.0 : 0.0;
-  if (!enough && counter) counter[0] += 1.0;
+  double acc = 0.0;
+  for (int b = threadIdx.x; b < count; b += 256) acc += P[b];
+  const double t = block_sum(acc, sm4);
+  if (threadIdx.x == 0) {
+    nrm1[0] = t;
+    const bool enough = t >= 0.5 * c1[i];
+    skip[0] = enough ? 1.0 : 0.0;
+    if (!enough && counter) counter[0] += 1.0;
+  }
 }
 
 // Column j of H and the next basis vector:  h = c1 (+ c2 if the second pass ran),  beta = ||w||,  v_{j+1} = w / beta.
@@ -339,9 +349,8 @@ void arnoldi_orth(Workspace& w, int64_t n, const double* u, const double* shift_
   // pass 1: w1 = u - shift v_j ; c1 = V^T w1 ; c1[i] = ||w1||^2 ; w1 -= V c1 ; nrm1 = ||w1||^2
   launch_rdots(g, V, ldv, n, i, u, shift_or_zero, nullptr, w1, w.partials, c1, st, nullptr, nullptr, 0, nullptr, true, brk);
   launch_axpy_norm(g, V, ldv, n, i, c1, w1, w.partials, nullptr, st, nullptr, brk);
-  launch_finalize_slot(w.partials, g.nw, nrm1, brk, st);
-  hipLaunchKernelGGL(k_dgks_decide, dim3(1), dim3(1), 0, st, (const double*)c1, i, (const double*)nrm1, skip,
-                     (const double*)brk, w.scal + 31);
+  hipLaunchKernelGGL(k_dgks_decide, dim3(1), dim3(256), 0, st, (const double*)c1, i, (const double*)w.partials, g.nw,
+                     nrm1, skip, (const double*)brk, w.scal + 31);
   // pass 2 (skipped on the device unless the DGKS test failed): w2 = w1 - V (V^T w1)
   launch_rdots(g, V, ldv, n, i, w1, w.zero, nullptr, w2, w.partials, c2, st, nullptr, nullptr, 0, nullptr, false, skip);
   launch_axpy_norm(g, V, ldv, n, i, c2, w2, w.partials, nullptr, st, nullptr, skip);
