@@ -57,6 +57,10 @@ class HipBackend(_engine_mod.Phases):
         self.op = None          # slab-local operator object (exposes .handle), set by attach_*
         self._shadow = None
 
+    def spawn(self, n_local):
+        """a backend of the same kind for slabs of another size (the replicated CG of two ranks)"""
+        return HipBackend(n_local, self.device)
+
     # -- helpers
     @staticmethod
     def _p(t):
@@ -236,6 +240,13 @@ class TorchDistComm:
             done.record(self._side)
         return done
 
+    def all_gather(self, slab, full):
+        """full = the slabs of all ranks in rank order (equal slabs)"""
+        if self.world == 1:
+            full.copy_(slab)
+            return
+        dist.all_gather_into_tensor(full, slab.contiguous(), group=self.group)
+
     def all_to_all(self, src, dst):
         """chunk j of src goes to rank j, chunk j of dst comes from rank j (equal chunks; own chunk copied).
         Over RCCL this is ``all_to_all_single``; elsewhere (gloo in the CPU tests) the same exchange is written
@@ -249,6 +260,14 @@ class TorchDistComm:
         chunk = src.numel() // P
         dst[me * chunk:(me + 1) * chunk].copy_(src[me * chunk:(me + 1) * chunk])
         self.sendrecv([(src[j * chunk:(j + 1) * chunk], dst[j * chunk:(j + 1) * chunk], j) for j in range(P) if j != me])
+
+
+class _SelfComm:
+    """the communicator of ONE rank: nothing to reduce, nothing to exchange (replicated solves)"""
+    rank, world = 0, 1
+
+    def allreduce(self, t):
+        pass
 
 
 def _vec(v):
@@ -547,6 +566,40 @@ class PartitionedTFIMOperator(PartitionedOperator):
             self._recv = []
         else:
             self._recv = [self.be.empty(nloc) for _ in range(self.p)]
+
+    # With TWO ranks every mat-vec moves one whole slab over the single xGMI link between the two GPUs (268 MB at 2^25
+    # rows: 3.5-5 ms) -- in the Lanczos step that hides behind the dots pass, in a CG iteration it does not: ~0.9 ms of
+    # slab-local work against the exchange.  The CG vectors are small next to the basis, so at P = 2 the solve is
+    # REPLICATED instead: b and the start vector are gathered once (two all-gathers), both ranks run the same
+    # single-device solve on the full vectors -- identical kernels on identical data, hence bit-identical results --
+    # and keep their slab.  Twice the local work per iteration (1.8 ms) and no exchange at all.  From four ranks on the
+    # transposed exchange is cheaper than replication and the partitioned solve is kept.  "auto" | True | False.
+    replicate_cg = "auto"
+
+    def _replicated(self):
+        rep = self.replicate_cg
+        return (self.world == 2) if rep == "auto" else (bool(rep) and self.world > 1)
+
+    def _replica_operator(self):
+        if getattr(self, "_replica", None) is None:
+            be = self.be.spawn(1 << self.L)
+            self._replica = PartitionedTFIMOperator(self.L, self.g, self.device, backend=be, comm=_SelfComm(), overlap=False)
+            self._replica.force_driver = self.force_driver and self._replica._local_native() is None
+            self._replica.poll_every = self.poll_every
+        return self._replica
+
+    def solve_shifted(self, E0, b, x0, eps=1e-7, maxiter=None):
+        if not self._replicated() or not hasattr(self.be, "spawn") or not hasattr(self.comm, "all_gather"):
+            return super().solve_shifted(E0, b, x0, eps=eps, maxiter=maxiter)
+        n = 1 << self.L
+        b_full, x_full = self.be.empty(n), self.be.empty(n)
+        self.comm.all_gather(_vec(b), b_full)
+        self.comm.all_gather(_vec(x0), x_full)
+        rep = self._replica_operator()
+        x_full = rep.solve_shifted(E0, b_full, x_full, eps=eps, maxiter=self.dim if maxiter is None else maxiter)
+        self.last_cg_iters, self.last_cg_resnorm = rep.last_cg_iters, rep.last_cg_resnorm
+        x0.copy_(x_full[self.row_offset:self.row_offset + self.nloc])
+        return x0
 
     def use_pairwise_exchange(self):
         """switch to the pairwise hypercube exchange (one full slab per partner), e.g. if the transposed form is

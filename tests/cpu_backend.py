@@ -13,6 +13,9 @@ class CpuBackend:
         self.n = int(n_local)
         self.op = None      # no native single-GPU operand: the distributed driver always runs
 
+    def spawn(self, n_local):
+        return CpuBackend(n_local)
+
     def empty(self, *shape):
         return torch.zeros(*shape, dtype=F64)
 

@@ -57,6 +57,11 @@ def _host_staged_comm():
             super().all_to_all(hs, hd)
             dst.copy_(hd)
 
+        def all_gather(self, slab, full):
+            hf = torch.empty(full.shape, dtype=full.dtype)
+            super().all_gather(slab.cpu(), hf)
+            full.copy_(hf)
+
     return HostStagedComm()
 
 

@@ -29,7 +29,7 @@ def _free_port():
     return port
 
 
-def _case_driver(rank, world, overlap=False, tau=None):
+def _case_driver(rank, world, overlap=False, tau=None, replicate="auto"):
     """hand-written forward + backward of partitioned.PartitionedTFIM (no autograd)"""
     from cpu_backend import CpuBackend
     from dominantsparseeigenad_amd import engine
@@ -40,6 +40,7 @@ def _case_driver(rank, world, overlap=False, tau=None):
     g = torch.tensor([G], dtype=torch.float64)
     solver = PartitionedTFIM(L, g, "cpu", backend=CpuBackend(nloc), eps=1e-12)
     solver.overlap = overlap
+    solver.op.replicate_cg = replicate
     if tau is not None:
         engine.SHADOW_TAU = tau
     q0 = torch.from_numpy(normal_vector(nloc, 5000, offset=off))
@@ -224,3 +225,17 @@ def test_bench_multi_rank_control_flow_dry_run(world, launcher):
     assert cfg["distributed_self_check"].startswith("overlapped exchange verified")
     assert abs(cfg["E0_per_site"] - cfg["E0_per_site_closed_form"]) < 1e-9
     assert "roofline" not in d and "cpu_baseline" not in d
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_replicated_cg_equals_partitioned_cg(world):
+    """PartitionedTFIMOperator.replicate_cg: the adjoint solve gathered and run on every rank in full (the default at
+    two ranks, where a mat-vec would move a whole slab over one link) against the row-partitioned solve: same number
+    of iterations, same eigenpair, gradient equal to the CG tolerance; replicated scalars bit-identical on all ranks."""
+    part = _run(world, "_case_driver", False, None, False)
+    repl = _run(world, "_case_driver", False, None, True)
+    for r in range(world):
+        assert repl[r][0] == repl[0][0] and repl[r][2] == repl[0][2] and repl[r][3] == repl[0][3]
+        assert repl[r][0] == part[r][0] and torch.equal(torch.from_numpy(repl[r][1]), torch.from_numpy(part[r][1]))
+    assert repl[0][3] == part[0][3]
+    assert abs(repl[0][2] - part[0][2]) < 1e-10 * abs(part[0][2])
