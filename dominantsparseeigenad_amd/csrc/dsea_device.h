@@ -10,12 +10,6 @@ namespace dsea {
 // ------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;  // butterfly: every lane holds the same, order-fixed total
-}
-
 // Four wave-wide sums at once without the LDS crossbar: on gfx950 ``__shfl_xor`` is a ds_bpermute (a round trip
 // through the LDS pipeline, ~100+ cycles, seven of them in a dependent chain for the transposed butterfly the dots
 // pass used) during which a wave that is alone on its SIMD has no loads in flight.  v_permlane32_swap / v_permlane16_swap
@@ -54,6 +48,30 @@ __device__ __forceinline__ double wave_sum4_rows(double a0, double a1, double a2
   v += dpp_row_shr_f64<0x112>(v);
   v += dpp_row_shr_f64<0x111>(v);
   return v;
+}
+
+// One wave-wide sum, the total in EVERY lane, without the LDS crossbar (six dependent ds_bpermute round trips before):
+// half-waves and alternate rows are folded with the gfx950 permlane swaps (both registers hold the same value, so
+// all lanes keep a valid partial sum), the 16 lanes of a row with four DPP row rotations.  Fixed order: deterministic.
+template <int CTRL>   // DPP row_ror:n = 0x120 + n
+__device__ __forceinline__ double dpp_row_ror_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  double a = v, b = v;
+  permlane32_swap_f64(a, b);
+  v = a + b;                       // lane i: x[i mod 32] + x[i mod 32 + 32]
+  a = v;
+  b = v;
+  permlane16_swap_f64(a, b);
+  v = a + b;                       // lane i: the four rows' values of column i mod 16
+  v += dpp_row_ror_f64<0x128>(v);
+  v += dpp_row_ror_f64<0x124>(v);
+  v += dpp_row_ror_f64<0x122>(v);
+  v += dpp_row_ror_f64<0x121>(v);
+  return v;                        // every lane holds the same, order-fixed total
 }
 
 // block of 256 threads = 4 waves; returns the total in thread 0 (fixed order w0+w1+w2+w3)
