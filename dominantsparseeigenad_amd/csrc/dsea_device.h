@@ -74,6 +74,22 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;                        // every lane holds the same, order-fixed total
 }
 
+// wave-wide maximum in every lane, the same way
+__device__ __forceinline__ double wave_max(double v) {
+  double a = v, b = v;
+  permlane32_swap_f64(a, b);
+  v = fmax(a, b);
+  a = v;
+  b = v;
+  permlane16_swap_f64(a, b);
+  v = fmax(a, b);
+  v = fmax(v, dpp_row_ror_f64<0x128>(v));
+  v = fmax(v, dpp_row_ror_f64<0x124>(v));
+  v = fmax(v, dpp_row_ror_f64<0x122>(v));
+  v = fmax(v, dpp_row_ror_f64<0x121>(v));
+  return v;
+}
+
 // block of 256 threads = 4 waves; returns the total in thread 0 (fixed order w0+w1+w2+w3)
 __device__ __forceinline__ double block_sum(double v, double* sm4) {
   v = wave_sum(v);

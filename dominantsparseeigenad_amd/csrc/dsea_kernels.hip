@@ -489,8 +489,7 @@ __global__ __launch_bounds__(256) void k_axpy_norm_lp(const double* __restrict__
     const double v = c[b];
     m = fmax(m, v * v);
   }
-#pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) m = fmax(m, __shfl_xor(m, s, 64));
+  m = wave_max(m);
   const bool use_lp = m <= tau2 * c[i];
   if (widx == 0 && lane == 0 && lp_count) lp_count[use_lp ? 0 : 1] += 1.0;
   constexpr int64_t TILE = 512 * RPS;
@@ -527,8 +526,7 @@ __global__ __launch_bounds__(W * 64) void k_axpy_norm_lp_split(const double* __r
     const double v = c[b];
     m = fmax(m, v * v);
   }
-#pragma unroll
-  for (int sft = 32; sft >= 1; sft >>= 1) m = fmax(m, __shfl_xor(m, sft, 64));
+  m = wave_max(m);
   const bool use_lp = m <= tau2 * c[i];
   if (tile == 0 && threadIdx.x == 0 && lp_count) lp_count[use_lp ? 0 : 1] += 1.0;
   const bool full = row + 8 <= n;
