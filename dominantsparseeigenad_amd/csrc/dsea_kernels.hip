@@ -58,11 +58,17 @@ __global__ __launch_bounds__(256) void k_finalize_multi(const double* __restrict
 // ------------------------------------------------------------------------------------------
 // Lanczos phase 1: r = u - alpha q1 - beta q2 ; partial c[j] = Q[j].r     (Lanczos.py:61,66)
 // ------------------------------------------------------------------------------------------
-template <int RPL, bool GUARD>
+template <int NP>
+struct RdotsPre {   // the first tile's rows of u, q_{i-1}, q_{i-2}, requested before any scalar is waited for
+  double2 uu[NP], qa[NP], qb[NP];
+};
+
+template <int RPL, bool GUARD, bool PRE>
 __device__ __forceinline__ void rdots_tile(const double* __restrict__ Q, int64_t ldq, int i, int64_t n,
                                            int64_t base, int lane, const double* __restrict__ u,
                                            double a, double b, double* __restrict__ r,
-                                           double* __restrict__ sP, bool accumulate, bool want_rr) {
+                                           double* __restrict__ sP, bool accumulate, bool want_rr,
+                                           const RdotsPre<RPL / 2>& pre) {
   // sP: this wave's row of i + 1 partial sums in LDS.  They are NOT stored to global memory inside the loop: on
   // gfx9 loads and stores share the in-order vmcnt counter, so a store issued between two trips makes the next
   // trip's loads wait for the store's acknowledgement from L2 (measured: 12.6 us of a 273 us pass at i = 199 for the
@@ -75,10 +81,17 @@ __device__ __forceinline__ void rdots_tile(const double* __restrict__ Q, int64_t
 #pragma unroll
   for (int t = 0; t < NP; ++t) {
     const int64_t row = base + t * 128 + lane * 2;
-    double2 uu = ld2<GUARD>(u, row, n);
-    double2 qa = ld2<GUARD>(q1, row, n);
-    double2 qb = make_double2(0.0, 0.0);
-    if (q2) qb = ld2<GUARD>(q2, row, n);
+    double2 uu, qa, qb;
+    if (PRE) {
+      uu = pre.uu[t];
+      qa = pre.qa[t];
+      qb = pre.qb[t];
+    } else {
+      uu = ld2<GUARD>(u, row, n);
+      qa = ld2<GUARD>(q1, row, n);
+      qb = make_double2(0.0, 0.0);
+      if (q2) qb = ld2<GUARD>(q2, row, n);
+    }
     // (u - alpha*q) - beta*q' with each product rounded on its own, as the torch expression does
     rv[t].x = __dsub_rn(__dsub_rn(uu.x, __dmul_rn(a, qa.x)), __dmul_rn(b, qb.x));
     rv[t].y = __dsub_rn(__dsub_rn(uu.y, __dmul_rn(a, qa.y)), __dmul_rn(b, qb.y));
@@ -159,11 +172,27 @@ __global__ __launch_bounds__(256) void k_rdots(const double* __restrict__ Q, int
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;                                                     // 4, 2 or 1 waves per block
   const int64_t widx = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6);
-  if (broken(brk)) return;                                                             // (uniform over the block)
   constexpr int64_t TILE = 64 * RPL;
   extern __shared__ double rdots_lds[];                                                // [wpb waves][i + 1]
   double* __restrict__ sP = rdots_lds + (threadIdx.x >> 6) * (i + 1);
   const int cnt = i + (want_rr ? 1 : 0);
+  // The first tile's rows of u, q, q' are requested HERE, before the break record and the alpha partials are waited
+  // for: three dependent memory round trips of the prologue become one.
+  RdotsPre<RPL / 2> pre;
+  const bool pre_ok = widx < nw && widx * TILE + TILE <= n;
+  if (pre_ok) {
+    const double* __restrict__ q1 = Q + (int64_t)(i - 1) * ldq;
+    const double* __restrict__ q2 = (i >= 2) ? Q + (int64_t)(i - 2) * ldq : nullptr;
+#pragma unroll
+    for (int t = 0; t < RPL / 2; ++t) {
+      const int64_t row = widx * TILE + t * 128 + lane * 2;
+      pre.uu[t] = ld2<false>(u, row, n);
+      pre.qa[t] = ld2<false>(q1, row, n);
+      pre.qb[t] = make_double2(0.0, 0.0);
+      if (q2) pre.qb[t] = ld2<false>(q2, row, n);
+    }
+  }
+  if (broken(brk)) return;                                                             // (uniform over the block)
   if (widx < nw) {
     // alpha_{i-1}: either finalised already (phase API) or still as the mat-vec's per-block partials
     double a;
@@ -179,10 +208,12 @@ __global__ __launch_bounds__(256) void k_rdots(const double* __restrict__ Q, int
     bool first = true;
     for (int64_t tile = widx; tile < ntiles; tile += nw) {
       const int64_t base = tile * TILE;
-      if (base + TILE <= n)
-        rdots_tile<RPL, false>(Q, ldq, i, n, base, lane, u, a, b, r, sP, !first, want_rr != 0);
+      if (first && pre_ok)
+        rdots_tile<RPL, false, true>(Q, ldq, i, n, base, lane, u, a, b, r, sP, false, want_rr != 0, pre);
+      else if (base + TILE <= n)
+        rdots_tile<RPL, false, false>(Q, ldq, i, n, base, lane, u, a, b, r, sP, !first, want_rr != 0, pre);
       else
-        rdots_tile<RPL, true>(Q, ldq, i, n, base, lane, u, a, b, r, sP, !first, want_rr != 0);
+        rdots_tile<RPL, true, false>(Q, ldq, i, n, base, lane, u, a, b, r, sP, !first, want_rr != 0, pre);
       first = false;
     }
   } else {
