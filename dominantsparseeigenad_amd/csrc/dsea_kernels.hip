@@ -1218,14 +1218,23 @@ __global__ __launch_bounds__(256) void k_cg_update_fused(double* __restrict__ x,
                                                          const double* __restrict__ dP, int dCount,
                                                          int64_t n, double* __restrict__ P) {
   __shared__ double sm5[5];
+  // the first tile's rows are requested before the stop flag and the partial sums are waited for (one memory round
+  // trip for the prologue instead of two in a row; up to 2^21 rows a block has exactly one tile)
+  const int64_t stride = (int64_t)gridDim.x * 512;
+  const int64_t row0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+  double2 xv = ld2<true>(x, row0, n), rv = ld2<true>(r, row0, n);
+  double2 dv = ld2<true>(d, row0, n), av = ld2<true>(Ad, row0, n);
   if (state[DSEA_CG_DONE] != 0.0) return;
   const double dAd = sum_partials_block(dP, dCount, sm5);
   const double alpha = state[parity ? DSEA_CG_RRNEW : DSEA_CG_RR] / dAd;
   double acc = 0.0;
-  const int64_t stride = (int64_t)gridDim.x * 512;
-  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; row < n; row += stride) {
-    double2 xv = ld2<true>(x, row, n), rv = ld2<true>(r, row, n);
-    double2 dv = ld2<true>(d, row, n), av = ld2<true>(Ad, row, n);
+  for (int64_t row = row0; row < n; row += stride) {
+    if (row != row0) {
+      xv = ld2<true>(x, row, n);
+      rv = ld2<true>(r, row, n);
+      dv = ld2<true>(d, row, n);
+      av = ld2<true>(Ad, row, n);
+    }
     xv.x = __dadd_rn(xv.x, __dmul_rn(alpha, dv.x));
     xv.y = __dadd_rn(xv.y, __dmul_rn(alpha, dv.y));
     rv.x = __dsub_rn(rv.x, __dmul_rn(alpha, av.x));
@@ -1246,6 +1255,9 @@ __global__ __launch_bounds__(256) void k_cg_direction_fused(const double* __rest
                                                             const double* __restrict__ rP, int rCount,
                                                             double eps, int64_t n) {
   __shared__ double sm5[5];
+  const int64_t stride = (int64_t)gridDim.x * 512;
+  const int64_t row0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+  double2 rv = ld2<true>(r, row0, n), dv = ld2<true>(d, row0, n);       // (requested first, see k_cg_update_fused)
   if (state[DSEA_CG_DONE] != 0.0) return;
   const double rr_new = sum_partials_block(rP, rCount, sm5);
   const double rr = state[parity ? DSEA_CG_RRNEW : DSEA_CG_RR];
@@ -1259,9 +1271,11 @@ __global__ __launch_bounds__(256) void k_cg_direction_fused(const double* __rest
   }
   if (conv) return;
   const double beta = rr_new / rr;
-  const int64_t stride = (int64_t)gridDim.x * 512;
-  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; row < n; row += stride) {
-    double2 rv = ld2<true>(r, row, n), dv = ld2<true>(d, row, n);
+  for (int64_t row = row0; row < n; row += stride) {
+    if (row != row0) {
+      rv = ld2<true>(r, row, n);
+      dv = ld2<true>(d, row, n);
+    }
     dv.x = __dadd_rn(rv.x, __dmul_rn(beta, dv.x));
     dv.y = __dadd_rn(rv.y, __dmul_rn(beta, dv.y));
     st2<true>(d, row, n, dv);
