@@ -319,6 +319,11 @@ __global__ __launch_bounds__(W * 64) void k_rdots_split(const double* __restrict
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t tile = blockIdx.x;
   const int64_t row = tile * 128 + lane * 2;
+  // (the tile's rows of u, q, q' are requested before the break record and the alpha partials are waited for)
+  const double* __restrict__ q1 = Q + (int64_t)(i - 1) * ldq;
+  const double2 uu = ld2<true>(u, row, n), qa = ld2<true>(q1, row, n);
+  double2 qb = make_double2(0.0, 0.0);
+  if (i >= 2) qb = ld2<true>(Q + (int64_t)(i - 2) * ldq, row, n);
   if (broken(brk)) return;
   double a;
   if (aCount > 0) {
@@ -329,10 +334,6 @@ __global__ __launch_bounds__(W * 64) void k_rdots_split(const double* __restrict
   }
   const double b = beta ? beta[0] : 0.0;
   if (brk && tile == 0 && wv == 0 && lane == 0) brk[1] = fmax(brk[1], fmax(fabs(a), fabs(b)));
-  const double* __restrict__ q1 = Q + (int64_t)(i - 1) * ldq;
-  const double2 uu = ld2<true>(u, row, n), qa = ld2<true>(q1, row, n);
-  double2 qb = make_double2(0.0, 0.0);
-  if (i >= 2) qb = ld2<true>(Q + (int64_t)(i - 2) * ldq, row, n);
   double2 rv;
   rv.x = __dsub_rn(__dsub_rn(uu.x, __dmul_rn(a, qa.x)), __dmul_rn(b, qb.x));
   rv.y = __dsub_rn(__dsub_rn(uu.y, __dmul_rn(a, qa.y)), __dmul_rn(b, qb.y));
