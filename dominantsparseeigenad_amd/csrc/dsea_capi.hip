@@ -274,6 +274,18 @@ int dsea_ws_set_persist(dsea_ws_t ws, int mode) {
   return DSEA_OK;
 }
 
+namespace {
+// geometry of the bf16-shadow correction pass: 0 = split form (16 waves share a 512-row tile and split the basis
+// vectors), 1 / 2 = a wave owns 512 / 1024 rows and walks all vectors.  Below 2^20 rows the wave-owned form has
+// too few waves to cover the latency of its serial walk (512 waves at n = 2^18 / 2^19): measured per launch (k = 200
+// average) n = 2^18: 24.4 -> 17.7 us, 2^19: 31.8 -> 28.1 us with the split form; from 2^20 rows on the wave-owned form
+// wins (2^20: 37.0 vs 55.3 us, 2^21: 75.0 vs 99.9 us).
+inline int lp_rows_per_step(int64_t n, bool dots_are_split) {
+  if (dots_are_split || n < ((int64_t)1 << 20)) return 0;
+  return 2;
+}
+}  // namespace
+
 int dsea_ws_set_split(dsea_ws_t ws, int waves) {
   if (!ws) return DSEA_ERR_ARG;
   if (waves != -1 && waves != 0 && waves != 4 && waves != 8 && waves != 16) return DSEA_ERR_ARG;
@@ -490,7 +502,7 @@ int dsea_lanczos_axpy_norm(dsea_ws_t ws, const double* Q, int64_t ldq, int64_t n
   if (w.shadow && w.shadow_rows >= i && w.shadow_ld >= n && !w.geom(n).split_w) {
     // a bf16 shadow of this basis is registered: stream it (premise checked on the device against c[i] = r.r)
     double* nP = w.aux + DSEA_MAX_WAVE_TILES;
-    const int rps = n >= 512 * 2 * 512 ? 2 : 1;
+    const int rps = lp_rows_per_step(n, false);
     int nn = launch_axpy_norm_lp(n, rps, Q, ldq, w.shadow, w.shadow_ld, i, c, w.lp_tau, r, nP, w.scal + 16, st);
     launch_finalize1(nP, nn, nrm2_out, st);
   } else {
@@ -629,7 +641,7 @@ int dsea_plz_correct(dsea_ws_t ws, const double* Q, int64_t ldq, int64_t n, int 
   if (row >= 1) {
     REQUIRE(Q && c && ldq >= n && (ldq % 2 == 0) && aligned16(Q), DSEA_ERR_ARG);
     if (w.shadow && w.shadow_rows > row && w.shadow_ld >= n && !w.geom(n).split_w) {
-      const int rps = n >= 512 * 2 * 512 ? 2 : 1;
+      const int rps = lp_rows_per_step(n, false);
       int nn = launch_axpy_norm_lp(n, rps, Q, ldq, w.shadow, w.shadow_ld, row, c, w.lp_tau, r, nP, w.scal + 16, st,
                                    w.prof ? w.prof->next(PROF_AXPY) : nullptr);
       launch_finalize1(nP, nn, pair_out, st);
@@ -703,7 +715,7 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
       return DSEA_ERR_HIP;
     }
   }
-  const int rps = g.split_w ? 0 : (n >= 512 * 2 * 512 ? 2 : 1);   // 0 = split form (small n)
+  const int rps = lp_rows_per_step(n, g.split_w != 0);   // 0 = split form
   launch_dot(q0, q0, n, P, nrm2, st);
   launch_scale_store(q0, nrm2, Q, nullptr, n, st, Qs);
   const bool has_fused_tail = (op->d.kind == OP_TFIM && op->d.tfim.L_local >= 1) || op->d.kind == OP_SELL ||
