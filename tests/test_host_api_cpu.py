@@ -304,3 +304,42 @@ def test_skip_zero_rhs_option(golden):
     assert abs(out[True][0] - hf) < 1e-13 * abs(hf)
     assert abs(out[True][0] - float(gd["dE0"][0])) < 1e-9 * abs(float(gd["dE0"][0]))
     assert abs(out[True][1] - float(gd["d2E0"][0])) < 1e-8 * abs(float(gd["d2E0"][0]))
+
+
+def test_arnoldi_stage_schedule():
+    """krylov._next_stage_end: first test after STAGE_FIRST columns, then half that, then extrapolated from the residual
+    decay; always moves forward by at least STAGE_MIN, never past ncv, and lands exactly on ncv rather than leaving a
+    stub; STAGE_FIRST = 0 (or a small ncv) gives the single full-length cycle of ARPACK's schedule."""
+    from dominantsparseeigenad_amd import krylov
+    m, tol = 200, 1e-13
+    assert krylov._next_stage_end(0, 0, m, [], tol) == krylov.STAGE_FIRST
+    assert krylov._next_stage_end(32, 0, m, [(32, 1e-3)], tol) == 32 + krylov.STAGE_FIRST // 2
+    # geometric decay 0.7 per column from 1e-3 at column 32: 1e-13 needs ~65 more columns -> clipped to STAGE_MAX
+    hist = [(32, 1e-3), (48, 1e-3 * 0.7 ** 16)]
+    j1 = krylov._next_stage_end(48, 0, m, hist, tol)
+    assert 48 + krylov.STAGE_MIN <= j1 <= 48 + krylov.STAGE_MAX
+    # fast decay: a short stage, but not shorter than STAGE_MIN
+    assert krylov._next_stage_end(48, 0, m, [(32, 1e-3), (48, 1e-12)], tol) == 48 + krylov.STAGE_MIN
+    # stagnation (no decay): the default step
+    assert krylov._next_stage_end(48, 0, m, [(32, 1e-3), (48, 2e-3)], tol) == 48 + krylov.STAGE_FIRST // 2
+    # close to the end: go to ncv instead of leaving fewer than STAGE_MIN columns
+    assert krylov._next_stage_end(190, 0, m, [(170, 1e-5), (190, 1e-6)], tol) == m
+    # after a thick restart with p kept vectors the first stage starts from p
+    assert krylov._next_stage_end(66, 66, m, [], tol) == 66 + krylov.STAGE_MIN
+    assert krylov._next_stage_end(10, 10, m, [], tol) == krylov.STAGE_FIRST
+    # small ncv or staging switched off: one stage
+    assert krylov._next_stage_end(0, 0, 36, [], tol) == 36
+    saved = krylov.STAGE_FIRST
+    try:
+        krylov.STAGE_FIRST = 0
+        assert krylov._next_stage_end(0, 0, m, [], tol) == m
+    finally:
+        krylov.STAGE_FIRST = saved
+    # the schedule always terminates at ncv
+    j, hist = 0, []
+    for _ in range(100):
+        j = krylov._next_stage_end(j, 0, m, hist, tol)
+        hist.append((j, 1.0))
+        if j >= m:
+            break
+    assert j == m
