@@ -7,17 +7,24 @@ One "step" = one pass of the hot path over synthetic inputs already resident in 
     forward   symeig.DominantSparseSymeig.apply(g, k, dim, device)      (Lanczos, k vectors, full reorth)
     backward  torch.autograd.grad(E0 + psi.t, g)                         (projected CG adjoint solve + hook)
 
-Workloads
-    N = 1 (default)        BASELINE.json configs[1]: TFIM L=20 (n = 2^20), k = 200, fp64, g = 1.0
-    N > 1, --scaling weak  (default) 2^25 rows per GPU, k = 200: L = 25 + log2 N; N = 8 is BASELINE configs[4]
-                           (TFIM L=28 row-partitioned over 8 GPUs, 53.7 GB of basis + 13.4 GB bf16 shadow per GPU)
-    --scaling strong       fixed TFIM L=28 at every N with the same k = 100 (the largest k whose basis, 215 GB, fits
-                           the one 288 GB GPU of the N = 1 point; there the bf16 shadow is dropped)
+Workloads (what the K timed steps run, i.e. what `value` / `ms_per_step` are quoted on)
+    N = 1 (default)   BASELINE.json configs[1]: TFIM L=20 (n = 2^20), k = 200, fp64, g = 1.0.  The same run then times,
+                      OUTSIDE the K steps, the two one-GPU anchors of the multi-GPU curves (config.one_gpu_anchors):
+                      L = 28, k = 100 (strong) and 2^25 rows, k = 200 (weak).
+    N > 1 (default)   STRONG scaling, north_star's curve: TFIM L=28 (n = 2^28) row-partitioned over the N GPUs with
+                      k = 100 at every N (the largest k whose basis, 215 GB, fits the one 288 GB GPU of the anchor).
+                      After the timed steps the WEAK point (2^25 rows per GPU, k = 200; N = 8 is BASELINE configs[4]:
+                      L = 28 with 53.7 GB of basis + 13.4 GB bf16 shadow per GPU) is timed too and reported as
+                      config.weak_scaling_point.
+    --scaling weak|strong   time only that one point.
     --gpus N without a launcher starts its own N worker processes (python -m torch.distributed.run) BEFORE any GPU
     call and relays rank 0's JSON line; under torchrun (WORLD_SIZE set) it is a worker.
 
-value = algorithmic GB/s of the whole job:  8 n (k^2 + 12k + 11m + 17) bytes / step time  (SURVEY.md 8d;
-m = CG iterations actually run).  Prints ONE JSON line (rank 0) as the last line of stdout.
+value = HBM GB/s of the whole job: bytes the step's kernels move (traffic model below; at the headline size checked
+against rocprofv3 PMC counters, profiles/pmc_traffic.json) / step time.  It is bounded by N x 8 TB/s.  The figure of
+SURVEY.md 8d -- ALGORITHMIC bytes 8 n (k^2 + 12k + 11m + 17) of the reference's algorithm / step time (m = CG
+iterations actually run) -- is config.algorithmic_GBs; it may exceed the peak because the correction pass streams a
+bf16 storage shadow of the basis.  Prints ONE JSON line (rank 0) as the last line of stdout.
 """
 from __future__ import annotations
 
@@ -46,6 +53,15 @@ ADJOINT_DEV_EPS7 = "3e-10..1.6e-9 relative (reference's own seed-to-seed spread:
 def algorithmic_bytes(n, k, m):
     """forward 8n(k^2+12k-7), backward 8n(11m+24)."""
     return 8.0 * n * (k * k + 12 * k + 11 * m + 17)
+
+
+def traffic_model_bytes(n, k, m, shadow_steps):
+    """HBM bytes one step of THIS implementation moves, as a model: SURVEY 8d's per-phase count with the correction
+    pass of ``shadow_steps`` Lanczos steps reading the bf16 shadow (2 instead of 8 bytes per basis element: step i
+    saves 6 n i bytes) plus the k shadow rows written once (2 n each).  At L = 20, k = 200, m = 90: 239.3 GB against
+    249.9 GB counted by the PMC (the difference is the TFIM mat-vec's cross-XCD re-reads)."""
+    saved = 6.0 * n * sum(range(1, int(shadow_steps) + 1))
+    return algorithmic_bytes(n, k, m) - saved + (2.0 * n * k if shadow_steps else 0.0)
 
 
 def analytic_E0_per_site(L, g):
@@ -206,12 +222,210 @@ def launch_workers(n):
     raise SystemExit(proc.returncode if proc.returncode else (0 if final is not None else 1))
 
 
+# one-GPU anchors of the two multi-GPU curves as last measured on an MI355X by `bench.py --gpus 1` of this repository
+# (profiles/, with the commit of the run); the N = 1 line re-measures them live (config.one_gpu_anchors)
+STORED_ANCHORS = {
+    "strong_L28_k100_ms": 5204.96, "strong_source": "profiles/r02_bench_L28_k100_one_gpu_final_kernels.json (commit ba73e41)",
+    "weak_2p25_rows_k200_ms": 1350.0, "weak_source": "profiles/r02_bench_partitioned_driver_2p25_rows_final_kernels.json (commit ba73e41)",
+}
+
+
+class Problem:
+    """One TFIM workload behind the reference API: operator, pinned draws, step() = forward + backward."""
+
+    def __init__(self, args, L, k, world, rank, dev, dry, partitioned_path, reorth="full"):
+        from dominantsparseeigenad_amd import engine
+        import dominantsparseeigenad_amd.symeig as symeig
+        from dominantsparseeigenad_amd.synthetic import normal_vector
+        self.engine, self.symeig = engine, symeig
+        self.L, self.k, self.world, self.rank, self.dev, self.dry = L, k, world, rank, dev, dry
+        self.partitioned = partitioned_path
+        self.reorth = reorth
+        p = int(np.log2(world))
+        self.p, self.Lloc = p, L - p
+        self.nloc, self.n = 1 << (L - p), 1 << L
+        off = rank * self.nloc
+        # one GPU cannot hold the fp64 basis AND its bf16 shadow at L = 28, k = 100 (215 + 54 GB of 288 GB)
+        free_b, total_b = (0, 1 << 62) if dry else torch.cuda.mem_get_info(dev)
+        need_shadow = 10.0 * self.nloc * k + 16 * 8.0 * self.nloc
+        self.use_shadow = not (need_shadow > 0.92 * total_b or reorth == "none")
+
+        def slab(seed):
+            return torch.from_numpy(normal_vector(self.nloc, seed, offset=off)).to(dev)
+
+        self.g = torch.tensor([1.0], dtype=torch.float64, device=dev, requires_grad=True)
+        self.draws = [slab(SEED + 10 + c) for c in range(3)]  # q0, unused second draw, CG start vector
+        tvec = slab(SEED + 1)
+        self.notes = {}
+        if not partitioned_path:
+            from dominantsparseeigenad_amd.operators import TFIMOperator
+            self.tvec = tvec / tvec.norm()
+            self.op = TFIMOperator(L, dev)
+            self.op.g = self.g
+            self.A_operand = self.op.H
+            if args.operator != "matrix-free":
+                self.A_operand = self.op.to_csr(layout=args.operator)      # explicit matrix (values fixed at the current g)
+            self.dot = torch.matmul
+        else:
+            from dominantsparseeigenad_amd import partitioned
+            backend = None
+            if dry:   # the torch test double of the slab kernels (test infrastructure; never on the product path)
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                from cpu_backend import CpuBackend
+                backend = CpuBackend(self.nloc)
+            self.op = partitioned.PartitionedTFIMOperator(L, self.g, dev, backend=backend, overlap=True if dry else "auto")
+            self.op.force_driver = True
+            self.A_operand = self.op.H
+            self.dot = self.op.dot
+            self.tvec = tvec / self.op.dot(tvec, tvec).sqrt()
+        self.last = {}
+
+    def barrier(self):
+        if not self.dry:
+            torch.cuda.synchronize()
+        if self.partitioned:
+            import torch.distributed as dist
+            dist.barrier()
+            if not self.dry:
+                torch.cuda.synchronize()
+
+    def activate(self):
+        """(re-)bind the module-global primitive to this problem's operator (reference symeig.py:66,87: last set wins)"""
+        from dominantsparseeigenad_amd import Lanczos as _LZ
+        _LZ.REORTH_DEFAULT = self.reorth
+        self.engine.USE_SHADOW = self.use_shadow
+        self.symeig.setDominantSparseSymeig(self.A_operand, self.op.Hadjoint_to_gadjoint)
+        self.f = self.symeig.DominantSparseSymeig.apply
+
+    def step(self):
+        with PinnedRandn(self.draws):
+            E0, psi = self.f(self.g, self.k, self.n, self.dev)
+            loss = E0 + self.dot(psi, self.tvec)
+            (gl,) = torch.autograd.grad(loss, self.g)
+        self.last["psi"] = psi.detach()
+        return E0, gl
+
+    def eigen_residual(self, E0, psi):
+        """||H psi - E0 psi|| over all ranks: the self-check of the distributed run (outside the timed region)"""
+        res = self.op.H(psi) - E0.detach() * psi
+        return float(self.dot(res, res).sqrt())
+
+    def cg_iterations(self):
+        return self.op.last_cg_iters if self.partitioned else self.engine.last_cg.iters
+
+    def first_contact(self):
+        """first contact with the collectives of this stack.  The decision to leave the transposed all-to-all form
+        is COLLECTIVE (an all-reduced failure flag): a rank-local fallback would leave the others in a collective"""
+        if not (self.partitioned and self.op.transposed):
+            return
+        import torch.distributed as dist
+        failed = torch.zeros(1, dtype=torch.float64, device=self.dev)
+        try:
+            probe = torch.zeros(self.world * 8, dtype=torch.float64, device=self.dev)
+            self.op.comm.all_to_all(probe, torch.empty_like(probe))
+            if not self.dry:
+                torch.cuda.synchronize()
+        except Exception as exc:  # noqa: BLE001
+            failed[0] = 1.0
+            self.notes["distributed_fallback_reason"] = "%s: %s" % (type(exc).__name__, str(exc)[:120])
+        dist.all_reduce(failed)
+        if failed.item() > 0:
+            self.op.use_pairwise_exchange()
+            self.notes["distributed_fallback"] = "transposed exchange unavailable on %d rank(s): pairwise slab " \
+                                                 "exchange used" % int(failed.item())
+
+    def measure(self, steps, warmup):
+        """W untimed steps, [distributed self-check], barrier, EXACTLY K timed steps, barrier; returns seconds
+        (max over ranks), E0, dloss/dg"""
+        self.activate()
+        self.first_contact()
+        E0 = gl = None
+        for _ in range(warmup):
+            E0, gl = self.step()
+        self.barrier()
+        if self.partitioned:
+            op, notes = self.op, self.notes
+            # the overlapped exchange is verified before anything is timed; if the eigen-residual is not at the
+            # level the sequential exchange reaches, the run falls back to the sequential exchange
+            if warmup == 0:
+                E0, gl = self.step()
+            resid = self.eigen_residual(E0, self.last["psi"])
+            notes["slab_exchange"] = ("none (one rank)" if op.p == 0 else
+                                      ("transposed all-to-all form" if op.transposed else "pairwise hypercube partners")
+                                      + (", overlapped with the dots / correction passes" if op.overlap else ""))
+            if op.p > 0 and op.overlap:
+                op.overlap = False
+                E0s, _ = self.step()
+                resid_seq = self.eigen_residual(E0s, self.last["psi"])
+                op.overlap = True
+                if not (resid <= 10.0 * resid_seq + 1e-9):
+                    op.overlap = False
+                    notes["distributed_self_check"] = "overlapped exchange failed its self-check (residual %.2e vs " \
+                                                      "%.2e sequential): sequential exchange timed instead" % (resid, resid_seq)
+                else:
+                    notes["distributed_self_check"] = "overlapped exchange verified: eigen-residual %.2e (sequential " \
+                                                      "%.2e), %d premise fallbacks" % (resid, resid_seq, op.overlap_fallbacks)
+            else:
+                notes["distributed_self_check"] = "eigen-residual %.2e" % resid
+            self.barrier()
+        # ---- timed region: exactly K steps, no instrumentation inside
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            E0, gl = self.step()
+        self.barrier()
+        dt = time.perf_counter() - t0
+        if self.partitioned:
+            import torch.distributed as dist
+            tmax = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = tmax.item()
+        return dt, E0, gl
+
+    def describe(self, operator="matrix-free", scaling=None):
+        mode = "row-partitioned over %d GPUs%s" % (self.world, ", %s scaling" % scaling if scaling else "") \
+            if self.partitioned else "one GPU"
+        return "TFIM L=%d (n=2^%d, %d rows/GPU) DominantSparseSymeig k=%d fwd+bwd, g=1.0, loss=E0+psi.t, " \
+               "operand=%s, %s" % (self.L, self.L, self.nloc, self.k, operator, mode)
+
+    def release(self):
+        """drop the operator and the arena basis (the next problem of this process may need the memory)"""
+        self.op = self.A_operand = self.f = None
+        self.draws = self.tvec = None
+        self.last = {}
+        self.engine.BasisArena.release()
+        self.engine.Workspace.clear_cache()
+        if not self.dry:
+            torch.cuda.empty_cache()
+
+
+def rank_evidence(world, rank, local_rank, dev, dry):
+    """what proves the collectives span N distinct GPUs: every rank's device, gathered to rank 0"""
+    import torch.distributed as dist
+    mine = {"rank": rank, "local_rank": local_rank, "host": socket.gethostname(), "pid": os.getpid()}
+    if not dry:
+        pr = torch.cuda.get_device_properties(dev)
+        mine.update(device=pr.name, pci="%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0),
+                                                             getattr(pr, "pci_device_id", 0)),
+                    uuid=str(getattr(pr, "uuid", "")), hbm_GB=round(pr.total_memory / 1e9, 1))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": gathered}
+    if not dry:
+        try:
+            info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            pass
+        info["distinct_devices"] = len({(r["host"], r.get("pci"), r.get("uuid")) for r in gathered})
+    return info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="N > 1: time only this point (default: strong timed, weak reported beside it)")
     ap.add_argument("--L", type=int, default=None, help="chain length (default: by --gpus / --scaling)")
     ap.add_argument("--L-local", type=int, default=None, help="log2 rows per GPU (weak scaling)")
     ap.add_argument("--k", type=int, default=None)
@@ -228,6 +442,9 @@ def main():
                          "configuration in 31.5 s with 8 threads, 33.8 s with 64 and 554 s with all 256")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp64-basis batch and the config-3 figures")
+    ap.add_argument("--no-anchors", action="store_true",
+                    help="N = 1: skip the live one-GPU anchors of the multi-GPU curves (L = 28, k = 100 and 2^25 rows, "
+                         "k = 200: ~40 s and 230 GB of HBM)")
     ap.add_argument("--rpl", type=int, default=0)
     ap.add_argument("--operator", choices=["matrix-free", "sell", "csr"], default="matrix-free",
                     help="operand form of the TFIM operator at N=1: native matrix-free kernel (headline) or the "
@@ -241,8 +458,9 @@ def main():
                     help="CONTROL-FLOW CHECK ONLY, no measurement: the multi-rank path of this script (self-launch, "
                          "row-partitioned operator behind the reference API, collective fallback decision, exchange "
                          "self-check, max-over-ranks timing, rank-0 JSON) on CPU processes over gloo with the torch test "
-                         "double of the slab kernels (tests/cpu_backend.py).  Use a small --L / --k.  The line it prints "
-                         "is labelled as a dry run and carries no roofline / cpu_baseline.")
+                         "double of the slab kernels (tests/cpu_backend.py).  Without --L / --k the default two-point "
+                         "schedule of N > 1 runs at toy sizes.  The line it prints is labelled as a dry run and carries "
+                         "no roofline / cpu_baseline.")
     args = ap.parse_args()
     dry = args.dry_run_cpu
 
@@ -263,59 +481,40 @@ def main():
         dev = torch.device("cuda", local_rank)
 
     from dominantsparseeigenad_amd import _lib, engine
-    from dominantsparseeigenad_amd import Lanczos as _LZ
-    import dominantsparseeigenad_amd.symeig as symeig
-    _LZ.REORTH_DEFAULT = args.reorth
-    from dominantsparseeigenad_amd.synthetic import normal_vector
     lib = None if dry else _lib.load()
 
     p = int(np.log2(world))
     assert (1 << p) == world, "world size must be a power of two"
     partitioned_path = world > 1 or args.force_partitioned or dry
-    strong = args.scaling == "strong"
+    # ---- which point is timed
+    explicit = args.L is not None or args.L_local is not None
+    if world == 1:
+        scaling = args.scaling or "weak"
+    else:
+        scaling = args.scaling or ("weak" if explicit else "strong")
+    strong = scaling == "strong"
+    toy = dry and not explicit            # dry run of the default schedule: toy sizes
     if args.L is not None:
         L = args.L
     elif strong:
-        L = 28
+        L = 10 if toy else 28
     elif args.L_local is not None:
         L = args.L_local + p
+    elif toy:
+        L = 7 + p
     else:
         L = 20 if world == 1 else 25 + p
-    Lloc = L - p
-    k = args.k if args.k is not None else (100 if strong else 200)
-    nloc, n = 1 << Lloc, 1 << L
-    off = rank * nloc
+    k = args.k if args.k is not None else ((80 if strong else 60) if toy else (100 if strong else 200))
+    # the weak point reported beside the timed strong one (default schedule of N > 1 only)
+    weak_extra = world > 1 and args.scaling is None and not explicit and args.reorth == "full"
+    nloc, n = 1 << (L - p), 1 << L
     big = nloc >= (1 << 24)
     steps = args.steps if args.steps is not None else (3 if big else 10)
     warmup = args.warmup if args.warmup is not None else (1 if big else 2)
-    # one GPU cannot hold the fp64 basis AND its bf16 shadow at L = 28, k = 100 (215 + 54 GB of 288 GB)
-    free_b, total_b = (0, 1 << 62) if dry else torch.cuda.mem_get_info(dev)
-    need_shadow = 10.0 * nloc * k + 16 * 8.0 * nloc
-    if need_shadow > 0.92 * total_b or args.reorth == "none":
-        engine.USE_SHADOW = False
 
-    def slab(seed):
-        return torch.from_numpy(normal_vector(nloc, seed, offset=off)).to(dev)
-
-    g = torch.tensor([1.0], dtype=torch.float64, device=dev, requires_grad=True)
-    draws = [slab(SEED + 10 + c) for c in range(3)]  # q0, unused second draw, CG start vector
-    tvec = slab(SEED + 1)
-
-    if not partitioned_path:
-        from dominantsparseeigenad_amd.operators import TFIMOperator
-        tvec = tvec / tvec.norm()
-        op = TFIMOperator(L, dev)
-        op.g = g
-        A_operand = op.H
-        if args.operator != "matrix-free":
-            A_operand = op.to_csr(layout=args.operator)      # explicit matrix (values fixed at the current g)
-        dot = torch.matmul
-
-        def barrier():
-            torch.cuda.synchronize()
-    else:
+    evidence = None
+    if partitioned_path:
         import torch.distributed as dist
-        from dominantsparseeigenad_amd import partitioned
         if not dist.is_initialized():
             if world == 1:
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -324,100 +523,19 @@ def main():
                 dist.init_process_group("gloo", rank=rank, world_size=world)
             else:
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        backend = None
-        if dry:   # the torch test double of the slab kernels (test infrastructure; never on the product path)
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            from cpu_backend import CpuBackend
-            backend = CpuBackend(nloc)
-        op = partitioned.PartitionedTFIMOperator(L, g, dev, backend=backend, overlap=True if dry else "auto")
-        op.force_driver = True
-        A_operand = op.H
-        dot = op.dot
-        tvec = tvec / op.dot(tvec, tvec).sqrt()
-
-        def barrier():
-            if not dry:
-                torch.cuda.synchronize()
-            dist.barrier()
-            if not dry:
-                torch.cuda.synchronize()
-
-    symeig.setDominantSparseSymeig(A_operand, op.Hadjoint_to_gadjoint)
-    f = symeig.DominantSparseSymeig.apply
-    last = {}
-
-    def step():
-        with PinnedRandn(draws):
-            E0, psi = f(g, k, n, dev)
-            loss = E0 + dot(psi, tvec)
-            (gl,) = torch.autograd.grad(loss, g)
-        last["psi"] = psi.detach()
-        return E0, gl
-
-    def eigen_residual(E0, psi):
-        """||H psi - E0 psi|| over all ranks: the self-check of the distributed run (outside the timed region)"""
-        res = op.H(psi) - E0.detach() * psi
-        return float(dot(res, res).sqrt())
+        evidence = rank_evidence(world, rank, local_rank, dev, dry)
 
     if os.environ.get("DSEA_PLACEMENT_TRIES"):
         engine.BasisArena.PLACEMENT_TRIES = int(os.environ["DSEA_PLACEMENT_TRIES"])
+
+    prob = Problem(args, L, k, world, rank, dev, dry, partitioned_path, reorth=args.reorth)
     ws = None if dry else engine.Workspace.get(nloc, k, dev)
     if args.rpl and ws is not None:
         ws.set_rows_per_lane(args.rpl)
-
-    notes = {}
-    if partitioned_path and op.transposed:
-        # first contact with the collectives of this stack.  The decision to leave the transposed all-to-all form
-        # is COLLECTIVE (an all-reduced failure flag): a rank-local fallback would leave the others in a collective
-        import torch.distributed as dist
-        failed = torch.zeros(1, dtype=torch.float64, device=dev)
-        try:
-            probe = torch.zeros(world * 8, dtype=torch.float64, device=dev)
-            op.comm.all_to_all(probe, torch.empty_like(probe))
-            if not dry:
-                torch.cuda.synchronize()
-        except Exception as exc:  # noqa: BLE001
-            failed[0] = 1.0
-            notes["distributed_fallback_reason"] = "%s: %s" % (type(exc).__name__, str(exc)[:120])
-        dist.all_reduce(failed)
-        if failed.item() > 0:
-            op.use_pairwise_exchange()
-            notes["distributed_fallback"] = "transposed exchange unavailable on %d rank(s): pairwise slab exchange used" \
-                                            % int(failed.item())
-    for _ in range(warmup):
-        E0, gl = step()
-    barrier()
-    if partitioned_path:
-        # the overlapped exchange is verified before anything is timed; if the eigen-residual is not at the
-        # level the sequential exchange reaches, the run falls back to the sequential exchange
-        if warmup == 0:
-            E0, gl = step()
-        resid = eigen_residual(E0, last["psi"])
-        notes["slab_exchange"] = ("none (one rank)" if op.p == 0 else
-                                  ("transposed all-to-all form" if op.transposed else "pairwise hypercube partners")
-                                  + (", overlapped with the dots / correction passes" if op.overlap else ""))
-        if op.p > 0 and op.overlap:
-            op.overlap = False
-            E0s, _ = step()
-            resid_seq = eigen_residual(E0s, last["psi"])
-            op.overlap = True
-            if not (resid <= 10.0 * resid_seq + 1e-9):
-                op.overlap = False
-                notes["distributed_self_check"] = "overlapped exchange failed its self-check (residual %.2e vs %.2e " \
-                                                  "sequential): sequential exchange timed instead" % (resid, resid_seq)
-            else:
-                notes["distributed_self_check"] = "overlapped exchange verified: eigen-residual %.2e (sequential %.2e), " \
-                                                  "%d premise fallbacks" % (resid, resid_seq, op.overlap_fallbacks)
-        else:
-            notes["distributed_self_check"] = "eigen-residual %.2e" % resid
-        barrier()
-    # ---- timed region: exactly K steps, no instrumentation inside
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        E0, gl = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    m = op.last_cg_iters if partitioned_path else engine.last_cg.iters
+    dt, E0, gl = prob.measure(steps, warmup)
+    notes = prob.notes
+    m = prob.cg_iterations()
+    step, barrier = prob.step, prob.barrier
     # ---- per-launch durations of the dominant kernels: the same K steps again, this time with a HIP event
     # pair recorded on the launch stream around every reorth / mat-vec launch (the event records cost ~4 %
     # of a step, which is why they are kept out of the timed region above)
@@ -427,6 +545,7 @@ def main():
     dt_instr = None
     ev_steps = min(steps, 5) if big else steps
     if use_events:
+        ws = engine.Workspace.get(nloc, k, dev)
         _lib.check(lib.dsea_profile_begin(ws.handle, 3 * k * ev_steps + 8), "dsea_profile_begin")
         t1 = time.perf_counter()
         for _ in range(ev_steps):
@@ -438,6 +557,7 @@ def main():
     # ---- the same step with the all-fp64 correction pass (no bf16 shadow of the basis): the figure to hold
     # against real HBM traffic
     ms_fp64 = ms_basisfree = None
+    from dominantsparseeigenad_amd import Lanczos as _LZ
     if not args.no_extras and not partitioned_path and args.reorth == "full" and not big:
         # the same workload with the basis-free two-pass Lanczos (reorth='none'): a DIFFERENT forward algorithm (no
         # full re-orthogonalisation, Lanczos.py:66), same eigenpair and gradient to rounding -- reported beside the
@@ -464,43 +584,133 @@ def main():
         barrier()
         ms_fp64 = (time.perf_counter() - t2) / nb * 1e3
         engine.USE_SHADOW = True
-    if partitioned_path:
-        import torch.distributed as dist
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = tmax.item()
     ms_per_step = dt / steps * 1e3
-    total_bytes = algorithmic_bytes(n, k, m)
+    alg_bytes = algorithmic_bytes(n, k, m)
+    if lp_stats is not None:
+        shadow_steps = int(lp_stats[0])
+    else:
+        shadow_steps = (k - 1) if (prob.use_shadow and k > 1) else 0
+    total_bytes = traffic_model_bytes(n, k, m, shadow_steps)
     if args.reorth == "none":
         # the basis-free two-pass option is a DIFFERENT algorithm: it is priced with ITS OWN algorithmic bytes, not with
         # SURVEY 8d's full-reorthogonalisation figure (which it does not move).  Per Lanczos step and pass: mat-vec 2 +
         # three-term 4 + scale/store 2 vectors; the second pass also updates psi (2): 18 k vectors in all.
-        total_bytes = 8.0 * n * (18 * k + 11 * m + 24)
+        total_bytes = alg_bytes = 8.0 * n * (18 * k + 11 * m + 24)
     value = total_bytes / (ms_per_step * 1e-3) / 1e9
+    workload = prob.describe(args.operator, scaling if world > 1 else None)
+    E0_site, gl0 = E0.item() / L, float(gl.reshape(-1)[0].item())
+    overlap_fb = prob.op.overlap_fallbacks if partitioned_path else None
+
+    # ---- N > 1, default schedule: the weak point beside the timed strong one
+    weak_point = None
+    if weak_extra:
+        prob.release()
+        Lw, kw = ((7 + p, 60) if toy else (25 + p, 200))
+        try:
+            pw = Problem(args, Lw, kw, world, rank, dev, dry, True)
+            sw, ww = (2, 1) if toy else (3, 1)
+            dtw, E0w, _ = pw.measure(sw, ww)
+            mw = pw.cg_iterations()
+            msw = dtw / sw * 1e3
+            bw = traffic_model_bytes(1 << Lw, kw, mw, (kw - 1) if pw.use_shadow else 0)
+            weak_point = {"workload": pw.describe(args.operator, "weak"), "ms_per_step": round(msw, 4), "steps": sw,
+                          "warmup": ww, "GBs": round(bw / (msw * 1e-3) / 1e9, 2),
+                          "algorithmic_GBs": round(algorithmic_bytes(1 << Lw, kw, mw) / (msw * 1e-3) / 1e9, 2),
+                          "cg_iterations": int(mw), "E0_per_site": E0w.item() / Lw,
+                          "E0_per_site_closed_form": analytic_E0_per_site(Lw, 1.0),
+                          "one_gpu_anchor_ms": STORED_ANCHORS["weak_2p25_rows_k200_ms"],
+                          "weak_efficiency_vs_anchor": None if toy else round(STORED_ANCHORS["weak_2p25_rows_k200_ms"] / msw, 4)}
+            weak_point.update(pw.notes)
+            pw.release()
+        except Exception as exc:  # noqa: BLE001  (every rank runs the same code: the exception is collective)
+            weak_point = "failed: %s: %s" % (type(exc).__name__, str(exc)[:200])
+
+    # ---- N = 1, default workload: the live one-GPU anchors of the multi-GPU curves (outside the timed steps)
+    anchors = None
+    default_headline = world == 1 and not partitioned_path and not explicit and args.k is None and \
+        args.operator == "matrix-free" and args.reorth == "full"
+    if default_headline and not args.no_anchors and not dry:
+        prob_keep = prob
+        anchors = {}
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        for tag, La, ka, sa in (("weak_2p25_rows_k200", 25, 200, 3), ("strong_L28_k100", 28, 100, 2)):
+            need = 8.0 * (1 << La) * (ka + 8) * (1.25 if La == 25 else 1.0)
+            if need > 0.9 * total_b:
+                anchors[tag] = "skipped: needs %.0f GB of %.0f GB" % (need / 1e9, total_b / 1e9)
+                continue
+            try:
+                engine.BasisArena.release()
+                engine.Workspace.clear_cache()
+                torch.cuda.empty_cache()
+                pa = Problem(args, La, ka, 1, 0, dev, False, False)
+                dta, E0a, _ = pa.measure(sa, 1)
+                ma = pa.cg_iterations()
+                msa = dta / sa * 1e3
+                anchors[tag] = {"workload": pa.describe(), "ms_per_step": round(msa, 3), "steps": sa, "warmup": 1,
+                                "cg_iterations": int(ma), "bf16_shadow_of_basis": bool(pa.use_shadow),
+                                "GBs": round(traffic_model_bytes(1 << La, ka, ma, (ka - 1) if pa.use_shadow else 0) / (msa * 1e-3) / 1e9, 1),
+                                "algorithmic_GBs": round(algorithmic_bytes(1 << La, ka, ma) / (msa * 1e-3) / 1e9, 1),
+                                "E0_per_site_minus_closed_form": E0a.item() / La - analytic_E0_per_site(La, 1.0)}
+                pa.release()
+            except Exception as exc:  # noqa: BLE001
+                anchors[tag] = "failed: %s: %s" % (type(exc).__name__, str(exc)[:200])
+                engine.BasisArena.release()
+                torch.cuda.empty_cache()
+        prob = prob_keep
+        prob.activate()          # module-global primitive, shadow flag and reorth default back to the headline problem
 
     final_line = None
     if rank == 0:
-        mode = "row-partitioned over %d GPUs, %s scaling" % (world, args.scaling) if partitioned_path else "one GPU"
         out = {
             "metric": "DRY RUN on CPU processes (gloo, torch test double of the slab kernels): control flow of the "
                       "multi-rank bench only, not a measurement" if dry else
-                      "DominantSparseSymeig fwd+bwd algorithmic HBM GB/s (TFIM, fp64)" if args.reorth == "full" else
+                      "DominantSparseSymeig fwd+bwd ms & HBM GB/s (TFIM, fp64)" if args.reorth == "full" else
                       "DominantSparseSymeig fwd+bwd GB/s, basis-free two-pass Lanczos option (TFIM, fp64; not the "
                       "reference's full-reorthogonalisation algorithm)",
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "TFIM L=%d (n=2^%d, %d rows/GPU) DominantSparseSymeig k=%d fwd+bwd, g=1.0, "
-                                   "loss=E0+psi.t, operand=%s, %s" % (L, L, nloc, k, args.operator, mode),
-                       "cg_iterations": int(m), "algorithmic_bytes_per_step": total_bytes,
-                       "frac_of_hbm_peak_whole_step": round(value / (HBM_PEAK_GBS * world), 4),
-                       "bf16_shadow_of_basis": bool(engine.USE_SHADOW), "lanczos_reorthogonalisation": args.reorth,
-                       "E0_per_site": E0.item() / L, "E0_per_site_closed_form": analytic_E0_per_site(L, 1.0),
-                       "dloss_dg": float(gl.reshape(-1)[0].item()),
+            "config": {"workload": workload,
+                       "value_is": "HBM bytes the step's kernels move (traffic model: SURVEY 8d per-phase count with "
+                                   "the correction pass of %d Lanczos steps reading the bf16 shadow of the basis) / "
+                                   "step time, all ranks" % shadow_steps,
+                       "cg_iterations": int(m), "traffic_model_bytes_per_step": total_bytes,
+                       "frac_of_hbm_peak": round(value / (HBM_PEAK_GBS * world), 4),
+                       "algorithmic_bytes_per_step": alg_bytes,
+                       "algorithmic_GBs": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 2),
+                       "algorithmic_GBs_note": "SURVEY 8d figure: bytes of the REFERENCE's algorithm (all-fp64 basis) / "
+                                               "step time; it may exceed the HBM peak because the implementation "
+                                               "moves fewer bytes -- not a roofline fraction",
+                       "ms_at_hbm_peak_for_algorithmic_bytes": round(alg_bytes / (HBM_PEAK_GBS * world * 1e9) * 1e3, 3),
+                       "bf16_shadow_of_basis": bool(prob.use_shadow), "lanczos_reorthogonalisation": args.reorth,
+                       "E0_per_site": E0_site, "E0_per_site_closed_form": analytic_E0_per_site(L, 1.0),
+                       "dloss_dg": gl0,
                        "adjoint_vs_reference_at_eps1e-7": ADJOINT_DEV_EPS7,
                        "basis_placement_probe_us": [round(t, 1) for t in (engine.BasisArena.last_placement or [])]},
         }
         out["config"].update(notes)
+        if evidence is not None:
+            out["config"]["collectives"] = evidence
+        if world > 1:
+            anchor_ms = STORED_ANCHORS["strong_L28_k100_ms"] if strong else STORED_ANCHORS["weak_2p25_rows_k200_ms"]
+            canonical = (not explicit and args.k is None and not dry)
+            out["config"]["one_gpu_anchor"] = {
+                "ms_per_step": anchor_ms, "source": STORED_ANCHORS["strong_source" if strong else "weak_source"],
+                "live": "the N = 1 line of the same sequence re-measures it (config.one_gpu_anchors)",
+                ("speedup_vs_one_gpu" if strong else "weak_efficiency"):
+                    round(anchor_ms / ms_per_step, 4) if canonical else None}
+            if weak_point is not None:
+                out["config"]["weak_scaling_point"] = weak_point
+            if overlap_fb is not None:
+                out["config"]["overlap_premise_fallbacks"] = int(overlap_fb)
+        if world == 1 and not partitioned_path:
+            out["config"]["multi_gpu_schedule"] = (
+                "bench.py --gpus N (N > 1) times the STRONG point TFIM L=28, k=100 over N GPUs as value/ms_per_step and "
+                "reports the WEAK point (2^25 rows/GPU, k=200) as config.weak_scaling_point; their one-GPU anchors are "
+                "config.one_gpu_anchors of this line (speed-up at N = anchor ms / ms_per_step of the N-GPU line)")
+        if anchors is not None:
+            out["config"]["one_gpu_anchors"] = anchors
+            out["config"]["one_gpu_anchors_stored"] = STORED_ANCHORS
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         pmc = None
         if os.path.exists(tpath):
@@ -509,14 +719,13 @@ def main():
             except Exception:
                 pmc = None
         if not partitioned_path and L == 20 and k == 200 and args.operator == "matrix-free":
-            # `value` counts ALGORITHMIC bytes.  The correction pass streams a bf16 shadow of the
-            # basis, so the bytes that really cross the HBM interface are fewer: report both.
+            # the traffic model against the counters: bytes that crossed the HBM interface in a profiled run of this step
             if pmc and pmc.get("_total_hbm_bytes_per_step"):
                 real = float(pmc["_total_hbm_bytes_per_step"])
-                out["config"]["real_hbm_bytes_per_step"] = real
-                out["config"]["real_hbm_bytes_source"] = "rocprofv3 PMC FETCH_SIZE/WRITE_SIZE at commit %s" % pmc.get("_commit", "?")
-                out["value_real_traffic"] = round(real / (ms_per_step * 1e-3) / 1e9, 2)
-                out["config"]["frac_of_hbm_peak_real_traffic"] = round(real / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                out["config"]["pmc_hbm_bytes_per_step"] = real
+                out["config"]["pmc_source"] = "rocprofv3 PMC FETCH_SIZE/WRITE_SIZE at commit %s" % pmc.get("_commit", "?")
+                out["config"]["pmc_GBs"] = round(real / (ms_per_step * 1e-3) / 1e9, 2)
+                out["config"]["frac_of_hbm_peak_pmc_traffic"] = round(real / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         if ms_basisfree is not None:
             out["config"]["basisfree_two_pass_lanczos"] = {
                 "ms_per_step": round(ms_basisfree, 4), "E0_rel_dev_vs_full_reorth": bf_dev[0],
@@ -524,31 +733,37 @@ def main():
                 "note": "reorth='none' option: no stored basis, no re-orthogonalisation; not the reference's algorithm"}
         if ms_fp64 is not None:
             out["config"]["ms_per_step_fp64_basis"] = round(ms_fp64, 4)
-            out["config"]["GBs_fp64_basis"] = round(total_bytes / (ms_fp64 * 1e-3) / 1e9, 2)
+            out["config"]["GBs_fp64_basis"] = round(alg_bytes / (ms_fp64 * 1e-3) / 1e9, 2)
         if use_events and launches[0] > 0 and launches[1] > 0:
             dots_b, axpy_b = reorth_bytes_per_launch(nloc, k)
+            # the correction pass is priced with the bytes IT reads: bf16 shadow (2 bytes/element) when it is on
+            axpy_real = axpy_b if not prob.use_shadow else \
+                sum(2.0 * i + 16.0 for i in range(1, k)) / (k - 1) * nloc
             per = {
                 "k_rdots": (dots_b, total_ms[0] / launches[0], launches[0]),
-                "k_axpy_norm": (axpy_b, total_ms[1] / launches[1], launches[1]),
+                "k_axpy_norm": (axpy_real, total_ms[1] / launches[1], launches[1]),
             }
             name = max(per, key=lambda kk: per[kk][1] * per[kk][2])
             b, ms, cnt = per[name]
             traffic = None
             if pmc and L == 20 and k == 200:
                 traffic = pmc.get(name, {}).get("hbm_bytes_per_launch")
-            lp, fb = lp_stats if lp_stats is not None else (launches[1] if engine.USE_SHADOW else 0, 0)
+            lp, fb = lp_stats if lp_stats is not None else (launches[1] if prob.use_shadow else 0, 0)
             out["roofline"] = {
                 "kernel": name, "bound": "hbm", "achieved": round(b / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_commit": pmc.get("_commit") if (pmc and traffic) else None,
-                "avg_launch_ms": round(ms, 5), "launches": int(cnt), "algorithmic_bytes_per_launch": b,
-                "other": {kk: {"avg_launch_ms": round(v[1], 5), "achieved_GBs": round(v[0] / (v[1] * 1e-3) / 1e9, 1)}
+                "avg_launch_ms": round(ms, 5), "launches": int(cnt), "launches_per_step": int(cnt) // max(ev_steps, 1),
+                "algorithmic_bytes_per_launch": b,
+                "other": {kk: {"avg_launch_ms": round(v[1], 5), "achieved_GBs": round(v[0] / (v[1] * 1e-3) / 1e9, 1),
+                               "bytes_per_launch": v[0]}
                           for kk, v in per.items() if kk != name},
                 "spmv_avg_launch_ms": round(total_ms[2] / max(launches[2], 1), 5),
                 "measured": "HIP events on the launch stream, %d instrumented steps run right after the timed "
                             "region (%.3f ms/step with events)" % (ev_steps, dt_instr / ev_steps * 1e3),
-                "note": ("k_axpy_norm streams the bf16 shadow of the basis on %d of %d steps (fp64 fallback %d): "
-                         "its real traffic is ~1/4 of its algorithmic bytes" % (lp, lp + fb, fb)) if not partitioned_path
+                "note": ("k_axpy_norm streams the bf16 shadow of the basis on %d of %d steps (fp64 fallback %d) and is "
+                         "priced with the bytes it reads (2 per basis element + r in and out), not with SURVEY 8d's "
+                         "8 per element" % (lp, lp + fb, fb)) if not partitioned_path
                         else "rank 0's local kernels in the row-partitioned run",
             }
         if not args.no_extras and world == 1 and not partitioned_path and not big:
@@ -567,7 +782,7 @@ def main():
                     "value": r["GBs"], "unit": "GB/s", "cores": r["threads"], "kind": "port",
                     "sample": "oracle (torch-CPU port of reference Lanczos.py/CG.py/TFIM.H), TFIM L=%d, k=%d Lanczos "
                               "vectors, CG capped at %d iterations (ran %d), fwd+bwd %.1f s, table build %.1f s not "
-                              "timed; host: %s"
+                              "timed; GB/s of the algorithmic bytes (SURVEY 8d), which is what a CPU run moves; host: %s"
                               % (L, r["k"], args.cpu_cg_cap, r["cg_iterations"], r["fwd_bwd_s"], r["table_build_s"], host)}
             else:
                 # the FULL configuration (k as on the GPU, CG to the reference's tolerance)
@@ -580,8 +795,8 @@ def main():
                     "value": best["GBs"], "unit": "GB/s", "cores": best["threads"], "kind": "port",
                     "sample": "oracle (torch-CPU port of reference Lanczos.py/CG.py/TFIM.H incl. the gather-table "
                               "mat-vec) on the FULL workload: TFIM L=%d, k=%d, CG to ||r||<1e-7 (%d iterations): fwd "
-                              "%.1f s + bwd %.1f s; host: %s" % (L, k, best["cg_iterations"], best["fwd_s"],
-                                                                  best["bwd_s"], host),
+                              "%.1f s + bwd %.1f s; GB/s of the algorithmic bytes (SURVEY 8d); host: %s"
+                              % (L, k, best["cg_iterations"], best["fwd_s"], best["bwd_s"], host),
                     "ms_per_step": round(best["fwd_bwd_s"] * 1e3, 1), "runs": runs}
         # RCCL / HIP runtime banners go through C stdio: flush them first so the JSON is the last line
         import ctypes

@@ -176,8 +176,8 @@ int dsea_ws_create(void* device_buffer, size_t bytes, int64_t n, int kmax, dsea_
 static void prof_free(Workspace& w) {
   if (!w.prof) return;
   for (int e = 0; e < w.prof->capacity; ++e) {
-    hipEventDestroy(w.prof->pairs[e].a);
-    hipEventDestroy(w.prof->pairs[e].b);
+    (void)hipEventDestroy(w.prof->pairs[e].a);
+    (void)hipEventDestroy(w.prof->pairs[e].b);
   }
   delete[] w.prof->pairs;
   delete w.prof;
@@ -823,8 +823,9 @@ int dsea_arnoldi_extend(dsea_op_t op, dsea_ws_t ws, const double* shift, double*
   Workspace& w = ws->w;
   double* brk = w.scal + DSEA_SCAL_BREAK;
   if (j0 == 0) {   // a new factorisation: clear the break record (a continued one keeps it)
-    hipMemsetAsync(w.scal + 31, 0, sizeof(double), st);   // second-pass counter (dsea_arnoldi_second_passes)
-    if (hipMemsetAsync(brk, 0, 2 * sizeof(double), st) != hipSuccess) {
+    // second-pass counter (dsea_arnoldi_second_passes) and the break record
+    if (hipMemsetAsync(w.scal + 31, 0, sizeof(double), st) != hipSuccess ||
+        hipMemsetAsync(brk, 0, 2 * sizeof(double), st) != hipSuccess) {
       g_last_hip = (int)hipGetLastError();
       return DSEA_ERR_HIP;
     }

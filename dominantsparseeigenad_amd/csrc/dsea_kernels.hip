@@ -2575,6 +2575,20 @@ int launch_cg_persist(const OpDesc& op, const double* shift, const double* b, do
   if (G > 256) {
     return -1;
   }
+  {
+    // The workgroups spin on each other: all G must be resident at the same time.  One workgroup (<= 1024 threads,
+    // <= 70 KB of LDS) always fits a compute unit of its own, so G <= number of CUs of THIS device (256 on an MI355X in
+    // SPX mode, 32 per partition in CPX mode) guarantees co-residency on an otherwise idle device; beyond that the
+    // streaming form is used.  (A device shared with other work is caught by the bounded spins -> DSEA_ERR_TIMEOUT.)
+    static thread_local int cu_dev = -1, cu_count = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -2;
+    if (dev != cu_dev) {
+      if (hipDeviceGetAttribute(&cu_count, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -2;
+      cu_dev = dev;
+    }
+    if (G > cu_count) return -1;
+  }
   const size_t cbytes = merged ? (size_t)(16 + 4) * G * sizeof(unsigned long long)
                                : (size_t)(4 * nt + 8 * G) * sizeof(unsigned long long);
   if (hipMemsetAsync(comm, 0, cbytes, st) != hipSuccess) return -2;

@@ -28,6 +28,7 @@ struct Blas {
   bool ok = false;
   rocblas_handle h = nullptr;
   decltype(&rocblas_create_handle) create = nullptr;
+  decltype(&rocblas_destroy_handle) destroy = nullptr;
   decltype(&rocblas_set_stream) set_stream = nullptr;
   decltype(&rocblas_set_pointer_mode) set_pointer_mode = nullptr;
   decltype(&rocblas_set_atomics_mode) set_atomics_mode = nullptr;
@@ -37,13 +38,23 @@ struct Blas {
 };
 Blas g_blas;
 std::once_flag g_blas_once;
-// One rocBLAS handle PER STREAM (created on first use, bound to its stream once): switching the stream of a shared
-// handle while its earlier work may still be running is not safe for kernels that use the handle's device workspace,
-// and the left / right solves of the non-symmetric primitives run concurrently on two streams (eig._two_sides).
+// One rocBLAS handle PER (DEVICE, STREAM) (created on first use, bound to its stream once): switching the stream of a
+// shared handle while its earlier work may still be running is not safe for kernels that use the handle's device
+// workspace, and the left / right solves of the non-symmetric primitives run concurrently on two streams
+// (eig._two_sides).  The device is part of the key because PyTorch's default stream is the null stream on EVERY device:
+// a handle (and its device workspace) created on cuda:0 must not serve cuda:1.  The table holds MAX_STREAM_HANDLES
+// entries; beyond that the least recently used handle is destroyed and its slot reused (PyTorch's stream pool alone
+// has 32 streams), so the table never refuses a stream.
 constexpr int MAX_STREAM_HANDLES = 16;
-hipStream_t g_handle_stream[MAX_STREAM_HANDLES];
-rocblas_handle g_handle[MAX_STREAM_HANDLES];
+struct HandleSlot {
+  int device;
+  hipStream_t stream;
+  rocblas_handle handle;
+  uint64_t last_use;
+};
+HandleSlot g_slots[MAX_STREAM_HANDLES];
 int g_handles = 0;
+uint64_t g_use_clock = 0;
 
 void blas_init() {
   void* lib = dlopen("librocblas.so.5", RTLD_NOW | RTLD_NOLOAD);
@@ -55,6 +66,7 @@ void blas_init() {
   g_blas.field = reinterpret_cast<decltype(g_blas.field)>(dlsym(lib, name)); \
   if (!g_blas.field) return;
   BIND(create, "rocblas_create_handle")
+  BIND(destroy, "rocblas_destroy_handle")
   BIND(set_stream, "rocblas_set_stream")
   BIND(set_pointer_mode, "rocblas_set_pointer_mode")
   BIND(set_atomics_mode, "rocblas_set_atomics_mode")
@@ -63,27 +75,54 @@ void blas_init() {
   BIND(dgemm_sb, "rocblas_dgemm_strided_batched")
 #undef BIND
   if (g_blas.create(&g_blas.h) != rocblas_status_success) return;   // probe: the library is usable
+  g_blas.destroy(g_blas.h);   // handles are per (device, stream): created on first use in handle_for
+  g_blas.h = nullptr;
   g_blas.ok = true;
 }
 std::mutex g_blas_mutex;  // guards the handle table (calls on distinct handles run concurrently)
 
-// the handle of `st` (nullptr on failure)
+// the handle of (current device, `st`) (nullptr on failure)
 rocblas_handle handle_for(hipStream_t st) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   std::lock_guard<std::mutex> lock(g_blas_mutex);
+  ++g_use_clock;
   for (int i = 0; i < g_handles; ++i)
-    if (g_handle_stream[i] == st) return g_handle[i];
+    if (g_slots[i].device == dev && g_slots[i].stream == st) {
+      g_slots[i].last_use = g_use_clock;
+      return g_slots[i].handle;
+    }
+  int slot = g_handles;
+  if (g_handles >= MAX_STREAM_HANDLES) {   // evict the least recently used handle (its work is stream-ordered: the
+    slot = 0;                              // destroy call synchronises that handle's stream inside rocBLAS)
+    for (int i = 1; i < g_handles; ++i)
+      if (g_slots[i].last_use < g_slots[slot].last_use) slot = i;
+    int cur = dev;
+    if (g_slots[slot].device != cur) (void)hipSetDevice(g_slots[slot].device);
+    g_blas.destroy(g_slots[slot].handle);
+    if (g_slots[slot].device != cur) (void)hipSetDevice(cur);
+    g_slots[slot].handle = nullptr;
+  }
   rocblas_handle h = nullptr;
-  if (g_handles == 0) {
-    h = g_blas.h;   // reuse the probe handle for the first stream
-  } else if (g_handles >= MAX_STREAM_HANDLES || g_blas.create(&h) != rocblas_status_success) {
+  if (g_blas.create(&h) != rocblas_status_success) {
+    if (slot < g_handles) {   // keep the table dense: move the last entry into the freed slot
+      g_slots[slot] = g_slots[g_handles - 1];
+      --g_handles;
+    }
     return nullptr;
   }
-  if (g_blas.set_stream(h, st) != rocblas_status_success) return nullptr;
+  if (g_blas.set_stream(h, st) != rocblas_status_success) {
+    g_blas.destroy(h);
+    if (slot < g_handles) {
+      g_slots[slot] = g_slots[g_handles - 1];
+      --g_handles;
+    }
+    return nullptr;
+  }
   g_blas.set_pointer_mode(h, rocblas_pointer_mode_host);
   g_blas.set_atomics_mode(h, rocblas_atomics_not_allowed);  // bit-repeatable runs, like the rest of the path
-  g_handle_stream[g_handles] = st;
-  g_handle[g_handles] = h;
-  ++g_handles;
+  g_slots[slot] = HandleSlot{dev, st, h, g_use_clock};
+  if (slot == g_handles) ++g_handles;
   return h;
 }
 }  // namespace

@@ -87,10 +87,14 @@ def _two_sides(right, left, device):
     ready = torch.cuda.Event()
     ready.record(main)
     box = {}
+    grad_mode = torch.is_grad_enabled()         # grad mode is thread-local and defaults to ON in a new thread: the
+                                                # worker must run under the caller's mode (forward / backward of an
+                                                # autograd Function run under no_grad), or a torch-coded mat-vec that
+                                                # closes over a requires_grad tensor would record a graph per step
 
     def work():
         try:
-            with torch.cuda.device(device), torch.cuda.stream(side):
+            with torch.set_grad_enabled(grad_mode), torch.cuda.device(device), torch.cuda.stream(side):
                 side.wait_event(ready)          # the operands were produced on the caller's stream
                 box["out"] = tuple(left())
                 done = torch.cuda.Event()

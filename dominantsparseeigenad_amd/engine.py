@@ -72,6 +72,8 @@ class Workspace:
         self.handle = handle
         self.state = torch.zeros(_lib.CG_STATE_LEN, dtype=F64, device=self.device)
         self.scal = torch.zeros(16, dtype=F64, device=self.device)
+        self.busy = None            # name of the solver that currently owns this workspace (see ``owned_by``)
+        self.persist_mode = -1
 
     def __del__(self):
         try:
@@ -105,6 +107,14 @@ class Workspace:
     def clear_cache(cls):
         cls._cache.clear()
 
+    def owned_by(self, who):
+        """Context manager: a SOLVER (Lanczos / CG loop) owns the workspace for its duration.  A workspace is not
+        re-entrant (include/dsea.h): a solver started from inside the user mat-vec of another solver of the same size
+        on the same stream would share its scalar / CG-state / partial-sum buffers and corrupt both silently -- that
+        nesting raises instead.  (Single phase calls -- dots, projections -- from inside a mat-vec are fine: they keep
+        no state in the workspace between calls.)  Remedy for a genuinely nested solve: run it on another stream."""
+        return _Owned(self, who)
+
     def set_rows_per_lane(self, rpl):
         check(self.lib.dsea_ws_set_rows_per_lane(self.handle, int(rpl)), "dsea_ws_set_rows_per_lane")
 
@@ -114,6 +124,23 @@ class Workspace:
 
     def set_split(self, waves):
         check(self.lib.dsea_ws_set_split(self.handle, int(waves)), "dsea_ws_set_split")
+
+
+class _Owned:
+    def __init__(self, ws, who):
+        self.ws, self.who = ws, who
+
+    def __enter__(self):
+        if self.ws.busy is not None:
+            raise RuntimeError("%s was started while %s is running on the same workspace (same vector length %d, same "
+                               "device, same stream): a workspace is not re-entrant -- a solver nested inside the "
+                               "mat-vec of another one must run on a different stream (torch.cuda.stream(...))"
+                               % (self.who, self.ws.busy, self.ws.n))
+        self.ws.busy = self.who
+        return self.ws
+
+    def __exit__(self, *exc):
+        self.ws.busy = None
 
 
 def round_up(v, m):
@@ -128,7 +155,9 @@ class BasisArena:
     starts: allocating it afresh every time makes the caching allocator carve, split and re-map blocks of that size
     (at L = 28 the second call failed with 200 GiB "reserved but unallocated").  One buffer per (device, stream,
     tag), grown on demand, reused by every call.  ``Lanczos()`` -- which returns the basis to the caller -- does not
-    use it.  ``release()`` gives the memory back."""
+    use it.  ``release()`` gives the memory back; the arena also shrinks by itself when a request is far below what it
+    holds (SHRINK_RATIO).  Memory cost beyond the basis itself: the placement probe's transient candidates, capped by
+    PLACEMENT_BUDGET_BYTES (8 GiB)."""
 
     _bufs = {}
     # PLACEMENT.  The dots pass runs in one of two modes (256 vs 272 us per pass at n = 2^20, i = 199: 6.67 vs
@@ -139,34 +168,45 @@ class BasisArena:
     # memory, random or zero data make no difference.  Physical placement is not visible from user space, so it is
     # MEASURED: when the arena has to allocate a large fp64 basis it takes up to PLACEMENT_TRIES candidates that are
     # alive at the same time, times the real dots pass on each (three launches on whatever bytes the memory holds)
-    # and keeps the fastest.  Costs a few ms once per arena allocation and helps only where candidates differ; skipped
-    # when the candidates would not fit beside each other (L = 28 on one GPU); two candidates above 8 GB.  0 / 1 = off.
+    # and keeps the fastest.  Costs a few ms once per arena allocation and helps only where candidates differ; the
+    # extra candidates are capped by PLACEMENT_BUDGET_BYTES (none for a basis above 8 GiB).  PLACEMENT_TRIES 0 / 1 = off.
     PLACEMENT_TRIES = 3
     PLACEMENT_MIN_BYTES = 128 << 20
+    # The probe's EXTRA candidates (alive beside the one that is kept, for a few ms) may use at most this many bytes
+    # in total: the headline basis (1.7 GB) gets its three candidates, a 54 GB slab basis (config 5) gets none --
+    # placement probing never multiplies a large allocation.  0 switches the probe off.
+    PLACEMENT_BUDGET_BYTES = 8 << 30
+    # The arena SHRINKS: a request far below the held capacity (less than a quarter, and at least 1 GiB to give back)
+    # replaces the buffer, so one L = 28 solve does not pin 215 GB for the life of the process.
+    SHRINK_RATIO = 4
+    SHRINK_MIN_BYTES = 1 << 30
     last_placement = None           # [us per probe pass of each candidate], for the curious
 
     @classmethod
     def get(cls, device, tag, nbytes, probe=None):
         device = torch.device(device)
         key = (str(device), int(torch.cuda.current_stream(device).cuda_stream) if device.type == "cuda" else 0, tag)
+        nbytes = int(nbytes)
         with _CACHE_LOCK:
             buf = cls._bufs.get(key)
-            if buf is None or buf.numel() < nbytes:
+            too_big = buf is not None and buf.numel() > cls.SHRINK_RATIO * max(nbytes, 1) and \
+                buf.numel() - nbytes >= cls.SHRINK_MIN_BYTES
+            if buf is None or buf.numel() < nbytes or too_big:
                 if buf is not None:
                     del cls._bufs[key], buf
                     if device.type == "cuda":
-                        torch.cuda.empty_cache()
+                        torch.cuda.empty_cache()      # the old buffer goes back to the driver before the new one is taken
                 tries = 1
                 if probe is not None and device.type == "cuda" and nbytes >= cls.PLACEMENT_MIN_BYTES:
                     free_b, _ = torch.cuda.mem_get_info(device)
-                    tries = max(1, min(int(cls.PLACEMENT_TRIES), 2 if nbytes > (8 << 30) else 99,
-                                       int(0.7 * free_b // max(int(nbytes), 1))))
-                buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+                    tries = max(1, min(int(cls.PLACEMENT_TRIES), 1 + int(cls.PLACEMENT_BUDGET_BYTES // max(nbytes, 1)),
+                                       int(0.7 * free_b // max(nbytes, 1))))
+                buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
                 if tries > 1:
                     cands, nxt = [(probe(buf), buf)], None
                     for _ in range(tries - 1):
                         try:
-                            nxt = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+                            nxt = torch.empty(nbytes, dtype=torch.uint8, device=device)
                         except RuntimeError:          # out of memory after all: keep what we have
                             break
                         cands.append((probe(nxt), nxt))
@@ -217,6 +257,23 @@ def _dots_probe_us(buf, rows, ldq, n, device):
     e1.record()
     e1.synchronize()
     return e0.elapsed_time(e1) / 3 * 1e3
+
+
+def shadow_fits(device, k, ldq, n, arena=False):
+    """True if the bf16 shadow of a (k, ldq) basis can be allocated next to it with room for the work vectors of a
+    forward + backward pass (8 n-vectors).  At L = 28, k = 100 on one 288 GB GPU the fp64 basis is 215 GB and the shadow
+    would be another 54 GB: the solve then runs with the all-fp64 correction pass instead of dying in the allocator."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        return True
+    need = 2 * int(k) * int(ldq)
+    if arena:
+        held = BasisArena._bufs.get((str(device), int(torch.cuda.current_stream(device).cuda_stream), "Qs"))
+        if held is not None and held.numel() >= need:
+            return True
+    free_b, _ = torch.cuda.mem_get_info(device)
+    cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+    return need + 8 * 8 * int(n) <= free_b + max(int(cached), 0)
 
 
 def native_of(A):
@@ -300,24 +357,33 @@ def lanczos(A, k, n, device, q0, native=None, callable_A=None, arena=False):
     alphas = torch.empty(k, dtype=F64, device=device)
     betas = torch.empty(max(k - 1, 1), dtype=F64, device=device)
     q0 = as_vector(q0, n)
+    use_shadow = USE_SHADOW and k > 1 and shadow_fits(device, k, ldq, n, arena)
     if native is not None:
         shadow = None
-        if USE_SHADOW and k > 1:
-            shadow = new_shadow()
-            check(lib.dsea_ws_set_shadow(ws.handle, _ptr(shadow), ldq, int(k), float(SHADOW_TAU)), "dsea_ws_set_shadow")
-        try:
-            check(lib.dsea_lanczos_run(native.handle, ws.handle, int(k), _ptr(q0), _ptr(Q), ldq, _ptr(alphas),
-                                       _ptr(betas), st), "dsea_lanczos_run")
-            brk = ctypes.c_int(0)
-            check(lib.dsea_lanczos_status(ws.handle, byref(brk), st), "dsea_lanczos_status", allow=(_lib.ERR_BREAKDOWN,))
-            last_break = int(brk.value)
-        finally:
-            if shadow is not None:
-                check(lib.dsea_ws_set_shadow(ws.handle, None, 0, 0, 0.0), "dsea_ws_set_shadow")
+        with ws.owned_by("Lanczos (native operator)"):
+            if use_shadow:
+                shadow = new_shadow()
+                check(lib.dsea_ws_set_shadow(ws.handle, _ptr(shadow), ldq, int(k), float(SHADOW_TAU)), "dsea_ws_set_shadow")
+            try:
+                check(lib.dsea_lanczos_run(native.handle, ws.handle, int(k), _ptr(q0), _ptr(Q), ldq, _ptr(alphas),
+                                           _ptr(betas), st), "dsea_lanczos_run")
+                brk = ctypes.c_int(0)
+                check(lib.dsea_lanczos_status(ws.handle, byref(brk), st), "dsea_lanczos_status", allow=(_lib.ERR_BREAKDOWN,))
+                last_break = int(brk.value)
+            finally:
+                if shadow is not None:
+                    check(lib.dsea_ws_set_shadow(ws.handle, None, 0, 0, 0.0), "dsea_ws_set_shadow")
         if last_break:
-            # entries behind the breakdown were never written (torch.empty): make them recognisable
+            # The device loop stopped itself at step last_break (beta ~ 0: the Krylov space of q0 is exhausted).  What
+            # lies behind was never written: make it recognisable instead of handing out stale memory -- NaN alphas,
+            # zero betas, ZERO basis vectors -- and tell the caller (the reference has no test: Lanczos.py:69-70).
+            import warnings
             alphas[last_break:] = float("nan")
-            betas[last_break - 1:] = 0.0 if last_break - 1 < betas.numel() else 0.0
+            betas[last_break - 1:] = 0.0
+            Q[last_break:].zero_()
+            warnings.warn("Lanczos breakdown at step %d of %d: the Krylov space of the start vector has dimension %d; "
+                          "basis vectors %d.. are returned as zeros, T[%d:, %d:] holds NaN on its diagonal"
+                          % (last_break, k, last_break, last_break, last_break, last_break), RuntimeWarning)
         return Q, ldq, alphas, betas[: k - 1]
 
     # generic callable: the mat-vec is the caller's torch code, everything else is one phase call per stage;
@@ -326,30 +392,31 @@ def lanczos(A, k, n, device, q0, native=None, callable_A=None, arena=False):
     r = torch.empty(n, dtype=F64, device=device)
     c = torch.empty(k + 2, dtype=F64, device=device)
     shadow = None
-    if USE_SHADOW and k > 1:
-        shadow = new_shadow()
-        check(lib.dsea_ws_set_shadow(ws.handle, _ptr(shadow), ldq, int(k), float(SHADOW_TAU)), "dsea_ws_set_shadow")
     esz = 8
-    try:
-        check(lib.dsea_nrm2sq(ws.handle, _ptr(q0), n, _ptr(nrm2), st), "dsea_nrm2sq")
-        check(lib.dsea_lanczos_store(ws.handle, _ptr(q0), _ptr(nrm2), _ptr(Q), ldq, 0, None, n, st), "dsea_lanczos_store")
-        u = as_vector(callable_A(Q[0, :n]), n)
-        check(lib.dsea_dot(ws.handle, _ptr(Q), _ptr(u), n, _ptr(alphas), st), "dsea_dot")
-        for i in range(1, k):
-            a_ptr = c_void_p(alphas.data_ptr() + (i - 1) * esz)
-            b_ptr = c_void_p(betas.data_ptr() + (i - 2) * esz) if i >= 2 else c_void_p(None)
-            check(lib.dsea_lanczos_rdots(ws.handle, _ptr(Q), ldq, n, i, _ptr(u), a_ptr, b_ptr, _ptr(r), _ptr(c), st),
-                  "dsea_lanczos_rdots")
-            check(lib.dsea_lanczos_axpy_norm(ws.handle, _ptr(Q), ldq, n, i, _ptr(c), _ptr(r), _ptr(nrm2), st),
-                  "dsea_lanczos_axpy_norm")
-            check(lib.dsea_lanczos_store(ws.handle, _ptr(r), _ptr(nrm2), _ptr(Q), ldq, i,
-                                         c_void_p(betas.data_ptr() + (i - 1) * esz), n, st), "dsea_lanczos_store")
-            qi = Q[i]
-            u = as_vector(callable_A(qi[:n]), n)
-            check(lib.dsea_dot(ws.handle, _ptr(qi), _ptr(u), n, c_void_p(alphas.data_ptr() + i * esz), st), "dsea_dot")
-    finally:
-        if shadow is not None:
-            check(lib.dsea_ws_set_shadow(ws.handle, None, 0, 0, 0.0), "dsea_ws_set_shadow")
+    with ws.owned_by("Lanczos (callable operator)"):
+        if use_shadow:
+            shadow = new_shadow()
+            check(lib.dsea_ws_set_shadow(ws.handle, _ptr(shadow), ldq, int(k), float(SHADOW_TAU)), "dsea_ws_set_shadow")
+        try:
+            check(lib.dsea_nrm2sq(ws.handle, _ptr(q0), n, _ptr(nrm2), st), "dsea_nrm2sq")
+            check(lib.dsea_lanczos_store(ws.handle, _ptr(q0), _ptr(nrm2), _ptr(Q), ldq, 0, None, n, st), "dsea_lanczos_store")
+            u = as_vector(callable_A(Q[0, :n]), n)
+            check(lib.dsea_dot(ws.handle, _ptr(Q), _ptr(u), n, _ptr(alphas), st), "dsea_dot")
+            for i in range(1, k):
+                a_ptr = c_void_p(alphas.data_ptr() + (i - 1) * esz)
+                b_ptr = c_void_p(betas.data_ptr() + (i - 2) * esz) if i >= 2 else c_void_p(None)
+                check(lib.dsea_lanczos_rdots(ws.handle, _ptr(Q), ldq, n, i, _ptr(u), a_ptr, b_ptr, _ptr(r), _ptr(c), st),
+                      "dsea_lanczos_rdots")
+                check(lib.dsea_lanczos_axpy_norm(ws.handle, _ptr(Q), ldq, n, i, _ptr(c), _ptr(r), _ptr(nrm2), st),
+                      "dsea_lanczos_axpy_norm")
+                check(lib.dsea_lanczos_store(ws.handle, _ptr(r), _ptr(nrm2), _ptr(Q), ldq, i,
+                                             c_void_p(betas.data_ptr() + (i - 1) * esz), n, st), "dsea_lanczos_store")
+                qi = Q[i]
+                u = as_vector(callable_A(qi[:n]), n)
+                check(lib.dsea_dot(ws.handle, _ptr(qi), _ptr(u), n, c_void_p(alphas.data_ptr() + i * esz), st), "dsea_dot")
+        finally:
+            if shadow is not None:
+                check(lib.dsea_ws_set_shadow(ws.handle, None, 0, 0, 0.0), "dsea_ws_set_shadow")
     return Q, ldq, alphas, betas[: k - 1]
 
 
@@ -368,8 +435,9 @@ def lanczos_basisfree(native, k, n, device, q0, which="min"):
     alphas = torch.empty(k, dtype=F64, device=device)
     betas = torch.zeros(max(k - 1, 1), dtype=F64, device=device)
     q0 = as_vector(q0, n)
-    check(lib.dsea_lanczos_run_basisfree(native.handle, ws.handle, int(k), _ptr(q0), _ptr(Qrot), ldq, _ptr(alphas),
-                                         _ptr(betas), None, None, st), "dsea_lanczos_run_basisfree")
+    with ws.owned_by("Lanczos (basis-free)"):
+        check(lib.dsea_lanczos_run_basisfree(native.handle, ws.handle, int(k), _ptr(q0), _ptr(Qrot), ldq, _ptr(alphas),
+                                             _ptr(betas), None, None, st), "dsea_lanczos_run_basisfree")
     brk = ctypes.c_int(0)
     check(lib.dsea_lanczos_status(ws.handle, byref(brk), st), "dsea_lanczos_status", allow=(_lib.ERR_BREAKDOWN,))
     last_break = int(brk.value)
@@ -505,28 +573,30 @@ def cg(b, x0, *, native=None, callable_A=None, shift=None, eps=1e-7, maxiter=Non
         iters, res = c_int64(0), c_double(0.0)
         merged = CG_MERGED_REDUCTIONS if merged_reductions is None else bool(merged_reductions)
         prev_mode = getattr(ws, "persist_mode", -1)
-        if merged and prev_mode == -1:
-            ws.set_persist(100)
-        try:
-            rc = lib.dsea_cg_run(native.handle, ws.handle, _ptr(shift_t), _ptr(b), _ptr(x), _ptr(state), float(eps),
-                                 cap, int(poll_every), byref(iters), byref(res), st)
-            if rc == _lib.ERR_TIMEOUT:
-                # The persistent single-launch form needs all of its workgroups resident at the same time; if other
-                # work holds compute units (e.g. a second persistent solve on another stream) its bounded spins give
-                # up and report instead of hanging.  The solve is then repeated in the streaming form.
-                import warnings
-                warnings.warn("persistent CG launch timed out waiting for a peer workgroup (device shared with other "
-                              "work?): repeating the solve with the streaming kernels", RuntimeWarning)
-                x.copy_(as_vector(x0, n))
-                ws.set_persist(0)
-                try:
+        with ws.owned_by("CG (native operator)"):
+            if merged and prev_mode == -1:
+                ws.set_persist(100)
+            try:
+                rc = lib.dsea_cg_run(native.handle, ws.handle, _ptr(shift_t), _ptr(b), _ptr(x), _ptr(state), float(eps),
+                                     cap, int(poll_every), byref(iters), byref(res), st)
+                if rc == _lib.ERR_TIMEOUT:
+                    # The persistent single-launch form needs all of its workgroups resident at the same time; if other
+                    # work holds compute units (e.g. a second persistent solve on another stream) its bounded spins
+                    # give up and report instead of hanging.  The solve is repeated in the streaming form, and the
+                    # fallback is STICKY for this workspace: on a shared device every later solve would otherwise wait
+                    # out the same timeout again (``ws.set_persist(-1)`` re-enables the persistent form).
+                    import warnings
+                    warnings.warn("persistent CG launch timed out waiting for a peer workgroup (device shared with "
+                                  "other work?): repeating the solve with the streaming kernels, which this workspace "
+                                  "keeps using from now on", RuntimeWarning)
+                    x.copy_(as_vector(x0, n))
+                    ws.set_persist(0)
+                    prev_mode = 0
                     rc = lib.dsea_cg_run(native.handle, ws.handle, _ptr(shift_t), _ptr(b), _ptr(x), _ptr(state),
                                          float(eps), cap, int(poll_every), byref(iters), byref(res), st)
-                finally:
-                    ws.set_persist(prev_mode)
-        finally:
-            if merged and prev_mode == -1:
-                ws.set_persist(-1)
+            finally:
+                if merged and prev_mode == -1:
+                    ws.set_persist(-1)
         check(rc, "dsea_cg_run", allow=(_lib.ERR_NOT_CONVERGED,))
         last_cg.iters, last_cg.resnorm, last_cg.converged = iters.value, res.value, rc == 0
         return x
@@ -535,30 +605,31 @@ def cg(b, x0, *, native=None, callable_A=None, shift=None, eps=1e-7, maxiter=Non
     d = torch.empty(n, dtype=F64, device=device)
     done_ptr = c_void_p(state.data_ptr() + _lib.CG_DONE * 8)
     dad_ptr = c_void_p(state.data_ptr() + _lib.CG_DAD * 8)
-    Ax = as_vector(callable_A(x), n)
-    if Ax.data_ptr() == x.data_ptr():
-        Ax = Ax.clone()
-    if shift_t is not None:
-        check(lib.dsea_shift_dot(ws.handle, _ptr(x), _ptr(Ax), _ptr(shift_t), _ptr(ws.scal[1:2]), None, n, st),
-              "dsea_shift_dot")
-    check(lib.dsea_cg_init(ws.handle, _ptr(b), _ptr(Ax), _ptr(r), _ptr(d), _ptr(state), n, st), "dsea_cg_init")
-    check(lib.dsea_cg_init_check(ws.handle, _ptr(state), float(eps), st), "dsea_cg_init_check")
-    issued = 0
-    host = state.cpu()
-    while host[_lib.CG_DONE].item() == 0.0 and issued < cap:
-        chunk = min(int(poll_every), cap - issued)
-        for _ in range(chunk):
-            Ad = as_vector(callable_A(d), n)
-            if Ad.data_ptr() == d.data_ptr():
-                Ad = Ad.clone()
-            check(lib.dsea_shift_dot(ws.handle, _ptr(d), _ptr(Ad), _ptr(shift_t), dad_ptr, done_ptr, n, st),
+    with ws.owned_by("CG (callable operator)"):
+        Ax = as_vector(callable_A(x), n)
+        if Ax.data_ptr() == x.data_ptr():
+            Ax = Ax.clone()
+        if shift_t is not None:
+            check(lib.dsea_shift_dot(ws.handle, _ptr(x), _ptr(Ax), _ptr(shift_t), _ptr(ws.scal[1:2]), None, n, st),
                   "dsea_shift_dot")
-            check(lib.dsea_cg_update(ws.handle, _ptr(x), _ptr(r), _ptr(d), _ptr(Ad), _ptr(state), n, st),
-                  "dsea_cg_update")
-            check(lib.dsea_cg_check(ws.handle, _ptr(state), float(eps), st), "dsea_cg_check")
-            check(lib.dsea_cg_direction(ws.handle, _ptr(r), _ptr(d), _ptr(state), n, st), "dsea_cg_direction")
-        issued += chunk
+        check(lib.dsea_cg_init(ws.handle, _ptr(b), _ptr(Ax), _ptr(r), _ptr(d), _ptr(state), n, st), "dsea_cg_init")
+        check(lib.dsea_cg_init_check(ws.handle, _ptr(state), float(eps), st), "dsea_cg_init_check")
+        issued = 0
         host = state.cpu()
+        while host[_lib.CG_DONE].item() == 0.0 and issued < cap:
+            chunk = min(int(poll_every), cap - issued)
+            for _ in range(chunk):
+                Ad = as_vector(callable_A(d), n)
+                if Ad.data_ptr() == d.data_ptr():
+                    Ad = Ad.clone()
+                check(lib.dsea_shift_dot(ws.handle, _ptr(d), _ptr(Ad), _ptr(shift_t), dad_ptr, done_ptr, n, st),
+                      "dsea_shift_dot")
+                check(lib.dsea_cg_update(ws.handle, _ptr(x), _ptr(r), _ptr(d), _ptr(Ad), _ptr(state), n, st),
+                      "dsea_cg_update")
+                check(lib.dsea_cg_check(ws.handle, _ptr(state), float(eps), st), "dsea_cg_check")
+                check(lib.dsea_cg_direction(ws.handle, _ptr(r), _ptr(d), _ptr(state), n, st), "dsea_cg_direction")
+            issued += chunk
+            host = state.cpu()
     last_cg.iters = int(host[_lib.CG_ITERS].item())
     last_cg.resnorm = float(host[_lib.CG_RESNORM].item())
     last_cg.converged = host[_lib.CG_DONE].item() != 0.0

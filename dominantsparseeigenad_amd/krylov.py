@@ -117,6 +117,19 @@ def _wanted_pair(B, which):
     return th, y, evals
 
 
+# Diagnostics of the last call ON THE CALLING THREAD (arnoldi_cycles / arnoldi_columns / arnoldi_stages, gmres_cycles /
+# gmres_residual): the left and right problems of the non-symmetric primitives run on two host threads
+# (eig._two_sides), so module-level "last_*" attributes would be written from both without synchronisation.
+import threading as _threading  # noqa: E402
+
+DIAG = _threading.local()
+
+
+def last(name, default=None):
+    """diagnostic ``name`` of the last Arnoldi / GMRES call made by the calling thread"""
+    return getattr(DIAG, name, default)
+
+
 # Convergence of the wanted Ritz pair is tested after STAGES of the factorisation, not only once all ncv columns exist
 # (0 = the latter, ARPACK's schedule).  STAGE_FIRST: columns before the first test; later stage ends are extrapolated
 # from the observed residual decay.
@@ -268,9 +281,9 @@ def arnoldi_dominant(A, n, ncv, device, which="LM", v0=None, tol=1e-13, max_rest
         Hn[:p_new, p_new] = coupling * Z[me - 1, :p_new]
         Hd.copy_(torch.from_numpy(Hn))
         p = p_new
-    arnoldi_dominant.last_cycles = cycle + 1
-    arnoldi_dominant.last_columns = j              # columns of the last cycle's factorisation when it stopped
-    arnoldi_dominant.last_stages = stages_run
+    DIAG.arnoldi_cycles = cycle + 1
+    DIAG.arnoldi_columns = j              # columns of the last cycle's factorisation when it stopped
+    DIAG.arnoldi_stages = stages_run
     xv = torch.empty(n, dtype=F64, device=device)
     ys = torch.from_numpy(np.ascontiguousarray(y)).to(device)
     check(lib.dsea_ritz_combine(ws.handle, _ptr(V), ldv, n, int(ys.numel()), _ptr(ys), _ptr(xv), st()), "dsea_ritz_combine")
@@ -299,7 +312,7 @@ def gmres(A, b, shift=None, rtol=1e-12, atol=1e-12, restart=20, maxiter=None):
     x = torch.zeros(n, dtype=F64, device=device)
     sh = None if shift is None else shift.detach().reshape(-1)[:1].to(device=device, dtype=F64).contiguous()
     bnorm = float(b.norm())
-    gmres.last_cycles, gmres.last_residual = 0, 0.0
+    DIAG.gmres_cycles, DIAG.gmres_residual = 0, 0.0
     if bnorm == 0.0:
         return x                       # scipy returns x0 = 0 for a zero right-hand side
     target = max(rtol * bnorm, atol)
@@ -327,8 +340,8 @@ def gmres(A, b, shift=None, rtol=1e-12, atol=1e-12, restart=20, maxiter=None):
         info = state.cpu()
         if info[1].item() != 0.0:
             break
-    gmres.last_cycles = c + 1
-    gmres.last_residual = float(info[0].item()) if info is not None else float("nan")
+    DIAG.gmres_cycles = c + 1
+    DIAG.gmres_residual = float(info[0].item()) if info is not None else float("nan")
     return x
 
 

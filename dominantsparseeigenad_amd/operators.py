@@ -398,7 +398,14 @@ def dense_symmetric_operand(A):
     loops run inside libdsea."""
     if A.shape[0] >= 6144 or (A.dtype == torch.float32 and A.shape[0] >= 2048):
         return SymmetricDenseOperator(A)      # fp32 matrices are read as fp32: no promoted copy (Lanczos.py:47)
-    return DenseOperator(A)
+    try:
+        return DenseOperator(A)
+    except _lib.DseaError as exc:
+        # no rocBLAS in this process (dsea_op_create_dense -> DSEA_ERR_UNSUPPORTED on another ROCm stack): the
+        # hand-written upper-triangle mat-vec has no such dependency -- still inside the library, no torch arithmetic
+        if "unsupported" not in str(exc):
+            raise
+        return SymmetricDenseOperator(A)
 
 
 class TransferOperator:

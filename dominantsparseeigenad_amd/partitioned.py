@@ -345,6 +345,16 @@ class _LanczosState:
     pass
 
 
+class _NoOwner:
+    """stand-in for Workspace.owned_by when the backend has no library workspace (the CPU test double)"""
+
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
 class PartitionedOperator:
     """Base of the row-partitioned operators: owns the communicator, the slab backend and the two distributed
     loops (Lanczos forward, projected-CG adjoint); subclasses provide the mat-vec with its exchange."""
@@ -421,15 +431,18 @@ class PartitionedOperator:
         S.alphas, S.betas = be.zeros(k), be.zeros(max(k - 1, 1))
         S.c, S.pair = be.zeros(k + 2), be.zeros(2)
         S.r, S.u, S.y = q0_slab.detach().to(F64).clone(), be.empty(n), be.empty(n)
-        use_shadow = self.use_shadow and _engine_mod.USE_SHADOW and k > 1 and hasattr(be, "set_shadow")
-        if use_shadow:
-            be.set_shadow(k, S.ldq, arena)
-        try:
-            for i in range(k):
-                self.lanczos_step(i, S)
-        finally:
+        use_shadow = self.use_shadow and _engine_mod.USE_SHADOW and k > 1 and hasattr(be, "set_shadow") and \
+            _engine_mod.shadow_fits(self.device, k, S.ldq, n, arena)
+        ws = getattr(be, "ws", None)
+        with (ws.owned_by("row-partitioned Lanczos") if ws is not None else _NoOwner()):
             if use_shadow:
-                be.clear_shadow()
+                be.set_shadow(k, S.ldq, arena)
+            try:
+                for i in range(k):
+                    self.lanczos_step(i, S)
+            finally:
+                if use_shadow:
+                    be.clear_shadow()
         return S.Q, S.ldq, S.alphas, S.betas[:k - 1]
 
     def ritz_vector(self, Q, ldq, k, s_host):

@@ -31,6 +31,13 @@ def test_bench_line_single_gpu():
     assert abs(d["config"]["E0_per_site"] - d["config"]["E0_per_site_closed_form"]) < 1e-9
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # the line must survive a peak check: `value` counts bytes the kernels move, a fraction is a fraction, and the
+    # dominant kernel's launches fit into the step they belong to
+    assert d["value"] <= r["peak"] * d["n_gpus"] and 0 < d["config"]["frac_of_hbm_peak"] <= 1.0
+    assert 0 < r["frac"] <= 1.0
+    assert r["avg_launch_ms"] * r["launches_per_step"] <= d["ms_per_step"] * 1.1
+    assert d["config"]["algorithmic_GBs"] >= d["value"] and "frac_of_hbm_peak_whole_step" not in d["config"]
+    assert d["config"]["traffic_model_bytes_per_step"] <= d["config"]["algorithmic_bytes_per_step"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
 

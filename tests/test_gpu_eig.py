@@ -288,11 +288,11 @@ def test_staged_convergence_test_finds_the_same_pair_with_fewer_columns():
     try:
         krylov.STAGE_FIRST = 0
         lam_full, x_full = krylov.arnoldi_dominant(op, n, k, cuda, "LM", v0=v0)
-        assert krylov.arnoldi_dominant.last_columns == k and krylov.arnoldi_dominant.last_stages == 1
+        assert krylov.last('arnoldi_columns') == k and krylov.last('arnoldi_stages') == 1
         krylov.STAGE_FIRST = saved
         lam_st, x_st = krylov.arnoldi_dominant(op, n, k, cuda, "LM", v0=v0)
-        cols = krylov.arnoldi_dominant.last_columns
-        assert cols < k and krylov.arnoldi_dominant.last_stages >= 2, cols
+        cols = krylov.last('arnoldi_columns')
+        assert cols < k and krylov.last('arnoldi_stages') >= 2, cols
         AdT = Ad.transpose(1, 2).contiguous()
         fr = lambda v: torch.matmul(torch.matmul(Ad, v.reshape(D, D)), AdT).sum(0).reshape(-1)  # noqa: E731
         lam_cb, x_cb = krylov.arnoldi_dominant(krylov.TorchLinearOperator((n, n), fr, cuda), n, k, cuda, "LM", v0=v0)

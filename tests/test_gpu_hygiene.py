@@ -323,3 +323,100 @@ def test_more_than_2048_krylov_vectors():
     assert lib.dsea_ws_bytes(1 << 12, 8001, byref(nbytes)) == -1
     del Qk
     torch.cuda.empty_cache()
+
+
+def test_nested_solver_on_the_same_workspace_raises():
+    """A workspace is not re-entrant (include/dsea.h).  A solver started from inside the user mat-vec of another
+    solver of the same size on the same stream used to share -- and silently corrupt -- its scalar / CG-state buffers;
+    it now raises.  The same nested solve on ANOTHER STREAM has a workspace of its own and is fine."""
+    from dominantsparseeigenad_amd.CG import CG_torch
+    n = 512
+    A = torch.diag(torch.linspace(1.0, 3.0, n, dtype=F64)).to(dev())
+    b = unit(n, 8).to(dev())
+    side = torch.cuda.Stream()
+
+    def matvec_with_nested_solve(v):
+        CG_torch(lambda w: A @ w, b, torch.zeros_like(b), sparse=True)          # same n, same stream
+        return A @ v
+
+    with pytest.raises(RuntimeError, match="not re-entrant"):
+        symeigLanczos(matvec_with_nested_solve, 8, dev(), extreme="min", sparse=True, dim=n, q0=unit(n, 9).to(dev()))
+    assert engine.Workspace.get(n, 8, dev()).busy is None                         # released on the way out
+
+    def matvec_with_nested_solve_on_a_side_stream(v):
+        done = torch.cuda.Event()
+        with torch.cuda.stream(side):
+            side.wait_stream(torch.cuda.current_stream())
+            CG_torch(lambda w: A @ w, b, torch.zeros_like(b), sparse=True)
+            done.record(side)
+        torch.cuda.current_stream().wait_event(done)
+        return A @ v
+
+    lo, _ = symeigLanczos(matvec_with_nested_solve_on_a_side_stream, 8, dev(), extreme="min", sparse=True, dim=n,
+                          q0=unit(n, 9).to(dev()))
+    ref, _ = symeigLanczos(lambda v: A @ v, 8, dev(), extreme="min", sparse=True, dim=n, q0=unit(n, 9).to(dev()))
+    assert lo.item() == ref.item()
+
+
+def test_basis_arena_shrinks_and_caps_its_placement_probe(monkeypatch):
+    """engine.BasisArena: a request far below what the arena holds replaces the buffer (one large solve does not pin its
+    basis for the life of the process); the placement probe's extra candidates are capped by PLACEMENT_BUDGET_BYTES."""
+    engine.BasisArena.release()
+    monkeypatch.setattr(engine.BasisArena, "SHRINK_MIN_BYTES", 1 << 20)
+    big = engine.BasisArena.get(dev(), "Q", 64 << 20)
+    assert big.numel() == 64 << 20
+    same = engine.BasisArena.get(dev(), "Q", 32 << 20)            # within the ratio: reused
+    assert same.data_ptr() == big.data_ptr() and same.numel() == 64 << 20
+    del big, same
+    small = engine.BasisArena.get(dev(), "Q", 4 << 20)            # < 1/4 of the capacity: replaced by a small one
+    assert small.numel() == 4 << 20
+    del small
+    engine.BasisArena.release()
+    # probe budget: with a budget below one candidate no extra candidate is taken
+    calls = []
+    monkeypatch.setattr(engine.BasisArena, "PLACEMENT_MIN_BYTES", 1 << 20)
+    monkeypatch.setattr(engine.BasisArena, "PLACEMENT_BUDGET_BYTES", 1 << 20)
+    engine.BasisArena.get(dev(), "Q", 8 << 20, probe=lambda b: calls.append(1) or 1.0)
+    assert calls == []
+    engine.BasisArena.release()
+    monkeypatch.setattr(engine.BasisArena, "PLACEMENT_BUDGET_BYTES", 64 << 20)
+    engine.BasisArena.get(dev(), "Q", 8 << 20, probe=lambda b: calls.append(1) or 1.0)
+    assert len(calls) == 3
+    engine.BasisArena.release()
+
+
+def test_rocblas_handle_table_serves_more_streams_than_it_holds():
+    """the rocBLAS handle table of the GEMM-shaped operands was keyed by stream only, held 16 handles and
+    refused the 17th stream.  It is keyed by (device, stream) and evicts the least recently used handle: 40 streams
+    (PyTorch's pool alone has 32) all get a correct GEMV."""
+    from dominantsparseeigenad_amd.operators import DenseOperator
+    n = 96
+    A = torch.from_numpy(np.random.RandomState(0).randn(n, n)).to(dev())
+    v = unit(n, 4).to(dev())
+    want = A @ v
+    op = DenseOperator(A)
+    streams = [torch.cuda.Stream() for _ in range(40)]
+    for rep in range(2):
+        for s in streams:
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                y = op(v)
+            s.synchronize()
+            assert float((y - want).abs().max()) < 1e-13
+
+
+def test_shadow_is_dropped_when_it_does_not_fit(monkeypatch):
+    """engine.shadow_fits: the bf16 shadow is an optimisation; when the device cannot hold it next to the basis the
+    solve runs with the all-fp64 correction pass instead of failing in the allocator (L = 28, k = 100 on one GPU)."""
+    n, k = 1 << 14, 48
+    op = TFIMOperator(14, dev())
+    op.g = torch.tensor([1.0], dtype=F64, device=dev())
+    q0 = unit(n, 6).to(dev())
+    lo1, v1 = symeigLanczos(op, k, dev(), extreme="min", sparse=True, dim=n, q0=q0)
+    lp_on = engine.lanczos_lp_stats(n, dev())
+    monkeypatch.setattr(engine, "shadow_fits", lambda *a, **kw: False)
+    lo2, v2 = symeigLanczos(op, k, dev(), extreme="min", sparse=True, dim=n, q0=q0)
+    lp_off = engine.lanczos_lp_stats(n, dev())
+    assert lp_on[0] + lp_on[1] == k - 1 or lp_on == (0, 0)        # (small slabs may use the fp64 split kernels)
+    assert lp_off == (0, 0)
+    assert abs(lo1.item() - lo2.item()) < 1e-13 * abs(lo1.item()) and float((v1 - v2).abs().max()) < 1e-11

@@ -358,6 +358,47 @@ def test_adjoint_tight_eps_headline_size(monkeypatch):
     assert abs(dE.item() - dE_an.item()) < TOL * abs(dE_an.item()), (dE.item(), dE_an.item())
 
 
+@pytest.mark.parametrize("shadow", [True, False])
+def test_adjoint_1e10_at_headline_size_vs_oracle_fixture(monkeypatch, golden, shadow):
+    """BASELINE configs[1] (TFIM L=20, n = 2^20, k = 200) at the north-star tolerance for the psi-DEPENDENT adjoint:
+    loss = E0 + psi.t, psi.t, dloss/dg and dE0/dg against the pinned oracle run at eps = 1e-12 with the same injected
+    vectors (tests/golden/make_tight_adjoint.py; reference formulas symeig.py:77-86, CG.py:24-41), with the bf16 shadow
+    of the basis on and off.  Tolerance: 1e-10 relative; psi.t (two unit vectors, value -1.7e-3) at 1e-10 absolute of
+    ||psi|| ||t|| = 1."""
+    import dominantsparseeigenad_amd.CG as CG
+    gd = golden("tfim_L20_k200_g1.0_eps1e-12")
+    monkeypatch.setattr(CG, "EPS_DEFAULT", float(gd["eps"]))
+    monkeypatch.setattr(engine, "USE_SHADOW", shadow)
+    L, k, g = int(gd["L"]), int(gd["k"]), float(gd["g"])
+    n = 1 << L
+    op = TFIMOperator(L, dev())
+    op.g = torch.tensor([g], dtype=F64, device=dev(), requires_grad=True)
+    symeig.setDominantSparseSymeig(op.H, op.Hadjoint_to_gadjoint)
+    f = symeig.DominantSparseSymeig.apply
+    tvec = unit(n, int(gd["seed_t"])).to(dev())
+    with PatchRandn(int(gd["seed_draw"])) as draws:
+        E0, psi = f(op.g, k, n, dev())
+        sgn = 1.0 if float(psi.detach()[:64].cpu() @ torch.from_numpy(gd["psi_head"])) > 0 else -1.0
+        pt = psi.matmul(tvec) * sgn
+        loss = E0 + pt
+        (gl,) = torch.autograd.grad(loss, op.g)
+        assert draws.count == int(gd["ndraw_loss"])
+    assert engine.last_cg.converged and engine.last_cg.resnorm < float(gd["eps"])
+    assert abs(E0.item() - float(gd["E0"])) < 1e-12 * abs(float(gd["E0"]))
+    assert rel(psi.detach()[:64].cpu() * sgn, gd["psi_head"]) < 1e-9
+    assert abs(pt.item() - float(gd["psi_dot_t"])) < TOL, (pt.item(), float(gd["psi_dot_t"]))
+    assert abs(loss.item() - float(gd["loss"])) < TOL * abs(float(gd["loss"]))
+    assert abs(gl.item() - float(gd["dloss"])) < TOL * abs(float(gd["dloss"])), (gl.item(), float(gd["dloss"]))
+    with PatchRandn(int(gd["seed_draw"])):
+        E0b, _ = f(op.g, k, n, dev())
+        (dE0,) = torch.autograd.grad(E0b, op.g)
+    assert abs(dE0.item() - float(gd["dE0"])) < TOL * abs(float(gd["dE0"])), (dE0.item(), float(gd["dE0"]))
+    print("L=20 k=200 eps=1e-12 shadow=%s: dloss/dg rel %.2e, dE0/dg rel %.2e, psi.t abs %.2e, CG iterations %d (oracle %d)"
+          % (shadow, abs(gl.item() - float(gd["dloss"])) / abs(float(gd["dloss"])),
+             abs(dE0.item() - float(gd["dE0"])) / abs(float(gd["dE0"])), abs(pt.item() - float(gd["psi_dot_t"])),
+             engine.last_cg.iters, int(gd["cg_iters_E0"])))
+
+
 # ------------------------------------------------------------------ bf16 shadow of the basis (correction pass)
 @pytest.mark.parametrize("L", [18, 16])
 def test_shadow_basis_pass_is_exact_to_working_precision(monkeypatch, L):

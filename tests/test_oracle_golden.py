@@ -236,3 +236,25 @@ def test_host_branch_of_eig_reproduces_reference_fixtures():
     assert abs(lam.item() - float(gd["eigval"][0])) < 1e-12 * abs(float(gd["eigval"][0]))
     assert np.max(np.abs(rg - gd["r"])) < 1e-10 and np.max(np.abs(lg - gd["l"])) < 1e-9 * np.max(np.abs(gd["l"]))
     assert np.max(np.abs(gA.numpy() - gd["grad_A"])) < 1e-8 * np.max(np.abs(gd["grad_A"]))
+
+
+def test_tight_eps_headline_fixture_is_consistent_with_the_reference_fixture(golden):
+    """tests/golden/tfim_L20_k200_g1.0_eps1e-12.npz (pinned oracle at eps = 1e-12, make_tight_adjoint.py) against the
+    REFERENCE's own outputs for the same injected vectors at its hard-coded eps = 1e-7
+    (tfim_L20_k200_g1.0.npz, make_golden.py --big): the forward is independent of eps and must agree to rounding; the
+    adjoints may differ by what eps = 1e-7 leaves undetermined (~eps/gap) and no more; dE0/dg at
+    eps = 1e-12 equals the closed form (E0.py:9-23) to 1e-10."""
+    import torch
+    from oracle.operators import tfim_analytic_E0
+    tight, ref = golden("tfim_L20_k200_g1.0_eps1e-12"), golden("tfim_L20_k200_g1.0")
+    assert int(tight["seed_draw"]) == int(ref["seed_draw_E"]) and int(tight["seed_t"]) == int(ref["seed_t"])
+    assert abs(float(tight["E0"]) - float(ref["E0"])) < 1e-13 * abs(float(ref["E0"]))
+    assert np.max(np.abs(tight["psi_head"] - ref["psi_head"])) < 1e-13
+    assert abs(float(tight["psi_dot_t"]) - float(ref["psi_dot_t"])) < 1e-13
+    for key in ("dloss", "dE0"):
+        dev = abs(float(tight[key]) - float(np.ravel(ref[key])[0])) / abs(float(tight[key]))
+        assert dev < 2e-8, (key, dev)
+    gt = torch.tensor(1.0, dtype=torch.float64, requires_grad=True)
+    (dE_an,) = torch.autograd.grad(tfim_analytic_E0(20, gt), gt)
+    assert abs(float(tight["dE0"]) - dE_an.item()) < 1e-10 * abs(dE_an.item())
+    assert int(tight["cg_iters_loss"]) > 90          # eps = 1e-12 runs longer than the reference's ~90 iterations

@@ -196,19 +196,22 @@ def test_reference_api_on_partitioned_stencil_matches_reference_fixture(world):
     assert np.max(np.abs(grad - gd["grad"])) < 1e-5 * np.max(np.abs(gd["grad"]))   # CG hits the n-iteration cap
 
 
-@pytest.mark.parametrize("world,launcher", [(2, "self"), (4, "torchrun")])
-def test_bench_multi_rank_control_flow_dry_run(world, launcher):
+@pytest.mark.parametrize("world,launcher,explicit", [(2, "self", True), (4, "torchrun", False), (8, "self", False)])
+def test_bench_multi_rank_control_flow_dry_run(world, launcher, explicit):
     """bench.py's multi-rank path end to end on CPU processes (``--dry-run-cpu``: gloo + the torch test double of the
     slab kernels): self-launch of one worker per rank, or under the driver's own launcher line (python -m
     torch.distributed.run ... bench.py --gpus N --steps K --warmup W); row-partitioned operator behind the reference
     API, collective decision on the exchange form, overlapped-exchange self-check, max-over-ranks timing, ONE JSON line
-    from rank 0 as the last line of stdout.  No measurement is taken from it."""
+    from rank 0 as the last line of stdout.  Without --L / --k the DEFAULT SCHEDULE of N > 1 runs (toy sizes in a dry
+    run): the strong point is timed (value / ms_per_step, scaling "strong"), the weak point is reported beside it, the
+    one-GPU anchors and what proves the collectives spanned N ranks are in the line.  No measurement is taken from it."""
     import json
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    tail = [os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--dry-run-cpu",
-            "--L", "10", "--k", "60"]
+    tail = [os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--dry-run-cpu"]
+    if explicit:
+        tail += ["--L", "10", "--k", "60"]
     if launcher == "self":
         cmd = [sys.executable] + tail
     else:
@@ -225,6 +228,20 @@ def test_bench_multi_rank_control_flow_dry_run(world, launcher):
     assert cfg["distributed_self_check"].startswith("overlapped exchange verified")
     assert abs(cfg["E0_per_site"] - cfg["E0_per_site_closed_form"]) < 1e-9
     assert "roofline" not in d and "cpu_baseline" not in d
+    # what proves the collectives saw N ranks
+    col = cfg["collectives"]
+    assert col["world_size"] == world and col["backend"] == "gloo"
+    assert sorted(r["rank"] for r in col["ranks"]) == list(range(world)) and len({r["pid"] for r in col["ranks"]}) == world
+    if explicit:
+        assert d["scaling"] == "weak" and "weak_scaling_point" not in cfg
+    else:
+        assert d["scaling"] == "strong" and "strong scaling" in cfg["workload"]
+        wk = cfg["weak_scaling_point"]
+        assert "weak scaling" in wk["workload"] and wk["ms_per_step"] > 0
+        assert abs(wk["E0_per_site"] - wk["E0_per_site_closed_form"]) < 1e-9
+        assert wk["distributed_self_check"].startswith("overlapped exchange verified")
+        anchor = cfg["one_gpu_anchor"]
+        assert anchor["ms_per_step"] > 0 and "profiles/" in anchor["source"] and "speedup_vs_one_gpu" in anchor
 
 
 @pytest.mark.parametrize("world", [2, 4])

@@ -36,7 +36,7 @@ for rep in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     lam, xr = krylov.arnoldi_dominant(op, n, m, dev, "LM")
     torch.cuda.synchronize(); t1 = time.perf_counter()
-print("arnoldi_dominant: %.2f ms, %d cycle(s), lambda=%.12f" % ((t1 - t0) * 1e3, krylov.arnoldi_dominant.last_cycles, lam))
+print("arnoldi_dominant: %.2f ms, %d cycle(s), lambda=%.12f" % ((t1 - t0) * 1e3, krylov.last('arnoldi_cycles'), lam))
 krylov.STAGE_LOG = []
 torch.cuda.synchronize(); t0 = time.perf_counter()
 lam, xr = krylov.arnoldi_dominant(op, n, m, dev, "LM")
