@@ -20,6 +20,15 @@ CG_STATE_LEN = 8
 ERR_NOT_CONVERGED = -5
 ERR_BREAKDOWN = -7
 ERR_TIMEOUT = -8
+ERR_COMM = -9
+ERR_PREMISE = -10
+ERR_UNSUPPORTED = -6
+COMM_ID_BYTES = 128
+POP_OVERLAP, POP_PAIRWISE = 1, 2
+# caller-supplied collectives of dsea_comm_create_callbacks (device pointers + the stream the data was produced on)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_int64, c_void_p)
+ALLTOALL_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p)
+SENDRECV_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p)
 
 
 class DseaError(RuntimeError):
@@ -84,6 +93,26 @@ _SIGNATURES = {
                                     c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "dsea_plz_finish": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                 c_void_p, c_int64, c_void_p]),
+    "dsea_comm_unique_id": (c_int, [c_void_p]),
+    "dsea_comm_init_rank": (c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(c_void_p)]),
+    "dsea_comm_adopt": (c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(c_void_p)]),
+    "dsea_comm_create_callbacks": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
+    "dsea_comm_destroy": (c_int, [c_void_p]),
+    "dsea_comm_allreduce": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "dsea_comm_alltoall": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "dsea_pop_tfim_scratch_doubles": (c_size_t, [c_int, c_int]),
+    "dsea_pop_create_tfim": (c_int, [c_int, c_void_p, c_void_p, c_double, c_double, c_void_p, c_void_p, c_int, c_double,
+                                     POINTER(c_void_p)]),
+    "dsea_pop_create_stencil3": (c_int, [c_int64, c_double, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
+    "dsea_pop_destroy": (c_int, [c_void_p]),
+    "dsea_pop_set_flags": (c_int, [c_void_p, c_int]),
+    "dsea_pop_matvec": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dsea_pop_dot": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "dsea_pop_lanczos_run": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                     c_void_p]),
+    "dsea_pop_lanczos_status": (c_int, [c_void_p, c_void_p, POINTER(c_int), c_void_p]),
+    "dsea_pop_cg_run": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int64, c_int,
+                                POINTER(c_int64), POINTER(c_double), c_void_p]),
     "dsea_lanczos_run": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                  c_void_p]),
     "dsea_lanczos_run_basisfree": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,

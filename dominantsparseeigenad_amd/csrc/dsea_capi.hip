@@ -11,13 +11,6 @@
 
 using namespace dsea;
 
-struct dsea_op_s {
-  OpDesc d;
-};
-struct dsea_ws_s {
-  Workspace w;
-};
-
 namespace {
 thread_local int g_last_hip = 0;
 
@@ -96,7 +89,7 @@ TileGeom Workspace::geom(int64_t n_rows) const {
 
 extern "C" {
 
-int dsea_version(void) { return 100; }
+int dsea_version(void) { return 110; }
 
 const char* dsea_error_string(int status) {
   switch (status) {
@@ -109,6 +102,8 @@ const char* dsea_error_string(int status) {
     case DSEA_ERR_UNSUPPORTED: return "unsupported configuration";
     case DSEA_ERR_TIMEOUT: return "a workgroup of a persistent launch did not arrive in time";
     case DSEA_ERR_BREAKDOWN: return "Lanczos breakdown: the Krylov space is smaller than k";
+    case DSEA_ERR_COMM: return "a collective (RCCL call or caller-supplied callback) failed";
+    case DSEA_ERR_PREMISE: return "overlapped slab exchange: the premise max|c_j| <= tau ||r|| failed at some step";
     default: return "unknown status";
   }
 }

@@ -196,4 +196,12 @@ int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shif
                 double* P, hipStream_t st, EventPair* ev = nullptr);
 
 }  // namespace dsea
+
+// the opaque handles of include/dsea.h
+struct dsea_op_s {
+  dsea::OpDesc d;
+};
+struct dsea_ws_s {
+  dsea::Workspace w;
+};
 #endif

@@ -1,0 +1,591 @@
+// dsea_partitioned.hip -- row-partitioned solvers with the collectives inside the library (include/dsea.h,
+// "row-partitioned solvers").  Host code + one tiny kernel: the slab kernels are
+// the phase kernels of dsea_kernels.hip reached through the C ABI of dsea_capi.hip; what this file adds is the
+// SEQUENCING of a distributed Lanczos step / CG iteration -- kernels and RCCL calls issued back to back on the
+// caller's stream (slab exchange on a side stream), no host language and no host synchronisation in between.
+//
+// RCCL is bound at run time (dlopen of the copy already in the process -- PyTorch-ROCm ships and loads its own --
+// so that adopted ncclComm_t values are used with the library that created them).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <mutex>
+#include <new>
+
+#include "dsea_internal.h"
+
+using namespace dsea;
+
+namespace {
+struct Rccl {
+  bool ok = false;
+  decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+  decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+  decltype(&ncclCommDestroy) comm_destroy = nullptr;
+  decltype(&ncclAllReduce) all_reduce = nullptr;
+  decltype(&ncclSend) send = nullptr;
+  decltype(&ncclRecv) recv = nullptr;
+  decltype(&ncclGroupStart) group_start = nullptr;
+  decltype(&ncclGroupEnd) group_end = nullptr;
+  decltype(&ncclCommCount) comm_count = nullptr;
+  decltype(&ncclCommUserRank) comm_user_rank = nullptr;
+};
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+
+void rccl_init() {
+  void* lib = nullptr;
+  const char* names[] = {"librccl.so", "librccl.so.1"};
+  for (const char* nm : names)
+    if (!lib) lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);      // the copy the process already uses (PyTorch's)
+  for (const char* nm : names)
+    if (!lib) lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) return;
+#define BIND(field, name)                                                     \
+  g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(lib, name)); \
+  if (!g_rccl.field) return;
+  BIND(get_unique_id, "ncclGetUniqueId")
+  BIND(comm_init_rank, "ncclCommInitRank")
+  BIND(comm_destroy, "ncclCommDestroy")
+  BIND(all_reduce, "ncclAllReduce")
+  BIND(send, "ncclSend")
+  BIND(recv, "ncclRecv")
+  BIND(group_start, "ncclGroupStart")
+  BIND(group_end, "ncclGroupEnd")
+  BIND(comm_count, "ncclCommCount")
+  BIND(comm_user_rank, "ncclCommUserRank")
+#undef BIND
+  g_rccl.ok = true;
+}
+bool rccl_available() {
+  std::call_once(g_rccl_once, rccl_init);
+  return g_rccl.ok;
+}
+}  // namespace
+
+enum CommKind { COMM_RCCL_OWNED = 0, COMM_RCCL_ADOPTED = 1, COMM_CALLBACKS = 2, COMM_SELF = 3 };
+struct dsea_comm_s {
+  int kind, rank, world;
+  ncclComm_t coll, xchg;
+  dsea_allreduce_fn allreduce;
+  dsea_alltoall_fn alltoall;
+  dsea_sendrecv_fn sendrecv;
+  void* user;
+};
+
+struct dsea_pop_s {
+  OpKind kind;
+  dsea_comm_s* comm;
+  dsea_op_s local;        // slab-local operator
+  int64_t nloc;
+  int flags;
+  double tau;
+  // TFIM
+  int L, p;
+  const double* g_dev;
+  double g_const;         // remote part: y += -(g_dev ? *g_dev : 1) * g_scale * sum(partner slabs)
+  bool transposed;
+  double *xT, *zT, *z, *recv[8], *r_send;
+  hipStream_t side;
+  hipEvent_t ev_ready, ev_done;
+  // stencil
+  double* halo;
+  bool has_lo, has_hi;
+};
+
+namespace {
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+#define NCCL_OK(call)                      \
+  do {                                     \
+    if ((call) != ncclSuccess) return DSEA_ERR_COMM; \
+  } while (0)
+#define DSEA_TRY(call)            \
+  do {                            \
+    int rc__ = (call);            \
+    if (rc__ != DSEA_OK) return rc__; \
+  } while (0)
+#define HIP_TRY(call)                       \
+  do {                                      \
+    if ((call) != hipSuccess) return DSEA_ERR_HIP; \
+  } while (0)
+
+// ---- collectives on one communicator ------------------------------------------------------------------------------
+int comm_allreduce(dsea_comm_s* c, double* buf, int64_t count, hipStream_t st) {
+  if (c->world == 1 && c->kind != COMM_RCCL_OWNED && c->kind != COMM_RCCL_ADOPTED) return DSEA_OK;
+  if (c->kind == COMM_CALLBACKS) return c->allreduce(c->user, buf, count, (void*)st) == 0 ? DSEA_OK : DSEA_ERR_COMM;
+  // (world size 1 over RCCL: the call is still issued -- it is what the one-GPU tests exercise)
+  NCCL_OK(g_rccl.all_reduce(buf, buf, (size_t)count, ncclDouble, ncclSum, c->coll, st));
+  return DSEA_OK;
+}
+
+int comm_alltoall(dsea_comm_s* c, const double* send, double* recv, int64_t chunk, hipStream_t st) {
+  if (c->kind == COMM_CALLBACKS)
+    return c->alltoall(c->user, send, recv, chunk, (void*)st) == 0 ? DSEA_OK : DSEA_ERR_COMM;
+  if (c->kind == COMM_SELF || c->world == 1) {
+    HIP_TRY(hipMemcpyAsync(recv, send, (size_t)chunk * c->world * sizeof(double), hipMemcpyDeviceToDevice, st));
+    return DSEA_OK;
+  }
+  // an all-to-all IS this group of point-to-point operations; the own chunk is a device copy
+  HIP_TRY(hipMemcpyAsync(recv + (int64_t)c->rank * chunk, send + (int64_t)c->rank * chunk, (size_t)chunk * sizeof(double),
+                         hipMemcpyDeviceToDevice, st));
+  NCCL_OK(g_rccl.group_start());
+  for (int j = 0; j < c->world; ++j) {
+    if (j == c->rank) continue;
+    NCCL_OK(g_rccl.send(send + (int64_t)j * chunk, (size_t)chunk, ncclDouble, j, c->xchg, st));
+    NCCL_OK(g_rccl.recv(recv + (int64_t)j * chunk, (size_t)chunk, ncclDouble, j, c->xchg, st));
+  }
+  NCCL_OK(g_rccl.group_end());
+  return DSEA_OK;
+}
+
+struct P2P {
+  const double* send;
+  double* recv;
+  int64_t count;
+  int peer;
+};
+int comm_sendrecv(dsea_comm_s* c, const P2P* items, int n_items, hipStream_t st) {
+  if (n_items == 0) return DSEA_OK;
+  if (c->kind == COMM_CALLBACKS) {
+    for (int k = 0; k < n_items; ++k)
+      if (c->sendrecv(c->user, items[k].send, items[k].recv, items[k].count, items[k].peer, (void*)st) != 0)
+        return DSEA_ERR_COMM;
+    return DSEA_OK;
+  }
+  NCCL_OK(g_rccl.group_start());
+  for (int k = 0; k < n_items; ++k) {
+    NCCL_OK(g_rccl.send(items[k].send, (size_t)items[k].count, ncclDouble, items[k].peer, c->xchg, st));
+    NCCL_OK(g_rccl.recv(items[k].recv, (size_t)items[k].count, ncclDouble, items[k].peer, c->xchg, st));
+  }
+  NCCL_OK(g_rccl.group_end());
+  return DSEA_OK;
+}
+
+// ---- the overlap premise, on the device -----------------------------------------------------------------------------
+// rec[0] = first step i at which max_j c_j^2 > tau^2 * c[i] (c[i] = ||r||^2), 0 = never.  c is replicated (it has
+// been all-reduced), so every rank records the same step.
+__global__ __launch_bounds__(256) void k_premise(const double* __restrict__ c, int i, double tau, double* __restrict__ rec) {
+  __shared__ double sm[256];
+  double m = 0.0;
+  for (int j = threadIdx.x; j < i; j += 256) {
+    const double v = c[j] * c[j];
+    m = v > m ? v : m;
+  }
+  sm[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sm[threadIdx.x] = sm[threadIdx.x] > sm[threadIdx.x + s] ? sm[threadIdx.x] : sm[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double rr = c[i];
+    const bool ok = sm[0] <= tau * tau * rr;      // NaN -> violated
+    if (!ok && rec[0] == 0.0) rec[0] = (double)i;
+  }
+}
+
+// ---- TFIM slab exchange ------------------------------------------------------------------------------------------
+int tfim_exchange_on(dsea_pop_s* P, const double* x, hipStream_t s) {
+  dsea_comm_s* c = P->comm;
+  if (P->transposed) {
+    const int64_t chunk = P->nloc / c->world;
+    DSEA_TRY(comm_alltoall(c, x, P->xT, chunk, s));
+    DSEA_TRY(dsea_hypercube_flipsum(P->xT, P->zT, c->world, chunk, (void*)s));
+    DSEA_TRY(comm_alltoall(c, P->zT, P->z, chunk, s));
+    return DSEA_OK;
+  }
+  P2P items[8];
+  for (int b = 0; b < P->p; ++b) items[b] = P2P{x, P->recv[b], P->nloc, c->rank ^ (1 << b)};
+  return comm_sendrecv(c, items, P->p, s);
+}
+// start the exchange of slab x: on the side stream (ordered after what `main` has enqueued so far) when there is one,
+// otherwise inline on main.  x must stay untouched until tfim_exchange_finish.
+int tfim_exchange_start(dsea_pop_s* P, const double* x, hipStream_t main) {
+  if (P->p == 0) return DSEA_OK;
+  if (!P->side) return tfim_exchange_on(P, x, main);
+  HIP_TRY(hipEventRecord(P->ev_ready, main));
+  HIP_TRY(hipStreamWaitEvent(P->side, P->ev_ready, 0));
+  DSEA_TRY(tfim_exchange_on(P, x, P->side));
+  HIP_TRY(hipEventRecord(P->ev_done, P->side));
+  return DSEA_OK;
+}
+int tfim_exchange_finish(dsea_pop_s* P, hipStream_t main) {
+  if (P->p == 0 || !P->side) return DSEA_OK;
+  HIP_TRY(hipStreamWaitEvent(main, P->ev_done, 0));
+  return DSEA_OK;
+}
+inline int tfim_recv_list(dsea_pop_s* P, const double** out) {
+  if (P->p == 0) return 0;
+  if (P->transposed) {
+    out[0] = P->z;
+    return 1;
+  }
+  for (int b = 0; b < P->p; ++b) out[b] = P->recv[b];
+  return P->p;
+}
+// remote part of the mat-vec + shift + LOCAL x.y into dot_local
+int tfim_remote_part(dsea_pop_s* P, dsea_ws_t ws, const double* shift, const double* skip, const double* x, double* y,
+                     double* dot_local, hipStream_t st) {
+  const double* xs[8];
+  const int cnt = tfim_recv_list(P, xs);
+  return dsea_axpy_multi_dot(ws, P->g_dev ? -1.0 : -P->g_const, P->g_dev, xs, cnt, shift, skip, x, y, P->nloc, dot_local,
+                             (void*)st);
+}
+
+int stencil_halo_exchange(dsea_pop_s* P, const double* x, hipStream_t st) {
+  P2P items[2];
+  int n = 0;
+  if (P->has_lo) items[n++] = P2P{x, P->halo, 1, P->comm->rank - 1};
+  if (P->has_hi) items[n++] = P2P{x + (P->nloc - 1), P->halo + 1, 1, P->comm->rank + 1};
+  return comm_sendrecv(P->comm, items, n, st);
+}
+
+// y = (A - shift) x over all ranks, LOCAL x.y into dot_local (ws scalar)
+int pop_apply(dsea_pop_s* P, dsea_ws_t ws, const double* x, double* y, const double* shift, const double* skip,
+              double* dot_local, hipStream_t st) {
+  if (P->kind == OP_TFIM) {
+    DSEA_TRY(tfim_exchange_start(P, x, st));
+    DSEA_TRY(dsea_spmv(&P->local, nullptr, x, y, nullptr, nullptr, skip, (void*)st));
+    DSEA_TRY(tfim_exchange_finish(P, st));
+    return tfim_remote_part(P, ws, shift, skip, x, y, dot_local, st);
+  }
+  DSEA_TRY(stencil_halo_exchange(P, x, st));
+  return dsea_spmv(&P->local, ws, x, y, shift, dot_local, skip, (void*)st);
+}
+}  // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------- communicator
+int dsea_comm_unique_id(void* id_out) {
+  if (!id_out) return DSEA_ERR_ARG;
+  if (!rccl_available()) return DSEA_ERR_UNSUPPORTED;
+  static_assert(sizeof(ncclUniqueId) == DSEA_COMM_ID_BYTES, "unique id size");
+  ncclUniqueId id;
+  NCCL_OK(g_rccl.get_unique_id(&id));
+  memcpy(id_out, &id, sizeof(id));
+  return DSEA_OK;
+}
+
+int dsea_comm_init_rank(const void* id_coll, const void* id_xchg, int rank, int world, dsea_comm_t* out) {
+  if (!id_coll || !out || world < 1 || rank < 0 || rank >= world) return DSEA_ERR_ARG;
+  if (!rccl_available()) return DSEA_ERR_UNSUPPORTED;
+  dsea_comm_s* c = new (std::nothrow) dsea_comm_s;
+  if (!c) return DSEA_ERR_ARG;
+  memset(c, 0, sizeof(*c));
+  c->kind = COMM_RCCL_OWNED;
+  c->rank = rank;
+  c->world = world;
+  ncclUniqueId id;
+  memcpy(&id, id_coll, sizeof(id));
+  if (g_rccl.comm_init_rank(&c->coll, world, id, rank) != ncclSuccess) {
+    delete c;
+    return DSEA_ERR_COMM;
+  }
+  c->xchg = c->coll;
+  if (id_xchg) {
+    memcpy(&id, id_xchg, sizeof(id));
+    if (g_rccl.comm_init_rank(&c->xchg, world, id, rank) != ncclSuccess) {
+      g_rccl.comm_destroy(c->coll);
+      delete c;
+      return DSEA_ERR_COMM;
+    }
+  }
+  *out = c;
+  return DSEA_OK;
+}
+
+int dsea_comm_adopt(void* coll_comm, void* xchg_comm, int rank, int world, dsea_comm_t* out) {
+  if (!coll_comm || !out || world < 1 || rank < 0 || rank >= world) return DSEA_ERR_ARG;
+  if (!rccl_available()) return DSEA_ERR_UNSUPPORTED;
+  ncclComm_t cc = static_cast<ncclComm_t>(coll_comm);
+  int cnt = -1, ur = -1;
+  // the adopted handle must be a live communicator of this size and rank (a stale or foreign pointer fails here)
+  if (g_rccl.comm_count(cc, &cnt) != ncclSuccess || g_rccl.comm_user_rank(cc, &ur) != ncclSuccess) return DSEA_ERR_COMM;
+  if (cnt != world || ur != rank) return DSEA_ERR_ARG;
+  dsea_comm_s* c = new (std::nothrow) dsea_comm_s;
+  if (!c) return DSEA_ERR_ARG;
+  memset(c, 0, sizeof(*c));
+  c->kind = COMM_RCCL_ADOPTED;
+  c->rank = rank;
+  c->world = world;
+  c->coll = cc;
+  c->xchg = xchg_comm ? static_cast<ncclComm_t>(xchg_comm) : cc;
+  *out = c;
+  return DSEA_OK;
+}
+
+int dsea_comm_create_callbacks(int rank, int world, dsea_allreduce_fn allreduce, dsea_alltoall_fn alltoall,
+                               dsea_sendrecv_fn sendrecv, void* user, dsea_comm_t* out) {
+  if (!out || world < 1 || rank < 0 || rank >= world) return DSEA_ERR_ARG;
+  if (world > 1 && (!allreduce || !alltoall || !sendrecv)) return DSEA_ERR_ARG;
+  dsea_comm_s* c = new (std::nothrow) dsea_comm_s;
+  if (!c) return DSEA_ERR_ARG;
+  memset(c, 0, sizeof(*c));
+  c->kind = (world == 1 && !allreduce) ? COMM_SELF : COMM_CALLBACKS;
+  c->rank = rank;
+  c->world = world;
+  c->allreduce = allreduce;
+  c->alltoall = alltoall;
+  c->sendrecv = sendrecv;
+  c->user = user;
+  *out = c;
+  return DSEA_OK;
+}
+
+int dsea_comm_destroy(dsea_comm_t c) {
+  if (!c) return DSEA_OK;
+  if (c->kind == COMM_RCCL_OWNED && g_rccl.ok) {
+    if (c->xchg && c->xchg != c->coll) g_rccl.comm_destroy(c->xchg);
+    if (c->coll) g_rccl.comm_destroy(c->coll);
+  }
+  delete c;
+  return DSEA_OK;
+}
+
+int dsea_comm_allreduce(dsea_comm_t comm, double* buf, int64_t count, void* stream) {
+  if (!comm || !buf || count < 1) return DSEA_ERR_ARG;
+  return comm_allreduce(comm, buf, count, static_cast<hipStream_t>(stream));
+}
+
+int dsea_comm_alltoall(dsea_comm_t comm, const double* send, double* recv, int64_t chunk, void* stream) {
+  if (!comm || !send || !recv || chunk < 1 || send == recv) return DSEA_ERR_ARG;
+  return comm_alltoall(comm, send, recv, chunk, static_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------------------------------------- operators
+size_t dsea_pop_tfim_scratch_doubles(int L, int world) {
+  if (L < 1 || L > 62 || world < 1) return 0;
+  int p = 0;
+  while ((1 << p) < world) ++p;
+  if ((1 << p) != world || p > L) return 0;
+  const size_t nloc = (size_t)1 << (L - p);
+  return (size_t)((p > 3 ? p : 3) + 1) * nloc;
+}
+
+int dsea_pop_create_tfim(int L, dsea_comm_t comm, const double* g_dev, double g_const, double diag_scale,
+                         double* scratch, void* side_stream, int flags, double tau, dsea_pop_t* out) {
+  if (!out || !comm || L < 1 || L > 62 || tau < 0.0) return DSEA_ERR_ARG;
+  int p = 0;
+  while ((1 << p) < comm->world) ++p;
+  if ((1 << p) != comm->world || p > L || p > 8) return DSEA_ERR_ARG;
+  if (p > 0 && !scratch) return DSEA_ERR_ARG;
+  if (scratch && !aligned16(scratch)) return DSEA_ERR_ALIGN;
+  dsea_pop_s* P = new (std::nothrow) dsea_pop_s;
+  if (!P) return DSEA_ERR_ARG;
+  memset(static_cast<void*>(P), 0, sizeof(*P));
+  P->kind = OP_TFIM;
+  P->comm = comm;
+  P->L = L;
+  P->p = p;
+  P->nloc = (int64_t)1 << (L - p);
+  P->flags = flags;
+  P->tau = tau;
+  P->g_dev = g_dev;
+  P->g_const = g_const;
+  memset(&P->local.d, 0, sizeof(P->local.d));
+  P->local.d.tune_tile_log2 = DSEA_TFIM_TILE_LOG2;
+  P->local.d.kind = OP_TFIM;
+  P->local.d.n = P->nloc;
+  P->local.d.tfim = TfimParams{L, L - p, (int64_t)comm->rank * P->nloc, g_dev, g_const, diag_scale};
+  // exchange form: pairwise for two ranks (the transposed form would move the same bytes), transposed from four on
+  P->transposed = comm->world >= 4 && P->nloc >= comm->world && !(flags & DSEA_POP_PAIRWISE);
+  if (p > 0) {
+    // scratch layout: [r_send][xT zT z | recv_0 .. recv_{p-1}]   (both forms fit: (max(3, p) + 1) slabs)
+    P->r_send = scratch;
+    double* base = scratch + P->nloc;
+    P->xT = base;
+    P->zT = base + P->nloc;
+    P->z = base + 2 * P->nloc;
+    for (int b = 0; b < p; ++b) P->recv[b] = base + (int64_t)b * P->nloc;
+  }
+  P->side = static_cast<hipStream_t>(side_stream);
+  if (P->side) {
+    if (hipEventCreateWithFlags(&P->ev_ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&P->ev_done, hipEventDisableTiming) != hipSuccess) {
+      delete P;
+      return DSEA_ERR_HIP;
+    }
+  }
+  *out = P;
+  return DSEA_OK;
+}
+
+int dsea_pop_create_stencil3(int64_t n_local, double coef, const double* V_dev, double* halo2, dsea_comm_t comm,
+                             dsea_pop_t* out) {
+  if (!out || !comm || n_local < 1 || !V_dev || !halo2) return DSEA_ERR_ARG;
+  if (!aligned16(V_dev)) return DSEA_ERR_ALIGN;
+  dsea_pop_s* P = new (std::nothrow) dsea_pop_s;
+  if (!P) return DSEA_ERR_ARG;
+  memset(static_cast<void*>(P), 0, sizeof(*P));
+  P->kind = OP_STENCIL3;
+  P->comm = comm;
+  P->nloc = n_local;
+  P->halo = halo2;
+  P->has_lo = comm->rank > 0;
+  P->has_hi = comm->rank < comm->world - 1;
+  memset(&P->local.d, 0, sizeof(P->local.d));
+  P->local.d.tune_tile_log2 = DSEA_TFIM_TILE_LOG2;
+  P->local.d.kind = OP_STENCIL3;
+  P->local.d.n = n_local;
+  P->local.d.st3 = Stencil3Params{n_local, coef, V_dev, P->has_lo ? halo2 : nullptr, P->has_hi ? halo2 + 1 : nullptr};
+  *out = P;
+  return DSEA_OK;
+}
+
+int dsea_pop_destroy(dsea_pop_t P) {
+  if (!P) return DSEA_OK;
+  if (P->side) {
+    (void)hipEventDestroy(P->ev_ready);
+    (void)hipEventDestroy(P->ev_done);
+  }
+  delete P;
+  return DSEA_OK;
+}
+
+int dsea_pop_set_flags(dsea_pop_t P, int flags) {
+  if (!P) return DSEA_ERR_ARG;
+  const bool pairwise = (flags & DSEA_POP_PAIRWISE) != 0;
+  if (P->kind == OP_TFIM) P->transposed = P->comm->world >= 4 && P->nloc >= P->comm->world && !pairwise;
+  P->flags = flags;
+  return DSEA_OK;
+}
+
+int dsea_pop_matvec(dsea_pop_t P, dsea_ws_t ws, const double* x, double* y, const double* shift, double* dot_out,
+                    const double* skip_flag, void* stream) {
+  if (!P || !ws || !x || !y || x == y) return DSEA_ERR_ARG;
+  if (!aligned16(x) || !aligned16(y)) return DSEA_ERR_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  double* slot = dot_out ? dot_out : ws->w.scal + 36;
+  DSEA_TRY(pop_apply(P, ws, x, y, shift, skip_flag, slot, st));
+  if (dot_out) DSEA_TRY(comm_allreduce(P->comm, dot_out, 1, st));
+  return DSEA_OK;
+}
+
+int dsea_pop_dot(dsea_pop_t P, dsea_ws_t ws, const double* x, const double* y, int64_t n, double* out, void* stream) {
+  if (!P || !ws || !out) return DSEA_ERR_ARG;
+  DSEA_TRY(dsea_dot(ws, x, y, n, out, stream));
+  return comm_allreduce(P->comm, out, 1, static_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------------------------------------- Lanczos
+int dsea_pop_lanczos_run(dsea_pop_t P, dsea_ws_t ws, int k, const double* q0, double* Q, int64_t ldq, double* alphas,
+                         double* betas, void* stream) {
+  if (!P || !ws || !q0 || !Q || !alphas || !betas || k < 1) return DSEA_ERR_ARG;
+  const int64_t n = P->nloc;
+  if (ldq < n || ws->w.n < n) return DSEA_ERR_ARG;
+  if (k > ws->w.kmax && k != 1) return DSEA_ERR_WORKSPACE;
+  if (!aligned16(q0) || !aligned16(Q) || (ldq % 2) != 0) return DSEA_ERR_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Workspace& w = ws->w;
+  double* u = w.vec[0];
+  double* r = w.vec[1];
+  double* y = w.vec[2];
+  double* c = w.coef;
+  double* pair = w.scal + 32;
+  double* rec = w.scal + 34;      // overlap premise record
+  const bool tfim = P->kind == OP_TFIM;
+  const bool overlap = tfim && P->p > 0 && (P->flags & DSEA_POP_OVERLAP);
+  HIP_TRY(hipMemsetAsync(w.scal + 32, 0, 4 * sizeof(double), st));
+  HIP_TRY(hipMemsetAsync(w.scal + 16, 0, 2 * sizeof(double), st));      // shadow-path statistics of this run
+  for (int i = 0; i < k; ++i) {
+    const double* a_prev = i >= 1 ? alphas + (i - 1) : nullptr;
+    const double* b_prev = i >= 2 ? betas + (i - 2) : nullptr;
+    if (i == 0) {
+      HIP_TRY(hipMemcpyAsync(r, q0, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+      if (overlap) {
+        HIP_TRY(hipMemcpyAsync(P->r_send, q0, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        DSEA_TRY(tfim_exchange_start(P, P->r_send, st));
+      }
+    } else if (overlap) {
+      // the exchange of the UN-corrected r runs behind the dots and correction passes
+      DSEA_TRY(dsea_lanczos_form_r(ws, Q, ldq, n, i, u, a_prev, b_prev, r, P->r_send, stream));
+      DSEA_TRY(tfim_exchange_start(P, P->r_send, st));
+      // alpha = 0: r is rewritten with its own values (read from the snapshot, so that input and output of the
+      // kernel do not alias), c = Q^T r, c[i] = r.r
+      DSEA_TRY(dsea_plz_dots(ws, Q, ldq, n, i, P->r_send, w.zero, nullptr, r, c, stream));
+      DSEA_TRY(comm_allreduce(P->comm, c, i + 1, st));
+      hipLaunchKernelGGL(k_premise, dim3(1), dim3(256), 0, st, (const double*)c, i, P->tau, rec);
+    } else {
+      DSEA_TRY(dsea_plz_dots(ws, Q, ldq, n, i, u, a_prev, b_prev, r, c, stream));
+      DSEA_TRY(comm_allreduce(P->comm, c, i + 1, st));
+    }
+    DSEA_TRY(dsea_plz_correct(ws, Q, ldq, n, i, c, r, pair, stream));
+    if (tfim) {
+      if (!overlap) DSEA_TRY(tfim_exchange_start(P, r, st));       // r is final: exact, runs behind the local mat-vec
+      DSEA_TRY(dsea_spmv(&P->local, nullptr, r, y, nullptr, nullptr, nullptr, stream));
+      DSEA_TRY(tfim_exchange_finish(P, st));
+      DSEA_TRY(tfim_remote_part(P, ws, nullptr, nullptr, r, y, pair + 1, st));
+    } else {
+      DSEA_TRY(stencil_halo_exchange(P, r, st));
+      DSEA_TRY(dsea_spmv(&P->local, ws, r, y, nullptr, pair + 1, nullptr, stream));
+    }
+    DSEA_TRY(comm_allreduce(P->comm, pair, 2, st));
+    DSEA_TRY(dsea_plz_finish(ws, r, y, pair, Q + (int64_t)i * ldq, i, u, alphas + i, i >= 1 ? betas + (i - 1) : nullptr, n,
+                             stream));
+  }
+  return hipGetLastError() == hipSuccess ? DSEA_OK : DSEA_ERR_HIP;
+}
+
+int dsea_pop_lanczos_status(dsea_pop_t P, dsea_ws_t ws, int* step, void* stream) {
+  if (!P || !ws) return DSEA_ERR_ARG;
+  double h = 0.0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipMemcpyAsync(&h, ws->w.scal + 34, sizeof(h), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (step) *step = (int)h;
+  return h != 0.0 ? DSEA_ERR_PREMISE : DSEA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- CG
+int dsea_pop_cg_run(dsea_pop_t P, dsea_ws_t ws, const double* shift, const double* b, double* x, double* state,
+                    double eps, int64_t maxiter, int poll_every, int64_t* iters_out, double* resnorm_out,
+                    void* stream) {
+  if (!P || !ws || !b || !x || !state || maxiter < 0) return DSEA_ERR_ARG;
+  const int64_t n = P->nloc;
+  if (ws->w.n < n) return DSEA_ERR_ARG;
+  if (!aligned16(b) || !aligned16(x)) return DSEA_ERR_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Workspace& w = ws->w;
+  double* r = w.vec[1];
+  double* d = w.vec[2];
+  double* Ad = w.vec[3];
+  const double* done = state + DSEA_CG_DONE;
+  if (poll_every <= 0) poll_every = 16;
+  // r = b - A'x0 ; early out ; d = r                                   (CG.py:26-30)
+  DSEA_TRY(pop_apply(P, ws, x, Ad, shift, nullptr, w.scal + 36, st));
+  DSEA_TRY(dsea_cg_init(ws, b, Ad, r, d, state, n, stream));
+  DSEA_TRY(comm_allreduce(P->comm, state + DSEA_CG_RR, 1, st));
+  DSEA_TRY(dsea_cg_init_check(ws, state, eps, stream));
+  double host_state[DSEA_CG_STATE_LEN];
+  int64_t issued = 0;
+  bool finished = false;
+  HIP_TRY(hipMemcpyAsync(host_state, state, sizeof(host_state), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  finished = host_state[DSEA_CG_DONE] != 0.0 || maxiter == 0;
+  while (!finished) {
+    const int64_t chunk = (maxiter - issued) < poll_every ? (maxiter - issued) : poll_every;
+    for (int64_t it = 0; it < chunk; ++it) {
+      DSEA_TRY(pop_apply(P, ws, d, Ad, shift, done, state + DSEA_CG_DAD, st));          // A'd, local d.A'd  (CG.py:31/40)
+      DSEA_TRY(comm_allreduce(P->comm, state + DSEA_CG_DAD, 1, st));
+      DSEA_TRY(dsea_cg_update(ws, x, r, d, Ad, state, n, stream));                       // CG.py:31,33-34
+      DSEA_TRY(comm_allreduce(P->comm, state + DSEA_CG_RRNEW, 1, st));
+      DSEA_TRY(dsea_cg_check(ws, state, eps, stream));                                   // CG.py:35-38
+      DSEA_TRY(dsea_cg_direction(ws, r, d, state, n, stream));                           // CG.py:39
+    }
+    issued += chunk;
+    HIP_TRY(hipMemcpyAsync(host_state, state, sizeof(host_state), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    finished = (host_state[DSEA_CG_DONE] != 0.0) || issued >= maxiter;
+  }
+  if (iters_out) *iters_out = (int64_t)host_state[DSEA_CG_ITERS];
+  if (resnorm_out) *resnorm_out = host_state[DSEA_CG_RESNORM];
+  if (hipGetLastError() != hipSuccess) return DSEA_ERR_HIP;
+  return host_state[DSEA_CG_DONE] != 0.0 ? DSEA_OK : DSEA_ERR_NOT_CONVERGED;
+}
+
+}  // extern "C"

@@ -262,6 +262,151 @@ class TorchDistComm:
         self.sendrecv([(src[j * chunk:(j + 1) * chunk], dst[j * chunk:(j + 1) * chunk], j) for j in range(P) if j != me])
 
 
+# =========================================================================== library-side communicator
+def _device_view(ptr, count, device):
+    """zero-copy fp64 torch tensor over ``count`` doubles of device memory at ``ptr`` (used by the callback
+    communicator to hand the library's buffers to Python-level collectives)"""
+    class _Arr:
+        __cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(_Arr(), device=device)
+
+
+class NativeComm:
+    """A communicator handle of include/dsea.h (``dsea_comm_t``): what the library-side row-partitioned solvers
+    (``dsea_pop_lanczos_run`` / ``dsea_pop_cg_run``) issue their collectives on.  Three ways to get one:
+
+      * ``adopt_torch(group)``  -- the ncclComm_t values PyTorch's ProcessGroupNCCL already holds (``_comm_ptr()``):
+        the group's own communicator for the all-reduces and the communicator of a second process group for the slab
+        exchange (RCCL orders the operations of ONE communicator across streams; the exchange must not queue behind
+        the all-reduces it is meant to overlap);
+      * ``own(group)``          -- the library creates both RCCL communicators itself from two unique ids produced on
+        rank 0 and broadcast over ``group``;
+      * ``from_python(comm)``   -- any object with ``allreduce / all_to_all / sendrecv`` on torch tensors (the
+        host-staged gloo communicator of the one-GPU tests, MPI wrappers ...) as blocking callbacks.
+    """
+
+    def __init__(self, handle, rank, world, kind, keep=()):
+        self.handle, self.rank, self.world, self.kind = handle, rank, world, kind
+        self._keep = keep            # ctypes callbacks / process groups that must outlive the handle
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                from . import _lib
+                _lib.load().dsea_comm_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    @staticmethod
+    def _torch_comm_ptr(group, device):
+        """ncclComm_t of ``group`` on ``device`` as an integer (the communicator exists after the group's first
+        collective, or at once with eager initialisation)"""
+        t = torch.zeros(1, dtype=F64, device=device)
+        dist.all_reduce(t, group=group)
+        torch.cuda.synchronize(device)
+        backend = (group if group is not None else dist.group.WORLD)._get_backend(torch.device(device))
+        return int(backend._comm_ptr())
+
+    @classmethod
+    def adopt_torch(cls, group, device):
+        from . import _lib
+        lib = _lib.load()
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        ranks = dist.get_process_group_ranks(group if group is not None else dist.group.WORLD)
+        xgroup = dist.new_group(ranks=ranks, backend="nccl") if world > 1 else group
+        coll = cls._torch_comm_ptr(group, device)
+        xchg = cls._torch_comm_ptr(xgroup, device) if world > 1 else coll
+        h = c_void_p()
+        _lib.check(lib.dsea_comm_adopt(c_void_p(coll), c_void_p(xchg), rank, world, byref(h)), "dsea_comm_adopt")
+        return cls(h, rank, world, "rccl (adopted from torch.distributed: %s)" %
+                   ("two communicators" if xchg != coll else "one communicator"), keep=(group, xgroup))
+
+    @classmethod
+    def own(cls, group, device):
+        from . import _lib
+        import ctypes
+        lib = _lib.load()
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        ids = [None, None]
+        if rank == 0:
+            for j in range(2):
+                buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+                _lib.check(lib.dsea_comm_unique_id(buf), "dsea_comm_unique_id")
+                ids[j] = bytes(buf.raw)
+        dist.broadcast_object_list(ids, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        h = c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.dsea_comm_init_rank(ids[0], ids[1] if world > 1 else None, rank, world, byref(h)),
+                       "dsea_comm_init_rank")
+        return cls(h, rank, world, "rccl (library-owned, two communicators)")
+
+    @classmethod
+    def for_torch_group(cls, group, device):
+        """RCCL communicator pair for ``group``: adopted from torch where torch exposes its ncclComm_t, otherwise created
+        by the library (the choice depends only on the software stack, so every rank takes the same branch).
+        ``DSEA_COMM=own|adopt`` forces one."""
+        import os
+        mode = os.environ.get("DSEA_COMM", "")
+        backend_cls = getattr(torch._C._distributed_c10d, "ProcessGroupNCCL", None)
+        can_adopt = backend_cls is not None and hasattr(backend_cls, "_comm_ptr")
+        if mode == "own" or (mode != "adopt" and not can_adopt):
+            return cls.own(group, device)
+        return cls.adopt_torch(group, device)
+
+    @classmethod
+    def from_python(cls, comm, device):
+        from . import _lib
+        lib = _lib.load()
+        device = torch.device(device)
+
+        def on(stream):
+            return torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=device) if stream else
+                                     torch.cuda.default_stream(device))
+
+        def allreduce(user, buf, count, stream):
+            try:
+                with on(stream):
+                    comm.allreduce(_device_view(buf, count, device))
+                return 0
+            except Exception:       # noqa: BLE001 -- reported to the library as DSEA_ERR_COMM
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def alltoall(user, send, recv, chunk, stream):
+            try:
+                with on(stream):
+                    comm.all_to_all(_device_view(send, chunk * comm.world, device), _device_view(recv, chunk * comm.world, device))
+                return 0
+            except Exception:       # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def sendrecv(user, send, recv, count, peer, stream):
+            try:
+                with on(stream):
+                    comm.sendrecv([(_device_view(send, count, device), _device_view(recv, count, device), int(peer))])
+                return 0
+            except Exception:       # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        if comm.world == 1 and not hasattr(comm, "all_to_all"):
+            cbs = (None, None, None)
+            args = (None, None, None)
+        else:
+            cbs = (_lib.ALLREDUCE_FN(allreduce), _lib.ALLTOALL_FN(alltoall), _lib.SENDRECV_FN(sendrecv))
+            import ctypes
+            args = tuple(ctypes.cast(cb, c_void_p) for cb in cbs)
+        h = c_void_p()
+        _lib.check(lib.dsea_comm_create_callbacks(comm.rank, comm.world, args[0], args[1], args[2], None, byref(h)),
+                   "dsea_comm_create_callbacks")
+        return cls(h, comm.rank, comm.world, "callbacks (%s)" % type(comm).__name__, keep=cbs + (comm,))
+
+
 class _SelfComm:
     """the communicator of ONE rank: nothing to reduce, nothing to exchange (replicated solves)"""
     rank, world = 0, 1
@@ -377,6 +522,109 @@ class PartitionedOperator:
         self.force_driver = False
         self.last_cg_iters = 0
         self.last_cg_resnorm = float("nan")
+        # library-side driver (include/dsea.h "row-partitioned solvers"): communicator + partitioned-operator handles;
+        # None = the Python driver below (CPU test double, DSEA_DRIVER=python, transports without a library binding)
+        self._ncomm = None
+        self._pop = None
+        self.overlap_fallbacks = 0
+
+    def __del__(self):
+        self._destroy_pops()
+
+    def _destroy_pops(self):
+        try:
+            lib = self.be.lib
+            for name in ("_pop", "_pop_dHdg"):
+                h = getattr(self, name, None)
+                if h:
+                    lib.dsea_pop_destroy(h)
+                    setattr(self, name, None)
+        except Exception:
+            pass
+
+    def _make_native_comm(self):
+        """the library-side communicator for this operator's collectives, or None"""
+        import os
+        if not isinstance(self.be, HipBackend) or os.environ.get("DSEA_DRIVER", "") == "python":
+            return None
+        comm = self.comm
+        if isinstance(comm, _SelfComm):
+            return NativeComm.from_python(comm, self.device)
+        if type(comm) is TorchDistComm:
+            if dist.get_backend(comm.group) == "nccl":
+                return NativeComm.for_torch_group(comm.group, self.device)
+            return None      # gloo on device tensors is not stream-ordered: Python driver with explicit staging
+        if all(hasattr(comm, a) for a in ("allreduce", "all_to_all", "sendrecv")):
+            return NativeComm.from_python(comm, self.device)
+        return None
+
+    @property
+    def driver(self):
+        return "library (%s)" % self._ncomm.kind if self._pop else "python"
+
+    def _pop_flags(self):
+        return 0
+
+    def _lanczos_library(self, k, q0_slab, arena):
+        """the whole k-step loop inside libdsea (dsea_pop_lanczos_run): slab kernels and collectives issued back to
+        back by the library, no Python and no host synchronisation per step"""
+        from . import _lib
+        from ctypes import c_int
+        be, n, lib = self.be, self.nloc, self.be.lib
+        be.reserve(k)
+        ws = be.ws
+        ldq = (n + 31) // 32 * 32
+        Q = be.basis(k, ldq, arena)
+        alphas, betas = be.zeros(k), be.zeros(max(k - 1, 1))
+        q0 = _vec(q0_slab)
+        use_shadow = self.use_shadow and _engine_mod.USE_SHADOW and k > 1 and \
+            _engine_mod.shadow_fits(self.device, k, ldq, n, arena)
+        flags = self._pop_flags()
+        with ws.owned_by("row-partitioned Lanczos (library driver)"):
+            if use_shadow:
+                be.set_shadow(k, ldq, arena)
+            try:
+                for attempt in (0, 1):
+                    _lib.check(lib.dsea_pop_set_flags(self._pop, flags), "dsea_pop_set_flags")
+                    _lib.check(lib.dsea_pop_lanczos_run(self._pop, ws.handle, int(k), be._p(q0), be._p(Q), ldq,
+                                                        be._p(alphas), be._p(betas), be._st()), "dsea_pop_lanczos_run")
+                    step = c_int(0)
+                    rc = lib.dsea_pop_lanczos_status(self._pop, ws.handle, byref(step), be._st())
+                    if rc == _lib.ERR_PREMISE and attempt == 0:
+                        # some step's coefficients were not at rounding level (the same step on every rank: c is
+                        # replicated): the overlapped exchange sent an r that differs from the corrected one by more than
+                        # the mat-vec's own rounding -- discard the run and repeat it with the exchange after the correction
+                        self.overlap_fallbacks += 1
+                        flags &= ~_lib.POP_OVERLAP
+                        continue
+                    _lib.check(rc, "dsea_pop_lanczos_status")
+                    break
+            finally:
+                lib.dsea_pop_set_flags(self._pop, self._pop_flags())
+                if use_shadow:
+                    be.clear_shadow()
+        return Q, ldq, alphas, betas[:k - 1]
+
+    def _solve_library(self, E0, b, x0, eps, maxiter):
+        from . import _lib
+        from ctypes import c_double, c_int64
+        be, lib = self.be, self.be.lib
+        ws = be.ws
+        x, b = _vec(x0), _vec(b)
+        shift = E0.detach().reshape(-1)[:1].to(F64).contiguous() if E0 is not None else None
+        iters, res = c_int64(0), c_double(0.0)
+        cap = self.dim if maxiter is None else int(maxiter)
+        with ws.owned_by("row-partitioned CG (library driver)"):
+            lib.dsea_pop_set_flags(self._pop, self._pop_flags())
+            rc = lib.dsea_pop_cg_run(self._pop, ws.handle, be._p(shift), be._p(b), be._p(x), be._p(ws.state), float(eps),
+                                     cap, int(self.poll_every), byref(iters), byref(res), be._st())
+        _lib.check(rc, "dsea_pop_cg_run", allow=(_lib.ERR_NOT_CONVERGED,))
+        self.last_cg_iters, self.last_cg_resnorm = int(iters.value), float(res.value)
+        info = _engine_mod.last_cg
+        info.iters, info.resnorm, info.converged = self.last_cg_iters, self.last_cg_resnorm, rc == 0
+        if x.data_ptr() != x0.data_ptr():
+            x0.copy_(x)
+        return x0
 
     # ---- to be provided by subclasses
     def apply_shift_dot(self, x, y, shift, out, skip):
@@ -421,6 +669,8 @@ class PartitionedOperator:
         native = self._local_native()
         if self.world == 1 and native is not None and not self.force_driver:
             return _engine_mod.lanczos(native, k, self.nloc, self.device, q0_slab, native=native, arena=arena)
+        if self._pop:
+            return self._lanczos_library(k, q0_slab, arena)
         be, n = self.be, self.nloc
         if hasattr(be, "reserve"):
             be.reserve(k)
@@ -460,6 +710,8 @@ class PartitionedOperator:
             x = _engine_mod.cg(b, x0, native=native, shift=E0, eps=eps, maxiter=self.dim if maxiter is None else maxiter)
             self.last_cg_iters, self.last_cg_resnorm = _engine_mod.last_cg.iters, _engine_mod.last_cg.resnorm
             return x
+        if self._pop:
+            return self._solve_library(E0, b, x0, eps, maxiter)
         be, n = self.be, self.nloc
         state = be.zeros(8)
         r, d, Ad = be.empty(n), be.empty(n), be.empty(n)
@@ -570,6 +822,7 @@ class PartitionedTFIMOperator(PartitionedOperator):
         # step is long compared with a host round trip (>= 2^22 rows per rank).
         self.overlap = (self.nloc >= (1 << 22)) if overlap == "auto" else bool(overlap)
         self.overlap_fallbacks = 0
+        self._pairwise_forced = False
         # top-bit flips: pairwise slab exchange for P = 2; from P = 4 on the transposed form -- all-to-all,
         # local flip sum, all-to-all back -- which puts 1/P of a slab on each of the P-1 links per phase instead
         # of a whole slab on log2(P) links (P = 8: a quarter of the transfer time)
@@ -579,6 +832,33 @@ class PartitionedTFIMOperator(PartitionedOperator):
             self._recv = []
         else:
             self._recv = [self.be.empty(nloc) for _ in range(self.p)]
+        self._pop_dHdg = None
+        self._ncomm = self._make_native_comm()
+        if self._ncomm is not None:
+            self._create_pops()
+
+    def _create_pops(self):
+        """library-side partitioned operators for H and dH/dg (they share the exchange scratch and the side stream)"""
+        from . import _lib
+        lib = self.be.lib
+        nd = int(lib.dsea_pop_tfim_scratch_doubles(self.L, self.world)) if self.p > 0 else 0
+        self._scratch = self.be.empty(max(nd, 2))
+        self._side_stream = torch.cuda.Stream(device=self.device) if self.p > 0 else None
+        side = c_void_p(self._side_stream.cuda_stream) if self._side_stream is not None else c_void_p(None)
+        gdev = self.g.detach()
+        self._g_keep = gdev
+        tau = float(_engine_mod.SHADOW_TAU)
+        for name, gptr, diag in (("_pop", c_void_p(gdev.data_ptr()), 1.0), ("_pop_dHdg", c_void_p(None), 0.0)):
+            h = c_void_p()
+            _lib.check(lib.dsea_pop_create_tfim(self.L, self._ncomm.handle, gptr, 1.0, diag,
+                                                c_void_p(self._scratch.data_ptr()) if self.p > 0 else c_void_p(None),
+                                                side, self._pop_flags(), tau, byref(h)), "dsea_pop_create_tfim")
+            setattr(self, name, h)
+
+    def _pop_flags(self):
+        from . import _lib
+        return (_lib.POP_OVERLAP if (self.overlap and self.p > 0) else 0) | \
+            (_lib.POP_PAIRWISE if self._pairwise_forced else 0)
 
     # With TWO ranks every mat-vec moves one whole slab over the single xGMI link between the two GPUs (268 MB at 2^25
     # rows: 3.5-5 ms) -- in the Lanczos step that hides behind the dots pass, in a CG iteration it does not: ~0.9 ms of
@@ -618,7 +898,11 @@ class PartitionedTFIMOperator(PartitionedOperator):
         """switch to the pairwise hypercube exchange (one full slab per partner), e.g. if the transposed form is
         unavailable on some stack"""
         self.transposed = False
+        self._pairwise_forced = True
         self._recv = [self.be.empty(self.nloc) for _ in range(self.p)]
+        if self._pop:
+            for h in (self._pop, self._pop_dHdg):
+                self.be.lib.dsea_pop_set_flags(h, self._pop_flags())
 
     def _local_native(self):
         return getattr(self.be, "op", None)
@@ -650,6 +934,12 @@ class PartitionedTFIMOperator(PartitionedOperator):
     # ---- mat-vec on buffers
     def matvec(self, x, y, which="H"):
         """y = H x (or dH/dg x) on this slab: local low-bit part in HIP, top-bit flips from the partners"""
+        if self._pop:
+            from . import _lib
+            be = self.be
+            _lib.check(be.lib.dsea_pop_matvec(self._pop if which == "H" else self._pop_dHdg, be.ws.handle, be._p(x),
+                                              be._p(y), None, None, None, be._st()), "dsea_pop_matvec")
+            return
         self.be.tfim_local(x, y, which)
         for buf in self._exchange(x):
             if which == "H":
@@ -778,6 +1068,14 @@ class PartitionedStencil3Operator(PartitionedOperator):
         self._halo = backend.zeros(2)
         backend.attach_stencil(rows, self.coef, self._Vdata, self._halo, self.has_lo, self.has_hi)
         super().__init__(n, rows, off, device, comm, backend)
+        self._ncomm = self._make_native_comm()
+        if self._ncomm is not None:
+            from . import _lib
+            h = c_void_p()
+            _lib.check(self.be.lib.dsea_pop_create_stencil3(rows, float(self.coef), c_void_p(self._Vdata.data_ptr()),
+                                                            c_void_p(self._halo.data_ptr()), self._ncomm.handle, byref(h)),
+                       "dsea_pop_create_stencil3")
+            self._pop = h
 
     @property
     def potential(self):
@@ -798,6 +1096,17 @@ class PartitionedStencil3Operator(PartitionedOperator):
     def apply_shift_dot(self, x, y, shift, out, skip):
         self._halo_exchange(x)
         self.be.stencil_local(x, y, shift, out, skip)
+
+    def matvec(self, x, y, which="H"):
+        if which != "H":
+            raise ValueError("this operator has no '%s' map" % which)
+        if self._pop:
+            from . import _lib
+            be = self.be
+            _lib.check(be.lib.dsea_pop_matvec(self._pop, be.ws.handle, be._p(x), be._p(y), None, None, None, be._st()),
+                       "dsea_pop_matvec")
+            return
+        self.apply_shift_dot(x, y, None, None, None)
 
     def H(self, v):
         return _PartStencilApply.apply(v, self._V, self)

@@ -289,6 +289,86 @@ int dsea_axpy_multi_dot(dsea_ws_t ws, double a_host, const double *a_dev, const 
 int dsea_plz_finish(dsea_ws_t ws, const double *r, const double *y, const double *pair, double *q_out, int row,
                     double *u_out, double *alpha_out, double *beta_out, int64_t n, void *stream);
 
+/* ------------------------------------------------------------------ row-partitioned solvers with the collectives
+ * INSIDE the library ("multi-GPU variants taking ncclComm_t / rank / world").
+ * No reference counterpart (the reference is single-device).  One process per GPU; every n-vector is this rank's
+ * slab of contiguous rows.  The library issues its slab kernels and the RCCL calls back to back on the caller's
+ * stream -- no host language between two phases of a step, no host synchronisation inside the Lanczos loop.
+ *
+ * Communicator.  Two RCCL communicators per rank: one carries the latency-bound all-reduces of the inner products on
+ * the solver's stream, the other the bandwidth-bound slab exchange of the mat-vec on a side stream (RCCL orders the
+ * operations of ONE communicator even across streams, which would serialise the exchange with the all-reduces it is
+ * meant to hide behind).  Either adopt communicators that already exist (ncclComm_t values, e.g. the ones PyTorch's
+ * ProcessGroupNCCL holds: torch exposes them) or let the library create its own from two unique ids that the caller
+ * distributes (128 bytes each, produced on rank 0).  RCCL is bound at run time from the copy already in the process
+ * (DSEA_ERR_UNSUPPORTED if there is none).  For transports other than RCCL (MPI, gloo in the tests) the caller
+ * supplies three blocking callbacks instead; they receive DEVICE pointers and the stream the data was produced on.   */
+typedef struct dsea_comm_s *dsea_comm_t;
+#define DSEA_COMM_ID_BYTES 128
+#define DSEA_ERR_COMM (-9)     /* an RCCL call (or a caller-supplied collective) failed                        */
+#define DSEA_ERR_PREMISE (-10) /* overlapped exchange: the premise max|c_j| <= tau ||r|| failed at some step -- results of
+                                  this run must be discarded and the run repeated without overlap (identical decision
+                                  on every rank: c is replicated)                                               */
+int dsea_comm_unique_id(void *id_out /* DSEA_COMM_ID_BYTES */);
+int dsea_comm_init_rank(const void *id_coll, const void *id_xchg, int rank, int world, dsea_comm_t *out);
+/* adopt existing ncclComm_t values (xchg_comm may equal coll_comm or be null: then exchange and all-reduces share one
+ * communicator and are ordered by RCCL); the library never destroys adopted communicators                        */
+int dsea_comm_adopt(void *coll_comm, void *xchg_comm, int rank, int world, dsea_comm_t *out);
+typedef int (*dsea_allreduce_fn)(void *user, double *buf, int64_t count, void *stream);           /* in-place sum     */
+typedef int (*dsea_alltoall_fn)(void *user, const double *send, double *recv, int64_t chunk, void *stream);
+typedef int (*dsea_sendrecv_fn)(void *user, const double *send, double *recv, int64_t count, int peer, void *stream);
+int dsea_comm_create_callbacks(int rank, int world, dsea_allreduce_fn allreduce, dsea_alltoall_fn alltoall,
+                               dsea_sendrecv_fn sendrecv, void *user, dsea_comm_t *out);
+int dsea_comm_destroy(dsea_comm_t comm);
+/* the collectives themselves, as the solvers issue them (tests, user-side inner products) */
+int dsea_comm_allreduce(dsea_comm_t comm, double *buf, int64_t count, void *stream);
+int dsea_comm_alltoall(dsea_comm_t comm, const double *send, double *recv, int64_t chunk, void *stream);
+
+/* Row-partitioned operator = slab-local operator + communicator + exchange scratch.
+ *   tfim     : chain of L sites over world = 2^p ranks, this rank holds rows [rank 2^(L-p), (rank+1) 2^(L-p)).  Low-bit
+ *              flips are slab-local (dsea_op_create_tfim with L_local = L - p); the top p bits come from the partner
+ *              slabs rank ^ (1<<b): pairwise exchange (p whole slabs) for world = 2, TRANSPOSED form from world = 4 on
+ *              (all-to-all, dsea_hypercube_flipsum, all-to-all back: 2 (P-1)/P slabs spread over all links).
+ *              `scratch`: caller-owned, dsea_pop_tfim_scratch_doubles(L, world) doubles.  `side_stream` (nullable):
+ *              stream for the exchange; with it the exchange runs behind the slab-local work of the step.
+ *              flags: DSEA_POP_OVERLAP -- in the Lanczos step the exchange is started on the UN-corrected r before the
+ *              dots pass (r - r' = Q c is at the 1e-14 level while |c_j| <~ 1e-15 ||r||); the premise
+ *              max|c_j| <= tau ||r|| is checked ON THE DEVICE every step and recorded: dsea_pop_lanczos_status reports
+ *              DSEA_ERR_PREMISE after the run instead of a host round trip per step.  In the CG solve the vector is
+ *              final when the mat-vec starts, so the side-stream exchange is exact there.
+ *              DSEA_POP_PAIRWISE forces the pairwise form at any world size.
+ *   stencil3 : dsea_op_create_stencil3 semantics on contiguous slabs; halo2 = two device doubles the exchange fills
+ *              (x[-1] from rank-1, x[n] from rank+1; a missing neighbour is the Dirichlet zero).                    */
+typedef struct dsea_pop_s *dsea_pop_t;
+#define DSEA_POP_OVERLAP 1
+#define DSEA_POP_PAIRWISE 2
+size_t dsea_pop_tfim_scratch_doubles(int L, int world);
+int dsea_pop_create_tfim(int L, dsea_comm_t comm, const double *g_dev, double g_const, double diag_scale,
+                         double *scratch, void *side_stream, int flags, double tau, dsea_pop_t *out);
+int dsea_pop_create_stencil3(int64_t n_local, double coef, const double *V_dev, double *halo2, dsea_comm_t comm,
+                             dsea_pop_t *out);
+int dsea_pop_destroy(dsea_pop_t pop);
+int dsea_pop_set_flags(dsea_pop_t pop, int flags);
+/* y = (A - (*shift)) x over all ranks; if dot_out != null: *dot_out = GLOBAL x.y (all-reduced, identical on every
+ * rank); skip_flag as in dsea_spmv.                                                                              */
+int dsea_pop_matvec(dsea_pop_t pop, dsea_ws_t ws, const double *x, double *y, const double *shift, double *dot_out,
+                    const double *skip_flag, void *stream);
+/* out = GLOBAL x.y */
+int dsea_pop_dot(dsea_pop_t pop, dsea_ws_t ws, const double *x, const double *y, int64_t n, double *out, void *stream);
+/* k-step Lanczos with full re-orthogonalisation on slabs (reference Lanczos.py:49-77 distributed): per step the
+ * macro phases above with TWO all-reduces (coefficients + ||r||^2 ; ||r||^2, r.Ar) and ONE exchange, all issued by
+ * the library on `stream` / the side stream.  alphas[k], betas[max(k-1,1)] are replicated bit-identically.  A bf16
+ * shadow registered on the workspace is used and kept current.  No host synchronisation inside.                  */
+int dsea_pop_lanczos_run(dsea_pop_t pop, dsea_ws_t ws, int k, const double *q0, double *Q, int64_t ldq,
+                         double *alphas, double *betas, void *stream);
+/* SYNCHRONISES: DSEA_OK, or DSEA_ERR_PREMISE with *step = first step whose overlap premise failed                 */
+int dsea_pop_lanczos_status(dsea_pop_t pop, dsea_ws_t ws, int *step, void *stream);
+/* CG on (A - (*shift)) x = b on slabs (reference CG.py:24-41 distributed): per iteration one exchange and two scalar
+ * all-reduces; the stopping test runs on the device on replicated scalars, the host polls every `poll_every`
+ * iterations.  SYNCHRONISES before returning.  r, d, Ad: the workspace's vectors.                                 */
+int dsea_pop_cg_run(dsea_pop_t pop, dsea_ws_t ws, const double *shift, const double *b, double *x, double *state,
+                    double eps, int64_t maxiter, int poll_every, int64_t *iters_out, double *resnorm_out, void *stream);
+
 /* ------------------------------------------------------------------ whole solvers (native operator, one GPU)
  * k-step Lanczos with full re-orthogonalisation, entirely on the stream, no host sync.
  *   q0      : start vector (need not be normalised; Lanczos.py:52-53)

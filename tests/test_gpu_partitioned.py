@@ -91,6 +91,29 @@ def _case_driver(rank, world, backend, dev, overlap=False, replicate="auto"):
     return (E0.item(), psi.cpu().numpy().copy(), grad.item(), solver.last_cg_iters)
 
 
+def _case_driver_env(rank, world, backend, dev, overlap, env, tau=None):
+    """_case_driver with environment switches (DSEA_DRIVER=python: the Python driver; DSEA_COMM=own: library-created
+    RCCL communicators) -- returns which driver ran and the premise-fallback count as well"""
+    from dominantsparseeigenad_amd import engine
+    from dominantsparseeigenad_amd.partitioned import PartitionedTFIM
+    os.environ.update(env)
+    if tau is not None:
+        engine.SHADOW_TAU = tau
+    p = world.bit_length() - 1
+    nloc = 1 << (L - p)
+    off = rank * nloc
+    g = torch.tensor([G], dtype=torch.float64, device=dev)
+    solver = PartitionedTFIM(L, g, dev, eps=1e-12, comm=_comm(backend))
+    solver.overlap = overlap
+    q0 = torch.from_numpy(normal_vector(nloc, 5100, offset=off)).to(dev)
+    x0 = torch.from_numpy(normal_vector(nloc, 5102, offset=off)).to(dev)
+    t = torch.from_numpy(normal_vector(nloc, 5103, offset=off)).to(dev)
+    E0, psi, grad = solver.forward_backward(K, q0, x0, t)
+    torch.cuda.synchronize()
+    return (E0.item(), psi.cpu().numpy().copy(), grad.item(), solver.last_cg_iters, solver.op.driver,
+            solver.op.overlap_fallbacks)
+
+
 def _case_api_tfim(rank, world, backend, dev, tag, second_order, force_driver):
     """reference API on a row-partitioned TFIM operator (HIP slab kernels)"""
     from helpers import PatchRandn
@@ -278,3 +301,44 @@ def test_replicated_cg_on_hip_slabs_matches_partitioned_cg():
         assert repl[r][2] == repl[0][2]                                     # replicated gradient bit-identical on all ranks
     assert abs(repl[0][2] - part[0][2]) < 1e-9 * abs(part[0][2])
     assert abs(repl[0][3] - part[0][3]) <= 1                                # iteration counts (different summation orders)
+
+
+@pytest.mark.parametrize("world,backend,overlap", [(1, "nccl", False), (2, "gloo", True), (4, "gloo", True), (4, "gloo", False)])
+def test_library_driver_equals_python_driver(world, backend, overlap):
+    """include/dsea.h "row-partitioned solvers": dsea_pop_lanczos_run / dsea_pop_cg_run issue the slab kernels AND the
+    collectives from inside the library (RCCL at world size 1; caller-supplied callbacks -- host-staged gloo -- for
+    ranks sharing the GPU).  Same kernels in the same order as the Python driver of partitioned.py, so the results are
+    bit-identical: E0, psi, gradient, CG iteration count."""
+    lib_run = _run(world, backend, "_case_driver_env", overlap, {})
+    py_run = _run(world, backend, "_case_driver_env", overlap, {"DSEA_DRIVER": "python"})
+    for r in range(world):
+        assert lib_run[r][4].startswith("library") and py_run[r][4] == "python", (lib_run[r][4], py_run[r][4])
+        assert lib_run[r][0] == py_run[r][0] and lib_run[r][2] == py_run[r][2] and lib_run[r][3] == py_run[r][3]
+        assert np.array_equal(lib_run[r][1], py_run[r][1])
+        assert lib_run[r][5] == 0 and py_run[r][5] == 0
+    if world == 1:
+        assert "rccl" in lib_run[0][4]
+    else:
+        assert "callbacks" in lib_run[0][4]
+
+
+def test_library_owned_rccl_communicators_world1():
+    """dsea_comm_unique_id / dsea_comm_init_rank: the library creates its own pair of RCCL communicators (ids produced on
+    rank 0 and broadcast) instead of adopting torch's; same numbers as the adopted pair."""
+    own = _run(1, "nccl", "_case_driver_env", False, {"DSEA_COMM": "own"})
+    adopt = _run(1, "nccl", "_case_driver_env", False, {"DSEA_COMM": "adopt"})
+    assert "library-owned" in own[0][4] and "adopted" in adopt[0][4]
+    assert own[0][0] == adopt[0][0] and own[0][2] == adopt[0][2] and np.array_equal(own[0][1], adopt[0][1])
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_overlap_premise_is_checked_on_the_device_and_a_violation_repeats_the_run(world):
+    """The overlapped exchange sends the UN-corrected r; its premise max|c_j| <= tau ||r|| is evaluated by a kernel each
+    step and read ONCE after the run (dsea_pop_lanczos_status -> DSEA_ERR_PREMISE), not by a host round trip per step.
+    tau = 0 makes every step violate it: the run is discarded and repeated with the exchange after the correction --
+    the result equals the non-overlapped run bit for bit and exactly one fallback is counted."""
+    forced = _run(world, "gloo", "_case_driver_env", True, {}, 0.0)
+    plain = _run(world, "gloo", "_case_driver_env", False, {}, 0.0)
+    for r in range(world):
+        assert forced[r][5] == 1 and plain[r][5] == 0
+        assert forced[r][0] == plain[r][0] and forced[r][2] == plain[r][2] and np.array_equal(forced[r][1], plain[r][1])

@@ -2,7 +2,7 @@
 """Random configurations of the row-partitioned path on ONE GPU (ranks share the device, collectives staged through
 the host over gloo): world size, chain length, Krylov dimension (k = 40 INCLUDED), coupling, overlapped exchange,
 replicated CG -- against the single-device path on the same synthetic vectors, JUDGED AGAINST THE SINGLE-DEVICE PATH'S
-OWN SPREAD.
+OWN SPREAD, at the reference's CG tolerance (eps = 1e-7, CG.py:25) and at the tight one (1e-12).
 
 Why a spread: with k too small the Ritz pair (theta, psi) is not converged; the adjoint system (A - theta) x = b of
 reference symeig.py:81 / CG.py:120 is then INDEFINITE (theta lies inside the spectrum), CG on it is not a convergent
@@ -13,8 +13,10 @@ single-GPU path is run in several rounding-different but equally valid geometrie
     auto | rows-per-lane 4 | rows-per-lane 16 | split 4 | bf16 shadow off
 
 (include/dsea.h: dsea_ws_set_rows_per_lane / dsea_ws_set_split; engine.USE_SHADOW) and the partitioned result must lie
-within  max(1e-8, 10 x self-spread)  of the default single-GPU result (E0: 1e-10 relative, always).  The eigen-residual
-||H psi - theta psi|| is printed: a self-spread above 1e-8 must come with an unconverged pair.
+within  max(tol(eps), 10 x self-spread)  of the default single-GPU result (E0: 1e-10 relative, always).  The
+eigen-residual ||H psi - theta psi|| is printed: a self-spread above 1e-8 must come with a pair that is unconverged AT
+THAT eps (residual > eps: b = t - (psi.t) psi then keeps a component of size ~residual along the true eigenvector, which
+(A - theta) amplifies by 1 / (theta - lambda_min) ~ gap / residual^2 once CG resolves it).
 
     python tools/fuzz_partitioned.py [--cases 30] [--seed 0]          (worker processes are started once per world size)
 """
@@ -31,6 +33,8 @@ import torch  # noqa: E402
 import torch.multiprocessing as mp  # noqa: E402
 
 VARIANTS = ("auto", "rpl4", "rpl16", "split4", "noshadow")
+EPS_LIST = (1e-7, 1e-12)      # the reference's hard-coded CG tolerance (CG.py:25) and the tight one of the 1e-10 parity tests
+TOL = {1e-7: 2e-8, 1e-12: 1e-8}
 
 
 def single(L, k, g0, variant="auto", eps=1e-12):
@@ -87,7 +91,6 @@ def worker(rank, world, port, cases, ret):
         from helpers import PatchRandn
         from test_gpu_partitioned import _host_staged_comm
         out = []
-        CG.EPS_DEFAULT = 1e-12
         for (L, k, g0, overlap, replicate) in cases:
             n = 1 << L
             nloc = n // world
@@ -100,12 +103,16 @@ def worker(rank, world, port, cases, ret):
             t_full = torch.from_numpy(normal_vector(n, 77))
             t_full = t_full / t_full.norm()
             t = t_full[off:off + nloc].to(dev)
-            with PatchRandn(4242, offset=off):
-                E0, psi = symeig.DominantSparseSymeig.apply(g, k, op.dim, dev)
-                sgn = 1.0 if op.dot(psi.detach(), t).item() > 0 else -1.0
-                (gl,) = torch.autograd.grad(E0 + sgn * op.dot(psi, t), g)
-            torch.cuda.synchronize()
-            out.append((E0.item(), gl.item(), op.overlap_fallbacks, op.last_cg_iters))
+            per_eps = []
+            for eps in EPS_LIST:
+                CG.EPS_DEFAULT = eps
+                with PatchRandn(4242, offset=off):
+                    E0, psi = symeig.DominantSparseSymeig.apply(g, k, op.dim, dev)
+                    sgn = 1.0 if op.dot(psi.detach(), t).item() > 0 else -1.0
+                    (gl,) = torch.autograd.grad(E0 + sgn * op.dot(psi, t), g)
+                torch.cuda.synchronize()
+                per_eps.append((E0.item(), gl.item(), op.overlap_fallbacks, op.last_cg_iters))
+            out.append(per_eps)
         ret[rank] = out
     finally:
         dist.destroy_process_group()
@@ -141,35 +148,40 @@ def main():
         mp.spawn(worker, args=(world, port, [c[1:] for _, c in sub], ret), nprocs=world, join=True)
         for j, (i, _) in enumerate(sub):
             results[i] = [ret[r][j] for r in range(world)]
-    bad = unexplained = 0
+    bad = unexplained = illposed = 0
     worst_ok = 0.0
-    print("# %s --cases %d --seed %d   (tolerance for the gradient: max(1e-8, 10 x single-GPU self-spread))"
-          % (os.path.basename(__file__), args.cases, args.seed))
+    print("# %s --cases %d --seed %d" % (os.path.basename(__file__), args.cases, args.seed))
+    print("# per case and CG tolerance eps: partitioned vs default single-GPU gradient | single-GPU SELF-SPREAD over %d "
+          "rounding-different geometries | verdict.  Tolerance max(%g (eps 1e-7) / %g (eps 1e-12), 10 x self-spread); a case "
+          "whose single-GPU path disagrees with ITSELF by more than 1e-3 is ILL-POSED (not judged); any self-spread above "
+          "1e-8 must come with a Ritz residual above eps (the projected system (A - theta) x = b is then inconsistent at "
+          "that tolerance), else it is flagged UNEXPLAINED." % (len(VARIANTS), TOL[1e-7], TOL[1e-12]))
     for i, (world, L, k, g0, overlap, replicate) in enumerate(cases):
-        runs = {v: single(L, k, g0, v) for v in VARIANTS}
-        E_s, g_s, resid, it_s, conv_s = runs["auto"]
-        spread = max(abs(runs[v][1] - g_s) / abs(g_s) for v in VARIANTS)
-        E_spread = max(abs(runs[v][0] - E_s) / abs(E_s) for v in VARIANTS)
-        g_eps7 = single(L, k, g0, "auto", eps=1e-7)[1]      # the reference's hard-coded tolerance (CG.py:25), for scale
-        E_p, g_p, fb, it_p = results[i][0]
-        same = all(tuple(results[i][r][:2]) == tuple(results[i][0][:2]) for r in range(world))
-        dE, dg = abs(E_p - E_s) / abs(E_s), abs(g_p - g_s) / abs(g_s)
-        tol = max(1e-8, 10.0 * spread)
-        ok = dE <= 1e-10 and dg <= tol and same
-        # a spread above 1e-8 is only legitimate with an unconverged Ritz pair (indefinite adjoint system)
-        explained = spread <= 1e-8 or resid > 1e-7
-        bad += not ok
-        unexplained += not explained
-        if ok and spread <= 1e-8:
-            worst_ok = max(worst_ok, dg)
-        print("%s world=%d L=%2d k=%3d g=%.1f overlap=%-5s replicate=%-5s  E0 dev %.1e  grad dev %.1e | single-GPU "
-              "self-spread: E0 %.1e grad %.1e (eps 1e-7 vs 1e-12: %.1e), ||H psi - theta psi|| %.1e, CG its %d/%d%s | "
-              "premise fallbacks %d%s"
-              % ("ok  " if ok else "FAIL", world, L, k, g0, overlap, replicate, dE, dg, E_spread, spread,
-                 abs(g_eps7 - g_s) / abs(g_s), resid, it_s, it_p, "" if conv_s else " (not converged)", fb,
-                 "" if explained else "  UNEXPLAINED SPREAD"), flush=True)
-    print("cases %d  failures %d  unexplained self-spreads %d  worst gradient deviation among well-posed cases %.1e"
-          % (args.cases, bad, unexplained, worst_ok))
+        head = "world=%d L=%2d k=%3d g=%.1f overlap=%-5s replicate=%-5s" % (world, L, k, g0, overlap, replicate)
+        for e, eps in enumerate(EPS_LIST):
+            runs = {v: single(L, k, g0, v, eps=eps) for v in VARIANTS}
+            E_s, g_s, resid, it_s, conv_s = runs["auto"]
+            spread = max(abs(runs[v][1] - g_s) / abs(g_s) for v in VARIANTS)
+            E_spread = max(abs(runs[v][0] - E_s) / abs(E_s) for v in VARIANTS)
+            E_p, g_p, fb, it_p = results[i][0][e]
+            same = all(tuple(results[i][r][e][:2]) == tuple(results[i][0][e][:2]) for r in range(world))
+            dE, dg = abs(E_p - E_s) / abs(E_s), abs(g_p - g_s) / abs(g_s)
+            ill = spread > 1e-3
+            ok = dE <= 1e-10 and same and E_spread <= 1e-10 and (ill or dg <= max(TOL[eps], 10.0 * spread))
+            explained = spread <= 1e-8 or resid > eps
+            bad += not ok
+            unexplained += not explained
+            illposed += ill
+            if ok and spread <= 1e-8:
+                worst_ok = max(worst_ok, dg)
+            verdict = "FAIL" if not ok else ("ILL-POSED" if ill else "ok")
+            print("%-9s %s eps=%.0e  E0 dev %.1e  grad dev %.1e | self-spread E0 %.1e grad %.1e | ||H psi - theta psi|| "
+                  "%.1e  CG its %d (single) / %d (partitioned)%s  premise fallbacks %d%s"
+                  % (verdict, head, eps, dE, dg, E_spread, spread, resid, it_s, it_p,
+                     "" if conv_s else " not converged", fb, "" if explained else "  UNEXPLAINED SPREAD"), flush=True)
+    print("cases %d x %d tolerances  failures %d  unexplained self-spreads %d  ill-posed (single-GPU path disagrees with "
+          "itself by > 1e-3) %d  worst gradient deviation among cases with self-spread <= 1e-8: %.1e"
+          % (args.cases, len(EPS_LIST), bad, unexplained, illposed, worst_ok))
     return 1 if (bad or unexplained) else 0
 
 
