@@ -247,6 +247,8 @@ int stencil_halo_exchange(dsea_pop_s* P, const double* x, hipStream_t st) {
 // y = (A - shift) x over all ranks, LOCAL x.y into dot_local (ws scalar)
 int pop_apply(dsea_pop_s* P, dsea_ws_t ws, const double* x, double* y, const double* shift, const double* skip,
               double* dot_local, hipStream_t st) {
+  if (P->kind == OP_TFIM && P->p == 0)   // one rank: nothing to exchange, shift and dot ride on the mat-vec itself
+    return dsea_spmv(&P->local, ws, x, y, shift, dot_local, skip, (void*)st);
   if (P->kind == OP_TFIM) {
     DSEA_TRY(tfim_exchange_start(P, x, st));
     DSEA_TRY(dsea_spmv(&P->local, nullptr, x, y, nullptr, nullptr, skip, (void*)st));
@@ -515,7 +517,9 @@ int dsea_pop_lanczos_run(dsea_pop_t P, dsea_ws_t ws, int k, const double* q0, do
       DSEA_TRY(comm_allreduce(P->comm, c, i + 1, st));
     }
     DSEA_TRY(dsea_plz_correct(ws, Q, ldq, n, i, c, r, pair, stream));
-    if (tfim) {
+    if (tfim && P->p == 0) {
+      DSEA_TRY(dsea_spmv(&P->local, ws, r, y, nullptr, pair + 1, nullptr, stream));
+    } else if (tfim) {
       if (!overlap) DSEA_TRY(tfim_exchange_start(P, r, st));       // r is final: exact, runs behind the local mat-vec
       DSEA_TRY(dsea_spmv(&P->local, nullptr, r, y, nullptr, nullptr, nullptr, stream));
       DSEA_TRY(tfim_exchange_finish(P, st));
