@@ -225,8 +225,8 @@ def launch_workers(n):
 # one-GPU anchors of the two multi-GPU curves as last measured on an MI355X by `bench.py --gpus 1` of this repository
 # (profiles/, with the commit of the run); the N = 1 line re-measures them live (config.one_gpu_anchors)
 STORED_ANCHORS = {
-    "strong_L28_k100_ms": 5204.96, "strong_source": "profiles/r02_bench_L28_k100_one_gpu_final_kernels.json (commit ba73e41)",
-    "weak_2p25_rows_k200_ms": 1350.0, "weak_source": "profiles/r02_bench_partitioned_driver_2p25_rows_final_kernels.json (commit ba73e41)",
+    "strong_L28_k100_ms": 5164.32, "strong_source": "profiles/r03_bench.json config.one_gpu_anchors.strong_L28_k100 (commit 0859cad)",
+    "weak_2p25_rows_k200_ms": 1246.13, "weak_source": "profiles/r03_bench.json config.one_gpu_anchors.weak_2p25_rows_k200 (commit 0859cad)",
 }
 
 
@@ -241,6 +241,7 @@ class Problem:
         self.L, self.k, self.world, self.rank, self.dev, self.dry = L, k, world, rank, dev, dry
         self.partitioned = partitioned_path
         self.reorth = reorth
+        self.notes = {}
         p = int(np.log2(world))
         self.p, self.Lloc = p, L - p
         self.nloc, self.n = 1 << (L - p), 1 << L
@@ -256,7 +257,6 @@ class Problem:
         self.g = torch.tensor([1.0], dtype=torch.float64, device=dev, requires_grad=True)
         self.draws = [slab(SEED + 10 + c) for c in range(3)]  # q0, unused second draw, CG start vector
         tvec = slab(SEED + 1)
-        self.notes = {}
         if not partitioned_path:
             from dominantsparseeigenad_amd.operators import TFIMOperator
             self.tvec = tvec / tvec.norm()
@@ -273,7 +273,21 @@ class Problem:
                 sys.path.insert(0, os.path.join(ROOT, "tests"))
                 from cpu_backend import CpuBackend
                 backend = CpuBackend(self.nloc)
-            self.op = partitioned.PartitionedTFIMOperator(L, self.g, dev, backend=backend, overlap=True if dry else "auto")
+            # The library-side driver (RCCL calls issued by libdsea) needs its communicators; if creating them fails on
+            # ANY rank the decision to use the Python driver instead is taken collectively (an all-reduced flag)
+            import torch.distributed as dist
+            failed = torch.zeros(1, dtype=torch.float64, device=dev)
+            try:
+                self.op = partitioned.PartitionedTFIMOperator(L, self.g, dev, backend=backend, overlap=True if dry else "auto")
+            except Exception as exc:  # noqa: BLE001
+                failed[0] = 1.0
+                self.notes["partitioned_driver_fallback_reason"] = "%s: %s" % (type(exc).__name__, str(exc)[:160])
+            dist.all_reduce(failed)
+            if failed.item() > 0:
+                os.environ["DSEA_DRIVER"] = "python"
+                self.op = partitioned.PartitionedTFIMOperator(L, self.g, dev, backend=backend, overlap=True if dry else "auto")
+                self.notes["partitioned_driver_fallback"] = "library driver unavailable on %d rank(s): Python driver used" \
+                                                            % int(failed.item())
             self.op.force_driver = True
             self.A_operand = self.op.H
             self.dot = self.op.dot
@@ -350,6 +364,7 @@ class Problem:
             if warmup == 0:
                 E0, gl = self.step()
             resid = self.eigen_residual(E0, self.last["psi"])
+            notes["partitioned_driver"] = getattr(op, "driver", "python")
             notes["slab_exchange"] = ("none (one rank)" if op.p == 0 else
                                       ("transposed all-to-all form" if op.transposed else "pairwise hypercube partners")
                                       + (", overlapped with the dots / correction passes" if op.overlap else ""))

@@ -79,6 +79,11 @@ class HipBackend(_engine_mod.Phases):
         handle = self.op.handle if which == "H" else self.op._dHdg.handle
         self._ck(self.lib.dsea_spmv(handle, None, self._p(x), self._p(y), None, None, None, self._st()), "dsea_spmv")
 
+    def tfim_local_shift_dot(self, x, y, shift, out, skip):
+        """one rank: y = (H - shift) x with the local x.y from the mat-vec's own epilogue (nothing to exchange)"""
+        self._ck(self.lib.dsea_spmv(self.op.handle, self.ws.handle, self._p(x), self._p(y), self._p(shift),
+                                    self._p(out), self._p(skip), self._st()), "dsea_spmv")
+
     def attach_stencil(self, n_local, coef, V, halo, has_lo, has_hi):
         """3-point stencil on this slab; halo[0] / halo[1] are the neighbours' edge elements (device doubles
         filled by the halo exchange); a missing neighbour is the Dirichlet zero of schrodinger1D.py:20-21"""
@@ -951,6 +956,9 @@ class PartitionedTFIMOperator(PartitionedOperator):
         """y = (H - shift) x with the remote part, the shift and the local x.y in ONE kernel after the exchange.
         The exchange is started first (side stream) and runs behind the slab-local part of the mat-vec -- x is final
         here, so unlike the Lanczos overlap nothing is approximated."""
+        if self.p == 0 and hasattr(self.be, "tfim_local_shift_dot"):
+            self.be.tfim_local_shift_dot(x, y, shift, out if out is not None else self.be.zeros(1), skip)
+            return
         if self.p > 0 and hasattr(self.comm, "start_pair_exchange"):
             token = self._start_exchange(x)
             self.be.tfim_local(x, y, "H")
@@ -994,9 +1002,15 @@ class PartitionedTFIMOperator(PartitionedOperator):
             if i >= 1:
                 be.plz_dots(S.Q, S.ldq, n, i, S.u, prev_a, prev_b, S.r, S.c)
                 self.comm.allreduce(S.c[:i + 1])
-            be.plz_correct_matvec(S.Q, S.ldq, i, S.c, S.r, S.y, S.pair)
-            recv = self._exchange(S.r)
-        be.axpy_multi_dot(-1.0, self.g.detach(), recv, None, None, S.r, S.y, S.pair[1:2])
+            if self.p == 0 and hasattr(be, "tfim_local_shift_dot"):
+                be.plz_correct(S.Q, S.ldq, n, i, S.c, S.r, S.pair)
+                be.tfim_local_shift_dot(S.r, S.y, None, S.pair[1:2], None)
+                recv = None
+            else:
+                be.plz_correct_matvec(S.Q, S.ldq, i, S.c, S.r, S.y, S.pair)
+                recv = self._exchange(S.r)
+        if recv is not None:
+            be.axpy_multi_dot(-1.0, self.g.detach(), recv, None, None, S.r, S.y, S.pair[1:2])
         self.comm.allreduce(S.pair)
         be.plz_finish(S.r, S.y, S.pair, S.Q[i], i, S.u, S.alphas[i:i + 1], S.betas[i - 1:i] if i >= 1 else None)
 
