@@ -146,6 +146,7 @@ int dsea_ws_create(void* device_buffer, size_t bytes, int64_t n, int kmax, dsea_
   ws->w.rpl_override = 0;
   ws->w.split_override = -1;
   ws->w.persist_override = -1;
+  ws->w.lz_persist = -1;
   ws->w.prof = nullptr;
   ws->w.shadow = nullptr;
   ws->w.shadow_ld = 0;
@@ -266,6 +267,12 @@ int dsea_ws_set_persist(dsea_ws_t ws, int mode) {
     return DSEA_ERR_ARG;
   if (mode >= 100 && geo == -1) return DSEA_ERR_ARG;
   ws->w.persist_override = mode;
+  return DSEA_OK;
+}
+
+int dsea_ws_set_lanczos_persist(dsea_ws_t ws, int mode) {
+  if (!ws || (mode != -1 && mode != 0 && mode != 1)) return DSEA_ERR_ARG;
+  ws->w.lz_persist = mode;
   return DSEA_OK;
 }
 
@@ -710,6 +717,22 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
       return DSEA_ERR_HIP;
     }
   }
+  // README-sized problems (n <= 8192, k <= 512; full-space TFIM / halo-free stencil): the whole loop as ONE launch
+  // (dsea_lanczos_persist.hip).  The granule buffers live in the partial-sum area, unused by that form.
+  // (automatic: up to 32 workgroups = 4096 rows, where it is measured to win; mode 1 forces it up to its envelope)
+  if (w.lz_persist != 0 && (w.lz_persist == 1 || n <= 4096) && !prof && lanczos_persist_applicable(op->d, n, k) &&
+      lanczos_persist_comm_bytes(n, k) <= (size_t)DSEA_MAX_WAVE_TILES * (size_t)((w.kmax < 1 ? 1 : w.kmax) + 1) * sizeof(double)) {
+    if (hipMemsetAsync(w.scal + DSEA_SCAL_LZ_FAIL, 0, sizeof(double), st) != hipSuccess) {
+      g_last_hip = (int)hipGetLastError();
+      return DSEA_ERR_HIP;
+    }
+    const int pr = launch_lanczos_persist(op->d, k, q0, Q, ldq, alphas, betas, brk, w.scal + DSEA_SCAL_LZ_FAIL, P, st);
+    if (pr == -2) {
+      g_last_hip = (int)hipGetLastError();
+      return DSEA_ERR_HIP;
+    }
+    if (pr == 0) return check_launch();
+  }
   const int rps = lp_rows_per_step(n, g.split_w != 0);   // 0 = split form
   launch_dot(q0, q0, n, P, nrm2, st);
   launch_scale_store(q0, nrm2, Q, nullptr, n, st, Qs);
@@ -962,7 +985,7 @@ int dsea_gmres_cycle(dsea_op_t op, dsea_ws_t ws, const double* shift, const doub
 
 int dsea_lanczos_status(dsea_ws_t ws, int* break_step, void* stream) {
   if (!ws) return DSEA_ERR_ARG;
-  double h[2] = {0.0, 0.0};
+  double h[DSEA_SCAL_LZ_FAIL - DSEA_SCAL_BREAK + 1];
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (hipMemcpyAsync(h, ws->w.scal + DSEA_SCAL_BREAK, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess ||
       hipStreamSynchronize(st) != hipSuccess) {
@@ -970,6 +993,7 @@ int dsea_lanczos_status(dsea_ws_t ws, int* break_step, void* stream) {
     return DSEA_ERR_HIP;
   }
   if (break_step) *break_step = (int)h[0];
+  if (h[DSEA_SCAL_LZ_FAIL - DSEA_SCAL_BREAK] != 0.0) return DSEA_ERR_TIMEOUT;   // single-launch form: a peer was lost
   return h[0] != 0.0 ? DSEA_ERR_BREAKDOWN : DSEA_OK;
 }
 

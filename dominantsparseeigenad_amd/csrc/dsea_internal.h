@@ -16,6 +16,7 @@
 #define DSEA_PERSIST_CG_MAX_TILES 1024 /* persistent single-launch CG: n <= 2^19 rows                       */
 #define DSEA_SCALARS 64
 #define DSEA_SCAL_BREAK 20    /* scal[20] = breakdown step, scal[21] = running scale (see broken())     */
+#define DSEA_SCAL_LZ_FAIL 38  /* scal[38] = 1 when the single-launch Lanczos lost a peer workgroup (timeout) */
 
 namespace dsea {
 
@@ -111,6 +112,7 @@ struct Workspace {
   int rpl_override;
   int split_override;  // -1 automatic, 0 off, 4/8/16 forced
   int persist_override;  // persistent single-launch CG: -1 automatic, 0 off, 1/2/4 = row pairs per thread forced
+  int lz_persist;        // single-launch Lanczos for small problems: -1 automatic (on where it applies), 0 off
   double* partials;  // DSEA_MAX_WAVE_TILES * max(kmax,1) doubles (also >= DSEA_MAX_EW_BLOCKS)
   double* aux;       // 4 * DSEA_MAX_WAVE_TILES doubles: small partial buffers that must not alias `partials`
   double* coef;      // kmax doubles
@@ -194,6 +196,11 @@ int launch_cg_persist(const OpDesc& op, const double* shift, const double* b, do
                       int64_t maxiter, void* comm, int ppt_override, hipStream_t st);
 int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shift, const double* skip,
                 double* P, hipStream_t st, EventPair* ev = nullptr);
+// dsea_lanczos_persist.hip
+bool lanczos_persist_applicable(const OpDesc& op, int64_t n, int k);
+size_t lanczos_persist_comm_bytes(int64_t n, int k);
+int launch_lanczos_persist(const OpDesc& op, int k, const double* q0, double* Q, int64_t ldq, double* alphas,
+                           double* betas, double* brk, double* fail, void* comm, hipStream_t st);
 
 }  // namespace dsea
 

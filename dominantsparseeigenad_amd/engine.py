@@ -27,6 +27,11 @@ SHADOW_TAU = 1e-12
 # upper-triangle mat-vec (operators.SymmetricDenseOperator): only the upper triangle of the tensor is read.  Set to
 # False to apply them with torch.matmul (rocBLAS GEMV on the full matrix) instead.
 DENSE_SYMMETRIC_KERNEL = True
+# README-sized problems (full-space TFIMOperator, Stencil3Operator; k <= 512): the whole Lanczos loop as ONE launch
+# (csrc/dsea_lanczos_persist.hip).  Same algorithm and expressions, T equal to the multi-launch form to rounding (not bit
+# for bit).  True = automatic (n <= 4096, where it is measured to win), "force" = wherever it applies (n <= 8192),
+# False keeps every workspace on the multi-launch kernels.
+LANCZOS_PERSIST = True
 last_lp_steps = (0, 0)
 last_break = 0
 
@@ -74,6 +79,7 @@ class Workspace:
         self.scal = torch.zeros(16, dtype=F64, device=self.device)
         self.busy = None            # name of the solver that currently owns this workspace (see ``owned_by``)
         self.persist_mode = -1
+        self.lanczos_persist_mode = -1
 
     def __del__(self):
         try:
@@ -121,6 +127,12 @@ class Workspace:
     def set_persist(self, mode):
         check(self.lib.dsea_ws_set_persist(self.handle, int(mode)), "dsea_ws_set_persist")
         self.persist_mode = int(mode)
+
+    def set_lanczos_persist(self, mode):
+        """single-launch Lanczos for README-sized problems (include/dsea.h dsea_ws_set_lanczos_persist): -1 = automatic
+        (on where it applies), 0 = off"""
+        check(self.lib.dsea_ws_set_lanczos_persist(self.handle, int(mode)), "dsea_ws_set_lanczos_persist")
+        self.lanczos_persist_mode = int(mode)
 
     def set_split(self, waves):
         check(self.lib.dsea_ws_set_split(self.handle, int(waves)), "dsea_ws_set_split")
@@ -365,10 +377,28 @@ def lanczos(A, k, n, device, q0, native=None, callable_A=None, arena=False):
                 shadow = new_shadow()
                 check(lib.dsea_ws_set_shadow(ws.handle, _ptr(shadow), ldq, int(k), float(SHADOW_TAU)), "dsea_ws_set_shadow")
             try:
+                want = 0 if (not LANCZOS_PERSIST or getattr(ws, "lanczos_persist_lost", False)) else \
+                    (1 if LANCZOS_PERSIST == "force" else -1)
+                if ws.lanczos_persist_mode != want:
+                    ws.set_lanczos_persist(want)
                 check(lib.dsea_lanczos_run(native.handle, ws.handle, int(k), _ptr(q0), _ptr(Q), ldq, _ptr(alphas),
                                            _ptr(betas), st), "dsea_lanczos_run")
                 brk = ctypes.c_int(0)
-                check(lib.dsea_lanczos_status(ws.handle, byref(brk), st), "dsea_lanczos_status", allow=(_lib.ERR_BREAKDOWN,))
+                rc = lib.dsea_lanczos_status(ws.handle, byref(brk), st)
+                if rc == _lib.ERR_TIMEOUT:
+                    # the single-launch form (README-sized problems) needs its <= 64 workgroups resident together; on a
+                    # device shared with other work its bounded spins give up.  Repeat with the multi-launch kernels and
+                    # keep this workspace on them (``ws.lanczos_persist_lost = False`` re-enables the single-launch form).
+                    import warnings
+                    warnings.warn("single-launch Lanczos timed out waiting for a peer workgroup (device shared with "
+                                  "other work?): repeating the run with the multi-launch kernels, which this workspace "
+                                  "keeps using from now on", RuntimeWarning)
+                    ws.lanczos_persist_lost = True
+                    ws.set_lanczos_persist(0)
+                    check(lib.dsea_lanczos_run(native.handle, ws.handle, int(k), _ptr(q0), _ptr(Q), ldq, _ptr(alphas),
+                                               _ptr(betas), st), "dsea_lanczos_run")
+                    rc = lib.dsea_lanczos_status(ws.handle, byref(brk), st)
+                check(rc, "dsea_lanczos_status", allow=(_lib.ERR_BREAKDOWN,))
                 last_break = int(brk.value)
             finally:
                 if shadow is not None:

@@ -81,6 +81,15 @@ int dsea_ws_set_split(dsea_ws_t ws, int waves);
  * same iteration in exact arithmetic, NOT the rounding sequence of reference CG.py:31-40: an option for
  * latency-bound solves, never selected automatically.                                                           */
 int dsea_ws_set_persist(dsea_ws_t ws, int mode);
+/* tuning knob: single-launch Lanczos of dsea_lanczos_run for README-sized problems (full-space matrix-free TFIM with
+ * L <= 13, 3-point stencil without halo pointers with n <= 8192; k <= 512): the whole k-step loop is ONE launch of
+ * ceil(n/128) <= 64 workgroups that own 128 rows each and meet three times per step (norm + neighbour rows, alpha,
+ * re-orthogonalisation coefficients).  Same algorithm and the same expressions as the multi-launch kernels; partial
+ * sums are combined in a different order (per 128-row slab): T agrees with the multi-launch form to rounding, not bit
+ * for bit.  -1 = automatic (on up to n = 4096, where it is measured to win), 0 = off, 1 = on wherever it applies.  A lost
+ * peer workgroup (bounded spins) makes
+ * dsea_lanczos_status return DSEA_ERR_TIMEOUT; the caller then repeats the run with the knob off.                 */
+int dsea_ws_set_lanczos_persist(dsea_ws_t ws, int mode);
 
 /* Optional bf16 SHADOW of the Krylov basis (caller-owned, `rows` x `ld` uint16, ld % 8 == 0, 16-byte
  * aligned; null = off).  When registered, dsea_lanczos_run also stores every new basis vector rounded to
@@ -389,7 +398,8 @@ int dsea_lanczos_run_basisfree(dsea_op_t op, dsea_ws_t ws, int k, const double *
  * beta_{i-1} ON THE DEVICE with 1e-13 * max_j(|alpha_j|, |beta_j|); at the first one below it records step i,
  * leaves Q[i..], alphas[i..], betas[i..] untouched and turns its remaining launches into no-ops.  This call
  * SYNCHRONISES the stream and returns DSEA_OK, or DSEA_ERR_BREAKDOWN with *break_step = i: the Krylov space of q0
- * has dimension i and the leading i x i block of T holds exact eigenpairs of the operator.                      */
+ * has dimension i and the leading i x i block of T holds exact eigenpairs of the operator; DSEA_ERR_TIMEOUT if the
+ * single-launch form (dsea_ws_set_lanczos_persist) lost a peer workgroup -- the outputs are then undefined.       */
 int dsea_lanczos_status(dsea_ws_t ws, int *break_step, void *stream);
 
 /* ------------------------------------------------------------------ non-symmetric Krylov loops (row f-1)
