@@ -1016,10 +1016,15 @@ int dsea_cg_run(dsea_op_t op, dsea_ws_t ws, const double* shift, const double* b
   if (poll_every <= 0) poll_every = 16;
 
   // Small halo-1 operators: the whole solve in ONE persistent launch (k_cg_persist_stencil), bit-identical iterates.
-  // Its granule buffer lives in w.aux (the streaming form's partial buffers, unused there).
-  if (w.persist_override != 0 && persist_comm_bytes(n) <= (size_t)4 * DSEA_MAX_WAVE_TILES * sizeof(double)) {
-    const int pr = launch_cg_persist(op->d, shift, b, x, state, eps, maxiter, w.aux,
-                                     w.persist_override > 0 ? w.persist_override : 0, st);
+  // Its granule buffer lives in w.aux (the streaming form's partial buffers, unused there).  README-sized full-space
+  // TFIM operators (n <= 8192): k_cg_persist_tfim, granules in the partial-sum area.
+  const bool tfim_persist = w.persist_override != 0 && cg_persist_tfim_applicable(op->d) &&
+                            cg_persist_tfim_comm_bytes(n) <=
+                                (size_t)DSEA_MAX_WAVE_TILES * (size_t)((w.kmax < 1 ? 1 : w.kmax) + 1) * sizeof(double);
+  if (tfim_persist || (w.persist_override != 0 && persist_comm_bytes(n) <= (size_t)4 * DSEA_MAX_WAVE_TILES * sizeof(double))) {
+    const int pr = tfim_persist ? launch_cg_persist_tfim(op->d, shift, b, x, state, eps, maxiter, P, st)
+                                : launch_cg_persist(op->d, shift, b, x, state, eps, maxiter, w.aux,
+                                                    w.persist_override > 0 ? w.persist_override : 0, st);
     if (pr == -2) {
       g_last_hip = (int)hipGetLastError();
       return DSEA_ERR_HIP;

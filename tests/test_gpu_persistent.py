@@ -240,3 +240,59 @@ def test_single_launch_lanczos_is_the_default_and_deterministic_and_reports_brea
         lo, v = symeigLanczos(opd, 10, cuda, extreme="min", sparse=True, dim=64, q0=q)
     assert 1 <= engine.last_break <= 3 and any("breakdown" in str(w.message) for w in rec)
     assert abs(lo.item() + 6.0) < 1e-12 and torch.isfinite(v).all()
+
+
+# ------------------------------------------------------------------ single-launch CG for the TFIM operator (README sizes)
+@pytest.mark.parametrize("L", [1, 2, 3, 6, 7, 8, 10, 12, 13])
+def test_persistent_tfim_cg_matches_streaming_form_and_oracle(L):
+    """csrc/dsea_cg_persist_tfim.hip (n = 2^L <= 8192: one launch per solve, x / r / d in registers, two grid
+    exchanges per iteration) against the 3-launches-per-iteration kernels and the CPU oracle on the shifted system
+    (A - s) x = b of the adjoint solve (CG.py:120): fixed-iteration iterates to rounding, converged runs with the same
+    iteration count and a residual below eps."""
+    from dominantsparseeigenad_amd.operators import TFIMOperator
+    n = 1 << L
+    op = TFIMOperator(L, cuda, g=torch.tensor([1.05], dtype=F64, device=cuda))
+    b = torch.from_numpy(normal_vector(n, 300 + L)).to(cuda)
+    x0 = torch.from_numpy(normal_vector(n, 400 + L)).to(cuda)
+    shift = torch.tensor(-1.3 * L - 2.0, dtype=F64, device=cuda)       # below the spectrum: A - s is SPD
+    iters = min(25, n)
+    ref = _solve(op, b, x0, shift, 0, eps=0.0, maxiter=iters)
+    got = _solve(op, b, x0, shift, -1, eps=0.0, maxiter=iters)
+    assert got[1] == ref[1] == iters
+    scale = float(ref[0].abs().max())
+    assert float((got[0] - ref[0]).abs().max()) < 1e-12 * scale, float((got[0] - ref[0]).abs().max()) / scale
+    assert abs(got[2] - ref[2]) <= 1e-9 * max(ref[2], 1e-300) + 1e-18
+    # converged runs
+    ref = _solve(op, b, x0, shift, 0, eps=1e-9, maxiter=None)
+    got = _solve(op, b, x0, shift, -1, eps=1e-9, maxiter=None)
+    assert ref[3] and got[3] and abs(got[1] - ref[1]) <= 1 and got[2] < 1e-9
+    assert float((got[0] - ref[0]).abs().max()) < 1e-8 * scale
+    res = op.H(got[0]) - shift * got[0] - b
+    assert float(res.norm()) < 1e-8
+    # CPU oracle (gather-table operator), same start vector
+    model = oracle.TFIMTables(L, g=torch.tensor([1.05], dtype=F64))
+    s_host = float(shift)
+    xo = oracle.cg_solve(lambda v: model.H(v) - s_host * v, b.cpu(), x0.cpu(), sparse=True, eps=0.0, maxiter=iters)
+    gi = _solve(op, b, x0, shift, -1, eps=0.0, maxiter=iters)
+    assert float((gi[0].cpu() - xo).abs().max()) < 1e-11 * float(xo.abs().max())
+
+
+def test_persistent_tfim_cg_without_shift_and_zero_rhs_and_maxiter_zero():
+    from dominantsparseeigenad_amd.operators import TFIMOperator
+    L = 9
+    n = 1 << L
+    op = TFIMOperator(L, cuda, g=torch.tensor([0.7], dtype=F64, device=cuda))
+    b = torch.from_numpy(normal_vector(n, 11)).to(cuda)
+    x0 = torch.from_numpy(normal_vector(n, 12)).to(cuda)
+    # no shift: H is indefinite; a fixed number of iterations still has to agree with the streaming kernels
+    ref = _solve(op, b, x0, None, 0, eps=0.0, maxiter=12)
+    got = _solve(op, b, x0, None, -1, eps=0.0, maxiter=12)
+    assert got[1] == ref[1] == 12 and float((got[0] - ref[0]).abs().max()) < 1e-11 * float(ref[0].abs().max())
+    # early out: x0 already solves the system (CG.py:28-29)
+    shift = torch.tensor(-20.0, dtype=F64, device=cuda)
+    bb = op.H(x0) - shift * x0
+    got = _solve(op, bb, x0, shift, -1, eps=1e-7, maxiter=None)
+    assert got[1] == 0 and got[3] and torch.equal(got[0], x0)
+    # maxiter = 0: not converged, x untouched
+    got = _solve(op, b, x0, shift, -1, eps=1e-30, maxiter=0)
+    assert got[1] == 0 and not got[3] and torch.equal(got[0], x0)
