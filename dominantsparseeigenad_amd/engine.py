@@ -31,7 +31,9 @@ DENSE_SYMMETRIC_KERNEL = True
 # (csrc/dsea_lanczos_persist.hip).  Same algorithm and expressions, T equal to the multi-launch form to rounding (not bit
 # for bit).  True = automatic (n <= 4096, where it is measured to win), "force" = wherever it applies (n <= 8192),
 # False keeps every workspace on the multi-launch kernels.
-LANCZOS_PERSIST = True
+import os as _os
+_NO_PERSIST = _os.environ.get("DSEA_NO_PERSIST", "") == "1"
+LANCZOS_PERSIST = not _NO_PERSIST
 last_lp_steps = (0, 0)
 last_break = 0
 
@@ -80,6 +82,8 @@ class Workspace:
         self.busy = None            # name of the solver that currently owns this workspace (see ``owned_by``)
         self.persist_mode = -1
         self.lanczos_persist_mode = -1
+        if _NO_PERSIST:             # DSEA_NO_PERSIST=1: every solve on the multi-launch kernels (A/B measurements)
+            self.set_persist(0)
 
     def __del__(self):
         try:
