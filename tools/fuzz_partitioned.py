@@ -113,7 +113,8 @@ def worker(rank, world, port, cases, ret):
                 torch.cuda.synchronize()
                 per_eps.append((E0.item(), gl.item(), op.overlap_fallbacks, op.last_cg_iters))
             out.append(per_eps)
-        ret[rank] = out
+            drv = op.driver
+        ret[rank] = (out, drv)
     finally:
         dist.destroy_process_group()
 
@@ -134,7 +135,7 @@ def main():
         overlap = bool(rng.rand() < 0.6)
         replicate = [("auto"), True, False][int(rng.randint(0, 3))]
         cases.append((world, L, k, g0, overlap, replicate))
-    results = {}
+    results, drivers = {}, {}
     for world in (2, 4):
         sub = [(i, c) for i, c in enumerate(cases) if c[0] == world]
         if not sub:
@@ -147,10 +148,11 @@ def main():
         ret = mgr.dict()
         mp.spawn(worker, args=(world, port, [c[1:] for _, c in sub], ret), nprocs=world, join=True)
         for j, (i, _) in enumerate(sub):
-            results[i] = [ret[r][j] for r in range(world)]
+            results[i] = [ret[r][0][j] for r in range(world)]
+        drivers[world] = ret[0][1]
     bad = unexplained = illposed = 0
     worst_ok = 0.0
-    print("# %s --cases %d --seed %d" % (os.path.basename(__file__), args.cases, args.seed))
+    print("# %s --cases %d --seed %d   partitioned driver: %s" % (os.path.basename(__file__), args.cases, args.seed, drivers))
     print("# per case and CG tolerance eps: partitioned vs default single-GPU gradient | single-GPU SELF-SPREAD over %d "
           "rounding-different geometries | verdict.  Tolerance max(%g (eps 1e-7) / %g (eps 1e-12), 10 x self-spread); a case "
           "whose single-GPU path disagrees with ITSELF by more than 1e-3 is ILL-POSED (not judged); any self-spread above "
