@@ -108,15 +108,25 @@ REORTH_DEFAULT = "full"
 def symeigLanczos(A, k, device=torch.device("cpu"), extreme="both", *, sparse=False, dim=None, q0=None, reorth=None):
     """Extreme eigenvalue(s)/eigenvector(s); outputs as in Lanczos.py:88-105 (all torch tensors).
 
-    Keyword-only extension ``reorth``: "full" (default, reference Lanczos.py:66) or "none" -- basis-free two-pass
+    Keyword-only extension ``reorth``: "full" (default, reference Lanczos.py:66), "twice" (the same pass applied twice per
+    step: CGS2) or "none" -- basis-free two-pass
     Lanczos for native device operators: three rotating vectors instead of the k-vector basis (so k = 200 at
     n = 2^28 fits ONE GPU) and no k^2 n re-orthogonalisation traffic; the extreme Ritz pair is the same to rounding,
     interior Ritz values may appear more than once (not returned here)."""
     if extreme not in ("both", "min", "max"):
         raise ValueError("extreme must be 'both', 'min' or 'max'")
     reorth = REORTH_DEFAULT if reorth is None else reorth
-    if reorth not in ("full", "none"):
-        raise ValueError("reorth must be 'full' or 'none'")
+    if reorth not in ("full", "none", "twice"):
+        raise ValueError("reorth must be 'full', 'twice' or 'none'")
+    if reorth == "twice":
+        # CGS2: the Gram-Schmidt pass of Lanczos.py:66 applied twice per step (an option the reference lacks; device
+        # operators and callables on the GPU) -- same Krylov process, orthogonality of the basis at rounding level even
+        # next to an invariant subspace
+        prev, engine.REORTH_PASSES = engine.REORTH_PASSES, 2
+        try:
+            return symeigLanczos(A, k, device, extreme, sparse=sparse, dim=dim, q0=q0, reorth="full")
+        finally:
+            engine.REORTH_PASSES = prev
     if reorth == "none":
         native = engine.native_of(A) if sparse else None
         if native is None or getattr(native, "partitioned", False) or torch.device(device).type != "cuda":

@@ -147,6 +147,7 @@ int dsea_ws_create(void* device_buffer, size_t bytes, int64_t n, int kmax, dsea_
   ws->w.split_override = -1;
   ws->w.persist_override = -1;
   ws->w.lz_persist = -1;
+  ws->w.reorth_passes = 1;
   ws->w.prof = nullptr;
   ws->w.shadow = nullptr;
   ws->w.shadow_ld = 0;
@@ -267,6 +268,12 @@ int dsea_ws_set_persist(dsea_ws_t ws, int mode) {
     return DSEA_ERR_ARG;
   if (mode >= 100 && geo == -1) return DSEA_ERR_ARG;
   ws->w.persist_override = mode;
+  return DSEA_OK;
+}
+
+int dsea_ws_set_reorth_passes(dsea_ws_t ws, int passes) {
+  if (!ws || (passes != 1 && passes != 2)) return DSEA_ERR_ARG;
+  ws->w.reorth_passes = passes;
   return DSEA_OK;
 }
 
@@ -720,7 +727,7 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
   // README-sized problems (n <= 8192, k <= 512; full-space TFIM / halo-free stencil): the whole loop as ONE launch
   // (dsea_lanczos_persist.hip).  The granule buffers live in the partial-sum area, unused by that form.
   // (automatic: up to 32 workgroups = 4096 rows, where it is measured to win; mode 1 forces it up to its envelope)
-  if (w.lz_persist != 0 && (w.lz_persist == 1 || n <= 4096) && !prof && lanczos_persist_applicable(op->d, n, k) &&
+  if (w.lz_persist != 0 && w.reorth_passes == 1 && (w.lz_persist == 1 || n <= 4096) && !prof && lanczos_persist_applicable(op->d, n, k) &&
       lanczos_persist_comm_bytes(n, k) <= (size_t)DSEA_MAX_WAVE_TILES * (size_t)((w.kmax < 1 ? 1 : w.kmax) + 1) * sizeof(double)) {
     if (hipMemsetAsync(w.scal + DSEA_SCAL_LZ_FAIL, 0, sizeof(double), st) != hipSuccess) {
       g_last_hip = (int)hipGetLastError();
@@ -756,6 +763,20 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
                                  prof ? prof->next(PROF_AXPY) : nullptr, brk);
       else
         launch_axpy_norm(g, Q, ldq, n, i, w.coef, r, nP, nullptr, st, prof ? prof->next(PROF_AXPY) : nullptr, brk);
+      if (w.reorth_passes == 2) {
+        // CGS2 option (the reference makes ONE pass, Lanczos.py:66): c' = Q^T r of the corrected r, r -= Q c'.  The dots
+        // kernel rewrites r from a snapshot (alpha = 0) so that its input and output do not alias.
+        if (hipMemcpyAsync(w.vec[2], r, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+          g_last_hip = (int)hipGetLastError();
+          return DSEA_ERR_HIP;
+        }
+        launch_rdots(g, Q, ldq, n, i, w.vec[2], w.zero, nullptr, r, P, w.coef, st, nullptr, nullptr, 0, nullptr,
+                     Qs != nullptr, brk);
+        if (Qs)
+          nn = launch_axpy_norm_lp(n, rps, Q, ldq, Qs, lds, i, w.coef, w.lp_tau, r, nP, lp_count, st, nullptr, brk);
+        else
+          launch_axpy_norm(g, Q, ldq, n, i, w.coef, r, nP, nullptr, st, nullptr, brk);
+      }
       // beta_{i-1} ~ 0 (relative to the running |alpha|, |beta| scale): the tail records step i in brk and every
       // later launch of this run returns at once (Lanczos.py:69-70 would divide by it)
       na = launch_tfim_fused(op->d, r, nP, nn, Q + (int64_t)i * ldq, u, betas + (i - 1), aP, st,
@@ -779,6 +800,22 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
     } else {
       launch_axpy_norm(g, Q, ldq, n, i, w.coef, r, P, nullptr, st, prof ? prof->next(PROF_AXPY) : nullptr, brk);
       launch_finalize_slot(P, g.nw, nrm2, brk, st);
+    }
+    if (w.reorth_passes == 2) {   // CGS2 option, see the fused sequence above
+      if (hipMemcpyAsync(w.vec[2], r, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        g_last_hip = (int)hipGetLastError();
+        return DSEA_ERR_HIP;
+      }
+      launch_rdots(g, Q, ldq, n, i, w.vec[2], w.zero, nullptr, r, P, w.coef, st, nullptr, nullptr, 0, nullptr,
+                   Qs != nullptr, brk);
+      if (Qs) {
+        double* nP2 = w.aux + DSEA_MAX_WAVE_TILES;
+        int nn2 = launch_axpy_norm_lp(n, rps, Q, ldq, Qs, lds, i, w.coef, w.lp_tau, r, nP2, lp_count, st, nullptr, brk);
+        launch_finalize_slot(nP2, nn2, nrm2, brk, st);
+      } else {
+        launch_axpy_norm(g, Q, ldq, n, i, w.coef, r, P, nullptr, st, nullptr, brk);
+        launch_finalize_slot(P, g.nw, nrm2, brk, st);
+      }
     }
     double* qi = Q + (int64_t)i * ldq;
     launch_scale_store(r, nrm2, qi, betas + (i - 1), n, st, Qs ? Qs + (int64_t)i * lds : nullptr, brk, i);

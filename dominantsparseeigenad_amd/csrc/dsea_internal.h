@@ -113,6 +113,7 @@ struct Workspace {
   int split_override;  // -1 automatic, 0 off, 4/8/16 forced
   int persist_override;  // persistent single-launch CG: -1 automatic, 0 off, 1/2/4 = row pairs per thread forced
   int lz_persist;        // single-launch Lanczos for small problems: -1 automatic (on where it applies), 0 off
+  int reorth_passes;     // Gram-Schmidt passes per Lanczos step: 1 (the reference, Lanczos.py:66) or 2 (CGS2 option)
   double* partials;  // DSEA_MAX_WAVE_TILES * max(kmax,1) doubles (also >= DSEA_MAX_EW_BLOCKS)
   double* aux;       // 4 * DSEA_MAX_WAVE_TILES doubles: small partial buffers that must not alias `partials`
   double* coef;      // kmax doubles

@@ -31,6 +31,9 @@ DENSE_SYMMETRIC_KERNEL = True
 # (csrc/dsea_lanczos_persist.hip).  Same algorithm and expressions, T equal to the multi-launch form to rounding (not bit
 # for bit).  True = automatic (n <= 4096, where it is measured to win), "force" = wherever it applies (n <= 8192),
 # False keeps every workspace on the multi-launch kernels.
+# Gram-Schmidt passes per Lanczos step: 1 = the reference (Lanczos.py:66); 2 = CGS2 option (``reorth="twice"`` of
+# Lanczos.symeigLanczos / Lanczos.Lanczos): the pass is repeated on the corrected vector.
+REORTH_PASSES = 1
 import os as _os
 _NO_PERSIST = _os.environ.get("DSEA_NO_PERSIST", "") == "1"
 LANCZOS_PERSIST = not _NO_PERSIST
@@ -381,6 +384,9 @@ def lanczos(A, k, n, device, q0, native=None, callable_A=None, arena=False):
                 shadow = new_shadow()
                 check(lib.dsea_ws_set_shadow(ws.handle, _ptr(shadow), ldq, int(k), float(SHADOW_TAU)), "dsea_ws_set_shadow")
             try:
+                if getattr(ws, "reorth_passes", 1) != int(REORTH_PASSES):
+                    check(lib.dsea_ws_set_reorth_passes(ws.handle, int(REORTH_PASSES)), "dsea_ws_set_reorth_passes")
+                    ws.reorth_passes = int(REORTH_PASSES)
                 want = 0 if (not LANCZOS_PERSIST or getattr(ws, "lanczos_persist_lost", False)) else \
                     (1 if LANCZOS_PERSIST == "force" else -1)
                 if ws.lanczos_persist_mode != want:
@@ -427,6 +433,7 @@ def lanczos(A, k, n, device, q0, native=None, callable_A=None, arena=False):
     c = torch.empty(k + 2, dtype=F64, device=device)
     shadow = None
     esz = 8
+    zero = torch.zeros(1, dtype=F64, device=device)
     with ws.owned_by("Lanczos (callable operator)"):
         if use_shadow:
             shadow = new_shadow()
@@ -443,6 +450,12 @@ def lanczos(A, k, n, device, q0, native=None, callable_A=None, arena=False):
                       "dsea_lanczos_rdots")
                 check(lib.dsea_lanczos_axpy_norm(ws.handle, _ptr(Q), ldq, n, i, _ptr(c), _ptr(r), _ptr(nrm2), st),
                       "dsea_lanczos_axpy_norm")
+                if int(REORTH_PASSES) == 2:      # CGS2 option: the same pass again on the corrected vector (alpha = 0)
+                    r2 = r.clone()
+                    check(lib.dsea_lanczos_rdots(ws.handle, _ptr(Q), ldq, n, i, _ptr(r2), _ptr(zero), None, _ptr(r),
+                                                 _ptr(c), st), "dsea_lanczos_rdots")
+                    check(lib.dsea_lanczos_axpy_norm(ws.handle, _ptr(Q), ldq, n, i, _ptr(c), _ptr(r), _ptr(nrm2), st),
+                          "dsea_lanczos_axpy_norm")
                 check(lib.dsea_lanczos_store(ws.handle, _ptr(r), _ptr(nrm2), _ptr(Q), ldq, i,
                                              c_void_p(betas.data_ptr() + (i - 1) * esz), n, st), "dsea_lanczos_store")
                 qi = Q[i]

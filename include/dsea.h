@@ -90,6 +90,10 @@ int dsea_ws_set_persist(dsea_ws_t ws, int mode);
  * peer workgroup (bounded spins) makes
  * dsea_lanczos_status return DSEA_ERR_TIMEOUT; the caller then repeats the run with the knob off.                 */
 int dsea_ws_set_lanczos_persist(dsea_ws_t ws, int mode);
+/* Gram-Schmidt passes per step of dsea_lanczos_run: 1 = the reference (single-pass classical Gram-Schmidt against all
+ * previous vectors, Lanczos.py:66), 2 = the pass is repeated on the corrected vector ("CGS2": orthogonality at rounding
+ * level even where one pass leaves eps ||u|| / beta) -- an option the reference lacks, never selected automatically. */
+int dsea_ws_set_reorth_passes(dsea_ws_t ws, int passes);
 
 /* Optional bf16 SHADOW of the Krylov basis (caller-owned, `rows` x `ld` uint16, ld % 8 == 0, 16-byte
  * aligned; null = off).  When registered, dsea_lanczos_run also stores every new basis vector rounded to
