@@ -1058,10 +1058,16 @@ int dsea_cg_run(dsea_op_t op, dsea_ws_t ws, const double* shift, const double* b
   const bool tfim_persist = w.persist_override != 0 && cg_persist_tfim_applicable(op->d) &&
                             cg_persist_tfim_comm_bytes(n) <=
                                 (size_t)DSEA_MAX_WAVE_TILES * (size_t)((w.kmax < 1 ? 1 : w.kmax) + 1) * sizeof(double);
-  if (tfim_persist || (w.persist_override != 0 && persist_comm_bytes(n) <= (size_t)4 * DSEA_MAX_WAVE_TILES * sizeof(double))) {
-    const int pr = tfim_persist ? launch_cg_persist_tfim(op->d, shift, b, x, state, eps, maxiter, P, st)
-                                : launch_cg_persist(op->d, shift, b, x, state, eps, maxiter, w.aux,
-                                                    w.persist_override > 0 ? w.persist_override : 0, st);
+  // 2^14 ... 2^20 rows: k_cg_persist_tfim_big (iterates bit-identical to the streaming form; d double-buffered in the
+  // workspace vectors the streaming form uses for d and A'd, granules in w.aux)
+  const bool tfim_big = w.persist_override != 0 && cg_persist_tfim_big_applicable(op->d) &&
+                        cg_persist_tfim_big_comm_bytes(n) <= (size_t)4 * DSEA_MAX_WAVE_TILES * sizeof(double);
+  if (tfim_big || tfim_persist ||
+      (w.persist_override != 0 && persist_comm_bytes(n) <= (size_t)4 * DSEA_MAX_WAVE_TILES * sizeof(double))) {
+    const int pr = tfim_big ? launch_cg_persist_tfim_big(op->d, shift, b, x, state, eps, maxiter, w.aux, d, Ad, st)
+                   : tfim_persist ? launch_cg_persist_tfim(op->d, shift, b, x, state, eps, maxiter, P, st)
+                                  : launch_cg_persist(op->d, shift, b, x, state, eps, maxiter, w.aux,
+                                                      w.persist_override > 0 ? w.persist_override : 0, st);
     if (pr == -2) {
       g_last_hip = (int)hipGetLastError();
       return DSEA_ERR_HIP;

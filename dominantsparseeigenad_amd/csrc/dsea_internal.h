@@ -197,6 +197,11 @@ int launch_cg_persist(const OpDesc& op, const double* shift, const double* b, do
                       int64_t maxiter, void* comm, int ppt_override, hipStream_t st);
 int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shift, const double* skip,
                 double* P, hipStream_t st, EventPair* ev = nullptr);
+// dsea_cg_persist_tfim_big.hip
+bool cg_persist_tfim_big_applicable(const OpDesc& op);
+size_t cg_persist_tfim_big_comm_bytes(int64_t n);
+int launch_cg_persist_tfim_big(const OpDesc& op, const double* shift, const double* b, double* x, double* state,
+                               double eps, int64_t maxiter, void* comm, double* dbuf0, double* dbuf1, hipStream_t st);
 // dsea_cg_persist_tfim.hip
 bool cg_persist_tfim_applicable(const OpDesc& op);
 size_t cg_persist_tfim_comm_bytes(int64_t n);

@@ -296,3 +296,33 @@ def test_persistent_tfim_cg_without_shift_and_zero_rhs_and_maxiter_zero():
     # maxiter = 0: not converged, x untouched
     got = _solve(op, b, x0, shift, -1, eps=1e-30, maxiter=0)
     assert got[1] == 0 and not got[3] and torch.equal(got[0], x0)
+
+
+# ------------------------------------------------------------------ single-launch TFIM CG at 2^14 ... 2^20 rows
+@pytest.mark.parametrize("L", [14, 15, 17, 19, 20])
+def test_persistent_tfim_cg_large_is_bit_identical_to_streaming_form(L):
+    """csrc/dsea_cg_persist_tfim_big.hip (x / r / d in registers for the whole solve, d exchanged through device-coherent
+    buffer stores / loads, partial sums reproduced per mat-vec tile and per 512-row tile in the streaming kernels' order):
+    the iterates are BIT-IDENTICAL to the mat-vec + update + direction launches (torch.equal), with the same iteration
+    counts and residual norms -- fixed-iteration and converged runs, with and without shift.  L = 20 is BASELINE
+    configs[1]'s adjoint solve."""
+    from dominantsparseeigenad_amd.operators import TFIMOperator
+    n = 1 << L
+    op = TFIMOperator(L, cuda, g=torch.tensor([1.0], dtype=F64, device=cuda))
+    b = torch.from_numpy(normal_vector(n, 500 + L)).to(cuda)
+    x0 = torch.from_numpy(normal_vector(n, 600 + L)).to(cuda)
+    shift = torch.tensor(-1.3 * L - 1.0, dtype=F64, device=cuda)       # below the spectrum: A - s is SPD
+    for sh in (shift, None):
+        ref = _solve(op, b, x0, sh, 0, eps=0.0, maxiter=30)
+        got = _solve(op, b, x0, sh, -1, eps=0.0, maxiter=30)
+        assert got[1] == ref[1] == 30 and got[2] == ref[2], (got[1:], ref[1:])
+        assert torch.equal(got[0], ref[0]), float((got[0] - ref[0]).abs().max())
+    ref = _solve(op, b, x0, shift, 0, eps=1e-8, maxiter=None)
+    got = _solve(op, b, x0, shift, -1, eps=1e-8, maxiter=None)
+    assert ref[3] and got[3] and got[1] == ref[1] and got[2] == ref[2] and torch.equal(got[0], ref[0])
+    # early out and maxiter = 0
+    bb = op.H(x0) - shift * x0
+    got = _solve(op, bb, x0, shift, -1, eps=1e-6, maxiter=None)
+    assert got[1] == 0 and got[3] and torch.equal(got[0], x0)
+    got = _solve(op, b, x0, shift, -1, eps=1e-30, maxiter=0)
+    assert got[1] == 0 and not got[3] and torch.equal(got[0], x0)
