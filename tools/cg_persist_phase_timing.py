@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Per-phase time of k_cg_persist_tfim_big (one workgroup's view, us per iteration).  Needs a library built with
+-DDSEA_CGB_TIMING (the kernel then leaves its phase clocks in the first doubles of the d buffer):
+    make -C dominantsparseeigenad_amd/csrc libdsea_TIM.so
+    DSEA_LIB=$PWD/dominantsparseeigenad_amd/csrc/libdsea_TIM.so python tools/cg_persist_phase_timing.py"""
 import os, sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch
