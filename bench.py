@@ -55,12 +55,15 @@ def algorithmic_bytes(n, k, m):
     return 8.0 * n * (k * k + 12 * k + 11 * m + 17)
 
 
-def traffic_model_bytes(n, k, m, shadow_steps):
+def traffic_model_bytes(n, k, m, shadow_steps, cg_vectors_per_iteration=11.0):
     """HBM bytes one step of THIS implementation moves, as a model: SURVEY 8d's per-phase count with the correction
     pass of ``shadow_steps`` Lanczos steps reading the bf16 shadow (2 instead of 8 bytes per basis element: step i
     saves 6 n i bytes) plus the k shadow rows written once (2 n each).  At L = 20, k = 200, m = 90: 239.3 GB against
-    249.9 GB counted by the PMC (the difference is the TFIM mat-vec's cross-XCD re-reads)."""
+    249.9 GB counted by the PMC (the difference is the TFIM mat-vec's cross-XCD re-reads).
+    ``cg_vectors_per_iteration``: 11 for the streaming CG; the persistent single-launch CG keeps x, r, d in
+    registers and moves only d (one write + the out-of-tile reads, 4 vectors' worth through the fabric): 5."""
     saved = 6.0 * n * sum(range(1, int(shadow_steps) + 1))
+    saved += 8.0 * n * m * (11.0 - float(cg_vectors_per_iteration))
     return algorithmic_bytes(n, k, m) - saved + (2.0 * n * k if shadow_steps else 0.0)
 
 
@@ -605,7 +608,10 @@ def main():
         shadow_steps = int(lp_stats[0])
     else:
         shadow_steps = (k - 1) if (prob.use_shadow and k > 1) else 0
-    total_bytes = traffic_model_bytes(n, k, m, shadow_steps)
+    # the adjoint solve runs as one persistent launch for the full-space TFIM operator up to 2^20 rows
+    cg_persistent = (not partitioned_path) and args.operator == "matrix-free" and 14 <= L <= 20 and \
+        os.environ.get("DSEA_NO_PERSIST", "") != "1"
+    total_bytes = traffic_model_bytes(n, k, m, shadow_steps, 5.0 if cg_persistent else 11.0)
     if args.reorth == "none":
         # the basis-free two-pass option is a DIFFERENT algorithm: it is priced with ITS OWN algorithmic bytes, not with
         # SURVEY 8d's full-reorthogonalisation figure (which it does not move).  Per Lanczos step and pass: mat-vec 2 +
@@ -689,7 +695,9 @@ def main():
                        "value_is": "HBM bytes the step's kernels move (traffic model: SURVEY 8d per-phase count with "
                                    "the correction pass of %d Lanczos steps reading the bf16 shadow of the basis) / "
                                    "step time, all ranks" % shadow_steps,
-                       "cg_iterations": int(m), "traffic_model_bytes_per_step": total_bytes,
+                       "cg_iterations": int(m), "cg_form": "persistent single launch (x, r, d in registers)" if cg_persistent
+                       else "streaming (mat-vec, update, direction launches)",
+                       "traffic_model_bytes_per_step": total_bytes,
                        "frac_of_hbm_peak": round(value / (HBM_PEAK_GBS * world), 4),
                        "algorithmic_bytes_per_step": alg_bytes,
                        "algorithmic_GBs": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 2),
