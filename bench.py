@@ -228,8 +228,8 @@ def launch_workers(n):
 # one-GPU anchors of the two multi-GPU curves as last measured on an MI355X by `bench.py --gpus 1` of this repository
 # (profiles/, with the commit of the run); the N = 1 line re-measures them live (config.one_gpu_anchors)
 STORED_ANCHORS = {
-    "strong_L28_k100_ms": 5086.29, "strong_source": "profiles/r03_bench.json config.one_gpu_anchors.strong_L28_k100 (commit c389a0a)",
-    "weak_2p25_rows_k200_ms": 1282.81, "weak_source": "profiles/r03_bench.json config.one_gpu_anchors.weak_2p25_rows_k200 (commit c389a0a)",
+    "strong_L28_k100_ms": 5252.19, "strong_source": "profiles/r03_bench.json config.one_gpu_anchors.strong_L28_k100 (commit e4e76db; other boxes of the round: 5086, 5164)",
+    "weak_2p25_rows_k200_ms": 1318.21, "weak_source": "profiles/r03_bench.json config.one_gpu_anchors.weak_2p25_rows_k200 (commit e4e76db; other boxes of the round: 1246, 1283)",
 }
 
 
