@@ -49,6 +49,7 @@ _SIGNATURES = {
     "dsea_ws_set_persist": (c_int, [c_void_p, c_int]),
     "dsea_ws_set_lanczos_persist": (c_int, [c_void_p, c_int]),
     "dsea_ws_set_reorth_passes": (c_int, [c_void_p, c_int]),
+    "dsea_ws_set_fault_injection": (c_int, [c_void_p, c_int]),
     "dsea_ws_set_shadow": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_double]),
     "dsea_lanczos_lp_stats": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), c_void_p]),
     "dsea_profile_begin": (c_int, [c_void_p, c_int]),

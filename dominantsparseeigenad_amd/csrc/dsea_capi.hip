@@ -148,6 +148,7 @@ int dsea_ws_create(void* device_buffer, size_t bytes, int64_t n, int kmax, dsea_
   ws->w.persist_override = -1;
   ws->w.lz_persist = -1;
   ws->w.reorth_passes = 1;
+  ws->w.lose_peer = 0;
   ws->w.prof = nullptr;
   ws->w.shadow = nullptr;
   ws->w.shadow_ld = 0;
@@ -268,6 +269,12 @@ int dsea_ws_set_persist(dsea_ws_t ws, int mode) {
     return DSEA_ERR_ARG;
   if (mode >= 100 && geo == -1) return DSEA_ERR_ARG;
   ws->w.persist_override = mode;
+  return DSEA_OK;
+}
+
+int dsea_ws_set_fault_injection(dsea_ws_t ws, int lose_peer) {
+  if (!ws) return DSEA_ERR_ARG;
+  ws->w.lose_peer = lose_peer ? 1 : 0;
   return DSEA_OK;
 }
 
@@ -724,16 +731,17 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
       return DSEA_ERR_HIP;
     }
   }
+  // the lost-peer record of the single-launch form is per run (dsea_lanczos_status reads it)
+  if (hipMemsetAsync(w.scal + DSEA_SCAL_LZ_FAIL, 0, sizeof(double), st) != hipSuccess) {
+    g_last_hip = (int)hipGetLastError();
+    return DSEA_ERR_HIP;
+  }
   // README-sized problems (n <= 8192, k <= 512; full-space TFIM / halo-free stencil): the whole loop as ONE launch
   // (dsea_lanczos_persist.hip).  The granule buffers live in the partial-sum area, unused by that form.
   // (automatic: up to 32 workgroups = 4096 rows, where it is measured to win; mode 1 forces it up to its envelope)
   if (w.lz_persist != 0 && w.reorth_passes == 1 && (w.lz_persist == 1 || n <= 4096) && !prof && lanczos_persist_applicable(op->d, n, k) &&
       lanczos_persist_comm_bytes(n, k) <= (size_t)DSEA_MAX_WAVE_TILES * (size_t)((w.kmax < 1 ? 1 : w.kmax) + 1) * sizeof(double)) {
-    if (hipMemsetAsync(w.scal + DSEA_SCAL_LZ_FAIL, 0, sizeof(double), st) != hipSuccess) {
-      g_last_hip = (int)hipGetLastError();
-      return DSEA_ERR_HIP;
-    }
-    const int pr = launch_lanczos_persist(op->d, k, q0, Q, ldq, alphas, betas, brk, w.scal + DSEA_SCAL_LZ_FAIL, P, st);
+    const int pr = launch_lanczos_persist(op->d, k, q0, Q, ldq, alphas, betas, brk, w.scal + DSEA_SCAL_LZ_FAIL, P, st, w.lose_peer);
     if (pr == -2) {
       g_last_hip = (int)hipGetLastError();
       return DSEA_ERR_HIP;
@@ -842,7 +850,8 @@ int dsea_lanczos_run_basisfree(dsea_op_t op, dsea_ws_t ws, int k, const double* 
   double* aP = w.aux;
   double* nP = w.aux + DSEA_MAX_WAVE_TILES;
   double* brk = w.scal + DSEA_SCAL_BREAK;
-  if (hipMemsetAsync(brk, 0, 2 * sizeof(double), st) != hipSuccess) {
+  if (hipMemsetAsync(brk, 0, 2 * sizeof(double), st) != hipSuccess ||
+      hipMemsetAsync(w.scal + DSEA_SCAL_LZ_FAIL, 0, sizeof(double), st) != hipSuccess) {
     g_last_hip = (int)hipGetLastError();
     return DSEA_ERR_HIP;
   }
@@ -880,6 +889,7 @@ int dsea_arnoldi_extend(dsea_op_t op, dsea_ws_t ws, const double* shift, double*
   if (j0 == 0) {   // a new factorisation: clear the break record (a continued one keeps it)
     // second-pass counter (dsea_arnoldi_second_passes) and the break record
     if (hipMemsetAsync(w.scal + 31, 0, sizeof(double), st) != hipSuccess ||
+        hipMemsetAsync(w.scal + DSEA_SCAL_LZ_FAIL, 0, sizeof(double), st) != hipSuccess ||
         hipMemsetAsync(brk, 0, 2 * sizeof(double), st) != hipSuccess) {
       g_last_hip = (int)hipGetLastError();
       return DSEA_ERR_HIP;
@@ -901,7 +911,8 @@ int dsea_arnoldi_orth(dsea_ws_t ws, const double* u, const double* shift, double
   hipStream_t st = static_cast<hipStream_t>(stream);
   Workspace& w = ws->w;
   double* brk = w.scal + DSEA_SCAL_BREAK;
-  if (j == 0 && hipMemsetAsync(brk, 0, 2 * sizeof(double), st) != hipSuccess) {
+  if (j == 0 && (hipMemsetAsync(brk, 0, 2 * sizeof(double), st) != hipSuccess ||
+                 hipMemsetAsync(w.scal + DSEA_SCAL_LZ_FAIL, 0, sizeof(double), st) != hipSuccess)) {
     g_last_hip = (int)hipGetLastError();
     return DSEA_ERR_HIP;
   }
@@ -1064,8 +1075,8 @@ int dsea_cg_run(dsea_op_t op, dsea_ws_t ws, const double* shift, const double* b
                         cg_persist_tfim_big_comm_bytes(n) <= (size_t)4 * DSEA_MAX_WAVE_TILES * sizeof(double);
   if (tfim_big || tfim_persist ||
       (w.persist_override != 0 && persist_comm_bytes(n) <= (size_t)4 * DSEA_MAX_WAVE_TILES * sizeof(double))) {
-    const int pr = tfim_big ? launch_cg_persist_tfim_big(op->d, shift, b, x, state, eps, maxiter, w.aux, d, Ad, st)
-                   : tfim_persist ? launch_cg_persist_tfim(op->d, shift, b, x, state, eps, maxiter, P, st)
+    const int pr = tfim_big ? launch_cg_persist_tfim_big(op->d, shift, b, x, state, eps, maxiter, w.aux, d, Ad, st, w.lose_peer)
+                   : tfim_persist ? launch_cg_persist_tfim(op->d, shift, b, x, state, eps, maxiter, P, st, w.lose_peer)
                                   : launch_cg_persist(op->d, shift, b, x, state, eps, maxiter, w.aux,
                                                       w.persist_override > 0 ? w.persist_override : 0, st);
     if (pr == -2) {

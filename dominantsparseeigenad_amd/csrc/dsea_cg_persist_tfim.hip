@@ -61,6 +61,7 @@ struct CgtArgs {
   long long maxiter;
   unsigned long long* comm;   // granules: [G] d.Ad | [G][1 + 128] r.r + rows of r | [G][128] rows of x0 ; zeroed per launch
   int G;
+  int lose_peer;   // test hook: the last workgroup exits at once
 };
 
 __global__ __launch_bounds__(256) void k_cg_persist_tfim(CgtArgs a) {
@@ -72,6 +73,7 @@ __global__ __launch_bounds__(256) void k_cg_persist_tfim(CgtArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g = blockIdx.x, G = a.G;
+  if (a.lose_peer && G > 1 && g == G - 1) return;
   const int L = a.tf.L;
   const int64_t n = (int64_t)1 << L, row = (int64_t)g * CGT_ROWS + 2 * lane;
   const int nlocal = L < 7 ? L : 7, nfar = L - nlocal;
@@ -278,7 +280,7 @@ size_t cg_persist_tfim_comm_bytes(int64_t n) {
 }
 // returns 0 if launched, -1 if not applicable, -2 on a HIP error
 int launch_cg_persist_tfim(const OpDesc& op, const double* shift, const double* b, double* x, double* state, double eps,
-                           int64_t maxiter, void* comm, hipStream_t st) {
+                           int64_t maxiter, void* comm, hipStream_t st, int lose_peer) {
   if (!cg_persist_tfim_applicable(op)) return -1;
   const int64_t n = op.n;
   const int G = (int)((n + CGT_ROWS - 1) / CGT_ROWS);
@@ -303,6 +305,7 @@ int launch_cg_persist_tfim(const OpDesc& op, const double* shift, const double* 
   a.maxiter = (long long)maxiter;
   a.comm = static_cast<unsigned long long*>(comm);
   a.G = G;
+  a.lose_peer = lose_peer;
   hipLaunchKernelGGL(k_cg_persist_tfim, dim3(G), dim3(256), 0, st, a);
   return 0;
 }

@@ -84,6 +84,7 @@ struct CgbArgs {
   unsigned long long* comm;   // granules: [ntiles] d.Ad | [4 ntiles] r.r | [ntiles] flags ; zeroed per launch
   double* dbuf[2];            // d of even / odd iterations (n doubles each)
   int ntiles;
+  int lose_peer;              // test hook: the last workgroup exits at once
 };
 
 struct CgbSm {
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(256 * NVB) void k_cg_persist_tfim_big(CgbArgs a) {
   __shared__ double2 tile2[NVB][CGB_TILE / 2];
   __shared__ CgbSm sm;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, vb = tid >> 8, t = tid & 255, wv4 = wave & 3;
+  if (a.lose_peer && gridDim.x > 1 && blockIdx.x == gridDim.x - 1) return;
   const int tile = blockIdx.x * NVB + vb;
   const int L = a.tf.L, nfar = L - CGB_T;
   const int64_t n = (int64_t)1 << L, base = (int64_t)tile * CGB_TILE;
@@ -390,7 +392,8 @@ size_t cg_persist_tfim_big_comm_bytes(int64_t n) {
 }
 // returns 0 if launched, -1 if not applicable, -2 on a HIP error.  dbuf0 / dbuf1: two scratch vectors of n doubles.
 int launch_cg_persist_tfim_big(const OpDesc& op, const double* shift, const double* b, double* x, double* state,
-                               double eps, int64_t maxiter, void* comm, double* dbuf0, double* dbuf1, hipStream_t st) {
+                               double eps, int64_t maxiter, void* comm, double* dbuf0, double* dbuf1, hipStream_t st,
+                               int lose_peer) {
   if (!cg_persist_tfim_big_applicable(op)) return -1;
   const int64_t n = op.n;
   const int ntiles = (int)(n / CGB_TILE);
@@ -419,6 +422,7 @@ int launch_cg_persist_tfim_big(const OpDesc& op, const double* shift, const doub
   a.dbuf[0] = dbuf0;
   a.dbuf[1] = dbuf1;
   a.ntiles = ntiles;
+  a.lose_peer = lose_peer;
   if (nvb == 2)
     hipLaunchKernelGGL((k_cg_persist_tfim_big<2>), dim3(G), dim3(512), 0, st, a);
   else

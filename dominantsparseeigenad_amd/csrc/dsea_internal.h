@@ -113,6 +113,7 @@ struct Workspace {
   int split_override;  // -1 automatic, 0 off, 4/8/16 forced
   int persist_override;  // persistent single-launch CG: -1 automatic, 0 off, 1/2/4 = row pairs per thread forced
   int lz_persist;        // single-launch Lanczos for small problems: -1 automatic (on where it applies), 0 off
+  int lose_peer;         // TEST HOOK (dsea_ws_set_fault_injection): the last workgroup of a persistent launch exits at once
   int reorth_passes;     // Gram-Schmidt passes per Lanczos step: 1 (the reference, Lanczos.py:66) or 2 (CGS2 option)
   double* partials;  // DSEA_MAX_WAVE_TILES * max(kmax,1) doubles (also >= DSEA_MAX_EW_BLOCKS)
   double* aux;       // 4 * DSEA_MAX_WAVE_TILES doubles: small partial buffers that must not alias `partials`
@@ -201,17 +202,18 @@ int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shif
 bool cg_persist_tfim_big_applicable(const OpDesc& op);
 size_t cg_persist_tfim_big_comm_bytes(int64_t n);
 int launch_cg_persist_tfim_big(const OpDesc& op, const double* shift, const double* b, double* x, double* state,
-                               double eps, int64_t maxiter, void* comm, double* dbuf0, double* dbuf1, hipStream_t st);
+                               double eps, int64_t maxiter, void* comm, double* dbuf0, double* dbuf1, hipStream_t st,
+                               int lose_peer = 0);
 // dsea_cg_persist_tfim.hip
 bool cg_persist_tfim_applicable(const OpDesc& op);
 size_t cg_persist_tfim_comm_bytes(int64_t n);
 int launch_cg_persist_tfim(const OpDesc& op, const double* shift, const double* b, double* x, double* state, double eps,
-                           int64_t maxiter, void* comm, hipStream_t st);
+                           int64_t maxiter, void* comm, hipStream_t st, int lose_peer = 0);
 // dsea_lanczos_persist.hip
 bool lanczos_persist_applicable(const OpDesc& op, int64_t n, int k);
 size_t lanczos_persist_comm_bytes(int64_t n, int k);
 int launch_lanczos_persist(const OpDesc& op, int k, const double* q0, double* Q, int64_t ldq, double* alphas,
-                           double* betas, double* brk, double* fail, void* comm, hipStream_t st);
+                           double* betas, double* brk, double* fail, void* comm, hipStream_t st, int lose_peer = 0);
 
 }  // namespace dsea
 

@@ -98,6 +98,7 @@ struct LzpArgs {
   double* fail;  // set to 1 when a peer did not arrive in time
   unsigned long long* comm;
   int G, kslots;
+  int lose_peer;   // test hook: the last workgroup exits at once (its peers must time out, not hang)
 };
 
 __global__ __launch_bounds__(1024) void k_lanczos_persist(LzpArgs a) {
@@ -113,6 +114,7 @@ __global__ __launch_bounds__(1024) void k_lanczos_persist(LzpArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int g = blockIdx.x, G = a.G;
+  if (a.lose_peer && G > 1 && g == G - 1) return;
   const int64_t n = a.n, base = (int64_t)g * LZP_ROWS, row = base + 2 * lane;
   const bool tfim = a.opk == OP_TFIM;
   const int Lbits = tfim ? a.tf.L : 0;
@@ -383,7 +385,7 @@ size_t lanczos_persist_comm_bytes(int64_t n, int k) {
 
 // returns 0 if launched, -1 if not applicable (caller runs the streaming form), -2 on a HIP error
 int launch_lanczos_persist(const OpDesc& op, int k, const double* q0, double* Q, int64_t ldq, double* alphas,
-                           double* betas, double* brk, double* fail, void* comm, hipStream_t st) {
+                           double* betas, double* brk, double* fail, void* comm, hipStream_t st, int lose_peer) {
   const int64_t n = op.n;
   if (!lanczos_persist_applicable(op, n, k)) return -1;
   const int G = (int)((n + LZP_ROWS - 1) / LZP_ROWS);
@@ -415,6 +417,7 @@ int launch_lanczos_persist(const OpDesc& op, int k, const double* q0, double* Q,
   a.comm = static_cast<unsigned long long*>(comm);
   a.G = G;
   a.kslots = k + 1;
+  a.lose_peer = lose_peer;
   hipLaunchKernelGGL(k_lanczos_persist, dim3(G), dim3(1024), 0, st, a);
   return 0;
 }

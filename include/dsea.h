@@ -94,6 +94,10 @@ int dsea_ws_set_lanczos_persist(dsea_ws_t ws, int mode);
  * previous vectors, Lanczos.py:66), 2 = the pass is repeated on the corrected vector ("CGS2": orthogonality at rounding
  * level even where one pass leaves eps ||u|| / beta) -- an option the reference lacks, never selected automatically. */
 int dsea_ws_set_reorth_passes(dsea_ws_t ws, int passes);
+/* TEST HOOK for the persistent single-launch forms (Lanczos, TFIM CG): with lose_peer != 0 the last workgroup of such a
+ * launch exits at once, so its peers run into their bounded spins -- exercises the DSEA_ERR_TIMEOUT path and the
+ * host's fall-back to the multi-launch kernels (a launch then takes the 3 s of the timeout).                      */
+int dsea_ws_set_fault_injection(dsea_ws_t ws, int lose_peer);
 
 /* Optional bf16 SHADOW of the Krylov basis (caller-owned, `rows` x `ld` uint16, ld % 8 == 0, 16-byte
  * aligned; null = off).  When registered, dsea_lanczos_run also stores every new basis vector rounded to

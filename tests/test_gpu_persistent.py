@@ -326,3 +326,67 @@ def test_persistent_tfim_cg_large_is_bit_identical_to_streaming_form(L):
     assert got[1] == 0 and got[3] and torch.equal(got[0], x0)
     got = _solve(op, b, x0, shift, -1, eps=1e-30, maxiter=0)
     assert got[1] == 0 and not got[3] and torch.equal(got[0], x0)
+
+
+# ------------------------------------------------------------------ a lost peer workgroup: time out, fall back, stay there
+def test_lost_peer_times_out_and_the_host_falls_back_to_the_multi_launch_kernels():
+    """The persistent single-launch forms spin on each other; every spin is bounded (3 s).  With the test hook
+    dsea_ws_set_fault_injection the last workgroup of a launch exits at once: the launch must END (not hang the GPU),
+    report DSEA_ERR_TIMEOUT, and the host must repeat the solve on the multi-launch kernels -- same result as if the
+    single-launch form had never been tried -- warn, and keep that workspace on the multi-launch kernels."""
+    import time
+    import warnings
+    from dominantsparseeigenad_amd import _lib
+    from dominantsparseeigenad_amd.Lanczos import symeigLanczos
+    from dominantsparseeigenad_amd.operators import TFIMOperator
+    lib = _lib.load()
+    # -- single-launch Lanczos (n = 1024: 8 workgroups)
+    L, k = 10, 60
+    n = 1 << L
+    op = TFIMOperator(L, cuda, g=torch.tensor([1.0], dtype=F64, device=cuda))
+    q0 = torch.from_numpy(normal_vector(n, 21)).to(cuda)
+    engine.LANCZOS_PERSIST = False
+    try:
+        ref_lo, ref_v = symeigLanczos(op, k, cuda, extreme="min", sparse=True, dim=n, q0=q0)
+    finally:
+        engine.LANCZOS_PERSIST = True
+    ws = engine.Workspace.get(n, k, cuda)
+    ws.lanczos_persist_lost = False
+    _lib.check(lib.dsea_ws_set_fault_injection(ws.handle, 1), "dsea_ws_set_fault_injection")
+    try:
+        t0 = time.time()
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            lo, v = symeigLanczos(op, k, cuda, extreme="min", sparse=True, dim=n, q0=q0)
+        waited = time.time() - t0
+        assert any("single-launch Lanczos timed out" in str(w.message) for w in rec)
+        assert 2.0 < waited < 20.0, waited
+        assert lo.item() == ref_lo.item() and torch.equal(v, ref_v)
+        assert ws.lanczos_persist_lost and ws.lanczos_persist_mode == 0
+        t0 = time.time()
+        symeigLanczos(op, k, cuda, extreme="min", sparse=True, dim=n, q0=q0)      # sticky: no second timeout
+        assert time.time() - t0 < 1.0
+    finally:
+        lib.dsea_ws_set_fault_injection(ws.handle, 0)
+        ws.lanczos_persist_lost = False
+    # -- single-launch CG, both TFIM forms (n = 1024: 8 workgroups; n = 2^15: 16 workgroups)
+    for Lc in (10, 15):
+        nc = 1 << Lc
+        opc = TFIMOperator(Lc, cuda, g=torch.tensor([1.0], dtype=F64, device=cuda))
+        b = torch.from_numpy(normal_vector(nc, 31)).to(cuda)
+        x0 = torch.from_numpy(normal_vector(nc, 32)).to(cuda)
+        shift = torch.tensor(-40.0, dtype=F64, device=cuda)
+        ref = _solve(opc, b, x0, shift, 0, eps=1e-9, maxiter=None)
+        wsc = engine.Workspace.get(nc, 8, cuda)
+        _lib.check(lib.dsea_ws_set_fault_injection(wsc.handle, 1), "dsea_ws_set_fault_injection")
+        try:
+            with warnings.catch_warnings(record=True) as rec:
+                warnings.simplefilter("always")
+                x = engine.cg(b, x0, native=opc, shift=shift, eps=1e-9)
+            assert any("persistent CG launch timed out" in str(w.message) for w in rec)
+            assert engine.last_cg.converged and engine.last_cg.iters == ref[1]
+            assert torch.equal(x, ref[0])
+            assert wsc.persist_mode == 0                                              # sticky
+        finally:
+            lib.dsea_ws_set_fault_injection(wsc.handle, 0)
+            wsc.set_persist(-1)
