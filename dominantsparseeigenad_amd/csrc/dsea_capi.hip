@@ -1078,7 +1078,7 @@ int dsea_cg_run(dsea_op_t op, dsea_ws_t ws, const double* shift, const double* b
     const int pr = tfim_big ? launch_cg_persist_tfim_big(op->d, shift, b, x, state, eps, maxiter, w.aux, d, Ad, st, w.lose_peer)
                    : tfim_persist ? launch_cg_persist_tfim(op->d, shift, b, x, state, eps, maxiter, P, st, w.lose_peer)
                                   : launch_cg_persist(op->d, shift, b, x, state, eps, maxiter, w.aux,
-                                                      w.persist_override > 0 ? w.persist_override : 0, st);
+                                                      w.persist_override > 0 ? w.persist_override : 0, st, w.lose_peer);
     if (pr == -2) {
       g_last_hip = (int)hipGetLastError();
       return DSEA_ERR_HIP;

@@ -195,7 +195,7 @@ void launch_gmres_solve(const double* H, int ldh, int m, const double* g, const 
                         hipStream_t st);
 size_t persist_comm_bytes(int64_t n);
 int launch_cg_persist(const OpDesc& op, const double* shift, const double* b, double* x, double* state, double eps,
-                      int64_t maxiter, void* comm, int ppt_override, hipStream_t st);
+                      int64_t maxiter, void* comm, int ppt_override, hipStream_t st, int lose_peer = 0);
 int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shift, const double* skip,
                 double* P, hipStream_t st, EventPair* ev = nullptr);
 // dsea_cg_persist_tfim_big.hip

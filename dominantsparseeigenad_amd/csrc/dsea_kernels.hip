@@ -1657,6 +1657,7 @@ struct PersistArgs {
   long long maxiter;
   unsigned long long* comm;  // granules: [2*ntiles] phase A | [2*ntiles] phase C | [4*G] r edges | [4*G] x edges ; zeroed per launch
   int ntiles;
+  int lose_peer;   // test hook (dsea_ws_set_fault_injection): the last workgroup exits at once
 };
 
 // shared scratch behind the d-with-halo array: wave partials of up to 4 sub-rounds, the broadcast slots
@@ -1757,6 +1758,7 @@ __global__ __launch_bounds__(256 * NVB) void k_cg_persist_stencil(PersistArgs a)
   PersistSm* sm = reinterpret_cast<PersistSm*>(lds + ROWS + 4);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, vb = tid >> 8, t = tid & 255;
   const int g = blockIdx.x, G = gridDim.x;
+  if (a.lose_peer && G > 1 && g == G - 1) return;
   const int64_t n = a.p.n;
   gu64* commA = (gu64*)a.comm;
   gu64* commC = commA + 2 * (int64_t)a.ntiles;
@@ -1950,6 +1952,7 @@ __global__ __launch_bounds__(256 * NVB) void k_cg_persist_stencil_merged(Persist
   PersistSmM* sm = reinterpret_cast<PersistSmM*>(lds + ROWS + 4);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, vb = tid >> 8, t = tid & 255;
   const int g = blockIdx.x, G = gridDim.x;
+  if (a.lose_peer && G > 1 && g == G - 1) return;
   const int64_t n = a.p.n;
   gu64* commS = (gu64*)a.comm;                       // [2 parities][G][4 values][2 granules]
   gu64* commX = commS + 16 * (int64_t)G;             // x edges of the start-up: [G][2][2]
@@ -2543,7 +2546,7 @@ size_t persist_comm_bytes(int64_t n) {
   return (size_t)(4 * nt + 20 * 256) * sizeof(unsigned long long);   // (the merged form needs 20 G <= 20 * 256)
 }
 int launch_cg_persist(const OpDesc& op, const double* shift, const double* b, double* x, double* state, double eps,
-                      int64_t maxiter, void* comm, int ppt_override, hipStream_t st) {
+                      int64_t maxiter, void* comm, int ppt_override, hipStream_t st, int lose_peer) {
   // mode >= 100: the merged-reduction form (one exchange per iteration, k_cg_persist_stencil_merged) with the
   // geometry code mode - 100
   const bool merged = ppt_override >= 100;
@@ -2602,6 +2605,7 @@ int launch_cg_persist(const OpDesc& op, const double* shift, const double* b, do
   a.maxiter = (long long)maxiter;
   a.comm = static_cast<unsigned long long*>(comm);
   a.ntiles = (int)nt;
+  a.lose_peer = lose_peer;
   const size_t lds = (size_t)(tpw * 512 + 4) * sizeof(double) + (merged ? sizeof(PersistSmM) : sizeof(PersistSm));
 #define PERSIST_CASE(P, V)                                                                                      \
   if (ppt == P && nvb == V) {                                                                                   \

@@ -369,22 +369,26 @@ def test_lost_peer_times_out_and_the_host_falls_back_to_the_multi_launch_kernels
     finally:
         lib.dsea_ws_set_fault_injection(ws.handle, 0)
         ws.lanczos_persist_lost = False
-    # -- single-launch CG, both TFIM forms (n = 1024: 8 workgroups; n = 2^15: 16 workgroups)
-    for Lc in (10, 15):
-        nc = 1 << Lc
-        opc = TFIMOperator(Lc, cuda, g=torch.tensor([1.0], dtype=F64, device=cuda))
+    # -- single-launch CG: both TFIM forms (n = 1024: 8 workgroups; n = 2^15: 16 workgroups) and the stencil form
+    for Lc in (10, 15, "stencil"):
+        if Lc == "stencil":
+            nc = 20000
+            opc = _problem(nc, seed=90)[0]
+        else:
+            nc = 1 << Lc
+            opc = TFIMOperator(Lc, cuda, g=torch.tensor([1.0], dtype=F64, device=cuda))
         b = torch.from_numpy(normal_vector(nc, 31)).to(cuda)
         x0 = torch.from_numpy(normal_vector(nc, 32)).to(cuda)
         shift = torch.tensor(-40.0, dtype=F64, device=cuda)
-        ref = _solve(opc, b, x0, shift, 0, eps=1e-9, maxiter=None)
+        ref = _solve(opc, b, x0, shift, 0, eps=0.0, maxiter=40)
         wsc = engine.Workspace.get(nc, 8, cuda)
         _lib.check(lib.dsea_ws_set_fault_injection(wsc.handle, 1), "dsea_ws_set_fault_injection")
         try:
             with warnings.catch_warnings(record=True) as rec:
                 warnings.simplefilter("always")
-                x = engine.cg(b, x0, native=opc, shift=shift, eps=1e-9)
+                x = engine.cg(b, x0, native=opc, shift=shift, eps=0.0, maxiter=40)
             assert any("persistent CG launch timed out" in str(w.message) for w in rec)
-            assert engine.last_cg.converged and engine.last_cg.iters == ref[1]
+            assert engine.last_cg.iters == ref[1] == 40
             assert torch.equal(x, ref[0])
             assert wsc.persist_mode == 0                                              # sticky
         finally:
