@@ -217,6 +217,18 @@ int launch_lanczos_persist(const OpDesc& op, int k, const double* q0, double* Q,
 
 }  // namespace dsea
 
+// Host-side polling of the CG state without draining the stream (dsea_capi.hip): the state of chunk j is copied into
+// pinned memory behind an event while chunk j + 1 is already enqueued -- the device never waits for the host round trip
+// (the launches of a chunk issued after convergence are no-ops on the device: every CG kernel tests the DONE flag).
+namespace dsea {
+struct StatePoller {
+  double* pinned;        // 2 x DSEA_CG_STATE_LEN doubles of page-locked host memory
+  hipEvent_t ev[2];
+  bool ok;
+};
+StatePoller* state_poller();   // per host thread, created on first use, nullptr if the runtime refuses
+}  // namespace dsea
+
 // the opaque handles of include/dsea.h
 struct dsea_op_s {
   dsea::OpDesc d;

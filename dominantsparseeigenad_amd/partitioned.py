@@ -521,7 +521,10 @@ class PartitionedOperator:
         self.be = be
         self.space = PartitionedSpace(comm, be)
         self.use_shadow = True
-        self.poll_every = 8
+        # CG: the host looks at the device-side stop flag every ``poll_every`` iterations.  After convergence the rest of
+        # a chunk still runs its collectives (a slab exchange cannot be skipped by a device flag), so with large slabs --
+        # an iteration of ~2 ms at 2^25 rows against a ~60 us poll -- short chunks waste less than they cost.
+        self.poll_every = 2 if (int(n_local) >= (1 << 24) and comm.world > 1) else 8
         # world size 1: the slab is the whole operator, so the in-library single-GPU loops apply; set this to run
         # the distributed driver anyway (tests, host-overhead measurements)
         self.force_driver = False
