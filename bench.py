@@ -196,6 +196,71 @@ def c3_figures(dev):
                        "in exact arithmetic, 6e-14 relative deviation after 40 iterations), off by default"}
 
 
+def live_pmc_traffic(timeout_s=240):
+    """HBM bytes per launch of every kernel of ONE step of the headline workload, from the PMC counters, measured NOW on
+    this box: two rocprofv3 passes (FETCH_SIZE, WRITE_SIZE: separate passes, --kernel-trace only, as
+    MI355X_MICROARCH.md prescribes) over `bench.py --steps 1 --warmup 1` as CHILD processes.  Must be called before
+    this process touches the GPU (a process that has initialised the GPU must not start other programs on this pool).
+    Units: KiB -> x 1024; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads -> x 2.
+    Returns (dict in the format of profiles/pmc_traffic.json, None) or (None, reason)."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    acc = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        outdir = tempfile.mkdtemp(prefix="dsea_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", outdir, "-o", "p", "--",
+               sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+               "--no-extras", "--no-anchors", "--no-kernel-events", "--no-live-pmc"]
+        env = dict(os.environ, TMPDIR="/tmp", DSEA_BENCH_CHILD="1")
+        try:
+            proc = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                  text=True, timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            shutil.rmtree(outdir, ignore_errors=True)
+            return None, "rocprofv3 --pmc %s pass timed out after %d s" % (counter, timeout_s)
+        except OSError as exc:
+            shutil.rmtree(outdir, ignore_errors=True)
+            return None, "rocprofv3 could not be started: %s" % exc
+        files = glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True)
+        if proc.returncode != 0 or not files:
+            shutil.rmtree(outdir, ignore_errors=True)
+            return None, "rocprofv3 --pmc %s pass failed (rc %s): %s" % (counter, proc.returncode, proc.stdout[-200:].replace("\n", " "))
+        per = collections.defaultdict(lambda: [0, 0.0])
+        with open(files[0]) as f:
+            for row in csv.DictReader(f):
+                if row.get("Counter_Name") != counter:
+                    continue
+                short = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("dsea::", "").split("<")[0]
+                per[short][0] += 1
+                per[short][1] += float(row["Counter_Value"])
+        acc[counter] = per
+        shutil.rmtree(outdir, ignore_errors=True)
+    out = {"_method": "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in two separate passes over one warm-up + one timed "
+                      "step of this script on this box, child processes started before the timed run; bytes = "
+                      "FETCH_SIZE[KiB]*1024*2 (gfx950 wide-read correction) + WRITE_SIZE[KiB]*1024"}
+    steps = 2
+    for name in sorted(acc["FETCH_SIZE"]):
+        if not name.startswith("k_"):
+            continue
+        nf, fs = acc["FETCH_SIZE"][name]
+        nw, wsz = acc["WRITE_SIZE"].get(name, [0, 0.0])
+        rd = fs / nf * 1024 * 2
+        wr = (wsz / nw * 1024) if nw else 0.0
+        out[name] = {"launches": nf, "fetch_bytes_per_launch": rd, "write_bytes_per_launch": wr,
+                     "hbm_bytes_per_launch": rd + wr}
+    out["_steps_profiled"] = steps
+    out["_total_hbm_bytes_per_step"] = sum(v["launches"] * v["hbm_bytes_per_launch"] for kk, v in out.items()
+                                           if kk.startswith("k_")) / steps
+    out["_commit"] = "live"
+    return out, None
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -463,6 +528,9 @@ def main():
     ap.add_argument("--no-anchors", action="store_true",
                     help="N = 1: skip the live one-GPU anchors of the multi-GPU curves (L = 28, k = 100 and 2^25 rows, "
                          "k = 200: ~40 s and 230 GB of HBM)")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="N = 1 headline run: do not measure roofline.traffic / pmc_* live with two rocprofv3 --pmc child "
+                         "passes (~20 s each) before the timed run; the committed profiles/pmc_traffic.json is quoted instead")
     ap.add_argument("--rpl", type=int, default=0)
     ap.add_argument("--operator", choices=["matrix-free", "sell", "csr"], default="matrix-free",
                     help="operand form of the TFIM operator at N=1: native matrix-free kernel (headline) or the "
@@ -490,6 +558,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    live_pmc, live_pmc_note = None, None
+    headline_defaults = (world == 1 and not dry and not args.force_partitioned and args.L is None and args.L_local is None
+                         and args.k is None and args.operator == "matrix-free" and args.reorth == "full")
+    if headline_defaults and not args.no_live_pmc and os.environ.get("DSEA_BENCH_CHILD", "") != "1":
+        # child processes, BEFORE this process initialises the GPU
+        t_pmc = time.time()
+        live_pmc, live_pmc_note = live_pmc_traffic()
+        live_pmc_note = live_pmc_note or "two rocprofv3 --pmc passes took %.0f s" % (time.time() - t_pmc)
     if dry:
         dev = torch.device("cpu")
         torch.set_num_threads(1)
@@ -735,8 +811,10 @@ def main():
             out["config"]["one_gpu_anchors"] = anchors
             out["config"]["one_gpu_anchors_stored"] = STORED_ANCHORS
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        pmc = None
-        if os.path.exists(tpath):
+        pmc = live_pmc
+        if live_pmc_note:
+            out["config"]["pmc_live"] = live_pmc_note
+        if pmc is None and os.path.exists(tpath):
             try:
                 pmc = json.load(open(tpath))
             except Exception:
@@ -746,7 +824,9 @@ def main():
             if pmc and pmc.get("_total_hbm_bytes_per_step"):
                 real = float(pmc["_total_hbm_bytes_per_step"])
                 out["config"]["pmc_hbm_bytes_per_step"] = real
-                out["config"]["pmc_source"] = "rocprofv3 PMC FETCH_SIZE/WRITE_SIZE at commit %s" % pmc.get("_commit", "?")
+                out["config"]["pmc_source"] = ("rocprofv3 PMC FETCH_SIZE/WRITE_SIZE measured in THIS run (child processes, same box)"
+                                               if pmc.get("_commit") == "live" else
+                                               "rocprofv3 PMC FETCH_SIZE/WRITE_SIZE at commit %s (committed file)" % pmc.get("_commit", "?"))
                 out["config"]["pmc_GBs"] = round(real / (ms_per_step * 1e-3) / 1e9, 2)
                 out["config"]["frac_of_hbm_peak_pmc_traffic"] = round(real / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         if ms_basisfree is not None:

@@ -63,3 +63,20 @@ def test_bench_line_partitioned_path():
     assert REQUIRED <= set(d) and d["scaling"] == "weak"
     assert "distributed_self_check" in d["config"]
     assert abs(d["config"]["E0_per_site"] - d["config"]["E0_per_site_closed_form"]) < 1e-9
+
+
+def test_headline_line_measures_its_pmc_traffic_live():
+    """The default N = 1 workload (BASELINE configs[1]) measures roofline.traffic in the run itself: two rocprofv3 --pmc
+    child passes (FETCH_SIZE, WRITE_SIZE, separate, --kernel-trace only) started before the process touches the GPU.
+    The dominant kernel's HBM traffic equals its algorithmic bytes to a few per cent (no wasted re-reads)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--no-extras", "--no-anchors"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.strip()][-1])
+    r, c = d["roofline"], d["config"]
+    assert "L=20" in c["workload"] and r["kernel"] == "k_rdots"
+    assert r["traffic_commit"] == "live", c.get("pmc_live")
+    assert 0.98 * r["algorithmic_bytes_per_launch"] < r["traffic"] < 1.05 * r["algorithmic_bytes_per_launch"]
+    assert "THIS run" in c["pmc_source"] and 0.9 < c["pmc_hbm_bytes_per_step"] / c["traffic_model_bytes_per_step"] < 1.15
+    assert d["value"] <= 8000.0 and 0 < r["frac"] <= 1.0
