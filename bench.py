@@ -561,7 +561,14 @@ def main():
     live_pmc, live_pmc_note = None, None
     headline_defaults = (world == 1 and not dry and not args.force_partitioned and args.L is None and args.L_local is None
                          and args.k is None and args.operator == "matrix-free" and args.reorth == "full")
-    if headline_defaults and not args.no_live_pmc and os.environ.get("DSEA_BENCH_CHILD", "") != "1":
+    # never from under a profiler: its preloaded library may already have initialised the GPU in THIS process, and a
+    # process that has done so must not start other programs on this pool
+    under_profiler = any(kk.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "RPD_")) for kk in os.environ) or \
+        "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or "roctracer" in os.environ.get("LD_PRELOAD", "").lower()
+    if under_profiler and headline_defaults and not args.no_live_pmc:
+        live_pmc_note = "skipped: running under a profiler (committed profiles/pmc_traffic.json quoted)"
+    if headline_defaults and not args.no_live_pmc and not under_profiler and not torch.cuda.is_initialized() and \
+            os.environ.get("DSEA_BENCH_CHILD", "") != "1":
         # child processes, BEFORE this process initialises the GPU
         t_pmc = time.time()
         live_pmc, live_pmc_note = live_pmc_traffic()
