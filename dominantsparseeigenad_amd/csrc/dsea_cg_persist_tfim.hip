@@ -25,24 +25,11 @@
 namespace dsea {
 
 namespace {
-typedef __attribute__((address_space(1))) unsigned long long cgt_gu64;
-#define CGT_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-#define CGT_TIMEOUT_TICKS 300000000ll /* 3 s of the 100 MHz wall clock */
+typedef gran_u64 cgt_gu64;
+#define CGT_TIMEOUT_TICKS DSEA_GRANULE_TIMEOUT_TICKS
 #define CGT_ROWS 128
 #define CGT_MAX_G 64
 
-__device__ __forceinline__ void cgt_put(cgt_gu64* g, unsigned epoch, double v) {
-  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-  const unsigned long long tag = (unsigned long long)epoch << 32;
-  __hip_atomic_store(g, tag | (b & 0xffffffffull), CGT_RLX_AGENT);
-  __hip_atomic_store(g + 1, tag | (b >> 32), CGT_RLX_AGENT);
-}
-__device__ __forceinline__ bool cgt_try_get(cgt_gu64* g, unsigned epoch, double& v) {
-  const unsigned long long lo = __hip_atomic_load(g, CGT_RLX_AGENT);
-  const unsigned long long hi = __hip_atomic_load(g + 1, CGT_RLX_AGENT);
-  v = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
-  return (unsigned)(lo >> 32) == epoch && (unsigned)(hi >> 32) == epoch;
-}
 __device__ __forceinline__ double cgt_tfim_diag(const TfimParams& p, int64_t i, uint64_t maskL) {
   const uint64_t gi = (uint64_t)(p.row_offset + i);
   const uint64_t rot = ((gi << 1) | (gi >> (p.L - 1))) & maskL;
@@ -123,7 +110,7 @@ __global__ __launch_bounds__(256) void k_cg_persist_tfim(CgtArgs a) {
     const long long t0 = wall_clock64();
     if (wv == 1 && lane < G) {
       double v = 0.0;
-      while (!cgt_try_get(base + (int64_t)lane * stride * 2, epoch, v)) {
+      while (!granule_try_get(base + (int64_t)lane * stride * 2, epoch, v)) {
         __builtin_amdgcn_s_sleep(1);
         if (wall_clock64() - t0 > CGT_TIMEOUT_TICKS) {
           s_b[1] = 1.0;
@@ -141,7 +128,7 @@ __global__ __launch_bounds__(256) void k_cg_persist_tfim(CgtArgs a) {
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
           pv[b] = 0.0;
-          if (b < nfar) ok &= cgt_try_get(rows_from + ((int64_t)(g ^ (1 << b)) * row_stride + row_off + rr) * 2, epoch, pv[b]);
+          if (b < nfar) ok &= granule_try_get(rows_from + ((int64_t)(g ^ (1 << b)) * row_stride + row_off + rr) * 2, epoch, pv[b]);
         }
         if (!ok) {
           __builtin_amdgcn_s_sleep(1);
@@ -174,11 +161,11 @@ __global__ __launch_bounds__(256) void k_cg_persist_tfim(CgtArgs a) {
   // ---- r = b - A' x0 ; d = r ; rr = r.r                                          (CG.py:26-30)
   if (wv == 0) {
     xv = ld2<true>(a.x, row, n);
-    cgt_put(SX + ((int64_t)g * CGT_ROWS + 2 * lane) * 2, epoch, xv.x);
-    cgt_put(SX + ((int64_t)g * CGT_ROWS + 2 * lane + 1) * 2, epoch, xv.y);
+    granule_put(SX + ((int64_t)g * CGT_ROWS + 2 * lane) * 2, epoch, xv.x);
+    granule_put(SX + ((int64_t)g * CGT_ROWS + 2 * lane + 1) * 2, epoch, xv.y);
     s_w[2 * lane] = xv.x;
     s_w[2 * lane + 1] = xv.y;
-    if (lane == 0) cgt_put(SA + (int64_t)g * 2, epoch, 0.0);    // (the gather below reads G slab granules: publish a dummy)
+    if (lane == 0) granule_put(SA + (int64_t)g * 2, epoch, 0.0);    // (the gather below reads G slab granules: publish a dummy)
   }
   (void)gather(SA, 1, epoch, SX, CGT_ROWS, 0, s_wnb, fail);   // the partner slabs' rows of x0
   if (fail) {
@@ -200,9 +187,9 @@ __global__ __launch_bounds__(256) void k_cg_persist_tfim(CgtArgs a) {
       acc = fma(rv.y, rv.y, acc);
       acc = wave_sum(acc);
       cgt_gu64* mine = SB + (int64_t)g * (1 + CGT_ROWS) * 2;
-      cgt_put(mine + (1 + 2 * lane) * 2, epoch, rv.x);
-      cgt_put(mine + (2 + 2 * lane) * 2, epoch, rv.y);
-      if (lane == 0) cgt_put(mine, epoch, acc);
+      granule_put(mine + (1 + 2 * lane) * 2, epoch, rv.x);
+      granule_put(mine + (2 + 2 * lane) * 2, epoch, rv.y);
+      if (lane == 0) granule_put(mine, epoch, acc);
     }
   };
   publish_r();
@@ -228,7 +215,7 @@ __global__ __launch_bounds__(256) void k_cg_persist_tfim(CgtArgs a) {
       acc = fma(dv.x, Ad.x, acc);
       acc = fma(dv.y, Ad.y, acc);
       acc = wave_sum(acc);
-      if (lane == 0) cgt_put(SA + (int64_t)g * 2, epoch, acc);
+      if (lane == 0) granule_put(SA + (int64_t)g * 2, epoch, acc);
     }
     const double dAd = gather(SA, 1, epoch, nullptr, 0, 0, nullptr, fail);
     if (fail) break;

@@ -33,27 +33,14 @@
 namespace dsea {
 
 namespace {
-typedef __attribute__((address_space(1))) unsigned long long cgb_gu64;
+typedef gran_u64 cgb_gu64;
 typedef unsigned int cgb_v4u __attribute__((ext_vector_type(4)));
-#define CGB_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-#define CGB_TIMEOUT_TICKS 300000000ll /* 3 s of the 100 MHz wall clock */
+#define CGB_TIMEOUT_TICKS DSEA_GRANULE_TIMEOUT_TICKS
 #define CGB_T 11
 #define CGB_TILE 2048
 #define CGB_PER 4          /* row pairs per thread */
 #define CGB_SC1 16         /* aux bits of the buffer intrinsics: sc1 */
 
-__device__ __forceinline__ void cgb_put(cgb_gu64* g, unsigned epoch, double v) {
-  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-  const unsigned long long tag = (unsigned long long)epoch << 32;
-  __hip_atomic_store(g, tag | (b & 0xffffffffull), CGB_RLX_AGENT);
-  __hip_atomic_store(g + 1, tag | (b >> 32), CGB_RLX_AGENT);
-}
-__device__ __forceinline__ bool cgb_try_get(cgb_gu64* g, unsigned epoch, double& v) {
-  const unsigned long long lo = __hip_atomic_load(g, CGB_RLX_AGENT);
-  const unsigned long long hi = __hip_atomic_load(g + 1, CGB_RLX_AGENT);
-  v = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
-  return (unsigned)(lo >> 32) == epoch && (unsigned)(hi >> 32) == epoch;
-}
 __device__ __forceinline__ double cgb_tfim_diag(const TfimParams& p, int64_t i, uint64_t maskL) {
   const uint64_t gi = (uint64_t)(p.row_offset + i);
   const uint64_t rot = ((gi << 1) | (gi >> (p.L - 1))) & maskL;
@@ -208,7 +195,7 @@ __global__ __launch_bounds__(256 * NVB) void k_cg_persist_tfim_big(CgbArgs a) {
         for (int m = 0; m < 8; ++m) {
           pv[m] = 0.0;
           const int b = t + 256 * m;
-          if (b < count) ok &= cgb_try_get(src + 2 * (int64_t)b, epoch, pv[m]);
+          if (b < count) ok &= granule_try_get(src + 2 * (int64_t)b, epoch, pv[m]);
         }
         if (!ok) {
           __builtin_amdgcn_s_sleep(1);
@@ -256,7 +243,7 @@ __global__ __launch_bounds__(256 * NVB) void k_cg_persist_tfim_big(CgbArgs a) {
       __builtin_amdgcn_raw_buffer_store_b128(cgb_as_v4(dv[m]), rd, (int)((base + 2 * (int64_t)(t + 256 * m)) * 8), 0, CGB_SC1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t == 0) cgb_put(FL + 2 * (int64_t)tile, epoch, 1.0);
+    if (t == 0) granule_put(FL + 2 * (int64_t)tile, epoch, 1.0);
   };
   // wait until the partner tiles of this virtual block have published d under `epoch` (or later)
   auto wait_partners = [&](unsigned epoch, bool& fail) {
@@ -264,9 +251,7 @@ __global__ __launch_bounds__(256 * NVB) void k_cg_persist_tfim_big(CgbArgs a) {
       const long long t0 = wall_clock64();
       cgb_gu64* f = FL + 2 * (int64_t)(tile ^ (1 << t));
       for (;;) {
-        const unsigned long long lo = __hip_atomic_load(f, CGB_RLX_AGENT);
-        const unsigned long long hi = __hip_atomic_load(f + 1, CGB_RLX_AGENT);
-        if ((unsigned)(lo >> 32) >= epoch && (unsigned)(hi >> 32) >= epoch) break;
+        if (granule_epoch(f) >= epoch) break;
         __builtin_amdgcn_s_sleep(1);
         if (wall_clock64() - t0 > CGB_TIMEOUT_TICKS) {
           sm.fail = 1.0;
@@ -316,7 +301,7 @@ __global__ __launch_bounds__(256 * NVB) void k_cg_persist_tfim_big(CgbArgs a) {
     __syncthreads();
     if (t < CGB_PER) {     // block_sum's order: ((w0 + w1) + w2) + w3
       const double tot = ((sm.red4[vb][t][0] + sm.red4[vb][t][1]) + sm.red4[vb][t][2]) + sm.red4[vb][t][3];
-      cgb_put(PC + 2 * ((int64_t)tile * 4 + t), ep, tot);
+      granule_put(PC + 2 * ((int64_t)tile * 4 + t), ep, tot);
     }
   };
   publish_rr(epoch);
@@ -336,7 +321,7 @@ __global__ __launch_bounds__(256 * NVB) void k_cg_persist_tfim_big(CgbArgs a) {
     CGB_TICK(1)
     const double tilesum = vb_sum(acc);
     ++epoch;
-    if (t == 0) cgb_put(PA + 2 * (int64_t)tile, epoch, tilesum);
+    if (t == 0) granule_put(PA + 2 * (int64_t)tile, epoch, tilesum);
     const double dAd = gather(PA, a.ntiles, epoch, true, fail);
     if (fail) break;
     CGB_TICK(2)

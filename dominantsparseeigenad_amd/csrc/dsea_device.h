@@ -187,5 +187,34 @@ __device__ __forceinline__ double sum_partials_block(const double* __restrict__ 
   return sm5[4];
 }
 
+// ------------------------------------------------------------------------------------------
+// Data-tagged granules: the cross-workgroup exchange of the persistent single-launch solvers (k_cg_persist_stencil*,
+// k_cg_persist_tfim*, k_lanczos_persist).  A double travels as two 8-byte words, each carrying 32 bits of data and the
+// 32-bit epoch of the exchange; a reader accepts the value when both words carry the epoch it waits for.  Relaxed
+// agent-scope stores and polls, no fences, no separate flags (cdna_hip_programming.md Guideline 16, form R2); the
+// buffers are zeroed by the launcher before every launch (epoch 0 = "nothing yet").
+// ------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) unsigned long long gran_u64;
+#define DSEA_GRANULE_TIMEOUT_TICKS 300000000ll /* 3 s of the 100 MHz wall clock: a lost peer must not hang the GPU */
+__device__ __forceinline__ void granule_put(gran_u64* g, unsigned epoch, double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned long long tag = (unsigned long long)epoch << 32;
+  __hip_atomic_store(g, tag | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(g + 1, tag | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool granule_try_get(gran_u64* g, unsigned epoch, double& v) {
+  const unsigned long long lo = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long hi = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+  return (unsigned)(lo >> 32) == epoch && (unsigned)(hi >> 32) == epoch;
+}
+// the epoch a granule currently carries (the smaller of its two words' tags)
+__device__ __forceinline__ unsigned granule_epoch(gran_u64* g) {
+  const unsigned long long lo = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long hi = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned a = (unsigned)(lo >> 32), b = (unsigned)(hi >> 32);
+  return a < b ? a : b;
+}
+
 }  // namespace dsea
 #endif

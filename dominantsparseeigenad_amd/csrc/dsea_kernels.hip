@@ -1627,25 +1627,15 @@ __global__ __launch_bounds__(256) void k_symv_reduce(SymDenseParams p, const dou
 // (tests/test_gpu_persistent.py) and identical on every workgroup, so all take the same exit.
 // Reference: CG.py:24-41 with A' = A - shift (CG.py:120).
 // ------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef gran_u64 gu64;
 #define DSEA_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 #ifndef DSEA_PERSIST_SLEEP
 #define DSEA_PERSIST_SLEEP 1
 #endif
-#define DSEA_PERSIST_TIMEOUT_TICKS 300000000ll /* 3 s of the 100 MHz wall clock: a lost peer must not hang the GPU */
+#define DSEA_PERSIST_TIMEOUT_TICKS DSEA_GRANULE_TIMEOUT_TICKS
 
-__device__ __forceinline__ void put_f64(gu64* g, unsigned epoch, double v) {
-  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-  const unsigned long long tag = (unsigned long long)epoch << 32;
-  __hip_atomic_store(g, tag | (b & 0xffffffffull), DSEA_RLX_AGENT);
-  __hip_atomic_store(g + 1, tag | (b >> 32), DSEA_RLX_AGENT);
-}
-__device__ __forceinline__ bool try_get_f64(gu64* g, unsigned epoch, double& v) {
-  const unsigned long long lo = __hip_atomic_load(g, DSEA_RLX_AGENT);
-  const unsigned long long hi = __hip_atomic_load(g + 1, DSEA_RLX_AGENT);
-  v = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
-  return (unsigned)(lo >> 32) == epoch && (unsigned)(hi >> 32) == epoch;
-}
+__device__ __forceinline__ void put_f64(gu64* g, unsigned epoch, double v) { granule_put(g, epoch, v); }
+__device__ __forceinline__ bool try_get_f64(gu64* g, unsigned epoch, double& v) { return granule_try_get(g, epoch, v); }
 
 struct PersistArgs {
   Stencil3Params p;

@@ -44,28 +44,15 @@
 namespace dsea {
 
 namespace {
-typedef __attribute__((address_space(1))) unsigned long long lzp_gu64;
-#define LZP_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-#define LZP_TIMEOUT_TICKS 300000000ll /* 3 s of the 100 MHz wall clock */
+typedef gran_u64 lzp_gu64;
+#define LZP_TIMEOUT_TICKS DSEA_GRANULE_TIMEOUT_TICKS
 #define LZP_ROWS 128
 #define LZP_MAX_K 512
 #define LZP_MAX_G 64
 
-__device__ __forceinline__ void lzp_put(lzp_gu64* g, unsigned epoch, double v) {
-  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-  const unsigned long long tag = (unsigned long long)epoch << 32;
-  __hip_atomic_store(g, tag | (b & 0xffffffffull), LZP_RLX_AGENT);
-  __hip_atomic_store(g + 1, tag | (b >> 32), LZP_RLX_AGENT);
-}
-__device__ __forceinline__ bool lzp_try_get(lzp_gu64* g, unsigned epoch, double& v) {
-  const unsigned long long lo = __hip_atomic_load(g, LZP_RLX_AGENT);
-  const unsigned long long hi = __hip_atomic_load(g + 1, LZP_RLX_AGENT);
-  v = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
-  return (unsigned)(lo >> 32) == epoch && (unsigned)(hi >> 32) == epoch;
-}
 // spin until the granule carries `epoch`; false on timeout
 __device__ __forceinline__ bool lzp_wait(lzp_gu64* g, unsigned epoch, double& v, long long t0) {
-  while (!lzp_try_get(g, epoch, v)) {
+  while (!granule_try_get(g, epoch, v)) {
     __builtin_amdgcn_s_sleep(1);
     if (wall_clock64() - t0 > LZP_TIMEOUT_TICKS) return false;
   }
@@ -139,9 +126,9 @@ __global__ __launch_bounds__(1024) void k_lanczos_persist(LzpArgs a) {
     if (wv == 0) {
       const double acc = wave_sum(fma(rv.x, rv.x, rv.y * rv.y));
       lzp_gu64* mine = E3 + (int64_t)g * (1 + LZP_ROWS) * 2;
-      lzp_put(mine + (1 + 2 * lane) * 2, epoch, rv.x);
-      lzp_put(mine + (2 + 2 * lane) * 2, epoch, rv.y);
-      if (lane == 0) lzp_put(mine, epoch, acc);
+      granule_put(mine + (1 + 2 * lane) * 2, epoch, rv.x);
+      granule_put(mine + (2 + 2 * lane) * 2, epoch, rv.y);
+      if (lane == 0) granule_put(mine, epoch, acc);
     } else if (wv == 1) {
       if (lane < G) {
         double v = 0.0;
@@ -230,7 +217,7 @@ __global__ __launch_bounds__(1024) void k_lanczos_persist(LzpArgs a) {
       }
       // ---- EA: alpha_s = q_s . u  (Lanczos.py:72): slab partial published, everybody's gathered below
       const double pa = wave_sum(fma(x0, uu.x, x1 * uu.y));
-      if (lane == 0) lzp_put(EA + (int64_t)g * 2, epoch, pa);
+      if (lane == 0) granule_put(EA + (int64_t)g * 2, epoch, pa);
       s_u[2 * lane] = uu.x;
       s_u[2 * lane + 1] = uu.y;
     } else if (wv == 1) {
@@ -284,7 +271,7 @@ __global__ __launch_bounds__(1024) void k_lanczos_persist(LzpArgs a) {
     }
     __syncthreads();
     // ---- E2: publish the partials, gather everybody's, sum over workgroups in a fixed order
-    if (tid < nvec) lzp_put(E2 + ((int64_t)g * a.kslots + tid) * 2, epoch, s_cpart[tid]);
+    if (tid < nvec) granule_put(E2 + ((int64_t)g * a.kslots + tid) * 2, epoch, s_cpart[tid]);
     {
       // thread t -> coefficient j = t mod J, workgroup range `part` = t / J (J = power of two >= nvec): every thread polls at
       // most ceil(G / parts) granules, all in flight together; the ranges are then added in ascending order
@@ -304,7 +291,7 @@ __global__ __launch_bounds__(1024) void k_lanczos_persist(LzpArgs a) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
               pv[m] = 0.0;
-              if (wb + m < w1) ok &= lzp_try_get(E2 + ((int64_t)(wb + m) * a.kslots + j) * 2, epoch, pv[m]);
+              if (wb + m < w1) ok &= granule_try_get(E2 + ((int64_t)(wb + m) * a.kslots + j) * 2, epoch, pv[m]);
             }
             if (!ok) {
               __builtin_amdgcn_s_sleep(1);
