@@ -119,6 +119,12 @@ __global__ __launch_bounds__(1024) void k_lanczos_persist(LzpArgs a) {
   if (wv == 0) rv = ld2<true>(a.q0, row, n);
   __syncthreads();
 
+#ifdef DSEA_LZP_TIMING
+  long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = wall_clock64();
+#define LZP_TICK(k) { const long long tn = wall_clock64(); tacc[k] += tn - tprev; tprev = tn; }
+#else
+#define LZP_TICK(k)
+#endif
   for (int s = 0; s < a.k; ++s) {
     const unsigned epoch = (unsigned)(s + 1);
     const long long t0 = wall_clock64();
@@ -175,6 +181,7 @@ __global__ __launch_bounds__(1024) void k_lanczos_persist(LzpArgs a) {
         return;
       }
     }
+    LZP_TICK(0)
     // ---- q_s = r / beta (Lanczos.py:53,70), stored into the basis; u = A q_s on this slab
     if (wv == 0) {
       double2 q;
@@ -242,6 +249,7 @@ __global__ __launch_bounds__(1024) void k_lanczos_persist(LzpArgs a) {
     if (g == 0 && tid == 0) a.alphas[s] = alpha;
     scale = fmax(scale, fabs(alpha));
     if (s == a.k - 1) break;
+    LZP_TICK(1)
     // ---- three-term recurrence on the slab (Lanczos.py:61): r = u - alpha_s q_s - beta_{s-1} q_{s-1}
     if (wv == 0) {
       const double b = s >= 1 ? beta : 0.0;
@@ -270,6 +278,7 @@ __global__ __launch_bounds__(1024) void k_lanczos_persist(LzpArgs a) {
       if ((lane & 15) == 15 && jj < nvec) s_cpart[jj] = bsum;
     }
     __syncthreads();
+    LZP_TICK(2)
     // ---- E2: publish the partials, gather everybody's, sum over workgroups in a fixed order
     if (tid < nvec) granule_put(E2 + ((int64_t)g * a.kslots + tid) * 2, epoch, s_cpart[tid]);
     {
@@ -318,6 +327,7 @@ __global__ __launch_bounds__(1024) void k_lanczos_persist(LzpArgs a) {
       }
     }
     __syncthreads();
+    LZP_TICK(3)
     // ---- r -= sum_{j<=s} c_j q_j   (second half of Lanczos.py:66), the waves' partial sums combined in wave order
     double2 w = make_double2(0.0, 0.0);
     for (int cc = wv; cc < nchunks; cc += 16) {
@@ -352,7 +362,12 @@ __global__ __launch_bounds__(1024) void k_lanczos_persist(LzpArgs a) {
       rv.y = uu.y - tot.y;
     }
     __syncthreads();   // s_part / s_c / s_cpart are rewritten by the next step
+    LZP_TICK(4)
   }
+#ifdef DSEA_LZP_TIMING
+  if (g == 0 && tid == 0)
+    for (int q = 0; q < 5; ++q) a.alphas[q] = (double)tacc[q] * 0.01 / (double)a.k;   // us per step (overwrites alphas!)
+#endif
   if (g == 0 && tid == 0) a.brk[1] = scale;
 }
 
