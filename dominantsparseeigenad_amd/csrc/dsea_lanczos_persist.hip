@@ -49,6 +49,7 @@ typedef gran_u64 lzp_gu64;
 #define LZP_ROWS 128
 #define LZP_MAX_K 512
 #define LZP_MAX_G 64
+#define LZP_CACHE 112   // basis vectors whose own rows stay in LDS (112 KB of the CU's 160; a multiple of the chunk of 4)
 
 // spin until the granule carries `epoch`; false on timeout
 __device__ __forceinline__ bool lzp_wait(lzp_gu64* g, unsigned epoch, double& v, long long t0) {
@@ -93,10 +94,12 @@ __global__ __launch_bounds__(1024) void k_lanczos_persist(LzpArgs a) {
   __shared__ double s_cpart[LZP_MAX_K];      // this workgroup's partial dots
   __shared__ double s_red[1024];             // gather: partial sums over workgroup ranges, [part * J + j]
   __shared__ double2 s_part[16][64];         // correction pass: per-wave partial sums
+  __shared__ double2 s_cache[LZP_CACHE][64]; // own rows of q_0 .. q_{LZP_CACHE-1}: the two passes over the basis read these from LDS
   __shared__ double s_q[LZP_ROWS];           // own rows of q_s
+  __shared__ double s_qp[LZP_ROWS];          // own rows of q_{s-1}
   __shared__ double s_u[LZP_ROWS];           // own rows of u = A q_s
   __shared__ double s_nb[6][LZP_ROWS];       // TFIM: the rows of the (un-normalised) r of the up-to-6 partner workgroups
-  __shared__ double s_norm[LZP_MAX_G];
+  __shared__ double s_alpha;                 // alpha_s (s_b[0] still holds ||r||^2 when it is written)
   __shared__ double s_b[4];                  // [0] ||r||^2  [1] fail  [2] left edge  [3] right edge (stencil)
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -112,10 +115,9 @@ __global__ __launch_bounds__(1024) void k_lanczos_persist(LzpArgs a) {
   lzp_gu64* E3 = E2 + (int64_t)2 * G * a.kslots;
   lzp_gu64* EA = E3 + (int64_t)2 * G * (1 + LZP_ROWS);
   if (tid == 0) s_b[1] = 0.0;
+  if (tid < LZP_ROWS) s_q[tid] = 0.0;
   double scale = 0.0;                           // running max |alpha|, |beta| (same in every thread of every workgroup)
   double2 rv = make_double2(0.0, 0.0);          // wave 0: this lane's two rows of r
-  double2 qprev = make_double2(0.0, 0.0);       // wave 0: rows of q_{s-1}
-  double2 qcur = make_double2(0.0, 0.0);
   if (wv == 0) rv = ld2<true>(a.q0, row, n);
   __syncthreads();
 
@@ -136,11 +138,11 @@ __global__ __launch_bounds__(1024) void k_lanczos_persist(LzpArgs a) {
       granule_put(mine + (2 + 2 * lane) * 2, epoch, rv.y);
       if (lane == 0) granule_put(mine, epoch, acc);
     } else if (wv == 1) {
-      if (lane < G) {
-        double v = 0.0;
-        if (!lzp_wait(E3 + (int64_t)lane * (1 + LZP_ROWS) * 2, epoch, v, t0)) s_b[1] = 1.0;
-        s_norm[lane] = v;
-      }
+      // the G slab partials, one per lane, summed by the wave itself in its fixed order (identical in every workgroup)
+      double v = 0.0;
+      if (lane < G && !lzp_wait(E3 + (int64_t)lane * (1 + LZP_ROWS) * 2, epoch, v, t0)) s_b[1] = 1.0;
+      v = wave_sum(v);
+      if (lane == 0) s_b[0] = v;
     }
     if (tfim) {
       const int t = tid - 128;
@@ -163,12 +165,6 @@ __global__ __launch_bounds__(1024) void k_lanczos_persist(LzpArgs a) {
       if (tid == 0) a.fail[0] = 1.0;
       return;
     }
-    if (tid == 0) {
-      double tot = 0.0;
-      for (int w = 0; w < G; ++w) tot += s_norm[w];      // fixed order: identical in every workgroup
-      s_b[0] = tot;
-    }
-    __syncthreads();
     const double beta = sqrt(s_b[0]);
     if (s >= 1) {
       if (g == 0 && tid == 0) a.betas[s - 1] = beta;
@@ -188,13 +184,15 @@ __global__ __launch_bounds__(1024) void k_lanczos_persist(LzpArgs a) {
       q.x = rv.x / beta;
       q.y = rv.y / beta;
       st2<true>(a.Q + (int64_t)s * a.ldq, row, n, q);
+      if (s < LZP_CACHE) s_cache[s][lane] = q;
+      s_qp[2 * lane] = s_q[2 * lane];          // q_{s-1} (wave 0 is the only writer of both arrays)
+      s_qp[2 * lane + 1] = s_q[2 * lane + 1];
       s_q[2 * lane] = q.x;
       s_q[2 * lane + 1] = q.y;
-      qprev = qcur;
-      qcur = q;
-    }
-    __syncthreads();
-    if (wv == 0) {
+      // wave 0 alone writes and (until the barrier after EA) reads s_q: the wave's own LDS operations complete in order,
+      // the fence only stops the compiler from moving the reads above the writes
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
       double2 uu = make_double2(0.0, 0.0);
       const double x0 = s_q[2 * lane], x1 = s_q[2 * lane + 1];
       if (tfim) {
@@ -228,39 +226,29 @@ __global__ __launch_bounds__(1024) void k_lanczos_persist(LzpArgs a) {
       s_u[2 * lane] = uu.x;
       s_u[2 * lane + 1] = uu.y;
     } else if (wv == 1) {
-      if (lane < G) {
-        double v = 0.0;
-        if (!lzp_wait(EA + (int64_t)lane * 2, epoch, v, t0)) s_b[1] = 1.0;
-        s_norm[lane] = v;
-      }
+      double v = 0.0;
+      if (lane < G && !lzp_wait(EA + (int64_t)lane * 2, epoch, v, t0)) s_b[1] = 1.0;
+      v = wave_sum(v);
+      if (lane == 0) s_alpha = v;
     }
     __syncthreads();
     if (s_b[1] != 0.0) {
       if (tid == 0) a.fail[0] = 1.0;
       return;
     }
-    if (tid == 0) {
-      double tot = 0.0;
-      for (int w = 0; w < G; ++w) tot += s_norm[w];
-      s_b[0] = tot;
-    }
-    __syncthreads();
-    const double alpha = s_b[0];
+    const double alpha = s_alpha;
     if (g == 0 && tid == 0) a.alphas[s] = alpha;
     scale = fmax(scale, fabs(alpha));
     if (s == a.k - 1) break;
     LZP_TICK(1)
-    // ---- three-term recurrence on the slab (Lanczos.py:61): r = u - alpha_s q_s - beta_{s-1} q_{s-1}
-    if (wv == 0) {
+    // ---- three-term recurrence on the slab (Lanczos.py:61): r = u - alpha_s q_s - beta_{s-1} q_{s-1}, formed by EVERY
+    // wave for its lanes' two rows (each wave covers all 128 rows): no hand-over through LDS, no barrier
+    double2 uu;
+    {
       const double b = s >= 1 ? beta : 0.0;
-      double2 r1;
-      r1.x = __dsub_rn(__dsub_rn(s_u[2 * lane], __dmul_rn(alpha, qcur.x)), __dmul_rn(b, qprev.x));
-      r1.y = __dsub_rn(__dsub_rn(s_u[2 * lane + 1], __dmul_rn(alpha, qcur.y)), __dmul_rn(b, qprev.y));
-      s_u[2 * lane] = r1.x;
-      s_u[2 * lane + 1] = r1.y;
+      uu.x = __dsub_rn(__dsub_rn(s_u[2 * lane], __dmul_rn(alpha, s_q[2 * lane])), __dmul_rn(b, s_qp[2 * lane]));
+      uu.y = __dsub_rn(__dsub_rn(s_u[2 * lane + 1], __dmul_rn(alpha, s_q[2 * lane + 1])), __dmul_rn(b, s_qp[2 * lane + 1]));
     }
-    __syncthreads();
-    const double2 uu = make_double2(s_u[2 * lane], s_u[2 * lane + 1]);    // r before the correction
     // ---- partial c_j = q_j . r for j <= s (first half of Lanczos.py:66): chunks of four vectors, chunk cc -> wave cc mod 16
     const int nvec = s + 1;
     const int nchunks = (nvec + 3) / 4;
@@ -270,7 +258,7 @@ __global__ __launch_bounds__(1024) void k_lanczos_persist(LzpArgs a) {
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         double2 q = make_double2(0.0, 0.0);
-        if (j + v < nvec) q = ld2<true>(a.Q + (int64_t)(j + v) * a.ldq, row, n);
+        if (j + v < nvec) q = (j < LZP_CACHE) ? s_cache[j + v][lane] : ld2<true>(a.Q + (int64_t)(j + v) * a.ldq, row, n);
         acc[v] = fma(q.x, uu.x, q.y * uu.y);
       }
       const double bsum = wave_sum4_rows(acc[0], acc[1], acc[2], acc[3]);
@@ -339,7 +327,7 @@ __global__ __launch_bounds__(1024) void k_lanczos_persist(LzpArgs a) {
         q[v] = make_double2(0.0, 0.0);
         cj[v] = 0.0;
         if (j + v < nvec) {
-          q[v] = ld2<true>(a.Q + (int64_t)(j + v) * a.ldq, row, n);
+          q[v] = (j < LZP_CACHE) ? s_cache[j + v][lane] : ld2<true>(a.Q + (int64_t)(j + v) * a.ldq, row, n);
           cj[v] = s_c[j + v];
         }
       }
@@ -361,7 +349,7 @@ __global__ __launch_bounds__(1024) void k_lanczos_persist(LzpArgs a) {
       rv.x = uu.x - tot.x;
       rv.y = uu.y - tot.y;
     }
-    __syncthreads();   // s_part / s_c / s_cpart are rewritten by the next step
+    // no barrier here: s_part / s_c / s_cpart / s_red are next written behind the next step's E3 and EA barriers
     LZP_TICK(4)
   }
 #ifdef DSEA_LZP_TIMING
