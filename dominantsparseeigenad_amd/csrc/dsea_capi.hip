@@ -99,6 +99,8 @@ TileGeom Workspace::geom(int64_t n_rows) const {
   // regime).  Measured on MI355X at i = 199 (tools/kbench.py), dots pass one-wave-per-tile -> split:
   // n = 2^12: 27.7 -> 8.2 us, 2^14: 42.3 -> 8.7 us, 2^16: 46.4 -> 26.7 us, 2^17: 51.4 -> 43.9 us, 2^18: no gain.
   g.split_w = 0;
+  g.dots_w = 0;
+  g.dots_nt = 1;
   const int64_t tiles128 = (n_rows + 127) / 128;
   int sw = split_override;
   if (sw < 0 && rpl_override == 0) sw = tiles128 <= 256 ? 16 : (tiles128 <= 1024 ? 8 : 0);
@@ -108,6 +110,14 @@ TileGeom Workspace::geom(int64_t n_rows) const {
     g.ntiles = tiles128;
     g.nw = (int)tiles128;
     if (tiles128 > DSEA_MAX_WAVE_TILES) g.split_w = 0;  // cannot happen for automatic selection
+    // dots pass: beyond 640 tiles (BASELINE config 3: 782) blocks of 16 waves own TWO sub-tiles -- all blocks resident in one
+    // round, twice the loads in flight per trip, half the partials (MI355X, n = 1e5: 26.9 -> 23.0 us at i = 150, 49.9 -> 44.2 at
+    // i = 299 including the second stage; no gain at 625 tiles and below: profiles/r03_split_dots_subtiles.txt)
+    g.dots_w = g.split_w;
+    if (split_override < 0 && tiles128 > 640) {
+      g.dots_w = 16;
+      g.dots_nt = 2;
+    }
   }
   return g;
 }

@@ -88,6 +88,8 @@ struct TileGeom {
   int64_t ntiles;  // ceil(n / (64*rpl))
   int pstride;     // stride between the partial rows of two basis vectors (>= nw)
   int split_w;     // 0, or W = waves of one block that share a 128-row tile and split the basis (small n)
+  int dots_w;      // split form of the dots pass: waves per block ...
+  int dots_nt;     // ... and 128-row sub-tiles per block (1 or 2); partial count = ceil(ntiles / dots_nt)
 };
 
 // optional per-launch HIP-event timing of the dominant kernels (bench.py roofline); host objects only

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void k_axpy_norm(const double* __restrict__ Q,
 // (chunk c -> wave c mod W).  Dots: every c_j is still produced by exactly one wave (same partial layout).
 // Correction: the W partial sums of a tile are combined through LDS in wave order -- deterministic.
 // ------------------------------------------------------------------------------------------
-template <int W>
+template <int W, int NT>
 __global__ __launch_bounds__(W * 64) void k_rdots_split(const double* __restrict__ Q, int64_t ldq, int i,
                                                         int64_t n, const double* __restrict__ u,
                                                         const double* __restrict__ alpha,
@@ -316,14 +316,22 @@ __global__ __launch_bounds__(W * 64) void k_rdots_split(const double* __restrict
                                                         const double* __restrict__ aP, int aCount,
                                                         double* __restrict__ a_store, int want_rr,
                                                         double* __restrict__ brk) {
+  // NT = 128-row sub-tiles per block (NT = 2 beyond 640 tiles: twice the loads in flight per wave trip, half the partials
+  // for the second stage).  Requesting a wave's first chunk ahead of the alpha partials was measured and is SLOWER
+  // (config 3: 24.8 -> 28.3 us per launch), and forcing 64 VGPRs (two 1024-thread blocks per CU) gains nothing.
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t tile = blockIdx.x;
-  const int64_t row = tile * 128 + lane * 2;
+  const int64_t row = tile * (128 * NT) + lane * 2;
   // (the tile's rows of u, q, q' are requested before the break record and the alpha partials are waited for)
   const double* __restrict__ q1 = Q + (int64_t)(i - 1) * ldq;
-  const double2 uu = ld2<true>(u, row, n), qa = ld2<true>(q1, row, n);
-  double2 qb = make_double2(0.0, 0.0);
-  if (i >= 2) qb = ld2<true>(Q + (int64_t)(i - 2) * ldq, row, n);
+  double2 uu[NT], qa[NT], qb[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    uu[t] = ld2<true>(u, row + 128 * t, n);
+    qa[t] = ld2<true>(q1, row + 128 * t, n);
+    qb[t] = make_double2(0.0, 0.0);
+    if (i >= 2) qb[t] = ld2<true>(Q + (int64_t)(i - 2) * ldq, row + 128 * t, n);
+  }
   if (broken(brk)) return;
   double a;
   if (aCount > 0) {
@@ -334,31 +342,48 @@ __global__ __launch_bounds__(W * 64) void k_rdots_split(const double* __restrict
   }
   const double b = beta ? beta[0] : 0.0;
   if (brk && tile == 0 && wv == 0 && lane == 0) brk[1] = fmax(brk[1], fmax(fabs(a), fabs(b)));
-  double2 rv;
-  rv.x = __dsub_rn(__dsub_rn(uu.x, __dmul_rn(a, qa.x)), __dmul_rn(b, qb.x));
-  rv.y = __dsub_rn(__dsub_rn(uu.y, __dmul_rn(a, qa.y)), __dmul_rn(b, qb.y));
+  double2 rv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    rv[t].x = __dsub_rn(__dsub_rn(uu[t].x, __dmul_rn(a, qa[t].x)), __dmul_rn(b, qb[t].x));
+    rv[t].y = __dsub_rn(__dsub_rn(uu[t].y, __dmul_rn(a, qa[t].y)), __dmul_rn(b, qb[t].y));
+  }
   // The tile's i (+1) partial sums are collected in LDS and flushed once, r is written at the end from its
   // registers: no global store sits between the trips of a wave (see rdots_tile).
   extern __shared__ double split_lds[];     // [i + 1]
   if (wv == 0 && want_rr) {
-    const double acc = wave_sum(fma(rv.x, rv.x, rv.y * rv.y));
+    double p = fma(rv[0].x, rv[0].x, rv[0].y * rv[0].y);
+#pragma unroll
+    for (int t = 1; t < NT; ++t) p += fma(rv[t].x, rv[t].x, rv[t].y * rv[t].y);
+    const double acc = wave_sum(p);
     if (lane == 0) split_lds[i] = acc;
   }
   const int nchunks = (i + 3) / 4;
   for (int cc = wv; cc < nchunks; cc += W) {
     const int j = 4 * cc;
+    double2 q[4][NT];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        q[v][t] = make_double2(0.0, 0.0);
+        if (j + v < i) q[v][t] = ld2_stream<true>(Q + (int64_t)(j + v) * ldq, row + 128 * t, n);
+      }
     double acc[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      double2 q = make_double2(0.0, 0.0);
-      if (j + v < i) q = ld2_stream<true>(Q + (int64_t)(j + v) * ldq, row, n);
-      acc[v] = fma(q.x, rv.x, q.y * rv.y);
+      acc[v] = fma(q[v][0].x, rv[0].x, q[v][0].y * rv[0].y);
+#pragma unroll
+      for (int t = 1; t < NT; ++t) acc[v] += fma(q[v][t].x, rv[t].x, q[v][t].y * rv[t].y);
     }
     const double bsum = wave_sum4_rows(acc[0], acc[1], acc[2], acc[3]);
     const int jj = j + (lane >> 4);
     if ((lane & 15) == 15 && jj < i) split_lds[jj] = bsum;
   }
-  if (wv == 0) st2<true>(r, row, n, rv);
+  if (wv == 0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) st2<true>(r, row + 128 * t, n, rv[t]);
+  }
   __syncthreads();
   const int cnt = i + (want_rr ? 1 : 0);
   for (int idx = threadIdx.x; idx < cnt; idx += W * 64) P[(int64_t)idx * pstride + tile] = split_lds[idx];
@@ -2200,16 +2225,23 @@ void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, in
                   hipStream_t st, EventPair* ev, const double* aP, int aCount, double* a_store, bool want_rr,
                   double* brk) {
   if (g.split_w) {
-    const unsigned tiles = (unsigned)g.ntiles;
     const int wr = want_rr ? 1 : 0;
     const size_t slds = (size_t)(i + 1) * sizeof(double);     // the tile's partial sums (see k_rdots_split)
-    switch (g.split_w) {
-      case 4: KLAUNCH_LDS(ev, (k_rdots_split<4>), tiles, 256, slds, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, aP, aCount, a_store, wr, brk); break;
-      case 8: KLAUNCH_LDS(ev, (k_rdots_split<8>), tiles, 512, slds, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, aP, aCount, a_store, wr, brk); break;
-      default: KLAUNCH_LDS(ev, (k_rdots_split<16>), tiles, 1024, slds, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, aP, aCount, a_store, wr, brk); break;
+    const int nt = g.dots_nt;
+    const unsigned tiles = (unsigned)((g.ntiles + nt - 1) / nt);
+#define RDS(Wv, NTv) KLAUNCH_LDS(ev, (k_rdots_split<Wv, NTv>), tiles, Wv * 64, slds, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, aP, aCount, a_store, wr, brk)
+    if (nt == 2) {
+      RDS(16, 2);
+    } else {
+      switch (g.dots_w) {
+        case 4: RDS(4, 1); break;
+        case 8: RDS(8, 1); break;
+        default: RDS(16, 1); break;
+      }
     }
+#undef RDS
     hipLaunchKernelGGL(k_finalize_multi, dim3(want_rr ? i + 1 : i), dim3(256), 0, st, (const double*)P,
-                       (int64_t)g.pstride, g.nw, c_out, (const double*)brk);
+                       (int64_t)g.pstride, (int)tiles, c_out, (const double*)brk);
     return;
   }
   // one row of i + 1 partial sums per wave in LDS (see rdots_tile); 64 KiB of dynamic LDS hold 4 waves up to

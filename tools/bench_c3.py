@@ -16,12 +16,16 @@ h = 2.0 / N
 x = torch.from_numpy(np.linspace(-1.0, 1.0, num=N, endpoint=False)).to(dev)
 op = Stencil3Operator(N, h, 0.5 * x ** 2)
 q0 = torch.from_numpy(normal_vector(N, 1)).to(dev)
+if os.environ.get("C3_SPLIT"):      # A/B: force the split width (and with it one sub-tile per block in the dots pass)
+    engine.Workspace.get(N, k, dev).set_split(int(os.environ["C3_SPLIT"]))
 for it in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     lam, psi = symeigLanczos(op, k, dev, extreme="min", sparse=True, dim=N, q0=q0)
     torch.cuda.synchronize(); t1 = time.perf_counter()
 print("Lanczos N=%d k=%d: %.2f ms  (%.1f us/step; algorithmic %.0f GB/s)  theta=%.6f" % (
     N, k, (t1 - t0) * 1e3, (t1 - t0) / k * 1e6, 8.0 * N * (k * k + 12 * k) / (t1 - t0) / 1e9, lam.item()))
+if os.environ.get("C3_LANCZOS_ONLY"):
+    sys.exit(0)
 b = torch.from_numpy(normal_vector(N, 2)).to(dev); x0 = torch.from_numpy(normal_vector(N, 3)).to(dev)
 shift = torch.tensor(-1.0, dtype=torch.float64, device=dev)
 ws = engine.Workspace.get(N, 8, dev)
