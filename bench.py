@@ -148,6 +148,42 @@ def cpu_baseline(L, k, cg_cap, threads, model=None):
                    "GBs": round(algorithmic_bytes(n, k, m) / dt / 1e9, 3), "E0": E0.item(), "dloss_dg": gl.item()}
 
 
+def measured_ceilings(dev):
+    """the box's own streaming ceilings next to the 8 TB/s spec figure, measured with the library's probe
+    kernels (dsea_probe_stream: 8 non-temporal 16-byte loads in flight per lane, nothing else to do) on 1 GiB buffers
+    (beyond the 256 MiB Infinity Cache): a read-only pass and a copy (bytes read + written); torch's own copy kernel
+    beside them.  Best of 5 after 2 warm-ups, HIP events on the current stream."""
+    from dominantsparseeigenad_amd import engine, _lib
+    lib = _lib.load()
+    nel = 1 << 27                                   # 1 GiB of doubles
+    a = torch.ones(nel, dtype=torch.float64, device=dev)
+    b = torch.empty(nel, dtype=torch.float64, device=dev)
+    ws = engine.Workspace.get(4096, 8, dev)         # the probe only borrows its partial-sum buffer
+    st = engine._stream(dev)
+
+    def best(fn):
+        for _ in range(2):
+            fn()
+        t = 1e30
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            t = min(t, e0.elapsed_time(e1) * 1e-3)
+        return t
+    t_read = best(lambda: engine.check(lib.dsea_probe_stream(ws.handle, engine._ptr(a), None, nel, st), "dsea_probe_stream"))
+    t_copy = best(lambda: engine.check(lib.dsea_probe_stream(ws.handle, engine._ptr(a), engine._ptr(b), nel, st), "dsea_probe_stream"))
+    t_torch = best(lambda: b.copy_(a))
+    res = {"read_GBs": round(8.0 * nel / t_read / 1e9, 1), "copy_GBs": round(2 * 8.0 * nel / t_copy / 1e9, 1),
+           "torch_copy_GBs": round(2 * 8.0 * nel / t_torch / 1e9, 1),
+           "what": "1 GiB buffers: read-only reduction / copy (bytes read + written) by dsea_probe_stream, torch's "
+                   "copy_ beside them; best of 5, HIP events"}
+    del a, b
+    return res
+
+
 def c3_figures(dev):
     """BASELINE configs[2] in its well-posed restatement: 3-point stencil N = 100000
     (schrodinger1D.py:11-27 semantics), Lanczos k = 300 forward and CG over a FIXED 1000 iterations."""
@@ -877,6 +913,13 @@ def main():
                         else "rank 0's local kernels in the row-partitioned run",
             }
         if not args.no_extras and world == 1 and not partitioned_path and not big:
+            try:
+                ceil = measured_ceilings(dev)
+                out["config"]["measured_ceilings"] = ceil
+                if "roofline" in out:
+                    out["roofline"]["frac_of_measured_read_ceiling"] = round(out["roofline"]["achieved"] / ceil["read_GBs"], 4)
+            except Exception as exc:  # noqa: BLE001
+                out["config"]["measured_ceilings"] = "failed: %s" % exc
             try:
                 out["config"]["config3"] = c3_figures(dev)
             except Exception as exc:  # noqa: BLE001

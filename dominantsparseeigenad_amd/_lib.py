@@ -70,6 +70,7 @@ _SIGNATURES = {
     "dsea_shift_dot": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "dsea_axpy": (c_int, [c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "dsea_nrm2sq": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "dsea_probe_stream": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "dsea_scale_store": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "dsea_lanczos_rdots": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p]),

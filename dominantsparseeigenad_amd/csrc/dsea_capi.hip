@@ -502,6 +502,13 @@ int dsea_dot(dsea_ws_t ws, const double* x, const double* y, int64_t n, double* 
   return check_launch();
 }
 
+int dsea_probe_stream(dsea_ws_t ws, const double* x, double* y, int64_t n, void* stream) {
+  REQUIRE(ws && x && n >= 1, DSEA_ERR_ARG);
+  REQUIRE(aligned16(x) && (!y || aligned16(y)), DSEA_ERR_ALIGN);
+  launch_probe(x, y, n, ws->w.partials, 2048, static_cast<hipStream_t>(stream));
+  return check_launch();
+}
+
 int dsea_shift_dot(dsea_ws_t ws, const double* x, double* y, const double* shift, double* dot_out,
                    const double* skip_flag, int64_t n, void* stream) {
   REQUIRE(ws && x && y && dot_out && n >= 1, DSEA_ERR_ARG);

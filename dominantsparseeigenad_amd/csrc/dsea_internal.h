@@ -157,6 +157,7 @@ void launch_axpy_norm(const TileGeom& g, const double* Q, int64_t ldq, int64_t n
 void launch_ritz(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int k, const double* s,
                  double* out, hipStream_t st);
 void launch_dot(const double* x, const double* y, int64_t n, double* P, double* out, hipStream_t st);
+void launch_probe(const double* x, double* y, int64_t n, double* P, int nP, hipStream_t st);   // y != null: copy
 void launch_shift_dot(const double* x, double* y, const double* shift, const double* skip, int64_t n,
                       double* P, double* out, hipStream_t st);
 void launch_axpy(double a_host, const double* a_dev, const double* x, double* y, int64_t n, hipStream_t st);

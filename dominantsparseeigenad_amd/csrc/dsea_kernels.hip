@@ -2323,6 +2323,43 @@ void launch_ritz(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Measurement probes (bench.py "measured_ceilings"): what THIS box streams with nothing else to do.
+// A block walks tiles of 4096 doubles: 8 non-temporal 16-byte loads in flight per lane, no dependence between trips.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_probe_read(const double* __restrict__ x, int64_t n, double* __restrict__ P) {
+  __shared__ double sm4[4];
+  double acc = 0.0;
+  for (int64_t base = (int64_t)blockIdx.x * 4096; base < n; base += (int64_t)gridDim.x * 4096) {
+    double2 v[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v[t] = ld2_stream<true>(x, base + t * 512 + threadIdx.x * 2, n);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc += v[t].x + v[t].y;
+  }
+  const double tot = block_sum(acc, sm4);
+  if (threadIdx.x == 0) P[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_probe_copy(const double* __restrict__ x, double* __restrict__ y, int64_t n) {
+  for (int64_t base = (int64_t)blockIdx.x * 4096; base < n; base += (int64_t)gridDim.x * 4096) {
+    double2 v[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v[t] = ld2_stream<true>(x, base + t * 512 + threadIdx.x * 2, n);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) st2<true>(y, base + t * 512 + threadIdx.x * 2, n, v[t]);
+  }
+}
+
+void launch_probe(const double* x, double* y, int64_t n, double* P, int nP, hipStream_t st) {
+  int64_t tiles = (n + 4095) / 4096;
+  const int grid = (int)(tiles < nP ? tiles : nP);
+  if (y)
+    hipLaunchKernelGGL(k_probe_copy, dim3(grid), dim3(256), 0, st, x, y, n);
+  else
+    hipLaunchKernelGGL(k_probe_read, dim3(grid), dim3(256), 0, st, x, n, P);
+}
+
 void launch_dot(const double* x, const double* y, int64_t n, double* P, double* out, hipStream_t st) {
   const int nb = ew_blocks(n);
   hipLaunchKernelGGL(k_dot, dim3(nb), dim3(256), 0, st, x, y, n, P);

@@ -207,6 +207,11 @@ int dsea_axpy(dsea_ws_t ws, double a_host, const double *a_dev, const double *x,
 /* nrm2_out = ||x||^2 (local) */
 int dsea_nrm2sq(dsea_ws_t ws, const double *x, int64_t n, double *nrm2_out, void *stream);
 
+/* Measurement probe, not part of the path (bench.py "measured_ceilings"; SURVEY.md 8d asks for the box's own streaming
+ * ceiling beside the 8 TB/s spec figure): y == NULL streams x[0..n) once through a read-only reduction (per-block sums
+ * land in the workspace's partials), otherwise copies x to y; 8 non-temporal 16-byte loads in flight per lane. */
+int dsea_probe_stream(dsea_ws_t ws, const double *x, double *y, int64_t n, void *stream);
+
 /* q_out = r / sqrt(*nrm2) ; if beta_out != null: *beta_out = sqrt(*nrm2)   (Lanczos.py:53,69-70,75) */
 int dsea_scale_store(dsea_ws_t ws, const double *r, const double *nrm2, double *q_out,
                      double *beta_out, int64_t n, void *stream);

@@ -56,6 +56,10 @@ def test_bench_line_carries_honest_extras():
     assert d["config"]["ms_per_step_fp64_basis"] > 0 and d["config"]["bf16_shadow_of_basis"] is True
     c3 = d["config"]["config3"]
     assert c3["cg_iterations"] == 1000 and c3["cg_us_per_iteration"] > 0 and c3["lanczos_k300_ms"] > 0
+    # the box's own copy / read ceilings beside the spec peak; the dominant kernel cannot beat a read-only stream by much
+    ceil = d["config"]["measured_ceilings"]
+    assert 2000.0 < ceil["copy_GBs"] <= 8000.0 and 2000.0 < ceil["read_GBs"] <= 8000.0
+    assert 0.0 < d["roofline"]["frac_of_measured_read_ceiling"] < 1.5
 
 
 def test_bench_line_partitioned_path():
