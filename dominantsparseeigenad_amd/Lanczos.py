@@ -109,15 +109,27 @@ def symeigLanczos(A, k, device=torch.device("cpu"), extreme="both", *, sparse=Fa
     """Extreme eigenvalue(s)/eigenvector(s); outputs as in Lanczos.py:88-105 (all torch tensors).
 
     Keyword-only extension ``reorth``: "full" (default, reference Lanczos.py:66), "twice" (the same pass applied twice per
-    step: CGS2) or "none" -- basis-free two-pass
+    step: CGS2), "partial" (Simon's partial re-orthogonalisation for native device operators: the basis is
+    re-orthogonalised only when the omega recurrence estimates a loss of orthogonality beyond sqrt(eps) -- typically one
+    step in four to ten; Ritz values at full accuracy, basis orthogonal to ~1e-8; ``engine.last_reorth_steps`` counts) or
+    "none" -- basis-free two-pass
     Lanczos for native device operators: three rotating vectors instead of the k-vector basis (so k = 200 at
     n = 2^28 fits ONE GPU) and no k^2 n re-orthogonalisation traffic; the extreme Ritz pair is the same to rounding,
     interior Ritz values may appear more than once (not returned here)."""
     if extreme not in ("both", "min", "max"):
         raise ValueError("extreme must be 'both', 'min' or 'max'")
     reorth = REORTH_DEFAULT if reorth is None else reorth
-    if reorth not in ("full", "none", "twice"):
-        raise ValueError("reorth must be 'full', 'twice' or 'none'")
+    if reorth not in ("full", "none", "twice", "partial"):
+        raise ValueError("reorth must be 'full', 'twice', 'partial' or 'none'")
+    if reorth == "partial":
+        if not sparse or engine.native_of(A) is None or getattr(engine.native_of(A), "partitioned", False) or \
+                torch.device(device).type != "cuda":
+            raise NotImplementedError("reorth='partial' needs a native single-GPU operator")
+        prev, engine.PARTIAL_REORTH = engine.PARTIAL_REORTH, (0.0 if engine.PARTIAL_REORTH is None else engine.PARTIAL_REORTH)
+        try:
+            return symeigLanczos(A, k, device, extreme, sparse=sparse, dim=dim, q0=q0, reorth="full")
+        finally:
+            engine.PARTIAL_REORTH = prev
     if reorth == "twice":
         # CGS2: the Gram-Schmidt pass of Lanczos.py:66 applied twice per step (an option the reference lacks; device
         # operators and callables on the GPU) -- same Krylov process, orthogonality of the basis at rounding level even

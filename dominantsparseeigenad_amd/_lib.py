@@ -17,6 +17,7 @@ _lib = None
 
 CG_RR, CG_DAD, CG_RRNEW, CG_ALPHA, CG_BETA, CG_RESNORM, CG_DONE, CG_ITERS = range(8)
 CG_STATE_LEN = 8
+ERR_ARG = -1
 ERR_NOT_CONVERGED = -5
 ERR_BREAKDOWN = -7
 ERR_TIMEOUT = -8
@@ -52,6 +53,8 @@ _SIGNATURES = {
     "dsea_ws_set_fault_injection": (c_int, [c_void_p, c_int]),
     "dsea_ws_set_shadow": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_double]),
     "dsea_lanczos_lp_stats": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), c_void_p]),
+    "dsea_ws_set_partial_reorth": (c_int, [c_void_p, c_int, c_double]),
+    "dsea_lanczos_reorth_stats": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_double), c_void_p]),
     "dsea_profile_begin": (c_int, [c_void_p, c_int]),
     "dsea_profile_end": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_double)]),
     "dsea_op_create_tfim": (c_int, [c_int, c_int, c_int64, c_void_p, c_double, c_double, POINTER(c_void_p)]),

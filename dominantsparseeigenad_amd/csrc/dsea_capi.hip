@@ -183,6 +183,8 @@ int dsea_ws_create(void* device_buffer, size_t bytes, int64_t n, int kmax, dsea_
   ws->w.persist_override = -1;
   ws->w.lz_persist = -1;
   ws->w.reorth_passes = 1;
+  ws->w.partial_reorth = 0;
+  ws->w.pro_delta = 1.4901161193847656e-08;   // sqrt(2^-52)
   ws->w.lose_peer = 0;
   ws->w.prof = nullptr;
   ws->w.shadow = nullptr;
@@ -290,6 +292,20 @@ int dsea_lanczos_lp_stats(dsea_ws_t ws, int64_t* lp_steps, int64_t* fp64_steps, 
   return DSEA_OK;
 }
 
+int dsea_lanczos_reorth_stats(dsea_ws_t ws, int64_t* reorth_steps, double* anorm, void* stream) {
+  if (!ws || !reorth_steps) return DSEA_ERR_ARG;
+  double h[2] = {0.0, 0.0};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemcpyAsync(h, ws->w.scal + DSEA_SCAL_PRO + 2, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess) {
+    g_last_hip = (int)hipGetLastError();
+    return DSEA_ERR_HIP;
+  }
+  if (anorm) *anorm = h[0];
+  *reorth_steps = (int64_t)h[1];
+  return DSEA_OK;
+}
+
 int dsea_ws_set_rows_per_lane(dsea_ws_t ws, int rpl) {
   if (!ws) return DSEA_ERR_ARG;
   if (rpl != 0 && rpl != 2 && rpl != 4 && rpl != 8 && rpl != 16) return DSEA_ERR_ARG;
@@ -316,6 +332,13 @@ int dsea_ws_set_fault_injection(dsea_ws_t ws, int lose_peer) {
 int dsea_ws_set_reorth_passes(dsea_ws_t ws, int passes) {
   if (!ws || (passes != 1 && passes != 2)) return DSEA_ERR_ARG;
   ws->w.reorth_passes = passes;
+  return DSEA_OK;
+}
+
+int dsea_ws_set_partial_reorth(dsea_ws_t ws, int on, double delta) {
+  if (!ws || !(delta >= 0.0)) return DSEA_ERR_ARG;
+  ws->w.partial_reorth = on ? 1 : 0;
+  ws->w.pro_delta = delta > 0.0 ? delta : 1.4901161193847656e-08;
   return DSEA_OK;
 }
 
@@ -758,7 +781,7 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
   // optional bf16 shadow of the basis for the correction pass (see k_axpy_norm_lp)
   uint16_t* Qs = nullptr;
   int64_t lds = 0;
-  if (w.shadow && w.shadow_rows >= k && w.shadow_ld >= n && (!w.geom(n).split_w || n >= 32768)) {
+  if (!w.partial_reorth && w.shadow && w.shadow_rows >= k && w.shadow_ld >= n && (!w.geom(n).split_w || n >= 32768)) {
     // small slabs (split geometry) use the split form of the shadow pass; below 2^15 rows the basis is a few MB, the
     // step is launch-bound and the 128-row fp64 split kernels expose more parallelism
     Qs = w.shadow;
@@ -773,15 +796,16 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
       return DSEA_ERR_HIP;
     }
   }
-  // the lost-peer record of the single-launch form is per run (dsea_lanczos_status reads it)
-  if (hipMemsetAsync(w.scal + DSEA_SCAL_LZ_FAIL, 0, sizeof(double), st) != hipSuccess) {
+  // the lost-peer record of the single-launch form is per run (dsea_lanczos_status reads it); so is the state of the
+  // partial re-orthogonalisation (scal[38..43])
+  if (hipMemsetAsync(w.scal + DSEA_SCAL_LZ_FAIL, 0, (DSEA_SCAL_PRO + 4 - DSEA_SCAL_LZ_FAIL) * sizeof(double), st) != hipSuccess) {
     g_last_hip = (int)hipGetLastError();
     return DSEA_ERR_HIP;
   }
   // README-sized problems (n <= 8192, k <= 512; full-space TFIM / halo-free stencil): the whole loop as ONE launch
   // (dsea_lanczos_persist.hip).  The granule buffers live in the partial-sum area, unused by that form.
   // (automatic: up to 32 workgroups = 4096 rows, where it is measured to win; mode 1 forces it up to its envelope)
-  if (w.lz_persist != 0 && w.reorth_passes == 1 && (w.lz_persist == 1 || n <= 4096) && !prof && lanczos_persist_applicable(op->d, n, k) &&
+  if (w.lz_persist != 0 && w.reorth_passes == 1 && !w.partial_reorth && (w.lz_persist == 1 || n <= 4096) && !prof && lanczos_persist_applicable(op->d, n, k) &&
       lanczos_persist_comm_bytes(n, k) <= (size_t)DSEA_MAX_WAVE_TILES * (size_t)((w.kmax < 1 ? 1 : w.kmax) + 1) * sizeof(double)) {
     const int pr = launch_lanczos_persist(op->d, k, q0, Q, ldq, alphas, betas, brk, w.scal + DSEA_SCAL_LZ_FAIL, P, st, w.lose_peer);
     if (pr == -2) {
@@ -803,8 +827,28 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
     double* nP = w.aux + DSEA_MAX_WAVE_TILES;
     int na = launch_spmv(op->d, Q, u, nullptr, nullptr, aP, st, prof ? prof->next(PROF_SPMV) : nullptr);
     if (na < 0) return DSEA_ERR_UNSUPPORTED;
+    // partial re-orthogonalisation (option): the three-term vector goes to vec[2] with its norm, k_pro_update advances the
+    // orthogonality estimates and decides, the dots / correction kernels then run over the basis or over nothing
+    double* pro_flag = w.scal + DSEA_SCAL_PRO;
+    double* pro_om = w.aux + 2 * DSEA_MAX_WAVE_TILES;            // two rows of DSEA_MAX_WAVE_TILES (k <= DSEA_MAX_KRYLOV)
+    const double pro_eps1 = 64.0 * 2.220446049250313e-16;
     for (int i = 1; i < k; ++i) {
       const double* beta_prev = (i >= 2) ? betas + (i - 2) : nullptr;
+      if (w.partial_reorth) {
+        // (1) r = u - alpha q - beta q' and ||r||^2 -> coef[i]  (2) the estimates decide  (3) on a re-orthogonalised step:
+        // c = Q^T r (the kernel's copy of r goes to vec[2], unused), r -= Q c; otherwise both kernels return at once and
+        // the tail takes ||r||^2 = coef[i]
+        launch_rdots(g, Q, ldq, n, i, u, nullptr, beta_prev, r, P, nullptr, st, nullptr, aP, na, alphas + (i - 1),
+                     true, brk, w.zero, false);
+        launch_pro_update(alphas, betas, P + (int64_t)i * g.pstride, rdots_partial_count(g, i), w.coef + i, pro_om,
+                          DSEA_MAX_WAVE_TILES, pro_flag, pro_flag + 1, i, pro_eps1, w.pro_delta, brk, st);
+        launch_rdots(g, Q, ldq, n, i, r, w.zero, nullptr, w.vec[2], P, w.coef, st,
+                     prof ? prof->next(PROF_RDOTS) : nullptr, nullptr, 0, nullptr, false, brk, pro_flag, true);
+        launch_axpy_norm(g, Q, ldq, n, i, w.coef, r, nP, nullptr, st, prof ? prof->next(PROF_AXPY) : nullptr, brk, pro_flag);
+        na = launch_tfim_fused(op->d, r, nP, g.nw, Q + (int64_t)i * ldq, u, betas + (i - 1), aP, st,
+                               prof ? prof->next(PROF_SPMV) : nullptr, nullptr, brk, i);
+        continue;
+      }
       launch_rdots(g, Q, ldq, n, i, u, nullptr, beta_prev, r, P, w.coef, st,
                    prof ? prof->next(PROF_RDOTS) : nullptr, aP, na, alphas + (i - 1), Qs != nullptr, brk);
       int nn = g.nw;
@@ -835,6 +879,7 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
     launch_finalize_slot(aP, na, alphas + (k - 1), brk, st);
     return check_launch();
   }
+  if (w.partial_reorth) return DSEA_ERR_UNSUPPORTED;   // (operators without a fused tail: full re-orthogonalisation only)
   int nb = launch_spmv(op->d, Q, u, nullptr, nullptr, P, st, prof ? prof->next(PROF_SPMV) : nullptr);
   if (nb < 0) return DSEA_ERR_UNSUPPORTED;
   launch_finalize1(P, nb, alphas, st);

@@ -16,6 +16,7 @@
 #define DSEA_PERSIST_CG_MAX_TILES 1024 /* persistent single-launch CG: n <= 2^19 rows                       */
 #define DSEA_SCALARS 64
 #define DSEA_SCAL_BREAK 20    /* scal[20] = breakdown step, scal[21] = running scale (see broken())     */
+#define DSEA_SCAL_PRO 40      /* scal[40] = re-orthogonalise this step, [41] = and the next, [42] = ||A|| estimate, [43] = steps re-orthogonalised */
 #define DSEA_SCAL_LZ_FAIL 38  /* scal[38] = 1 when the single-launch Lanczos lost a peer workgroup (timeout) */
 
 namespace dsea {
@@ -117,6 +118,8 @@ struct Workspace {
   int lz_persist;        // single-launch Lanczos for small problems: -1 automatic (on where it applies), 0 off
   int lose_peer;         // TEST HOOK (dsea_ws_set_fault_injection): the last workgroup of a persistent launch exits at once
   int reorth_passes;     // Gram-Schmidt passes per Lanczos step: 1 (the reference, Lanczos.py:66) or 2 (CGS2 option)
+  int partial_reorth;    // 1 = re-orthogonalise only when the omega recurrence says so (option; dsea_ws_set_partial_reorth)
+  double pro_delta;      // its threshold on the estimated |q_i . q_k| (sqrt(eps))
   double* partials;  // DSEA_MAX_WAVE_TILES * max(kmax,1) doubles (also >= DSEA_MAX_EW_BLOCKS)
   double* aux;       // 4 * DSEA_MAX_WAVE_TILES doubles: small partial buffers that must not alias `partials`
   double* coef;      // kmax doubles
@@ -140,7 +143,9 @@ void launch_finalize_slot(const double* P, int count, double* out, const double*
 void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* u,
                   const double* alpha, const double* beta, double* r, double* P, double* c_out,
                   hipStream_t st, EventPair* ev = nullptr, const double* aP = nullptr, int aCount = 0,
-                  double* a_store = nullptr, bool want_rr = false, double* brk = nullptr);
+                  double* a_store = nullptr, bool want_rr = false, double* brk = nullptr,
+                  const double* sel = nullptr, bool sel_exit = false);   // sel: device flag of the partial re-orthogonalisation,
+                  // 0 = no basis vectors on this step (three-term update and ||r||^2 only; sel_exit: return at once)
 int launch_axpy_norm_lp(int64_t n, int rps, const double* Q, int64_t ldq, const uint16_t* Qs, int64_t lds, int i,
                         const double* c, double tau, double* r, double* P, double* lp_count, hipStream_t st,
                         EventPair* ev = nullptr, const double* brk = nullptr);
@@ -153,10 +158,14 @@ void launch_cg_direction_fused(const double* r, double* d, double* state, int pa
                                int rCount, double eps, int64_t n, hipStream_t st);
 void launch_axpy_norm(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* c,
                       double* r, double* P, double* nrm2_out, hipStream_t st, EventPair* ev = nullptr,
-                      const double* brk = nullptr);
+                      const double* brk = nullptr, const double* sel = nullptr);
 void launch_ritz(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int k, const double* s,
                  double* out, hipStream_t st);
 void launch_dot(const double* x, const double* y, int64_t n, double* P, double* out, hipStream_t st);
+void launch_pro_update(const double* alphas, const double* betas, const double* rrP, int rrCount, double* rr_store,
+                       double* om, int ld, double* flag, double* state, int i, double eps1, double delta,
+                       const double* brk, hipStream_t st);
+int rdots_partial_count(const TileGeom& g, int i);
 void launch_probe(const double* x, double* y, int64_t n, double* P, int nP, hipStream_t st);   // y != null: copy
 void launch_shift_dot(const double* x, double* y, const double* shift, const double* skip, int64_t n,
                       double* P, double* out, hipStream_t st);

@@ -37,9 +37,11 @@ __global__ __launch_bounds__(256) void k_finalize1(const double* __restrict__ pa
 // c[j] = sum_{w<nw} P[j*pstride + w]   (one 256-thread block per j, 4 independent loads in flight per lane)
 __global__ __launch_bounds__(256) void k_finalize_multi(const double* __restrict__ P, int64_t pstride,
                                                         int nw, double* __restrict__ c,
-                                                        const double* __restrict__ brk) {
+                                                        const double* __restrict__ brk,
+                                                        const double* __restrict__ gate) {
   __shared__ double sm4[4];
   if (broken(brk)) return;
+  if (gate != nullptr && gate[0] == 0.0) return;   // partial re-orthogonalisation: the dots pass did not run on this step
   const int j = blockIdx.x;
   const double* __restrict__ row = P + (int64_t)j * pstride;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -64,7 +66,7 @@ struct RdotsPre {   // the first tile's rows of u, q_{i-1}, q_{i-2}, requested b
 };
 
 template <int RPL, bool GUARD, bool PRE>
-__device__ __forceinline__ void rdots_tile(const double* __restrict__ Q, int64_t ldq, int i, int64_t n,
+__device__ __forceinline__ void rdots_tile(const double* __restrict__ Q, int64_t ldq, int i, int ii, int64_t n,
                                            int64_t base, int lane, const double* __restrict__ u,
                                            double a, double b, double* __restrict__ r,
                                            double* __restrict__ sP, bool accumulate, bool want_rr,
@@ -113,7 +115,8 @@ __device__ __forceinline__ void rdots_tile(const double* __restrict__ Q, int64_t
   // Direction alternates with the step parity (each c_j is an independent dot product, so the results do
   // not depend on it): the pass starts on the vectors the previous pass touched last, which are the ones
   // still resident in the 256 MiB Infinity Cache.
-  const int nchunks = i / 4;
+  // (ii = number of basis vectors dotted: i, or 0 on a step the partial re-orthogonalisation skips)
+  const int nchunks = ii / 4;
   const bool rev = (i & 1) != 0;
   auto single = [&](int j) {
     const double* __restrict__ qj = Q + (int64_t)j * ldq;
@@ -128,7 +131,7 @@ __device__ __forceinline__ void rdots_tile(const double* __restrict__ Q, int64_t
     if (lane == 0) sP[j] = accumulate ? (sP[j] + acc) : acc;
   };
   if (rev)
-    for (int j = i - 1; j >= 4 * nchunks; --j) single(j);
+    for (int j = ii - 1; j >= 4 * nchunks; --j) single(j);
   for (int cc = 0; cc < nchunks; ++cc) {
     const int j = 4 * (rev ? nchunks - 1 - cc : cc);
     const double* __restrict__ qj = Q + (int64_t)j * ldq;
@@ -155,7 +158,7 @@ __device__ __forceinline__ void rdots_tile(const double* __restrict__ Q, int64_t
     }
   }
   if (!rev)
-    for (int j = 4 * nchunks; j < i; ++j) single(j);
+    for (int j = 4 * nchunks; j < ii; ++j) single(j);
 #pragma unroll
   for (int t = 0; t < NP; ++t) st2<GUARD>(r, base + t * 128 + lane * 2, n, rv[t]);
 }
@@ -168,9 +171,11 @@ __global__ __launch_bounds__(256) void k_rdots(const double* __restrict__ Q, int
                                                double* __restrict__ P, int64_t pstride, int nw,
                                                int64_t ntiles, const double* __restrict__ aP, int aCount,
                                                double* __restrict__ a_store, int want_rr,
-                                               double* __restrict__ brk) {
+                                               double* __restrict__ brk, const double* __restrict__ sel,
+                                               int sel_exit) {
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;                                                     // 4, 2 or 1 waves per block
+  if (sel_exit && sel[0] == 0.0) return;      // partial re-orthogonalisation: nothing to do on this step
   const int64_t widx = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6);
   constexpr int64_t TILE = 64 * RPL;
   extern __shared__ double rdots_lds[];                                                // [wpb waves][i + 1]
@@ -205,15 +210,20 @@ __global__ __launch_bounds__(256) void k_rdots(const double* __restrict__ Q, int
     const double b = beta ? beta[0] : 0.0;
     // (read by the tail kernel of this step -- a later launch -- only)
     if (brk && widx == 0 && lane == 0) brk[1] = fmax(brk[1], fmax(fabs(a), fabs(b)));
+    // partial re-orthogonalisation (dsea_ws_set_partial_reorth): sel[0] == 0 = this step is not re-orthogonalised -- the
+    // three-term update (and ||r||^2) only, all coefficients exactly 0
+    const int ii = (sel != nullptr && sel[0] == 0.0) ? 0 : i;
+    if (ii != i)
+      for (int idx = lane; idx < i; idx += 64) sP[idx] = 0.0;
     bool first = true;
     for (int64_t tile = widx; tile < ntiles; tile += nw) {
       const int64_t base = tile * TILE;
       if (first && pre_ok)
-        rdots_tile<RPL, false, true>(Q, ldq, i, n, base, lane, u, a, b, r, sP, false, want_rr != 0, pre);
+        rdots_tile<RPL, false, true>(Q, ldq, i, ii, n, base, lane, u, a, b, r, sP, false, want_rr != 0, pre);
       else if (base + TILE <= n)
-        rdots_tile<RPL, false, false>(Q, ldq, i, n, base, lane, u, a, b, r, sP, !first, want_rr != 0, pre);
+        rdots_tile<RPL, false, false>(Q, ldq, i, ii, n, base, lane, u, a, b, r, sP, !first, want_rr != 0, pre);
       else
-        rdots_tile<RPL, true, false>(Q, ldq, i, n, base, lane, u, a, b, r, sP, !first, want_rr != 0, pre);
+        rdots_tile<RPL, true, false>(Q, ldq, i, ii, n, base, lane, u, a, b, r, sP, !first, want_rr != 0, pre);
       first = false;
     }
   } else {
@@ -237,7 +247,7 @@ __global__ __launch_bounds__(256) void k_rdots(const double* __restrict__ Q, int
 template <int RPL, bool GUARD, int MODE>
 __device__ __forceinline__ double axpy_tile(const double* __restrict__ Q, int64_t ldq, int i, int64_t n,
                                             int64_t base, int lane, const double* __restrict__ c,
-                                            double* __restrict__ r) {
+                                            double* __restrict__ r) {   // i = number of vectors combined
   constexpr int NP = RPL / 2;
   double2 w[NP];
 #pragma unroll
@@ -280,11 +290,18 @@ template <int RPL, int MODE>
 __global__ __launch_bounds__(256) void k_axpy_norm(const double* __restrict__ Q, int64_t ldq, int i,
                                                    int64_t n, const double* __restrict__ c,
                                                    double* __restrict__ r, double* __restrict__ P,
-                                                   int nw, int64_t ntiles, const double* __restrict__ brk) {
+                                                   int nw, int64_t ntiles, const double* __restrict__ brk,
+                                                   const double* __restrict__ sel) {
   const int lane = threadIdx.x & 63;
   const int64_t widx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (widx >= nw) return;
   if (broken(brk)) return;
+  if (sel != nullptr && sel[0] == 0.0) {
+    // partial re-orthogonalisation: no correction on this step; ||r||^2 is the dots pass's own c[i], handed on in the
+    // partial-sum layout the consumer expects (first partial = the value, the others 0)
+    if (MODE == 0 && lane == 0) P[widx] = (widx == 0) ? c[i] : 0.0;
+    return;
+  }
   constexpr int64_t TILE = 64 * RPL;
   double acc = 0.0;
   for (int64_t tile = widx; tile < ntiles; tile += nw) {
@@ -315,7 +332,9 @@ __global__ __launch_bounds__(W * 64) void k_rdots_split(const double* __restrict
                                                         double* __restrict__ P, int64_t pstride,
                                                         const double* __restrict__ aP, int aCount,
                                                         double* __restrict__ a_store, int want_rr,
-                                                        double* __restrict__ brk) {
+                                                        double* __restrict__ brk, const double* __restrict__ sel,
+                                                        int sel_exit) {
+  if (sel_exit && sel[0] == 0.0) return;      // partial re-orthogonalisation: nothing to do on this step
   // NT = 128-row sub-tiles per block (NT = 2 beyond 640 tiles: twice the loads in flight per wave trip, half the partials
   // for the second stage).  Requesting a wave's first chunk ahead of the alpha partials was measured and is SLOWER
   // (config 3: 24.8 -> 28.3 us per launch), and forcing 64 VGPRs (two 1024-thread blocks per CU) gains nothing.
@@ -358,7 +377,10 @@ __global__ __launch_bounds__(W * 64) void k_rdots_split(const double* __restrict
     const double acc = wave_sum(p);
     if (lane == 0) split_lds[i] = acc;
   }
-  const int nchunks = (i + 3) / 4;
+  const int ii = (sel != nullptr && sel[0] == 0.0) ? 0 : i;     // partial re-orthogonalisation: see k_rdots
+  if (ii != i)
+    for (int idx = threadIdx.x; idx < i; idx += W * 64) split_lds[idx] = 0.0;
+  const int nchunks = (ii + 3) / 4;
   for (int cc = wv; cc < nchunks; cc += W) {
     const int j = 4 * cc;
     double2 q[4][NT];
@@ -367,7 +389,7 @@ __global__ __launch_bounds__(W * 64) void k_rdots_split(const double* __restrict
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         q[v][t] = make_double2(0.0, 0.0);
-        if (j + v < i) q[v][t] = ld2_stream<true>(Q + (int64_t)(j + v) * ldq, row + 128 * t, n);
+        if (j + v < ii) q[v][t] = ld2_stream<true>(Q + (int64_t)(j + v) * ldq, row + 128 * t, n);
       }
     double acc[4];
 #pragma unroll
@@ -378,7 +400,7 @@ __global__ __launch_bounds__(W * 64) void k_rdots_split(const double* __restrict
     }
     const double bsum = wave_sum4_rows(acc[0], acc[1], acc[2], acc[3]);
     const int jj = j + (lane >> 4);
-    if ((lane & 15) == 15 && jj < i) split_lds[jj] = bsum;
+    if ((lane & 15) == 15 && jj < ii) split_lds[jj] = bsum;
   }
   if (wv == 0) {
 #pragma unroll
@@ -394,9 +416,14 @@ template <int W, int MODE>
 __global__ __launch_bounds__(W * 64) void k_axpy_norm_split(const double* __restrict__ Q, int64_t ldq, int i,
                                                             int64_t n, const double* __restrict__ c,
                                                             double* __restrict__ r, double* __restrict__ P,
-                                                            const double* __restrict__ brk) {
+                                                            const double* __restrict__ brk,
+                                                            const double* __restrict__ sel) {
   __shared__ double2 part[W][64];
   if (broken(brk)) return;
+  if (sel != nullptr && sel[0] == 0.0) {        // partial re-orthogonalisation: see k_axpy_norm
+    if (MODE == 0 && threadIdx.x == 0) P[blockIdx.x] = (blockIdx.x == 0) ? c[i] : 0.0;
+    return;
+  }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t tile = blockIdx.x;
   const int64_t row = tile * 128 + lane * 2;
@@ -2216,6 +2243,81 @@ static inline int tile_blocks(int64_t n) {
     }                                                                                             \
   } while (0)
 
+// ------------------------------------------------------------------------------------------
+// Partial re-orthogonalisation (Simon 1984; an OPTION -- the reference re-orthogonalises on every step, Lanczos.py:66).
+// omega_{i,k} estimates q_i . q_k from the scalars of the recurrence alone:
+//   beta_{i-1} omega_{i,k} = beta_k omega_{i-1,k+1} + (alpha_k - alpha_{i-1}) omega_{i-1,k} + beta_{k-1} omega_{i-1,k-1}
+//                            - beta_{i-2} omega_{i-2,k}  (+ a rounding term of the size of eps ||A||),   omega_{j,j} = 1
+// One block per step; when max_k |omega_{i,k}| exceeds delta (sqrt(eps)) this step AND the next one are re-orthogonalised
+// against the whole basis and their estimates restart at the rounding level.  om: two rows of `ld` doubles (row i & 1
+// is overwritten in place: new[k] needs the old row only at the same k).
+// state: [0] re-orthogonalise the next step too  [1] running estimate of ||A||  [2] number of re-orthogonalised steps
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pro_update(const double* __restrict__ alphas, const double* __restrict__ betas,
+                                                    const double* __restrict__ rrP, int rrCount,
+                                                    double* __restrict__ rr_store, double* __restrict__ om, int ld,
+                                                    double* __restrict__ flag, double* __restrict__ state, int i,
+                                                    double eps1, double delta, const double* __restrict__ brk) {
+  __shared__ double smax[256];
+  __shared__ double sm5[5];
+  if (broken(brk)) return;
+  // ||r_i||^2 before any correction: the dots kernel's per-block partials, summed here (no second-stage launch); the
+  // total is stored for the correction kernel, which hands it on as ||r||^2 on a step that is not re-orthogonalised
+  const double rr = sum_partials_block(rrP, rrCount, sm5);
+  if (threadIdx.x == 0) rr_store[0] = rr;
+  const double bcur = sqrt(rr);                            // = beta_{i-1} to rounding
+  const double a = alphas[i - 1];
+  const double bprev = (i >= 2) ? betas[i - 2] : 0.0;
+  const double anorm = fmax(state[1], fabs(a) + bcur + bprev);
+  double* __restrict__ o1 = om + (size_t)((i - 1) & 1) * ld;   // omega_{i-1, .}
+  double* __restrict__ o2 = om + (size_t)(i & 1) * ld;         // omega_{i-2, .}  -> omega_{i, .}
+  double mx = 0.0;
+  for (int k = threadIdx.x; k <= i - 1; k += 256) {
+    double v;
+    if (k == i - 1) {
+      v = eps1 * anorm / bcur;
+    } else {
+      const double w1k = o1[k];
+      const double w1p = (k + 1 == i - 1) ? 1.0 : o1[k + 1];
+      const double w1m = (k > 0) ? o1[k - 1] : 0.0;
+      const double w2k = (k == i - 2) ? 1.0 : o2[k];
+      double t = betas[k] * w1p + (alphas[k] - a) * w1k - bprev * w2k;
+      if (k > 0) t += betas[k - 1] * w1m;
+      const double d = eps1 * ((betas[k] + bcur) + anorm);
+      v = (t + copysign(d, t)) / bcur;
+    }
+    mx = fmax(mx, fabs(v));
+    // (o2[k] is only read by this thread at this k; the neighbours come from the other row)
+    o2[k] = v;
+  }
+  smax[threadIdx.x] = mx;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + s]);
+    __syncthreads();
+  }
+  mx = smax[0];
+  const bool forced = state[0] != 0.0;
+  const bool trig = !(mx <= delta);                       // also true for NaN
+  __syncthreads();                                        // everybody has read state[0]
+  if (trig || forced) {
+    for (int k = threadIdx.x; k <= i - 1; k += 256) o2[k] = eps1;
+  }
+  if (threadIdx.x == 0) {
+    flag[0] = (trig || forced) ? 1.0 : 0.0;
+    state[0] = trig ? 1.0 : 0.0;
+    state[1] = anorm;
+    if (trig || forced) state[2] += 1.0;
+  }
+}
+
+void launch_pro_update(const double* alphas, const double* betas, const double* rrP, int rrCount, double* rr_store,
+                       double* om, int ld, double* flag, double* state, int i, double eps1, double delta,
+                       const double* brk, hipStream_t st) {
+  hipLaunchKernelGGL(k_pro_update, dim3(1), dim3(256), 0, st, alphas, betas, rrP, rrCount, rr_store, om, ld, flag, state,
+                     i, eps1, delta, brk);
+}
+
 void launch_finalize1(const double* P, int count, double* out, hipStream_t st) {
   hipLaunchKernelGGL(k_finalize1, dim3(1), dim3(256), 0, st, P, count, out);
 }
@@ -2223,13 +2325,13 @@ void launch_finalize1(const double* P, int count, double* out, hipStream_t st) {
 void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* u,
                   const double* alpha, const double* beta, double* r, double* P, double* c_out,
                   hipStream_t st, EventPair* ev, const double* aP, int aCount, double* a_store, bool want_rr,
-                  double* brk) {
+                  double* brk, const double* sel, bool sel_exit) {
   if (g.split_w) {
     const int wr = want_rr ? 1 : 0;
     const size_t slds = (size_t)(i + 1) * sizeof(double);     // the tile's partial sums (see k_rdots_split)
     const int nt = g.dots_nt;
     const unsigned tiles = (unsigned)((g.ntiles + nt - 1) / nt);
-#define RDS(Wv, NTv) KLAUNCH_LDS(ev, (k_rdots_split<Wv, NTv>), tiles, Wv * 64, slds, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, aP, aCount, a_store, wr, brk)
+#define RDS(Wv, NTv) KLAUNCH_LDS(ev, (k_rdots_split<Wv, NTv>), tiles, Wv * 64, slds, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, aP, aCount, a_store, wr, brk, sel, sel_exit ? 1 : 0)
     if (nt == 2) {
       RDS(16, 2);
     } else {
@@ -2240,8 +2342,9 @@ void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, in
       }
     }
 #undef RDS
-    hipLaunchKernelGGL(k_finalize_multi, dim3(want_rr ? i + 1 : i), dim3(256), 0, st, (const double*)P,
-                       (int64_t)g.pstride, (int)tiles, c_out, (const double*)brk);
+    if (c_out)
+      hipLaunchKernelGGL(k_finalize_multi, dim3(want_rr ? i + 1 : i), dim3(256), 0, st, (const double*)P,
+                         (int64_t)g.pstride, (int)tiles, c_out, (const double*)brk, sel_exit ? sel : (const double*)nullptr);
     return;
   }
   // one row of i + 1 partial sums per wave in LDS (see rdots_tile); 64 KiB of dynamic LDS hold 4 waves up to
@@ -2250,30 +2353,39 @@ void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, in
   const int grid = (g.nw + wpb - 1) / wpb;
   const size_t lds = (size_t)wpb * (i + 1) * sizeof(double);
   LAUNCH_RPL(ev, k_rdots, g.rpl, grid, 64 * wpb, lds, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, g.nw,
-             g.ntiles, aP, aCount, a_store, want_rr ? 1 : 0, brk);
+             g.ntiles, aP, aCount, a_store, want_rr ? 1 : 0, brk, sel, sel_exit ? 1 : 0);
   // want_rr: one more row of partials (||r||^2) -> c_out[i]
-  hipLaunchKernelGGL(k_finalize_multi, dim3(want_rr ? i + 1 : i), dim3(256), 0, st, (const double*)P,
-                     (int64_t)g.pstride, grid, c_out, (const double*)brk);
+  if (c_out)   // (null: the caller's next kernel sums the partial rows it needs itself -- rdots_partial_count of them)
+    hipLaunchKernelGGL(k_finalize_multi, dim3(want_rr ? i + 1 : i), dim3(256), 0, st, (const double*)P,
+                       (int64_t)g.pstride, grid, c_out, (const double*)brk, sel_exit ? sel : (const double*)nullptr);
+}
+
+// partials per basis vector the dots pass of step i leaves in P (row stride g.pstride)
+int rdots_partial_count(const TileGeom& g, int i) {
+  if (g.split_w) return (int)((g.ntiles + g.dots_nt - 1) / g.dots_nt);
+  const int wpb = (i + 1) <= 2048 ? 4 : ((i + 1) <= 4096 ? 2 : 1);
+  return (g.nw + wpb - 1) / wpb;
 }
 
 void launch_axpy_norm(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* c,
-                      double* r, double* P, double* nrm2_out, hipStream_t st, EventPair* ev, const double* brk) {
+                      double* r, double* P, double* nrm2_out, hipStream_t st, EventPair* ev, const double* brk,
+                      const double* sel) {
   if (g.split_w) {
     const unsigned tiles = (unsigned)g.ntiles;
     switch (g.split_w) {
-      case 4: KLAUNCH(ev, (k_axpy_norm_split<4, 0>), tiles, 256, st, Q, ldq, i, n, c, r, P, brk); break;
-      case 8: KLAUNCH(ev, (k_axpy_norm_split<8, 0>), tiles, 512, st, Q, ldq, i, n, c, r, P, brk); break;
-      default: KLAUNCH(ev, (k_axpy_norm_split<16, 0>), tiles, 1024, st, Q, ldq, i, n, c, r, P, brk); break;
+      case 4: KLAUNCH(ev, (k_axpy_norm_split<4, 0>), tiles, 256, st, Q, ldq, i, n, c, r, P, brk, sel); break;
+      case 8: KLAUNCH(ev, (k_axpy_norm_split<8, 0>), tiles, 512, st, Q, ldq, i, n, c, r, P, brk, sel); break;
+      default: KLAUNCH(ev, (k_axpy_norm_split<16, 0>), tiles, 1024, st, Q, ldq, i, n, c, r, P, brk, sel); break;
     }
     if (nrm2_out) launch_finalize1(P, g.nw, nrm2_out, st);
     return;
   }
   const int grid = (g.nw + 3) / 4;
   switch (g.rpl) {
-    case 2: KLAUNCH(ev, (k_axpy_norm<2, 0>), grid, 256, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles, brk); break;
-    case 4: KLAUNCH(ev, (k_axpy_norm<4, 0>), grid, 256, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles, brk); break;
-    case 8: KLAUNCH(ev, (k_axpy_norm<8, 0>), grid, 256, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles, brk); break;
-    default: KLAUNCH(ev, (k_axpy_norm<16, 0>), grid, 256, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles, brk); break;
+    case 2: KLAUNCH(ev, (k_axpy_norm<2, 0>), grid, 256, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles, brk, sel); break;
+    case 4: KLAUNCH(ev, (k_axpy_norm<4, 0>), grid, 256, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles, brk, sel); break;
+    case 8: KLAUNCH(ev, (k_axpy_norm<8, 0>), grid, 256, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles, brk, sel); break;
+    default: KLAUNCH(ev, (k_axpy_norm<16, 0>), grid, 256, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles, brk, sel); break;
   }
   if (nrm2_out) launch_finalize1(P, g.nw, nrm2_out, st);  // null: the consumer sums the g.nw partials itself
 }
@@ -2308,18 +2420,18 @@ void launch_ritz(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int
     const unsigned tiles = (unsigned)g.ntiles;
     EventPair* ev = nullptr;
     switch (g.split_w) {
-      case 4: KLAUNCH(ev, (k_axpy_norm_split<4, 1>), tiles, 256, st, Q, ldq, k, n, s, out, nullP, nullc); break;
-      case 8: KLAUNCH(ev, (k_axpy_norm_split<8, 1>), tiles, 512, st, Q, ldq, k, n, s, out, nullP, nullc); break;
-      default: KLAUNCH(ev, (k_axpy_norm_split<16, 1>), tiles, 1024, st, Q, ldq, k, n, s, out, nullP, nullc); break;
+      case 4: KLAUNCH(ev, (k_axpy_norm_split<4, 1>), tiles, 256, st, Q, ldq, k, n, s, out, nullP, nullc, nullc); break;
+      case 8: KLAUNCH(ev, (k_axpy_norm_split<8, 1>), tiles, 512, st, Q, ldq, k, n, s, out, nullP, nullc, nullc); break;
+      default: KLAUNCH(ev, (k_axpy_norm_split<16, 1>), tiles, 1024, st, Q, ldq, k, n, s, out, nullP, nullc, nullc); break;
     }
     return;
   }
   const int grid = (g.nw + 3) / 4;
   switch (g.rpl) {
-    case 2: hipLaunchKernelGGL((k_axpy_norm<2, 1>), dim3(grid), dim3(256), 0, st, Q, ldq, k, n, s, out, nullP, g.nw, g.ntiles, nullc); break;
-    case 4: hipLaunchKernelGGL((k_axpy_norm<4, 1>), dim3(grid), dim3(256), 0, st, Q, ldq, k, n, s, out, nullP, g.nw, g.ntiles, nullc); break;
-    case 8: hipLaunchKernelGGL((k_axpy_norm<8, 1>), dim3(grid), dim3(256), 0, st, Q, ldq, k, n, s, out, nullP, g.nw, g.ntiles, nullc); break;
-    default: hipLaunchKernelGGL((k_axpy_norm<16, 1>), dim3(grid), dim3(256), 0, st, Q, ldq, k, n, s, out, nullP, g.nw, g.ntiles, nullc); break;
+    case 2: hipLaunchKernelGGL((k_axpy_norm<2, 1>), dim3(grid), dim3(256), 0, st, Q, ldq, k, n, s, out, nullP, g.nw, g.ntiles, nullc, nullc); break;
+    case 4: hipLaunchKernelGGL((k_axpy_norm<4, 1>), dim3(grid), dim3(256), 0, st, Q, ldq, k, n, s, out, nullP, g.nw, g.ntiles, nullc, nullc); break;
+    case 8: hipLaunchKernelGGL((k_axpy_norm<8, 1>), dim3(grid), dim3(256), 0, st, Q, ldq, k, n, s, out, nullP, g.nw, g.ntiles, nullc, nullc); break;
+    default: hipLaunchKernelGGL((k_axpy_norm<16, 1>), dim3(grid), dim3(256), 0, st, Q, ldq, k, n, s, out, nullP, g.nw, g.ntiles, nullc, nullc); break;
   }
 }
 

@@ -34,6 +34,11 @@ DENSE_SYMMETRIC_KERNEL = True
 # Gram-Schmidt passes per Lanczos step: 1 = the reference (Lanczos.py:66); 2 = CGS2 option (``reorth="twice"`` of
 # Lanczos.symeigLanczos / Lanczos.Lanczos): the pass is repeated on the corrected vector.
 REORTH_PASSES = 1
+# Partial re-orthogonalisation (``reorth="partial"`` of Lanczos.symeigLanczos / Lanczos.Lanczos; an option the reference
+# lacks): None = off (the reference's full re-orthogonalisation on every step), a float = the threshold on the estimated
+# loss of orthogonality that triggers a pair of full passes (0.0 = the default sqrt(eps)).  Native fused-tail operators only.
+PARTIAL_REORTH = None
+last_reorth_steps = None       # steps of the last native run that were re-orthogonalised (partial mode), else None
 import os as _os
 _NO_PERSIST = _os.environ.get("DSEA_NO_PERSIST", "") == "1"
 LANCZOS_PERSIST = not _NO_PERSIST
@@ -376,7 +381,13 @@ def lanczos(A, k, n, device, q0, native=None, callable_A=None, arena=False):
     alphas = torch.empty(k, dtype=F64, device=device)
     betas = torch.empty(max(k - 1, 1), dtype=F64, device=device)
     q0 = as_vector(q0, n)
-    use_shadow = USE_SHADOW and k > 1 and shadow_fits(device, k, ldq, n, arena)
+    partial = PARTIAL_REORTH is not None
+    if partial and (native is None or REORTH_PASSES != 1):
+        raise NotImplementedError("reorth='partial' needs a native device operator (TFIM, SELL/CSR, stencil) and one "
+                                  "Gram-Schmidt pass")
+    use_shadow = USE_SHADOW and k > 1 and not partial and shadow_fits(device, k, ldq, n, arena)
+    global last_reorth_steps
+    last_reorth_steps = None
     if native is not None:
         shadow = None
         with ws.owned_by("Lanczos (native operator)"):
@@ -387,6 +398,10 @@ def lanczos(A, k, n, device, q0, native=None, callable_A=None, arena=False):
                 if getattr(ws, "reorth_passes", 1) != int(REORTH_PASSES):
                     check(lib.dsea_ws_set_reorth_passes(ws.handle, int(REORTH_PASSES)), "dsea_ws_set_reorth_passes")
                     ws.reorth_passes = int(REORTH_PASSES)
+                if getattr(ws, "partial_reorth", None) != PARTIAL_REORTH:
+                    check(lib.dsea_ws_set_partial_reorth(ws.handle, 1 if partial else 0, float(PARTIAL_REORTH or 0.0)),
+                          "dsea_ws_set_partial_reorth")
+                    ws.partial_reorth = PARTIAL_REORTH
                 want = 0 if (not LANCZOS_PERSIST or getattr(ws, "lanczos_persist_lost", False)) else \
                     (1 if LANCZOS_PERSIST == "force" else -1)
                 if ws.lanczos_persist_mode != want:
@@ -410,6 +425,10 @@ def lanczos(A, k, n, device, q0, native=None, callable_A=None, arena=False):
                     rc = lib.dsea_lanczos_status(ws.handle, byref(brk), st)
                 check(rc, "dsea_lanczos_status", allow=(_lib.ERR_BREAKDOWN,))
                 last_break = int(brk.value)
+                if partial:
+                    cnt, an = ctypes.c_int64(0), c_double(0.0)
+                    check(lib.dsea_lanczos_reorth_stats(ws.handle, byref(cnt), byref(an), st), "dsea_lanczos_reorth_stats")
+                    last_reorth_steps = int(cnt.value)
             finally:
                 if shadow is not None:
                     check(lib.dsea_ws_set_shadow(ws.handle, None, 0, 0, 0.0), "dsea_ws_set_shadow")

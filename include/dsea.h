@@ -94,6 +94,17 @@ int dsea_ws_set_lanczos_persist(dsea_ws_t ws, int mode);
  * previous vectors, Lanczos.py:66), 2 = the pass is repeated on the corrected vector ("CGS2": orthogonality at rounding
  * level even where one pass leaves eps ||u|| / beta) -- an option the reference lacks, never selected automatically. */
 int dsea_ws_set_reorth_passes(dsea_ws_t ws, int passes);
+/* PARTIAL re-orthogonalisation for dsea_lanczos_run (Simon 1984) -- an option the reference lacks (it re-orthogonalises on
+ * every step, Lanczos.py:66; SURVEY.md 8 f-4 lists "selective reorth"), never selected automatically: a one-block kernel per
+ * step advances the estimates omega_{i,k} ~ q_i . q_k from alpha, beta alone; only when one of them exceeds `delta`
+ * (0 = the default sqrt(eps) = 1.49e-8) are this step and the next one re-orthogonalised against the whole basis, every other
+ * step costs the three-term update and the mat-vec.  The basis is then orthogonal to ~delta, T and the Ritz values keep
+ * full accuracy (semi-orthogonality), the Ritz vector keeps its residual.  Operators with a fused tail only (TFIM, SELL,
+ * stencil), multi-launch form, fp64 basis (no bf16 shadow: the coefficients are no longer at rounding level); otherwise
+ * dsea_lanczos_run returns DSEA_ERR_UNSUPPORTED.  dsea_lanczos_reorth_stats (synchronises) reports how many steps of the
+ * last run were re-orthogonalised and the ||A|| estimate the recurrence used.                                          */
+int dsea_ws_set_partial_reorth(dsea_ws_t ws, int on, double delta);
+int dsea_lanczos_reorth_stats(dsea_ws_t ws, int64_t *reorth_steps, double *anorm, void *stream);
 /* TEST HOOK for the persistent single-launch forms (Lanczos, TFIM CG): with lose_peer != 0 the last workgroup of such a
  * launch exits at once, so its peers run into their bounded spins -- exercises the DSEA_ERR_TIMEOUT path and the
  * host's fall-back to the multi-launch kernels (a launch then takes the 3 s of the timeout).                      */

@@ -1,0 +1,175 @@
+"""Partial re-orthogonalisation (``reorth="partial"``, include/dsea.h dsea_ws_set_partial_reorth): an OPTION the reference
+lacks (it re-orthogonalises on every step, Lanczos.py:66; SURVEY.md 8 f-4 lists "selective reorth").  Same Krylov
+process and stored basis; a one-block kernel advances the omega estimates of q_i . q_k per step and only the steps it
+selects run the dots / correction kernels over the basis.  Held here to the reference's schedule on the same inputs:
+extreme Ritz pair and gradient to the path's 1e-10, the leading block of T to rounding, the basis semi-orthogonal."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from dominantsparseeigenad_amd import _lib, engine  # noqa: E402
+from dominantsparseeigenad_amd import Lanczos as LZ  # noqa: E402
+from dominantsparseeigenad_amd.Lanczos import symeigLanczos, Lanczos  # noqa: E402
+from dominantsparseeigenad_amd.operators import CSROperator, TFIMOperator, Stencil3Operator  # noqa: E402
+import dominantsparseeigenad_amd.symeig as symeig  # noqa: E402
+from helpers import unit  # noqa: E402
+
+F64 = torch.float64
+SQRT_EPS = 1.4901161193847656e-08
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _stencil(n, grad=False):
+    xm = torch.from_numpy(np.linspace(-1.0, 1.0, num=n, endpoint=False)).to(dev())
+    V = (0.5 * xm ** 2)
+    if grad:
+        V.requires_grad_(True)
+    return Stencil3Operator(n, 2.0 / n, V), V
+
+
+def _basis(A, k, n, q0, partial):
+    old = engine.PARTIAL_REORTH
+    engine.PARTIAL_REORTH = 0.0 if partial else None
+    try:
+        Qk, T = Lanczos(A, k, dev(), sparse=True, dim=n, q0=q0)
+    finally:
+        engine.PARTIAL_REORTH = old
+    return Qk, T, engine.last_reorth_steps
+
+
+@pytest.mark.parametrize("case", ["tfim-L10-g1.0", "tfim-L12-g1.5", "tfim-L14-g1.0", "tfim-L13-g0.8", "sell-L10", "stencil-1000",
+                                  "stencil-300-k280", "stencil-20000"])
+def test_partial_reorthogonalisation_matches_the_reference_schedule(case):
+    if case.startswith("tfim"):
+        L = int(case.split("-")[1][1:])
+        gval = float(case.split("-")[2][1:])
+        n, k = 1 << L, 200
+        op = TFIMOperator(L, dev(), g=torch.tensor([gval], dtype=F64, device=dev()))
+    elif case == "sell-L10":
+        L, n, k = 10, 1 << 10, 150
+        t = TFIMOperator(L, dev(), g=torch.tensor([1.0], dtype=F64, device=dev()))
+        dense = torch.stack([t(torch.eye(n, dtype=F64, device=dev())[j]) for j in range(n)]).T.cpu()
+        op = CSROperator.from_dense(0.5 * (dense + dense.T), dev(), layout="sell")
+    else:
+        n = int(case.split("-")[1])
+        k = int(case.split("-")[2][1:]) if case.count("-") == 2 else 300
+        op, _ = _stencil(n)
+    q0 = unit(n, 41).to(dev())
+    lo_f, v_f = symeigLanczos(op, k, dev(), extreme="min", sparse=True, dim=n, q0=q0)
+    lo_p, v_p = symeigLanczos(op, k, dev(), extreme="min", sparse=True, dim=n, q0=q0, reorth="partial")
+    steps = engine.last_reorth_steps
+    assert steps is not None and 0 <= steps <= k - 1
+    Qp, Tp, steps2 = _basis(op, k, n, q0, True)
+    Qf, Tf, none = _basis(op, k, n, q0, False)
+    assert steps2 == steps and none is None
+    tn = float(Tf.abs().max())             # ~ ||A||: what rounding errors of a Lanczos run are relative to (2.5e5 for the stencil)
+    assert abs(lo_f.item() - lo_p.item()) < 1e-12 * tn
+    res_f = float((op(v_f) - lo_f * v_f).norm())
+    res_p = float((op(v_p) - lo_p * v_p).norm())
+    assert abs(float(v_p.norm()) - 1.0) < 1e-12
+    assert res_p < 4.0 * res_f + 1e-11 * tn
+    sgn = 1.0 if float(v_f @ v_p) > 0 else -1.0
+    if res_f < 1e-9 * tn:                  # a converged pair: the vectors agree to the path's tolerance
+        assert float((v_f - sgn * v_p).abs().max()) < 1e-10
+    # the basis: semi-orthogonal (Simon's bound sqrt(eps)); the leading block of T as in the reference's schedule
+    orth = float((Qp.T @ Qp - torch.eye(k, dtype=F64, device=dev())).abs().max())
+    lead = float((Tp - Tf)[:12, :12].abs().max())
+    print("%s: %d of %d steps re-orthogonalised, ||Q^T Q - I||_max %.1e, |dT[:12,:12]| %.1e, |dE0| %.1e, residual %.1e (full %.1e)"
+          % (case, steps, k - 1, orth, lead, abs(lo_f.item() - lo_p.item()), res_p, res_f))
+    assert orth < 10 * SQRT_EPS
+    assert lead < 1e-11 * tn
+    ev_p, ev_f = torch.linalg.eigvalsh(Tp), torch.linalg.eigvalsh(Tf)
+    assert abs(float(ev_p[0] - ev_f[0])) < 1e-12 * tn and abs(float(ev_p[-1] - ev_f[-1])) < 1e-12 * tn
+    if case.startswith("tfim"):
+        assert steps < (k - 1) // 2        # the point of the option: most steps are not re-orthogonalised
+
+
+def test_partial_reorthogonalisation_through_the_primitive_and_thresholds():
+    """module-level switch (the apply signature is the reference's): E0, psi . t and dloss/dg agree with the reference's
+    schedule at 1e-10; threshold knob: a tiny delta re-orthogonalises (almost) every step, a huge one never."""
+    L, k = 12, 200
+    n = 1 << L
+    op = TFIMOperator(L, dev(), g=torch.tensor([1.0], dtype=F64, device=dev(), requires_grad=True))
+    symeig.setDominantSparseSymeig(op.H, op.Hadjoint_to_gadjoint)
+    tvec = unit(n, 43).to(dev())
+    out = {}
+    from dominantsparseeigenad_amd import CG
+    old_eps = CG.EPS_DEFAULT
+    CG.EPS_DEFAULT = 1e-12
+    try:
+        for mode in ("full", "partial"):
+            LZ.REORTH_DEFAULT = mode
+            try:
+                torch.manual_seed(5)
+                E, psi = symeig.DominantSparseSymeig.apply(op.g, k, n, dev())
+                s = 1.0 if float(psi.detach()[0]) > 0 else -1.0
+                loss = E + s * psi.matmul(tvec)
+                (gr,) = torch.autograd.grad(loss, op.g)
+                out[mode] = (E.item(), s * float(psi.detach() @ tvec), float(gr))
+            finally:
+                LZ.REORTH_DEFAULT = "full"
+    finally:
+        CG.EPS_DEFAULT = old_eps
+    (Ef, pf, gf), (Ep, pp, gp) = out["full"], out["partial"]
+    print("E0 %.3e  psi.t %.3e  dloss/dg %.3e (relative deviations)" % (abs(Ef - Ep) / abs(Ef), abs(pf - pp), abs(gf - gp) / abs(gf)))
+    assert abs(Ef - Ep) < 1e-12 * abs(Ef) and abs(pf - pp) < 1e-10 and abs(gf - gp) < 1e-10 * abs(gf)
+    assert engine.PARTIAL_REORTH is None and LZ.REORTH_DEFAULT == "full"
+    q0 = unit(n, 44).to(dev())
+    counts = {}
+    for delta in (1e-15, 0.0, 1e-4, 1e300):
+        engine.PARTIAL_REORTH = delta
+        try:
+            lo, v = symeigLanczos(op.H, k, dev(), extreme="min", sparse=True, dim=n, q0=q0)
+        finally:
+            engine.PARTIAL_REORTH = None
+        counts[delta] = engine.last_reorth_steps
+        assert abs(lo.item() - Ef) < 1e-11 * abs(Ef)          # the extreme pair survives even without any re-orthogonalisation
+    print("steps re-orthogonalised by threshold:", counts)
+    assert counts[1e-15] >= k - 2 and counts[1e300] == 0 and counts[1e-15] >= counts[0.0] >= counts[1e-4] >= 1
+
+
+def test_partial_reorthogonalisation_says_where_it_does_not_apply():
+    n, k = 256, 40
+    A = torch.randn(n, n, dtype=F64)
+    A = (A + A.T).to(dev())
+    with pytest.raises(NotImplementedError):
+        symeigLanczos(lambda v: A @ v, k, dev(), extreme="min", sparse=True, dim=n, reorth="partial")
+    with pytest.raises(ValueError):
+        symeigLanczos(lambda v: A @ v, k, dev(), extreme="min", sparse=True, dim=n, reorth="sometimes")
+    # an operator kind without a fused tail (plain CSR): the library reports it instead of silently doing something else
+    csr = CSROperator.from_dense(A.cpu(), dev(), layout="csr")
+    with pytest.raises(RuntimeError):
+        symeigLanczos(csr, k, dev(), extreme="min", sparse=True, dim=n, reorth="partial")
+    lib = _lib.load()
+    ws = engine.Workspace.get(n, k, dev())
+    assert lib.dsea_ws_set_partial_reorth(ws.handle, 1, -1.0) == _lib.ERR_ARG
+    assert lib.dsea_ws_set_partial_reorth(None, 1, 0.0) == _lib.ERR_ARG
+    engine.check(lib.dsea_ws_set_partial_reorth(ws.handle, 0, 0.0), "dsea_ws_set_partial_reorth")
+    ws.partial_reorth = None
+    # ... and the default path is untouched afterwards
+    lo, _ = symeigLanczos(csr, k, dev(), extreme="min", sparse=True, dim=n)
+    assert torch.isfinite(lo)
+
+
+@pytest.mark.slow
+def test_partial_reorthogonalisation_at_the_headline_size():
+    """TFIM L = 20, k = 200: same E0 / eigenvector as the reference's schedule, a fraction of its basis traffic"""
+    L, k = 20, 200
+    n = 1 << L
+    op = TFIMOperator(L, dev(), g=torch.tensor([1.0], dtype=F64, device=dev()))
+    q0 = unit(n, 45).to(dev())
+    lo_f, v_f = symeigLanczos(op, k, dev(), extreme="min", sparse=True, dim=n, q0=q0)
+    lo_p, v_p = symeigLanczos(op, k, dev(), extreme="min", sparse=True, dim=n, q0=q0, reorth="partial")
+    steps = engine.last_reorth_steps
+    sgn = 1.0 if float(v_f @ v_p) > 0 else -1.0
+    print("L=20: %d of %d steps re-orthogonalised, |dE0| %.1e, max|dpsi| %.1e" % (steps, k - 1, abs(lo_f.item() - lo_p.item()),
+                                                                                  float((v_f - sgn * v_p).abs().max())))
+    assert abs(lo_f.item() - lo_p.item()) < 1e-12 * abs(lo_f.item())
+    assert float((v_f - sgn * v_p).abs().max()) < 1e-10
+    assert steps < 60
+    assert abs(lo_p.item() / L - (-1.2745494843182374)) < 1e-10       # closed form
