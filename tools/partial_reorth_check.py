@@ -16,6 +16,10 @@ cases = [("TFIM L=10", lambda: TFIMOperator(10, dev, g=torch.tensor([1.0], dtype
          ("stencil N=100000", lambda: Stencil3Operator(100000, 2.0 / 100000, 0.5 * torch.linspace(-1, 1, 100000, dtype=F64, device=dev) ** 2), 100000, 300)]
 if "--big" in sys.argv:
     cases = [("TFIM L=20", lambda: TFIMOperator(20, dev, g=torch.tensor([1.0], dtype=F64, device=dev)), 1 << 20, 200)]
+if "--L" in sys.argv:      # --L 28 --k 100: the one-GPU anchor of the strong-scaling curve
+    LL = int(sys.argv[sys.argv.index("--L") + 1]); kk = int(sys.argv[sys.argv.index("--k") + 1])
+    cases = [("TFIM L=%d" % LL, lambda: TFIMOperator(LL, dev, g=torch.tensor([1.0], dtype=F64, device=dev)), 1 << LL, kk)]
+REPS = 2 if "--L" in sys.argv else 3
 engine.LANCZOS_PERSIST = False
 for name, mk, n, k in cases:
     op = mk()
@@ -23,7 +27,7 @@ for name, mk, n, k in cases:
     res = {}
     for mode in ("full", "partial"):
         best = 1e30
-        for _ in range(3):
+        for _ in range(REPS):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             lam, psi = symeigLanczos(op, k, dev, extreme="min", sparse=True, dim=n, q0=q0, reorth=mode)
             torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
