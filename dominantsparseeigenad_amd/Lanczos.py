@@ -122,9 +122,9 @@ def symeigLanczos(A, k, device=torch.device("cpu"), extreme="both", *, sparse=Fa
     if reorth not in ("full", "none", "twice", "partial"):
         raise ValueError("reorth must be 'full', 'twice', 'partial' or 'none'")
     if reorth == "partial":
-        if not sparse or engine.native_of(A) is None or getattr(engine.native_of(A), "partitioned", False) or \
-                torch.device(device).type != "cuda":
-            raise NotImplementedError("reorth='partial' needs a native single-GPU operator")
+        if not sparse or engine.native_of(A) is None or torch.device(device).type != "cuda":
+            raise NotImplementedError("reorth='partial' needs a native device operator (single-GPU, or row-partitioned on "
+                                      "the library driver)")
         prev, engine.PARTIAL_REORTH = engine.PARTIAL_REORTH, (0.0 if engine.PARTIAL_REORTH is None else engine.PARTIAL_REORTH)
         try:
             return symeigLanczos(A, k, device, extreme, sparse=sparse, dim=dim, q0=q0, reorth="full")

@@ -39,7 +39,7 @@ WsLayout ws_layout(int64_t n, int kmax) {
   L.partials_off = off;
   off += (size_t)DSEA_MAX_WAVE_TILES * (size_t)(kk + 1) * sizeof(double);  // +1 row: ||r||^2 pseudo-vector
   L.aux_off = off;
-  off += (size_t)4 * DSEA_MAX_WAVE_TILES * sizeof(double);
+  off += (size_t)6 * DSEA_MAX_WAVE_TILES * sizeof(double);   // [0,1] alpha / norm partials  [2] axpy_multi_dot  [3] spare  [4,5] omega rows
   L.coef_off = off;
   off += (size_t)2 * round_up(kk + 2, 32) * sizeof(double);   // two coefficient vectors (Arnoldi: DGKS second pass)
   L.scal_off = off;
@@ -830,7 +830,7 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
     // partial re-orthogonalisation (option): the three-term vector goes to vec[2] with its norm, k_pro_update advances the
     // orthogonality estimates and decides, the dots / correction kernels then run over the basis or over nothing
     double* pro_flag = w.scal + DSEA_SCAL_PRO;
-    double* pro_om = w.aux + 2 * DSEA_MAX_WAVE_TILES;            // two rows of DSEA_MAX_WAVE_TILES (k <= DSEA_MAX_KRYLOV)
+    double* pro_om = w.aux + 4 * DSEA_MAX_WAVE_TILES;            // two rows of DSEA_MAX_WAVE_TILES (k <= DSEA_MAX_KRYLOV)
     const double pro_eps1 = 64.0 * 2.220446049250313e-16;
     for (int i = 1; i < k; ++i) {
       const double* beta_prev = (i >= 2) ? betas + (i - 2) : nullptr;

@@ -16,7 +16,7 @@
 #define DSEA_PERSIST_CG_MAX_TILES 1024 /* persistent single-launch CG: n <= 2^19 rows                       */
 #define DSEA_SCALARS 64
 #define DSEA_SCAL_BREAK 20    /* scal[20] = breakdown step, scal[21] = running scale (see broken())     */
-#define DSEA_SCAL_PRO 40      /* scal[40] = re-orthogonalise this step, [41] = and the next, [42] = ||A|| estimate, [43] = steps re-orthogonalised */
+#define DSEA_SCAL_PRO 40      /* scal[40] = re-orthogonalise this step, [41] = and the next, [42] = ||A|| estimate, [43] = steps re-orthogonalised, [44] = global ||r||^2 (row-partitioned run) */
 #define DSEA_SCAL_LZ_FAIL 38  /* scal[38] = 1 when the single-launch Lanczos lost a peer workgroup (timeout) */
 
 namespace dsea {

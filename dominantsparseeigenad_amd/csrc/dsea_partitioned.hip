@@ -491,7 +491,16 @@ int dsea_pop_lanczos_run(dsea_pop_t P, dsea_ws_t ws, int k, const double* q0, do
   double* pair = w.scal + 32;
   double* rec = w.scal + 34;      // overlap premise record
   const bool tfim = P->kind == OP_TFIM;
-  const bool overlap = tfim && P->p > 0 && (P->flags & DSEA_POP_OVERLAP);
+  // partial re-orthogonalisation (dsea_ws_set_partial_reorth): as in dsea_lanczos_run, with the norm the estimates need
+  // closed by one more scalar all-reduce per step; the exchange of the un-corrected r is not overlapped in this mode
+  const bool partial = w.partial_reorth != 0;
+  const bool overlap = tfim && P->p > 0 && (P->flags & DSEA_POP_OVERLAP) && !partial;
+  double* pro_flag = w.scal + DSEA_SCAL_PRO;
+  double* pro_rr = w.scal + DSEA_SCAL_PRO + 4;                   // global ||r||^2 of the un-corrected r
+  double* pro_om = w.aux + 4 * DSEA_MAX_WAVE_TILES;
+  const double pro_eps1 = 64.0 * 2.220446049250313e-16;
+  const TileGeom g = w.geom(n);
+  HIP_TRY(hipMemsetAsync(w.scal + DSEA_SCAL_PRO, 0, 5 * sizeof(double), st));
   HIP_TRY(hipMemsetAsync(w.scal + 32, 0, 4 * sizeof(double), st));
   HIP_TRY(hipMemsetAsync(w.scal + 16, 0, 2 * sizeof(double), st));      // shadow-path statistics of this run
   for (int i = 0; i < k; ++i) {
@@ -512,11 +521,27 @@ int dsea_pop_lanczos_run(dsea_pop_t P, dsea_ws_t ws, int k, const double* q0, do
       DSEA_TRY(dsea_plz_dots(ws, Q, ldq, n, i, P->r_send, w.zero, nullptr, r, c, stream));
       DSEA_TRY(comm_allreduce(P->comm, c, i + 1, st));
       hipLaunchKernelGGL(k_premise, dim3(1), dim3(256), 0, st, (const double*)c, i, P->tau, rec);
+    } else if (partial && i >= 1) {
+      // (1) r = u - alpha q - beta q', local ||r||^2 -> c[i]; (2) its global sum feeds the estimates, which decide on the
+      // device (identically on every rank: same scalars); (3) c = Q^T r (copy of r to y, unused) or nothing
+      launch_rdots(g, Q, ldq, n, i, u, a_prev, b_prev, r, w.partials, nullptr, st, nullptr, nullptr, 0, nullptr, true,
+                   nullptr, w.zero, false);
+      launch_finalize1(w.partials + (int64_t)i * g.pstride, rdots_partial_count(g, i), c + i, st);
+      HIP_TRY(hipMemcpyAsync(pro_rr, c + i, sizeof(double), hipMemcpyDeviceToDevice, st));
+      DSEA_TRY(comm_allreduce(P->comm, pro_rr, 1, st));
+      launch_pro_update(alphas, betas, pro_rr, 1, pro_rr, pro_om, DSEA_MAX_WAVE_TILES, pro_flag, pro_flag + 1, i, pro_eps1,
+                        w.pro_delta, nullptr, st);
+      HIP_TRY(hipMemsetAsync(c, 0, (size_t)i * sizeof(double), st));       // (what the all-reduce sums on the other steps)
+      launch_rdots(g, Q, ldq, n, i, r, w.zero, nullptr, y, w.partials, c, st, w.prof ? w.prof->next(PROF_RDOTS) : nullptr,
+                   nullptr, 0, nullptr, false, nullptr, pro_flag, true);
+      DSEA_TRY(comm_allreduce(P->comm, c, i, st));
+      launch_axpy_norm(g, Q, ldq, n, i, c, r, w.partials, pair, st, w.prof ? w.prof->next(PROF_AXPY) : nullptr, nullptr,
+                       pro_flag);
     } else {
       DSEA_TRY(dsea_plz_dots(ws, Q, ldq, n, i, u, a_prev, b_prev, r, c, stream));
       DSEA_TRY(comm_allreduce(P->comm, c, i + 1, st));
     }
-    DSEA_TRY(dsea_plz_correct(ws, Q, ldq, n, i, c, r, pair, stream));
+    if (!(partial && i >= 1)) DSEA_TRY(dsea_plz_correct(ws, Q, ldq, n, i, c, r, pair, stream));
     if (tfim && P->p == 0) {
       DSEA_TRY(dsea_spmv(&P->local, ws, r, y, nullptr, pair + 1, nullptr, stream));
     } else if (tfim) {

@@ -101,7 +101,8 @@ int dsea_ws_set_reorth_passes(dsea_ws_t ws, int passes);
  * step costs the three-term update and the mat-vec.  The basis is then orthogonal to ~delta, T and the Ritz values keep
  * full accuracy (semi-orthogonality), the Ritz vector keeps its residual.  Operators with a fused tail only (TFIM, SELL,
  * stencil), multi-launch form, fp64 basis (no bf16 shadow: the coefficients are no longer at rounding level); otherwise
- * dsea_lanczos_run returns DSEA_ERR_UNSUPPORTED.  dsea_lanczos_reorth_stats (synchronises) reports how many steps of the
+ * dsea_lanczos_run returns DSEA_ERR_UNSUPPORTED.  dsea_pop_lanczos_run honours it too (global norm by one more scalar
+ * all-reduce per step, identical decisions on every rank, no overlapped exchange).  dsea_lanczos_reorth_stats (synchronises) reports how many steps of the
  * last run were re-orthogonalised and the ||A|| estimate the recurrence used.                                          */
 int dsea_ws_set_partial_reorth(dsea_ws_t ws, int on, double delta);
 int dsea_lanczos_reorth_stats(dsea_ws_t ws, int64_t *reorth_steps, double *anorm, void *stream);

@@ -114,6 +114,28 @@ def _case_driver_env(rank, world, backend, dev, overlap, env, tau=None):
             solver.op.overlap_fallbacks)
 
 
+def _case_driver_partial(rank, world, backend, dev, partial):
+    """library driver with the partial re-orthogonalisation option (engine.PARTIAL_REORTH) on or off"""
+    from dominantsparseeigenad_amd import engine
+    from dominantsparseeigenad_amd.partitioned import PartitionedTFIM
+    p = world.bit_length() - 1
+    nloc = 1 << (L - p)
+    off = rank * nloc
+    g = torch.tensor([G], dtype=torch.float64, device=dev)
+    solver = PartitionedTFIM(L, g, dev, eps=1e-12, comm=_comm(backend))
+    solver.op.force_driver = True
+    q0 = torch.from_numpy(normal_vector(nloc, 5100, offset=off)).to(dev)
+    x0 = torch.from_numpy(normal_vector(nloc, 5102, offset=off)).to(dev)
+    t = torch.from_numpy(normal_vector(nloc, 5103, offset=off)).to(dev)
+    engine.PARTIAL_REORTH = 0.0 if partial else None
+    try:
+        E0, psi, grad = solver.forward_backward(K, q0, x0, t)
+    finally:
+        engine.PARTIAL_REORTH = None
+    torch.cuda.synchronize()
+    return (E0.item(), psi.cpu().numpy().copy(), grad.item(), engine.last_reorth_steps, solver.op.driver)
+
+
 def _case_api_tfim(rank, world, backend, dev, tag, second_order, force_driver):
     """reference API on a row-partitioned TFIM operator (HIP slab kernels)"""
     from helpers import PatchRandn
@@ -320,6 +342,29 @@ def test_library_driver_equals_python_driver(world, backend, overlap):
         assert "rccl" in lib_run[0][4]
     else:
         assert "callbacks" in lib_run[0][4]
+
+
+@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (4, "gloo")])
+def test_library_driver_partial_reorthogonalisation(world, backend):
+    """dsea_ws_set_partial_reorth on the row-partitioned library driver: the estimates take the GLOBAL norm (one more scalar
+    all-reduce per step), every rank takes the same decisions, the collectives are issued on every step (zeros on the
+    steps that are not re-orthogonalised).  Against the reference's schedule on the same slabs: E0 1e-12, psi 1e-10,
+    gradient 1e-9 (CG eps 1e-12); most steps are not re-orthogonalised."""
+    full = _run(world, backend, "_case_driver_partial", False)
+    part = _run(world, backend, "_case_driver_partial", True)
+    psi_f = np.concatenate([full[r][1] for r in range(world)])
+    psi_p = np.concatenate([part[r][1] for r in range(world)])
+    sgn = 1.0 if float(psi_f @ psi_p) > 0 else -1.0
+    for r in range(world):
+        assert part[r][4].startswith("library") and full[r][3] is None
+        assert part[r][0] == part[0][0] and part[r][2] == part[0][2] and part[r][3] == part[0][3]
+    print("world %d: %s of %d steps re-orthogonalised, |dE0| %.1e, max|dpsi| %.1e, gradient rel. %.1e"
+          % (world, part[0][3], K - 1, abs(part[0][0] - full[0][0]), np.max(np.abs(psi_f - sgn * psi_p)),
+             abs(part[0][2] - full[0][2]) / abs(full[0][2])))
+    assert abs(part[0][0] - full[0][0]) < 1e-12 * abs(full[0][0])
+    assert np.max(np.abs(psi_f - sgn * psi_p)) < 1e-10
+    assert abs(part[0][2] - full[0][2]) < 1e-9 * abs(full[0][2])
+    assert 1 <= part[0][3] < (K - 1) // 2
 
 
 def test_library_owned_rccl_communicators_world1():
