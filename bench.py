@@ -727,9 +727,11 @@ def main():
         except Exception as exc:  # noqa: BLE001
             ms_partial, pr_steps, pr_dev = None, None, str(exc)
         _LZ.REORTH_DEFAULT = "full"
-    if not args.no_extras and partitioned_path and args.reorth == "full" and not dry:
+    if not args.no_extras and partitioned_path and args.reorth == "full" and not dry and \
+            (world == 1 or os.environ.get("DSEA_BENCH_PARTIAL_EXTRA", "") == "1"):
         # row-partitioned run: the partial re-orthogonalisation option on the library driver (same collective sequence on
-        # every rank, one more scalar all-reduce per step) -- beside the timed figure, never in its place
+        # every rank, one more scalar all-reduce per step) -- beside the timed figure, never in its place.  On more than
+        # one rank only on request (DSEA_BENCH_PARTIAL_EXTRA=1): an extra must not be able to cost the line its headline.
         _LZ.REORTH_DEFAULT = "partial"
         try:
             step()
