@@ -75,7 +75,10 @@ def _lanczos_core(A, k, device, sparse, dim, q0, arena=False):
             from .operators import dense_symmetric_operand
             native = dense_symmetric_operand(A)
         if native is not None:
-            Q, ldq, alphas, betas = engine.lanczos(A, k, n, device, q0, native=native, arena=arena)
+            try:
+                Q, ldq, alphas, betas = engine.lanczos(A, k, n, device, q0, native=native, arena=arena)
+            except engine.PartialNeedsPhases:
+                Q, ldq, alphas, betas = engine.lanczos(A, k, n, device, q0, callable_A=amap, arena=arena)
         else:
             Q, ldq, alphas, betas = engine.lanczos(A, k, n, device, q0, callable_A=amap, arena=arena)
         return ("cuda", Q, ldq, n, alphas, betas, dtype)
@@ -122,9 +125,9 @@ def symeigLanczos(A, k, device=torch.device("cpu"), extreme="both", *, sparse=Fa
     if reorth not in ("full", "none", "twice", "partial"):
         raise ValueError("reorth must be 'full', 'twice', 'partial' or 'none'")
     if reorth == "partial":
-        if not sparse or engine.native_of(A) is None or torch.device(device).type != "cuda":
-            raise NotImplementedError("reorth='partial' needs a native device operator (single-GPU, or row-partitioned on "
-                                      "the library driver)")
+        if torch.device(device).type != "cuda":
+            raise NotImplementedError("reorth='partial' runs on the GPU (native operators, row-partitioned operators on "
+                                      "the library driver, callables)")
         prev, engine.PARTIAL_REORTH = engine.PARTIAL_REORTH, (0.0 if engine.PARTIAL_REORTH is None else engine.PARTIAL_REORTH)
         try:
             return symeigLanczos(A, k, device, extreme, sparse=sparse, dim=dim, q0=q0, reorth="full")

@@ -54,6 +54,8 @@ _SIGNATURES = {
     "dsea_ws_set_shadow": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_double]),
     "dsea_lanczos_lp_stats": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), c_void_p]),
     "dsea_ws_set_partial_reorth": (c_int, [c_void_p, c_int, c_double]),
+    "dsea_lanczos_partial_step": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p]),
     "dsea_lanczos_reorth_stats": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_double), c_void_p]),
     "dsea_profile_begin": (c_int, [c_void_p, c_int]),
     "dsea_profile_end": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_double)]),

@@ -593,6 +593,32 @@ int dsea_lanczos_axpy_norm(dsea_ws_t ws, const double* Q, int64_t ldq, int64_t n
   return check_launch();
 }
 
+int dsea_lanczos_partial_step(dsea_ws_t ws, const double* Q, int64_t ldq, int64_t n, int i, const double* u,
+                              const double* alphas, const double* betas, double* r, double* nrm2_out, void* stream) {
+  REQUIRE(ws && Q && u && alphas && betas && r && nrm2_out && n >= 1 && i >= 1 && ldq >= n, DSEA_ERR_ARG);
+  REQUIRE(i <= ws->w.kmax, DSEA_ERR_WORKSPACE);
+  REQUIRE(aligned16(Q) && aligned16(u) && aligned16(r) && (ldq % 2 == 0), DSEA_ERR_ALIGN);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Workspace& w = ws->w;
+  REQUIRE(w.n >= n, DSEA_ERR_WORKSPACE);
+  const TileGeom g = w.geom(n);
+  double* flag = w.scal + DSEA_SCAL_PRO;
+  double* om = w.aux + 4 * DSEA_MAX_WAVE_TILES;
+  if (i == 1 && hipMemsetAsync(flag, 0, 4 * sizeof(double), st) != hipSuccess) {   // a new run: estimates and counters restart
+    g_last_hip = (int)hipGetLastError();
+    return DSEA_ERR_HIP;
+  }
+  // the sequence of dsea_lanczos_run's partial mode, as one phase call around the caller's own mat-vec
+  launch_rdots(g, Q, ldq, n, i, u, alphas + (i - 1), i >= 2 ? betas + (i - 2) : nullptr, r, w.partials, nullptr, st, nullptr,
+               nullptr, 0, nullptr, true, nullptr, w.zero, false);
+  launch_pro_update(alphas, betas, w.partials + (int64_t)i * g.pstride, rdots_partial_count(g, i), w.coef + i, om,
+                    DSEA_MAX_WAVE_TILES, flag, flag + 1, i, 64.0 * 2.220446049250313e-16, w.pro_delta, nullptr, st);
+  launch_rdots(g, Q, ldq, n, i, r, w.zero, nullptr, w.vec[2], w.partials, w.coef, st, nullptr, nullptr, 0, nullptr, false,
+               nullptr, flag, true);
+  launch_axpy_norm(g, Q, ldq, n, i, w.coef, r, w.partials, nrm2_out, st, nullptr, nullptr, flag);
+  return check_launch();
+}
+
 int dsea_lanczos_store(dsea_ws_t ws, const double* r, const double* nrm2, double* Q, int64_t ldq, int row,
                        double* beta_out, int64_t n, void* stream) {
   REQUIRE(ws && r && nrm2 && Q && n >= 1 && row >= 0 && ldq >= n, DSEA_ERR_ARG);

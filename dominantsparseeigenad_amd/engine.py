@@ -36,7 +36,8 @@ DENSE_SYMMETRIC_KERNEL = True
 REORTH_PASSES = 1
 # Partial re-orthogonalisation (``reorth="partial"`` of Lanczos.symeigLanczos / Lanczos.Lanczos; an option the reference
 # lacks): None = off (the reference's full re-orthogonalisation on every step), a float = the threshold on the estimated
-# loss of orthogonality that triggers a pair of full passes (0.0 = the default sqrt(eps)).  Native fused-tail operators only.
+# loss of orthogonality that triggers a pair of full passes (0.0 = the default sqrt(eps)).  Device operators with a fused
+# tail (TFIM, SELL, stencil), row-partitioned operators on the library driver, and callables (one phase call per step).
 PARTIAL_REORTH = None
 last_reorth_steps = None       # steps of the last native run that were re-orthogonalised (partial mode), else None
 import os as _os
@@ -357,6 +358,11 @@ class Phases:
               "dsea_ritz_combine")
 
 
+class PartialNeedsPhases(NotImplementedError):
+    """reorth='partial' on a native operand whose whole-loop entry point does not take the option: the caller repeats the
+    run through the phase calls (Lanczos._lanczos_core does)"""
+
+
 # --------------------------------------------------------------------------- Lanczos
 def lanczos(A, k, n, device, q0, native=None, callable_A=None, arena=False):
     """k-step Lanczos on the GPU (reference Lanczos.py:49-77).
@@ -382,9 +388,8 @@ def lanczos(A, k, n, device, q0, native=None, callable_A=None, arena=False):
     betas = torch.empty(max(k - 1, 1), dtype=F64, device=device)
     q0 = as_vector(q0, n)
     partial = PARTIAL_REORTH is not None
-    if partial and (native is None or REORTH_PASSES != 1):
-        raise NotImplementedError("reorth='partial' needs a native device operator (TFIM, SELL/CSR, stencil) and one "
-                                  "Gram-Schmidt pass")
+    if partial and REORTH_PASSES != 1:
+        raise NotImplementedError("reorth='partial' and reorth='twice' exclude each other")
     use_shadow = USE_SHADOW and k > 1 and not partial and shadow_fits(device, k, ldq, n, arena)
     global last_reorth_steps
     last_reorth_steps = None
@@ -406,8 +411,12 @@ def lanczos(A, k, n, device, q0, native=None, callable_A=None, arena=False):
                     (1 if LANCZOS_PERSIST == "force" else -1)
                 if ws.lanczos_persist_mode != want:
                     ws.set_lanczos_persist(want)
-                check(lib.dsea_lanczos_run(native.handle, ws.handle, int(k), _ptr(q0), _ptr(Q), ldq, _ptr(alphas),
-                                           _ptr(betas), st), "dsea_lanczos_run")
+                rc0 = lib.dsea_lanczos_run(native.handle, ws.handle, int(k), _ptr(q0), _ptr(Q), ldq, _ptr(alphas),
+                                           _ptr(betas), st)
+                if partial and rc0 == _lib.ERR_UNSUPPORTED:
+                    # an operand without a fused Lanczos tail (plain CSR, dense): the option runs through the phase calls
+                    raise PartialNeedsPhases("operand without a fused tail")
+                check(rc0, "dsea_lanczos_run")
                 brk = ctypes.c_int(0)
                 rc = lib.dsea_lanczos_status(ws.handle, byref(brk), st)
                 if rc == _lib.ERR_TIMEOUT:
@@ -454,6 +463,10 @@ def lanczos(A, k, n, device, q0, native=None, callable_A=None, arena=False):
     esz = 8
     zero = torch.zeros(1, dtype=F64, device=device)
     with ws.owned_by("Lanczos (callable operator)"):
+        if getattr(ws, "partial_reorth", None) != PARTIAL_REORTH:
+            check(lib.dsea_ws_set_partial_reorth(ws.handle, 1 if partial else 0, float(PARTIAL_REORTH or 0.0)),
+                  "dsea_ws_set_partial_reorth")
+            ws.partial_reorth = PARTIAL_REORTH
         if use_shadow:
             shadow = new_shadow()
             check(lib.dsea_ws_set_shadow(ws.handle, _ptr(shadow), ldq, int(k), float(SHADOW_TAU)), "dsea_ws_set_shadow")
@@ -465,10 +478,16 @@ def lanczos(A, k, n, device, q0, native=None, callable_A=None, arena=False):
             for i in range(1, k):
                 a_ptr = c_void_p(alphas.data_ptr() + (i - 1) * esz)
                 b_ptr = c_void_p(betas.data_ptr() + (i - 2) * esz) if i >= 2 else c_void_p(None)
-                check(lib.dsea_lanczos_rdots(ws.handle, _ptr(Q), ldq, n, i, _ptr(u), a_ptr, b_ptr, _ptr(r), _ptr(c), st),
-                      "dsea_lanczos_rdots")
-                check(lib.dsea_lanczos_axpy_norm(ws.handle, _ptr(Q), ldq, n, i, _ptr(c), _ptr(r), _ptr(nrm2), st),
-                      "dsea_lanczos_axpy_norm")
+                if partial:
+                    # the option's device-side sequence as ONE phase call (three-term update, omega estimates, gated dots
+                    # and correction); the mat-vec below stays the caller's code
+                    check(lib.dsea_lanczos_partial_step(ws.handle, _ptr(Q), ldq, n, i, _ptr(u), _ptr(alphas), _ptr(betas),
+                                                        _ptr(r), _ptr(nrm2), st), "dsea_lanczos_partial_step")
+                else:
+                    check(lib.dsea_lanczos_rdots(ws.handle, _ptr(Q), ldq, n, i, _ptr(u), a_ptr, b_ptr, _ptr(r), _ptr(c), st),
+                          "dsea_lanczos_rdots")
+                    check(lib.dsea_lanczos_axpy_norm(ws.handle, _ptr(Q), ldq, n, i, _ptr(c), _ptr(r), _ptr(nrm2), st),
+                          "dsea_lanczos_axpy_norm")
                 if int(REORTH_PASSES) == 2:      # CGS2 option: the same pass again on the corrected vector (alpha = 0)
                     r2 = r.clone()
                     check(lib.dsea_lanczos_rdots(ws.handle, _ptr(Q), ldq, n, i, _ptr(r2), _ptr(zero), None, _ptr(r),
@@ -480,6 +499,10 @@ def lanczos(A, k, n, device, q0, native=None, callable_A=None, arena=False):
                 qi = Q[i]
                 u = as_vector(callable_A(qi[:n]), n)
                 check(lib.dsea_dot(ws.handle, _ptr(qi), _ptr(u), n, c_void_p(alphas.data_ptr() + i * esz), st), "dsea_dot")
+            if partial and k > 1:
+                cnt, an = ctypes.c_int64(0), c_double(0.0)
+                check(lib.dsea_lanczos_reorth_stats(ws.handle, byref(cnt), byref(an), st), "dsea_lanczos_reorth_stats")
+                last_reorth_steps = int(cnt.value)
         finally:
             if shadow is not None:
                 check(lib.dsea_ws_set_shadow(ws.handle, None, 0, 0, 0.0), "dsea_ws_set_shadow")

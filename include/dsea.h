@@ -241,6 +241,14 @@ int dsea_lanczos_rdots(dsea_ws_t ws, const double *Q, int64_t ldq, int64_t n, in
 int dsea_lanczos_axpy_norm(dsea_ws_t ws, const double *Q, int64_t ldq, int64_t n, int i,
                            const double *c, double *r, double *nrm2_out, void *stream);
 
+/* Phases 1 + 2 of step i under the PARTIAL re-orthogonalisation option (dsea_ws_set_partial_reorth's scheme as a phase call
+ * for a caller-supplied mat-vec): r = u - alphas[i-1] Q[i-1] - betas[i-2] Q[i-2]; the omega estimates advance from
+ * alphas[0..i-1], betas[0..i-2] (device arrays, as dsea_dot / dsea_lanczos_store leave them) and ||r||; if they ask for it
+ * -- decided on the device, no host synchronisation -- r -= Q Q^T r; *nrm2_out = ||r||^2.  i = 1 starts a new run.
+ * dsea_lanczos_reorth_stats reports the count.  fp64 basis (a registered bf16 shadow is not used).                  */
+int dsea_lanczos_partial_step(dsea_ws_t ws, const double *Q, int64_t ldq, int64_t n, int i, const double *u,
+                              const double *alphas, const double *betas, double *r, double *nrm2_out, void *stream);
+
 /* Q[row] = r / sqrt(*nrm2) (and the bf16 shadow row if registered) ; *beta_out = sqrt(*nrm2) (nullable)
  * (Lanczos.py:53,69-70,75 writing into the vector-contiguous basis)                                       */
 int dsea_lanczos_store(dsea_ws_t ws, const double *r, const double *nrm2, double *Q, int64_t ldq, int row,

@@ -133,18 +133,69 @@ def test_partial_reorthogonalisation_through_the_primitive_and_thresholds():
     assert counts[1e-15] >= k - 2 and counts[1e300] == 0 and counts[1e-15] >= counts[0.0] >= counts[1e-4] >= 1
 
 
+@pytest.mark.parametrize("form", ["callable", "native-csr", "dense-primitive"])
+def test_partial_reorthogonalisation_through_the_phase_calls(form):
+    """operands without a fused Lanczos tail -- a user's Python mat-vec (the reference's calling convention), plain CSR, the
+    dense primitive's tensor -- take the option through dsea_lanczos_partial_step: one phase call per step around the
+    caller's mat-vec, decisions on the device.  Hard case on purpose: a matrix with a cluster of well-separated low
+    eigenvalues, where Ritz values converge early and an un-re-orthogonalised Lanczos run loses orthogonality at once."""
+    n, k = 600, 150
+    gen = torch.Generator().manual_seed(11)
+    U, _ = torch.linalg.qr(torch.randn(n, n, dtype=F64, generator=gen))
+    ev = torch.cat([torch.tensor([-50.0, -40.0, -30.0, -20.0], dtype=F64), torch.linspace(0.0, 10.0, n - 4, dtype=F64)])
+    A = ((U * ev) @ U.T)
+    A = (0.5 * (A + A.T)).to(dev())
+    q0 = unit(n, 47).to(dev())
+    if form == "callable":
+        op, kw = (lambda v: A @ v), dict(sparse=True, dim=n)
+    elif form == "native-csr":
+        op, kw = CSROperator.from_dense(A.cpu(), dev(), layout="csr"), dict(sparse=True, dim=n)
+    else:
+        op, kw = A, dict()
+    lo_f, v_f = symeigLanczos(op, k, dev(), extreme="min", q0=q0, **kw)
+    lo_p, v_p = symeigLanczos(op, k, dev(), extreme="min", q0=q0, reorth="partial", **kw)
+    steps = engine.last_reorth_steps
+    engine.PARTIAL_REORTH = 0.0
+    try:
+        Qp, Tp = Lanczos(op, k, dev(), q0=q0, **kw)
+    finally:
+        engine.PARTIAL_REORTH = None
+    engine.PARTIAL_REORTH = 1e300           # never re-orthogonalise: what the option protects against
+    try:
+        Qn, Tn = Lanczos(op, k, dev(), q0=q0, **kw)
+    finally:
+        engine.PARTIAL_REORTH = None
+    eye = torch.eye(k, dtype=F64, device=dev())
+    orth, orth_none = float((Qp.T @ Qp - eye).abs().max()), float((Qn.T @ Qn - eye).abs().max())
+    sgn = 1.0 if float(v_f @ v_p) > 0 else -1.0
+    print("%s: %d of %d steps re-orthogonalised, ||Q^T Q - I||_max %.1e (never re-orthogonalised: %.1e), |dE0| %.1e, max|dpsi| %.1e"
+          % (form, steps, k - 1, orth, orth_none, abs(lo_f.item() - lo_p.item()), float((v_f - sgn * v_p).abs().max())))
+    assert 1 <= steps < k - 1
+    assert abs(lo_f.item() - lo_p.item()) < 1e-12 * 50.0 and abs(lo_p.item() + 50.0) < 1e-10
+    assert float((v_f - sgn * v_p).abs().max()) < 1e-10
+    assert orth < 10 * SQRT_EPS
+    assert orth_none > 1e-3                  # the hard case is hard: without the option's passes orthogonality is gone
+    # the spectrum of T has no spurious copies of the converged eigenvalues (the signature of lost orthogonality)
+    evT = torch.linalg.eigvalsh(Tp)
+    assert int((evT < -45.0).sum()) == 1 and int(((evT > -45.0) & (evT < -35.0)).sum()) == 1
+
+
 def test_partial_reorthogonalisation_says_where_it_does_not_apply():
     n, k = 256, 40
     A = torch.randn(n, n, dtype=F64)
-    A = (A + A.T).to(dev())
+    A = (A + A.T)
     with pytest.raises(NotImplementedError):
-        symeigLanczos(lambda v: A @ v, k, dev(), extreme="min", sparse=True, dim=n, reorth="partial")
+        symeigLanczos(lambda v: A @ v, k, torch.device("cpu"), extreme="min", sparse=True, dim=n, reorth="partial")
     with pytest.raises(ValueError):
         symeigLanczos(lambda v: A @ v, k, dev(), extreme="min", sparse=True, dim=n, reorth="sometimes")
-    # an operator kind without a fused tail (plain CSR): the library reports it instead of silently doing something else
-    csr = CSROperator.from_dense(A.cpu(), dev(), layout="csr")
-    with pytest.raises(RuntimeError):
-        symeigLanczos(csr, k, dev(), extreme="min", sparse=True, dim=n, reorth="partial")
+    A = A.to(dev())
+    old = engine.REORTH_PASSES
+    engine.REORTH_PASSES = 2
+    try:
+        with pytest.raises(NotImplementedError):
+            symeigLanczos(lambda v: A @ v, k, dev(), extreme="min", sparse=True, dim=n, reorth="partial")
+    finally:
+        engine.REORTH_PASSES = old
     lib = _lib.load()
     ws = engine.Workspace.get(n, k, dev())
     assert lib.dsea_ws_set_partial_reorth(ws.handle, 1, -1.0) == _lib.ERR_ARG
@@ -152,7 +203,7 @@ def test_partial_reorthogonalisation_says_where_it_does_not_apply():
     engine.check(lib.dsea_ws_set_partial_reorth(ws.handle, 0, 0.0), "dsea_ws_set_partial_reorth")
     ws.partial_reorth = None
     # ... and the default path is untouched afterwards
-    lo, _ = symeigLanczos(csr, k, dev(), extreme="min", sparse=True, dim=n)
+    lo, _ = symeigLanczos(lambda v: A @ v, k, dev(), extreme="min", sparse=True, dim=n)
     assert torch.isfinite(lo)
 
 
