@@ -34,10 +34,14 @@ def main():
     ap.add_argument("--skip-zero-rhs", type=int, default=0,
                     help="1: symeig.SKIP_ZERO_RHS -- the first backward of every point (a loss that ignores the "
                          "eigenvector) skips its CG solve of (A - E0) x = 0: two solves per E0 point instead of three")
+    ap.add_argument("--reorth", choices=["full", "partial", "twice", "none"], default="full",
+                    help="Lanczos.REORTH_DEFAULT for the primitives: 'full' = the reference's schedule (Lanczos.py:66); "
+                         "'partial' = re-orthogonalise only when the omega recurrence asks for it (an option the reference lacks)")
     args = ap.parse_args()
     import DominantSparseEigenAD.Lanczos as LZ
     import DominantSparseEigenAD.symeig as SE
     SE.SKIP_ZERO_RHS = bool(args.skip_zero_rhs)
+    LZ.REORTH_DEFAULT = args.reorth
     curE = np.load(os.path.join(args.data, "E0_N_%d.npz" % args.N))
     curC = np.load(os.path.join(args.data, "chiF_N_%d.npz" % args.N))
     dev = torch.device(args.device)
@@ -68,8 +72,9 @@ def main():
     if dev.type == "cuda":
         torch.cuda.synchronize()
     dt = time.time() - t0
-    print("N=%d k=%d: %d couplings in %.2f s (%.1f ms per point: E0, dE0, d2E0 and chi_F)" % (
-        args.N, args.k, len(idxs), dt, dt / len(idxs) * 1e3))
+    LZ.REORTH_DEFAULT = "full"
+    print("N=%d k=%d reorth=%s: %d couplings in %.2f s (%.1f ms per point: E0, dE0, d2E0 and chi_F)" % (
+        args.N, args.k, args.reorth, len(idxs), dt, dt / len(idxs) * 1e3))
     print("max relative deviation from the reference's stored curves:  E0 %.1e  dE0 %.1e  d2E0 %.1e  chiF %.1e" % (
         dev_E, dev_d, dev_d2, dev_c))
     return dev_E, dev_d, dev_d2, dev_c, dt
