@@ -921,7 +921,7 @@ def main():
             out["config"]["partial_reorth_lanczos"] = {
                 "ms_per_step": round(ms_partial, 4), "steps_reorthogonalised": pr_steps, "of": k - 1,
                 "E0_rel_dev_vs_full_reorth": pr_dev[0], "dloss_dg_rel_dev_vs_full_reorth": pr_dev[1],
-                "note": "reorth='partial' option (Simon's partial re-orthogonalisation, threshold sqrt(eps)): same stored "
+                "note": "reorth='partial' option (Simon's partial re-orthogonalisation, threshold 1e-10): same stored "
                         "basis, re-orthogonalised only on the steps the omega recurrence selects; not the reference's "
                         "schedule (Lanczos.py:66 re-orthogonalises on every step), never the headline"}
         if ms_fp64 is not None:

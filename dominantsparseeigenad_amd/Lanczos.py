@@ -113,8 +113,8 @@ def symeigLanczos(A, k, device=torch.device("cpu"), extreme="both", *, sparse=Fa
 
     Keyword-only extension ``reorth``: "full" (default, reference Lanczos.py:66), "twice" (the same pass applied twice per
     step: CGS2), "partial" (Simon's partial re-orthogonalisation for native device operators: the basis is
-    re-orthogonalised only when the omega recurrence estimates a loss of orthogonality beyond sqrt(eps) -- typically one
-    step in four to ten; Ritz values at full accuracy, basis orthogonal to ~1e-8; ``engine.last_reorth_steps`` counts) or
+    re-orthogonalised only when the omega recurrence estimates a loss of orthogonality beyond 1e-10 (engine.PARTIAL_REORTH
+    sets the threshold) -- typically one step in four to ten; Ritz values at full accuracy, Ritz vector to the threshold; ``engine.last_reorth_steps`` counts) or
     "none" -- basis-free two-pass
     Lanczos for native device operators: three rotating vectors instead of the k-vector basis (so k = 200 at
     n = 2^28 fits ONE GPU) and no k^2 n re-orthogonalisation traffic; the extreme Ritz pair is the same to rounding,

@@ -184,7 +184,7 @@ int dsea_ws_create(void* device_buffer, size_t bytes, int64_t n, int kmax, dsea_
   ws->w.lz_persist = -1;
   ws->w.reorth_passes = 1;
   ws->w.partial_reorth = 0;
-  ws->w.pro_delta = 1.4901161193847656e-08;   // sqrt(2^-52)
+  ws->w.pro_delta = DSEA_PRO_DELTA_DEFAULT;
   ws->w.lose_peer = 0;
   ws->w.prof = nullptr;
   ws->w.shadow = nullptr;
@@ -338,7 +338,7 @@ int dsea_ws_set_reorth_passes(dsea_ws_t ws, int passes) {
 int dsea_ws_set_partial_reorth(dsea_ws_t ws, int on, double delta) {
   if (!ws || !(delta >= 0.0)) return DSEA_ERR_ARG;
   ws->w.partial_reorth = on ? 1 : 0;
-  ws->w.pro_delta = delta > 0.0 ? delta : 1.4901161193847656e-08;
+  ws->w.pro_delta = delta > 0.0 ? delta : DSEA_PRO_DELTA_DEFAULT;
   return DSEA_OK;
 }
 

@@ -17,6 +17,10 @@
 #define DSEA_SCALARS 64
 #define DSEA_SCAL_BREAK 20    /* scal[20] = breakdown step, scal[21] = running scale (see broken())     */
 #define DSEA_SCAL_PRO 40      /* scal[40] = re-orthogonalise this step, [41] = and the next, [42] = ||A|| estimate, [43] = steps re-orthogonalised, [44] = global ||r||^2 (row-partitioned run) */
+/* default threshold of the partial re-orthogonalisation on the estimated |q_i . q_k|: the path's stated tolerance.  Simon's
+ * classical sqrt(eps) = 1.5e-8 keeps the Ritz VALUES at full accuracy; the corrections that are dropped from T (Q c with
+ * |c| up to the threshold) enter the residual of a Ritz VECTOR at first order, so the vector is only good to ~threshold */
+#define DSEA_PRO_DELTA_DEFAULT 1e-10
 #define DSEA_SCAL_LZ_FAIL 38  /* scal[38] = 1 when the single-launch Lanczos lost a peer workgroup (timeout) */
 
 namespace dsea {
@@ -119,7 +123,7 @@ struct Workspace {
   int lose_peer;         // TEST HOOK (dsea_ws_set_fault_injection): the last workgroup of a persistent launch exits at once
   int reorth_passes;     // Gram-Schmidt passes per Lanczos step: 1 (the reference, Lanczos.py:66) or 2 (CGS2 option)
   int partial_reorth;    // 1 = re-orthogonalise only when the omega recurrence says so (option; dsea_ws_set_partial_reorth)
-  double pro_delta;      // its threshold on the estimated |q_i . q_k| (sqrt(eps))
+  double pro_delta;      // its threshold on the estimated |q_i . q_k| (DSEA_PRO_DELTA_DEFAULT)
   double* partials;  // DSEA_MAX_WAVE_TILES * max(kmax,1) doubles (also >= DSEA_MAX_EW_BLOCKS)
   double* aux;       // 4 * DSEA_MAX_WAVE_TILES doubles: small partial buffers that must not alias `partials`
   double* coef;      // kmax doubles

@@ -2248,7 +2248,7 @@ static inline int tile_blocks(int64_t n) {
 // omega_{i,k} estimates q_i . q_k from the scalars of the recurrence alone:
 //   beta_{i-1} omega_{i,k} = beta_k omega_{i-1,k+1} + (alpha_k - alpha_{i-1}) omega_{i-1,k} + beta_{k-1} omega_{i-1,k-1}
 //                            - beta_{i-2} omega_{i-2,k}  (+ a rounding term of the size of eps ||A||),   omega_{j,j} = 1
-// One block per step; when max_k |omega_{i,k}| exceeds delta (sqrt(eps)) this step AND the next one are re-orthogonalised
+// One block per step; when max_k |omega_{i,k}| exceeds delta (default 1e-10) this step AND the next one are re-orthogonalised
 // against the whole basis and their estimates restart at the rounding level.  om: two rows of `ld` doubles (row i & 1
 // is overwritten in place: new[k] needs the old row only at the same k).
 // state: [0] re-orthogonalise the next step too  [1] running estimate of ||A||  [2] number of re-orthogonalised steps

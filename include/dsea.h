@@ -97,7 +97,8 @@ int dsea_ws_set_reorth_passes(dsea_ws_t ws, int passes);
 /* PARTIAL re-orthogonalisation for dsea_lanczos_run (Simon 1984) -- an option the reference lacks (it re-orthogonalises on
  * every step, Lanczos.py:66; SURVEY.md 8 f-4 lists "selective reorth"), never selected automatically: a one-block kernel per
  * step advances the estimates omega_{i,k} ~ q_i . q_k from alpha, beta alone; only when one of them exceeds `delta`
- * (0 = the default sqrt(eps) = 1.49e-8) are this step and the next one re-orthogonalised against the whole basis, every other
+ * (0 = the default 1e-10, the path's stated tolerance: the Ritz VECTOR is good to about delta ||A|| / gap; Simon's classical
+ * sqrt(eps) = 1.49e-8 is enough for the Ritz VALUES) are this step and the next one re-orthogonalised against the whole basis, every other
  * step costs the three-term update and the mat-vec.  The basis is then orthogonal to ~delta, T and the Ritz values keep
  * full accuracy (semi-orthogonality), the Ritz vector keeps its residual.  Operators with a fused tail only (TFIM, SELL,
  * stencil), multi-launch form, fp64 basis (no bf16 shadow: the coefficients are no longer at rounding level); otherwise
