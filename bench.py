@@ -353,7 +353,7 @@ class Problem:
         # one GPU cannot hold the fp64 basis AND its bf16 shadow at L = 28, k = 100 (215 + 54 GB of 288 GB)
         free_b, total_b = (0, 1 << 62) if dry else torch.cuda.mem_get_info(dev)
         need_shadow = 10.0 * self.nloc * k + 16 * 8.0 * self.nloc
-        self.use_shadow = not (need_shadow > 0.92 * total_b or reorth == "none")
+        self.use_shadow = not (need_shadow > 0.92 * total_b or reorth in ("none", "partial"))
 
         def slab(seed):
             return torch.from_numpy(normal_vector(self.nloc, seed, offset=off)).to(dev)
@@ -571,9 +571,11 @@ def main():
     ap.add_argument("--operator", choices=["matrix-free", "sell", "csr"], default="matrix-free",
                     help="operand form of the TFIM operator at N=1: native matrix-free kernel (headline) or the "
                          "explicit 21-nnz/row matrix in SELL-64 / CSR layout")
-    ap.add_argument("--reorth", choices=["full", "none"], default="full",
+    ap.add_argument("--reorth", choices=["full", "none", "partial"], default="full",
                     help="'none': basis-free two-pass Lanczos (no stored basis, no re-orthogonalisation) -- NOT the "
-                         "reference's algorithm, reported for what it is; lets k = 200 at L = 28 fit one GPU")
+                         "reference's algorithm, reported for what it is; lets k = 200 at L = 28 fit one GPU.  'partial': "
+                         "stored basis, re-orthogonalised only on the steps the omega recurrence selects (Simon) -- NOT the "
+                         "reference's schedule either, priced with its own bytes")
     ap.add_argument("--force-partitioned", action="store_true",
                     help="run the row-partitioned driver even with one rank (measures its host overhead)")
     ap.add_argument("--dry-run-cpu", action="store_true",
@@ -691,6 +693,7 @@ def main():
         dt_instr = time.perf_counter() - t1
         _lib.check(lib.dsea_profile_end(ws.handle, launches, total_ms), "dsea_profile_end")
     lp_stats = engine.lanczos_lp_stats(nloc, dev) if not partitioned_path else None
+    pr_timed_steps = engine.last_reorth_steps       # (partial option: steps the timed runs re-orthogonalised)
     # ---- the same step with the all-fp64 correction pass (no bf16 shadow of the basis): the figure to hold
     # against real HBM traffic
     ms_fp64 = ms_basisfree = ms_partial = None
@@ -776,6 +779,13 @@ def main():
         # SURVEY 8d's full-reorthogonalisation figure (which it does not move).  Per Lanczos step and pass: mat-vec 2 +
         # three-term 4 + scale/store 2 vectors; the second pass also updates psi (2): 18 k vectors in all.
         total_bytes = alg_bytes = 8.0 * n * (18 * k + 11 * m + 24)
+    pr_run_steps = None
+    if args.reorth == "partial":
+        # the partial re-orthogonalisation option, priced with ITS OWN bytes: every step mat-vec 2 + three-term 4 +
+        # scale/store 2 vectors; a re-orthogonalised step i adds the two passes over the basis, (i + 1) + (i + 2) vectors --
+        # R such steps, taken as spread evenly (mean i = k / 2); Ritz vector k + 1; backward as SURVEY 8d
+        pr_run_steps = int(pr_timed_steps or 0)
+        total_bytes = alg_bytes = 8.0 * n * (8 * k + pr_run_steps * (k + 3) + (k + 1) + 11 * m + 24)
     value = total_bytes / (ms_per_step * 1e-3) / 1e9
     workload = prob.describe(args.operator, scaling if world > 1 else None)
     E0_site, gl0 = E0.item() / L, float(gl.reshape(-1)[0].item())
@@ -845,15 +855,23 @@ def main():
             "metric": "DRY RUN on CPU processes (gloo, torch test double of the slab kernels): control flow of the "
                       "multi-rank bench only, not a measurement" if dry else
                       "DominantSparseSymeig fwd+bwd ms & HBM GB/s (TFIM, fp64)" if args.reorth == "full" else
+                      "DominantSparseSymeig fwd+bwd GB/s, partial re-orthogonalisation option (TFIM, fp64; not the "
+                      "reference's schedule: it re-orthogonalises on every step)" if args.reorth == "partial" else
                       "DominantSparseSymeig fwd+bwd GB/s, basis-free two-pass Lanczos option (TFIM, fp64; not the "
                       "reference's full-reorthogonalisation algorithm)",
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload,
-                       "value_is": "HBM bytes the step's kernels move (traffic model: SURVEY 8d per-phase count with "
-                                   "the correction pass of %d Lanczos steps reading the bf16 shadow of the basis) / "
-                                   "step time, all ranks" % shadow_steps,
+                       "value_is": ("the OPTION's own bytes (every Lanczos step mat-vec 2 + three-term 4 + scale/store 2 "
+                                    "vectors; each of the %d re-orthogonalised steps the two passes over the basis, taken at "
+                                    "the mean step index; Ritz vector; backward as SURVEY 8d) / step time, all ranks"
+                                    % pr_run_steps) if args.reorth == "partial" else
+                                   ("the OPTION's own bytes (18 k + 11 m + 24 vectors) / step time, all ranks"
+                                    if args.reorth == "none" else
+                                    "HBM bytes the step's kernels move (traffic model: SURVEY 8d per-phase count with "
+                                    "the correction pass of %d Lanczos steps reading the bf16 shadow of the basis) / "
+                                    "step time, all ranks" % shadow_steps),
                        "cg_iterations": int(m), "cg_form": "persistent single launch (x, r, d in registers)" if cg_persistent
                        else "streaming (mat-vec, update, direction launches)",
                        "traffic_model_bytes_per_step": total_bytes,
@@ -865,6 +883,7 @@ def main():
                                                "moves fewer bytes -- not a roofline fraction",
                        "ms_at_hbm_peak_for_algorithmic_bytes": round(alg_bytes / (HBM_PEAK_GBS * world * 1e9) * 1e3, 3),
                        "bf16_shadow_of_basis": bool(prob.use_shadow), "lanczos_reorthogonalisation": args.reorth,
+                       **({"steps_reorthogonalised": pr_run_steps, "of": k - 1} if pr_run_steps is not None else {}),
                        "E0_per_site": E0_site, "E0_per_site_closed_form": analytic_E0_per_site(L, 1.0),
                        "dloss_dg": gl0,
                        "adjoint_vs_reference_at_eps1e-7": ADJOINT_DEV_EPS7,
