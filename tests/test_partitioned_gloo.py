@@ -50,6 +50,31 @@ def _case_driver(rank, world, overlap=False, tau=None, replicate="auto"):
     return (E0.item(), psi.numpy().copy(), grad.item(), solver.last_cg_iters, solver.op.overlap_fallbacks)
 
 
+def _case_partial_on_python_driver(rank, world):
+    """the partial re-orthogonalisation option needs the library driver: the Python step driver says so on every rank (same
+    condition everywhere, no collective has been issued yet) instead of silently re-orthogonalising on every step"""
+    from cpu_backend import CpuBackend
+    from dominantsparseeigenad_amd import engine
+    from dominantsparseeigenad_amd.partitioned import PartitionedTFIM
+    p = world.bit_length() - 1
+    nloc = 1 << (L - p)
+    off = rank * nloc
+    solver = PartitionedTFIM(L, torch.tensor([G], dtype=torch.float64), "cpu", backend=CpuBackend(nloc), eps=1e-12)
+    q0 = torch.from_numpy(normal_vector(nloc, 5000, offset=off))
+    x0 = torch.from_numpy(normal_vector(nloc, 5002, offset=off))
+    t = torch.from_numpy(normal_vector(nloc, 5003, offset=off))
+    engine.PARTIAL_REORTH = 0.0
+    try:
+        solver.forward_backward(20, q0, x0, t)
+        raised = False
+    except NotImplementedError as exc:
+        raised = "library driver" in str(exc)
+    finally:
+        engine.PARTIAL_REORTH = None
+    E0, _, _ = solver.forward_backward(20, q0, x0, t)          # ... and the operator is usable afterwards
+    return (raised, bool(torch.isfinite(E0)))
+
+
 def _case_api_tfim(rank, world, tag):
     """E0, dE0, d2E0, loss gradient, chi_F through the reference API on a row-partitioned operator"""
     from cpu_backend import CpuBackend
@@ -242,6 +267,11 @@ def test_bench_multi_rank_control_flow_dry_run(world, launcher, explicit):
         assert wk["distributed_self_check"].startswith("overlapped exchange verified")
         anchor = cfg["one_gpu_anchor"]
         assert anchor["ms_per_step"] > 0 and "profiles/" in anchor["source"] and "speedup_vs_one_gpu" in anchor
+
+
+def test_partial_reorthogonalisation_needs_the_library_driver():
+    ret = _run(2, "_case_partial_on_python_driver")
+    assert all(r == (True, True) for r in ret), ret
 
 
 @pytest.mark.parametrize("world", [2, 4])
