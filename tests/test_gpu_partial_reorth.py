@@ -207,6 +207,31 @@ def test_partial_reorthogonalisation_says_where_it_does_not_apply():
     assert torch.isfinite(lo)
 
 
+@pytest.mark.parametrize("n,k", [(1, 1), (2, 1), (2, 2), (3, 3), (5, 2), (64, 64), (65, 70), (129, 129), (200, 230)])
+def test_partial_reorthogonalisation_edge_sizes_and_breakdown(n, k):
+    """degenerate sizes (k = 1: no step at all; k >= n: the Krylov space runs out and the device-side breakdown record
+    stops the run -- Lanczos.py:69-70 would divide by beta ~ 0) give what the full schedule gives"""
+    import warnings
+    op, _ = _stencil(n)
+    q0 = unit(n, 51).to(dev())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        lo_f, v_f = symeigLanczos(op, k, dev(), extreme="min", sparse=True, dim=n, q0=q0)
+        brk_f = engine.last_break
+        lo_p, v_p = symeigLanczos(op, k, dev(), extreme="min", sparse=True, dim=n, q0=q0, reorth="partial")
+        brk_p = engine.last_break
+    tn = 2.0 / (2.0 / max(n, 2)) ** 2 + 1.0
+    assert torch.isfinite(lo_p) and torch.isfinite(v_p).all()
+    assert abs(lo_f.item() - lo_p.item()) < 1e-11 * tn
+    if k > n:
+        assert brk_f > 0 and brk_p > 0 and abs(brk_f - brk_p) <= 1        # both stop where the Krylov space ends
+    sgn = 1.0 if float(v_f @ v_p) >= 0 else -1.0
+    res_f, res_p = float((op(v_f) - lo_f * v_f).norm()), float((op(v_p) - lo_p * v_p).norm())
+    assert res_p < 4.0 * res_f + 1e-10 * tn
+    if res_f < 1e-10 * tn:
+        assert float((v_f - sgn * v_p).abs().max()) < 1e-9
+
+
 @pytest.mark.slow
 def test_partial_reorthogonalisation_at_the_headline_size():
     """TFIM L = 20, k = 200: same E0 / eigenvector as the reference's schedule, a fraction of its basis traffic"""
