@@ -286,7 +286,7 @@ __device__ __forceinline__ double axpy_tile(const double* __restrict__ Q, int64_
   return acc;
 }
 
-template <int RPL, int MODE>
+template <int RPL, int MODE, bool SEL = false>
 __global__ __launch_bounds__(256) void k_axpy_norm(const double* __restrict__ Q, int64_t ldq, int i,
                                                    int64_t n, const double* __restrict__ c,
                                                    double* __restrict__ r, double* __restrict__ P,
@@ -296,7 +296,9 @@ __global__ __launch_bounds__(256) void k_axpy_norm(const double* __restrict__ Q,
   const int64_t widx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (widx >= nw) return;
   if (broken(brk)) return;
-  if (sel != nullptr && sel[0] == 0.0) {
+  // (SEL is a template parameter: the check, compiled into the default instantiation, cost the fp64 pass 5 % -- 231 -> 244 us
+  // at n = 2^20, i = 199 -- through nothing but a different register allocation)
+  if (SEL && sel[0] == 0.0) {
     // partial re-orthogonalisation: no correction on this step; ||r||^2 is the dots pass's own c[i], handed on in the
     // partial-sum layout the consumer expects (first partial = the value, the others 0)
     if (MODE == 0 && lane == 0) P[widx] = (widx == 0) ? c[i] : 0.0;
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(W * 64) void k_rdots_split(const double* __restrict
 }
 
 // MODE 0: r -= sum_j c_j Q_j, partial ||r||^2 ; MODE 1: out = sum_j c_j Q_j (Ritz vector)
-template <int W, int MODE>
+template <int W, int MODE, bool SEL = false>
 __global__ __launch_bounds__(W * 64) void k_axpy_norm_split(const double* __restrict__ Q, int64_t ldq, int i,
                                                             int64_t n, const double* __restrict__ c,
                                                             double* __restrict__ r, double* __restrict__ P,
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(W * 64) void k_axpy_norm_split(const double* __rest
                                                             const double* __restrict__ sel) {
   __shared__ double2 part[W][64];
   if (broken(brk)) return;
-  if (sel != nullptr && sel[0] == 0.0) {        // partial re-orthogonalisation: see k_axpy_norm
+  if (SEL && sel[0] == 0.0) {                   // partial re-orthogonalisation: see k_axpy_norm
     if (MODE == 0 && threadIdx.x == 0) P[blockIdx.x] = (blockIdx.x == 0) ? c[i] : 0.0;
     return;
   }
@@ -2372,21 +2374,42 @@ void launch_axpy_norm(const TileGeom& g, const double* Q, int64_t ldq, int64_t n
                       const double* sel) {
   if (g.split_w) {
     const unsigned tiles = (unsigned)g.ntiles;
-    switch (g.split_w) {
-      case 4: KLAUNCH(ev, (k_axpy_norm_split<4, 0>), tiles, 256, st, Q, ldq, i, n, c, r, P, brk, sel); break;
-      case 8: KLAUNCH(ev, (k_axpy_norm_split<8, 0>), tiles, 512, st, Q, ldq, i, n, c, r, P, brk, sel); break;
-      default: KLAUNCH(ev, (k_axpy_norm_split<16, 0>), tiles, 1024, st, Q, ldq, i, n, c, r, P, brk, sel); break;
+#define AXS(Wv, SELv) KLAUNCH(ev, (k_axpy_norm_split<Wv, 0, SELv>), tiles, Wv * 64, st, Q, ldq, i, n, c, r, P, brk, sel)
+    if (sel) {
+      switch (g.split_w) {
+        case 4: AXS(4, true); break;
+        case 8: AXS(8, true); break;
+        default: AXS(16, true); break;
+      }
+    } else {
+      switch (g.split_w) {
+        case 4: AXS(4, false); break;
+        case 8: AXS(8, false); break;
+        default: AXS(16, false); break;
+      }
     }
+#undef AXS
     if (nrm2_out) launch_finalize1(P, g.nw, nrm2_out, st);
     return;
   }
   const int grid = (g.nw + 3) / 4;
-  switch (g.rpl) {
-    case 2: KLAUNCH(ev, (k_axpy_norm<2, 0>), grid, 256, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles, brk, sel); break;
-    case 4: KLAUNCH(ev, (k_axpy_norm<4, 0>), grid, 256, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles, brk, sel); break;
-    case 8: KLAUNCH(ev, (k_axpy_norm<8, 0>), grid, 256, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles, brk, sel); break;
-    default: KLAUNCH(ev, (k_axpy_norm<16, 0>), grid, 256, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles, brk, sel); break;
+#define AXN(Rv, SELv) KLAUNCH(ev, (k_axpy_norm<Rv, 0, SELv>), grid, 256, st, Q, ldq, i, n, c, r, P, g.nw, g.ntiles, brk, sel)
+  if (sel) {
+    switch (g.rpl) {
+      case 2: AXN(2, true); break;
+      case 4: AXN(4, true); break;
+      case 8: AXN(8, true); break;
+      default: AXN(16, true); break;
+    }
+  } else {
+    switch (g.rpl) {
+      case 2: AXN(2, false); break;
+      case 4: AXN(4, false); break;
+      case 8: AXN(8, false); break;
+      default: AXN(16, false); break;
+    }
   }
+#undef AXN
   if (nrm2_out) launch_finalize1(P, g.nw, nrm2_out, st);  // null: the consumer sums the g.nw partials itself
 }
 
