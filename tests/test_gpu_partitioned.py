@@ -215,6 +215,19 @@ def _case_api_stencil(rank, world, backend, dev):
     return dict(E=E.item(), psi=psi.detach().cpu().numpy().copy(), loss=loss.item(), grad=gp.cpu().numpy().copy())
 
 
+def _case_api_stencil_partial(rank, world, backend, dev, partial):
+    """_case_api_stencil with the partial re-orthogonalisation option switched through the module-level default"""
+    from dominantsparseeigenad_amd import Lanczos as LZ
+    LZ.REORTH_DEFAULT = "partial" if partial else "full"
+    try:
+        out = _case_api_stencil(rank, world, backend, dev)
+    finally:
+        LZ.REORTH_DEFAULT = "full"
+    from dominantsparseeigenad_amd import engine
+    out["steps"] = engine.last_reorth_steps
+    return out
+
+
 def _worker(rank, world, port, backend, case, args, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dev = torch.device("cuda:0")
@@ -365,6 +378,27 @@ def test_library_driver_partial_reorthogonalisation(world, backend):
     assert np.max(np.abs(psi_f - sgn * psi_p)) < 1e-10
     assert abs(part[0][2] - full[0][2]) < 1e-9 * abs(full[0][2])
     assert 1 <= part[0][3] < (K - 1) // 2
+
+
+@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (3, "gloo")])
+def test_library_driver_partial_reorthogonalisation_on_the_stencil(world, backend):
+    """the same option behind the reference API on the row-partitioned 3-point stencil (halo exchange, uneven slabs at 3
+    ranks, k = N: the Krylov space is exhausted and every Ritz value converges -- the hardest schedule for the estimates)"""
+    full = _run(world, backend, "_case_api_stencil_partial", False)
+    part = _run(world, backend, "_case_api_stencil_partial", True)
+    psi_f = np.concatenate([full[r]["psi"] for r in range(world)])
+    psi_p = np.concatenate([part[r]["psi"] for r in range(world)])
+    g_f = np.concatenate([full[r]["grad"] for r in range(world)])
+    g_p = np.concatenate([part[r]["grad"] for r in range(world)])
+    sgn = 1.0 if float(psi_f @ psi_p) > 0 else -1.0
+    print("world %d: %s steps re-orthogonalised, |dE| %.1e, max|dpsi| %.1e, max|dgrad| %.1e (scale %.1e)"
+          % (world, part[0]["steps"], abs(full[0]["E"] - part[0]["E"]), np.max(np.abs(psi_f - sgn * psi_p)),
+             np.max(np.abs(g_f - g_p)), np.max(np.abs(g_f))))
+    assert part[0]["steps"] is not None and full[0]["steps"] is None
+    assert abs(full[0]["E"] - part[0]["E"]) < 1e-9 * max(abs(full[0]["E"]), 1.0)
+    assert np.max(np.abs(psi_f - sgn * psi_p)) < 1e-8
+    assert abs(full[0]["loss"] - part[0]["loss"]) < 1e-8
+    assert np.max(np.abs(g_f - g_p)) < 1e-6 * np.max(np.abs(g_f))
 
 
 def test_library_owned_rccl_communicators_world1():
