@@ -62,7 +62,12 @@ def main():
     ap.add_argument("--device", default="cuda" if torch.cuda.is_available() else "cpu")
     ap.add_argument("--dense", action="store_true", help="also run the dense variants (N <= 12)")
     ap.add_argument("--plot", action="store_true")
+    ap.add_argument("--reorth", choices=["full", "partial", "twice", "none"], default="full",
+                    help="Lanczos re-orthogonalisation of the sparse primitive on the GPU: 'full' = the reference's schedule "
+                         "(Lanczos.py:66); the others are options the reference lacks (DESIGN.md section 8)")
     args = ap.parse_args()
+    import DominantSparseEigenAD.Lanczos as _LZ
+    _LZ.REORTH_DEFAULT = args.reorth
     model = TFIM(args.N, torch.device(args.device))
     gs = np.linspace(0.5, 1.5, num=args.points)
     rows = []
