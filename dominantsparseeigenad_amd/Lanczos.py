@@ -78,6 +78,9 @@ def _lanczos_core(A, k, device, sparse, dim, q0, arena=False):
             try:
                 Q, ldq, alphas, betas = engine.lanczos(A, k, n, device, q0, native=native, arena=arena)
             except engine.PartialNeedsPhases:
+                if not sparse and dtype == torch.float32:      # (the phase calls are fp64: promote the matrix once)
+                    A64 = A.to(torch.float64)
+                    amap = lambda v: torch.matmul(A64, v)      # noqa: E731
                 Q, ldq, alphas, betas = engine.lanczos(A, k, n, device, q0, callable_A=amap, arena=arena)
         else:
             Q, ldq, alphas, betas = engine.lanczos(A, k, n, device, q0, callable_A=amap, arena=arena)

@@ -133,7 +133,7 @@ def test_partial_reorthogonalisation_through_the_primitive_and_thresholds():
     assert counts[1e-15] >= k - 2 and counts[1e300] == 0 and counts[1e-15] >= counts[0.0] >= counts[1.5e-8] >= counts[1e-4] >= 1
 
 
-@pytest.mark.parametrize("form", ["callable", "native-csr", "dense-primitive"])
+@pytest.mark.parametrize("form", ["callable", "native-csr", "dense-primitive", "dense-primitive-fp32"])
 def test_partial_reorthogonalisation_through_the_phase_calls(form):
     """operands without a fused Lanczos tail -- a user's Python mat-vec (the reference's calling convention), plain CSR, the
     dense primitive's tensor -- take the option through dsea_lanczos_partial_step: one phase call per step around the
@@ -150,8 +150,12 @@ def test_partial_reorthogonalisation_through_the_phase_calls(form):
         op, kw = (lambda v: A @ v), dict(sparse=True, dim=n)
     elif form == "native-csr":
         op, kw = CSROperator.from_dense(A.cpu(), dev(), layout="csr"), dict(sparse=True, dim=n)
+    elif form == "dense-primitive-fp32":     # Lanczos.py:47: the dense path follows A.dtype (fp64 loops on promoted operands)
+        A = A.to(torch.float32)
+        op, kw = A, dict()
     else:
         op, kw = A, dict()
+    fp32 = form.endswith("fp32")
     lo_f, v_f = symeigLanczos(op, k, dev(), extreme="min", q0=q0, **kw)
     lo_p, v_p = symeigLanczos(op, k, dev(), extreme="min", q0=q0, reorth="partial", **kw)
     steps = engine.last_reorth_steps
@@ -171,6 +175,11 @@ def test_partial_reorthogonalisation_through_the_phase_calls(form):
     print("%s: %d of %d steps re-orthogonalised, ||Q^T Q - I||_max %.1e (never re-orthogonalised: %.1e), |dE0| %.1e, max|dpsi| %.1e"
           % (form, steps, k - 1, orth, orth_none, abs(lo_f.item() - lo_p.item()), float((v_f - sgn * v_p).abs().max())))
     assert 1 <= steps < k - 1
+    if fp32:                                 # outputs are rounded to the tensor's dtype
+        assert lo_p.dtype == torch.float32 and v_p.dtype == torch.float32
+        assert abs(lo_f.item() - lo_p.item()) < 1e-5 and abs(lo_p.item() + 50.0) < 1e-3
+        assert float((v_f - sgn * v_p).abs().max()) < 1e-5 and orth < 1e-5
+        return
     assert abs(lo_f.item() - lo_p.item()) < 1e-12 * 50.0 and abs(lo_p.item() + 50.0) < 1e-10
     assert float((v_f - sgn * v_p).abs().max()) < 1e-10
     assert orth < 10 * DELTA
