@@ -258,3 +258,47 @@ def test_partial_reorthogonalisation_at_the_headline_size():
     assert float((v_f - sgn * v_p).abs().max()) < 1e-10
     assert steps < 60
     assert abs(lo_p.item() / L - (-1.2745494843182374)) < 1e-10       # closed form
+
+
+@pytest.mark.parametrize("tag", ["L16_k200_g1.0", "L20_k200_g1.0"])
+def test_partial_reorthogonalisation_against_the_reference_outputs(tag):
+    """the option held to what the REFERENCE ITSELF returned for the same injected vectors at full size (tests/golden,
+    generated by importing the reference): E0, the head and the sum of psi, the loss and both gradients at the tolerances of
+    tests/test_gpu_parity.py::test_headline_sizes_against_reference_scalars"""
+    import os
+    from helpers import PatchRandn
+    gd = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tfim_" + tag + ".npz"))
+    L, k, g = int(gd["L"]), int(gd["k"]), float(gd["g"])
+    n = 1 << L
+    op = TFIMOperator(L, dev())
+    op.g = torch.tensor([g], dtype=F64, device=dev(), requires_grad=True)
+    symeig.setDominantSparseSymeig(op.H, op.Hadjoint_to_gadjoint)
+    f = symeig.DominantSparseSymeig.apply
+    tvec = unit(n, int(gd["seed_t"])).to(dev())
+    LZ.REORTH_DEFAULT = "partial"
+    try:
+        with PatchRandn(int(gd["seed_draw_E"])):
+            E0, psi = f(op.g, k, n, dev())
+            steps = engine.last_reorth_steps
+            sgn = 1.0 if float(psi.detach()[:64].cpu() @ torch.from_numpy(gd["psi_head"])) > 0 else -1.0
+            loss = E0 + psi.matmul(tvec) * sgn
+            (gl,) = torch.autograd.grad(loss, op.g)
+        with PatchRandn(int(gd["seed_draw_E"])):
+            E0b, _ = f(op.g, k, n, dev())
+            (dE0,) = torch.autograd.grad(E0b, op.g)
+    finally:
+        LZ.REORTH_DEFAULT = "full"
+    head = psi.detach()[:64].cpu().numpy() * sgn
+    print("%s: %d of %d steps re-orthogonalised; vs the reference: E0 %.1e  psi head %.1e  loss %.1e  dloss/dg %.1e  dE0/dg %.1e (relative)"
+          % (tag, steps, k - 1, abs(E0.item() - float(gd["E0"])) / abs(float(gd["E0"])),
+             np.max(np.abs(head - gd["psi_head"])) / np.max(np.abs(gd["psi_head"])),
+             abs(loss.item() - float(gd["loss"])) / abs(float(gd["loss"])),
+             abs(gl.item() - float(gd["dloss"][0])) / abs(float(gd["dloss"][0])),
+             abs(dE0.item() - float(gd["dE0"][0])) / abs(float(gd["dE0"][0]))))
+    assert steps is not None and steps < (k - 1) // 2
+    assert abs(E0.item() - float(gd["E0"])) < 1e-10 * abs(float(gd["E0"]))
+    assert np.max(np.abs(head - gd["psi_head"])) < 1e-9 * np.max(np.abs(gd["psi_head"]))
+    assert abs(float(psi.detach().sum()) * sgn - float(gd["psi_sum"])) < 1e-9 * abs(float(gd["psi_sum"]))
+    assert abs(loss.item() - float(gd["loss"])) < 1e-10 * abs(float(gd["loss"]))
+    assert abs(gl.item() - float(gd["dloss"][0])) < 2e-8 * abs(float(gd["dloss"][0]))      # CG eps = 1e-7 (CG.py:25)
+    assert abs(dE0.item() - float(gd["dE0"][0])) < 2e-8 * abs(float(gd["dE0"][0]))
