@@ -211,10 +211,8 @@ __global__ __launch_bounds__(256) void k_rdots(const double* __restrict__ Q, int
     // (read by the tail kernel of this step -- a later launch -- only)
     if (brk && widx == 0 && lane == 0) brk[1] = fmax(brk[1], fmax(fabs(a), fabs(b)));
     // partial re-orthogonalisation (dsea_ws_set_partial_reorth): sel[0] == 0 = this step is not re-orthogonalised -- the
-    // three-term update (and ||r||^2) only, all coefficients exactly 0
+    // three-term update and ||r||^2 (row i of P) only; the coefficient rows of P are then NOT written
     const int ii = (sel != nullptr && sel[0] == 0.0) ? 0 : i;
-    if (ii != i)
-      for (int idx = lane; idx < i; idx += 64) sP[idx] = 0.0;
     bool first = true;
     for (int64_t tile = widx; tile < ntiles; tile += nw) {
       const int64_t base = tile * TILE;
@@ -233,7 +231,8 @@ __global__ __launch_bounds__(256) void k_rdots(const double* __restrict__ Q, int
   // stored: a quarter of the scattered 8-byte stores at the end of the kernel and a quarter of the values the
   // second stage (k_finalize_multi) has to sum.
   __syncthreads();
-  for (int idx = threadIdx.x; idx < cnt; idx += blockDim.x) {
+  const int row0 = (sel != nullptr && sel[0] == 0.0) ? i : 0;      // (a skipped step flushes its ||r||^2 row only)
+  for (int idx = row0 + threadIdx.x; idx < cnt; idx += blockDim.x) {
     double t = rdots_lds[idx];
     for (int w = 1; w < wpb; ++w) t += rdots_lds[w * (i + 1) + idx];
     P[(int64_t)idx * pstride + blockIdx.x] = t;
@@ -380,8 +379,6 @@ __global__ __launch_bounds__(W * 64) void k_rdots_split(const double* __restrict
     if (lane == 0) split_lds[i] = acc;
   }
   const int ii = (sel != nullptr && sel[0] == 0.0) ? 0 : i;     // partial re-orthogonalisation: see k_rdots
-  if (ii != i)
-    for (int idx = threadIdx.x; idx < i; idx += W * 64) split_lds[idx] = 0.0;
   const int nchunks = (ii + 3) / 4;
   for (int cc = wv; cc < nchunks; cc += W) {
     const int j = 4 * cc;
@@ -410,7 +407,7 @@ __global__ __launch_bounds__(W * 64) void k_rdots_split(const double* __restrict
   }
   __syncthreads();
   const int cnt = i + (want_rr ? 1 : 0);
-  for (int idx = threadIdx.x; idx < cnt; idx += W * 64) P[(int64_t)idx * pstride + tile] = split_lds[idx];
+  for (int idx = (ii != i ? i : 0) + threadIdx.x; idx < cnt; idx += W * 64) P[(int64_t)idx * pstride + tile] = split_lds[idx];
 }
 
 // MODE 0: r -= sum_j c_j Q_j, partial ||r||^2 ; MODE 1: out = sum_j c_j Q_j (Ritz vector)
