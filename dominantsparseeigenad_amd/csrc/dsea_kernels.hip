@@ -163,7 +163,8 @@ __device__ __forceinline__ void rdots_tile(const double* __restrict__ Q, int64_t
   for (int t = 0; t < NP; ++t) st2<GUARD>(r, base + t * 128 + lane * 2, n, rv[t]);
 }
 
-template <int RPL>
+// SEL: the partial re-orthogonalisation's gate compiled in (sel != null); the default instantiation carries none of it
+template <int RPL, bool SEL = false>
 __global__ __launch_bounds__(256) void k_rdots(const double* __restrict__ Q, int64_t ldq, int i,
                                                int64_t n, const double* __restrict__ u,
                                                const double* __restrict__ alpha,
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void k_rdots(const double* __restrict__ Q, int
                                                int sel_exit) {
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;                                                     // 4, 2 or 1 waves per block
-  if (sel_exit && sel[0] == 0.0) return;      // partial re-orthogonalisation: nothing to do on this step
+  if (SEL && sel_exit && sel[0] == 0.0) return;      // partial re-orthogonalisation: nothing to do on this step
   const int64_t widx = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6);
   constexpr int64_t TILE = 64 * RPL;
   extern __shared__ double rdots_lds[];                                                // [wpb waves][i + 1]
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) void k_rdots(const double* __restrict__ Q, int
     if (brk && widx == 0 && lane == 0) brk[1] = fmax(brk[1], fmax(fabs(a), fabs(b)));
     // partial re-orthogonalisation (dsea_ws_set_partial_reorth): sel[0] == 0 = this step is not re-orthogonalised -- the
     // three-term update and ||r||^2 (row i of P) only; the coefficient rows of P are then NOT written
-    const int ii = (sel != nullptr && sel[0] == 0.0) ? 0 : i;
+    const int ii = (SEL && sel[0] == 0.0) ? 0 : i;
     bool first = true;
     for (int64_t tile = widx; tile < ntiles; tile += nw) {
       const int64_t base = tile * TILE;
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(256) void k_rdots(const double* __restrict__ Q, int
   // stored: a quarter of the scattered 8-byte stores at the end of the kernel and a quarter of the values the
   // second stage (k_finalize_multi) has to sum.
   __syncthreads();
-  const int row0 = (sel != nullptr && sel[0] == 0.0) ? i : 0;      // (a skipped step flushes its ||r||^2 row only)
+  const int row0 = (SEL && sel[0] == 0.0) ? i : 0;      // (a skipped step flushes its ||r||^2 row only)
   for (int idx = row0 + threadIdx.x; idx < cnt; idx += blockDim.x) {
     double t = rdots_lds[idx];
     for (int w = 1; w < wpb; ++w) t += rdots_lds[w * (i + 1) + idx];
@@ -2351,8 +2352,21 @@ void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, in
   const int wpb = (i + 1) <= 2048 ? 4 : ((i + 1) <= 4096 ? 2 : 1);
   const int grid = (g.nw + wpb - 1) / wpb;
   const size_t lds = (size_t)wpb * (i + 1) * sizeof(double);
-  LAUNCH_RPL(ev, k_rdots, g.rpl, grid, 64 * wpb, lds, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, g.nw,
+  if (sel) {
+    switch (g.rpl) {
+      case 2: KLAUNCH_LDS(ev, (k_rdots<2, true>), grid, 64 * wpb, lds, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, g.nw,
+             g.ntiles, aP, aCount, a_store, want_rr ? 1 : 0, brk, sel, sel_exit ? 1 : 0); break;
+      case 4: KLAUNCH_LDS(ev, (k_rdots<4, true>), grid, 64 * wpb, lds, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, g.nw,
+             g.ntiles, aP, aCount, a_store, want_rr ? 1 : 0, brk, sel, sel_exit ? 1 : 0); break;
+      case 8: KLAUNCH_LDS(ev, (k_rdots<8, true>), grid, 64 * wpb, lds, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, g.nw,
+             g.ntiles, aP, aCount, a_store, want_rr ? 1 : 0, brk, sel, sel_exit ? 1 : 0); break;
+      default: KLAUNCH_LDS(ev, (k_rdots<16, true>), grid, 64 * wpb, lds, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, g.nw,
+             g.ntiles, aP, aCount, a_store, want_rr ? 1 : 0, brk, sel, sel_exit ? 1 : 0); break;
+    }
+  } else {
+    LAUNCH_RPL(ev, k_rdots, g.rpl, grid, 64 * wpb, lds, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, g.nw,
              g.ntiles, aP, aCount, a_store, want_rr ? 1 : 0, brk, sel, sel_exit ? 1 : 0);
+  }
   // want_rr: one more row of partials (||r||^2) -> c_out[i]
   if (c_out)   // (null: the caller's next kernel sums the partial rows it needs itself -- rdots_partial_count of them)
     hipLaunchKernelGGL(k_finalize_multi, dim3(want_rr ? i + 1 : i), dim3(256), 0, st, (const double*)P,
