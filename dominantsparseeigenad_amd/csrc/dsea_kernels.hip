@@ -35,13 +35,14 @@ __global__ __launch_bounds__(256) void k_finalize1(const double* __restrict__ pa
 }
 
 // c[j] = sum_{w<nw} P[j*pstride + w]   (one 256-thread block per j, 4 independent loads in flight per lane)
+template <bool GATE>
 __global__ __launch_bounds__(256) void k_finalize_multi(const double* __restrict__ P, int64_t pstride,
                                                         int nw, double* __restrict__ c,
                                                         const double* __restrict__ brk,
                                                         const double* __restrict__ gate) {
   __shared__ double sm4[4];
   if (broken(brk)) return;
-  if (gate != nullptr && gate[0] == 0.0) return;   // partial re-orthogonalisation: the dots pass did not run on this step
+  if (GATE && gate[0] == 0.0) return;   // partial re-orthogonalisation: the dots pass did not run on this step
   const int j = blockIdx.x;
   const double* __restrict__ row = P + (int64_t)j * pstride;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -2342,9 +2343,12 @@ void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, in
       }
     }
 #undef RDS
-    if (c_out)
-      hipLaunchKernelGGL(k_finalize_multi, dim3(want_rr ? i + 1 : i), dim3(256), 0, st, (const double*)P,
-                         (int64_t)g.pstride, (int)tiles, c_out, (const double*)brk, sel_exit ? sel : (const double*)nullptr);
+    if (c_out && sel_exit)
+      hipLaunchKernelGGL(k_finalize_multi<true>, dim3(want_rr ? i + 1 : i), dim3(256), 0, st, (const double*)P,
+                         (int64_t)g.pstride, (int)tiles, c_out, (const double*)brk, sel);
+    else if (c_out)
+      hipLaunchKernelGGL(k_finalize_multi<false>, dim3(want_rr ? i + 1 : i), dim3(256), 0, st, (const double*)P,
+                         (int64_t)g.pstride, (int)tiles, c_out, (const double*)brk, (const double*)nullptr);
     return;
   }
   // one row of i + 1 partial sums per wave in LDS (see rdots_tile); 64 KiB of dynamic LDS hold 4 waves up to
@@ -2368,9 +2372,13 @@ void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, in
              g.ntiles, aP, aCount, a_store, want_rr ? 1 : 0, brk, sel, sel_exit ? 1 : 0);
   }
   // want_rr: one more row of partials (||r||^2) -> c_out[i]
-  if (c_out)   // (null: the caller's next kernel sums the partial rows it needs itself -- rdots_partial_count of them)
-    hipLaunchKernelGGL(k_finalize_multi, dim3(want_rr ? i + 1 : i), dim3(256), 0, st, (const double*)P,
-                       (int64_t)g.pstride, grid, c_out, (const double*)brk, sel_exit ? sel : (const double*)nullptr);
+  // (c_out null: the caller's next kernel sums the partial rows it needs itself -- rdots_partial_count of them)
+  if (c_out && sel_exit)
+    hipLaunchKernelGGL(k_finalize_multi<true>, dim3(want_rr ? i + 1 : i), dim3(256), 0, st, (const double*)P,
+                       (int64_t)g.pstride, grid, c_out, (const double*)brk, sel);
+  else if (c_out)
+    hipLaunchKernelGGL(k_finalize_multi<false>, dim3(want_rr ? i + 1 : i), dim3(256), 0, st, (const double*)P,
+                       (int64_t)g.pstride, grid, c_out, (const double*)brk, (const double*)nullptr);
 }
 
 // partials per basis vector the dots pass of step i leaves in P (row stride g.pstride)
