@@ -329,8 +329,8 @@ def launch_workers(n):
 # one-GPU anchors of the two multi-GPU curves as last measured on an MI355X by `bench.py --gpus 1` of this repository
 # (profiles/, with the commit of the run); the N = 1 line re-measures them live (config.one_gpu_anchors)
 STORED_ANCHORS = {
-    "strong_L28_k100_ms": 5113.31, "strong_source": "profiles/r03_bench.json config.one_gpu_anchors.strong_L28_k100 (commit dc42b68; other boxes of the round: 5086 ... 5252)",
-    "weak_2p25_rows_k200_ms": 1299.83, "weak_source": "profiles/r03_bench.json config.one_gpu_anchors.weak_2p25_rows_k200 (commit dc42b68; other boxes of the round: 1246 ... 1318)",
+    "strong_L28_k100_ms": 5128.10, "strong_source": "profiles/r03_bench.json config.one_gpu_anchors.strong_L28_k100 (commit 7c75263; other boxes of the round: 5086 ... 5317)",
+    "weak_2p25_rows_k200_ms": 1250.42, "weak_source": "profiles/r03_bench.json config.one_gpu_anchors.weak_2p25_rows_k200 (commit 7c75263; other boxes of the round: 1246 ... 1318)",
 }
 
 
