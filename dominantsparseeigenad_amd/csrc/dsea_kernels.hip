@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void k_axpy_norm(const double* __restrict__ Q,
 // (chunk c -> wave c mod W).  Dots: every c_j is still produced by exactly one wave (same partial layout).
 // Correction: the W partial sums of a tile are combined through LDS in wave order -- deterministic.
 // ------------------------------------------------------------------------------------------
-template <int W, int NT>
+template <int W, int NT, bool SEL = false>
 __global__ __launch_bounds__(W * 64) void k_rdots_split(const double* __restrict__ Q, int64_t ldq, int i,
                                                         int64_t n, const double* __restrict__ u,
                                                         const double* __restrict__ alpha,
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(W * 64) void k_rdots_split(const double* __restrict
                                                         double* __restrict__ a_store, int want_rr,
                                                         double* __restrict__ brk, const double* __restrict__ sel,
                                                         int sel_exit) {
-  if (sel_exit && sel[0] == 0.0) return;      // partial re-orthogonalisation: nothing to do on this step
+  if (SEL && sel_exit && sel[0] == 0.0) return;      // partial re-orthogonalisation: nothing to do on this step
   // NT = 128-row sub-tiles per block (NT = 2 beyond 640 tiles: twice the loads in flight per wave trip, half the partials
   // for the second stage).  Requesting a wave's first chunk ahead of the alpha partials was measured and is SLOWER
   // (config 3: 24.8 -> 28.3 us per launch), and forcing 64 VGPRs (two 1024-thread blocks per CU) gains nothing.
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(W * 64) void k_rdots_split(const double* __restrict
     const double acc = wave_sum(p);
     if (lane == 0) split_lds[i] = acc;
   }
-  const int ii = (sel != nullptr && sel[0] == 0.0) ? 0 : i;     // partial re-orthogonalisation: see k_rdots
+  const int ii = (SEL && sel[0] == 0.0) ? 0 : i;     // partial re-orthogonalisation: see k_rdots
   const int nchunks = (ii + 3) / 4;
   for (int cc = wv; cc < nchunks; cc += W) {
     const int j = 4 * cc;
@@ -2332,7 +2332,15 @@ void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, in
     const size_t slds = (size_t)(i + 1) * sizeof(double);     // the tile's partial sums (see k_rdots_split)
     const int nt = g.dots_nt;
     const unsigned tiles = (unsigned)((g.ntiles + nt - 1) / nt);
-#define RDS(Wv, NTv) KLAUNCH_LDS(ev, (k_rdots_split<Wv, NTv>), tiles, Wv * 64, slds, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, aP, aCount, a_store, wr, brk, sel, sel_exit ? 1 : 0)
+#define RDS(Wv, NTv)                                                                                                         \
+  do {                                                                                                                       \
+    if (sel)                                                                                                                 \
+      KLAUNCH_LDS(ev, (k_rdots_split<Wv, NTv, true>), tiles, Wv * 64, slds, st, Q, ldq, i, n, u, alpha, beta, r, P,          \
+                  (int64_t)g.pstride, aP, aCount, a_store, wr, brk, sel, sel_exit ? 1 : 0);                                  \
+    else                                                                                                                     \
+      KLAUNCH_LDS(ev, (k_rdots_split<Wv, NTv, false>), tiles, Wv * 64, slds, st, Q, ldq, i, n, u, alpha, beta, r, P,         \
+                  (int64_t)g.pstride, aP, aCount, a_store, wr, brk, sel, 0);                                                 \
+  } while (0)
     if (nt == 2) {
       RDS(16, 2);
     } else {
