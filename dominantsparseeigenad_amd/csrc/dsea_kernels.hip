@@ -41,8 +41,10 @@ __global__ __launch_bounds__(256) void k_finalize_multi(const double* __restrict
                                                         const double* __restrict__ brk,
                                                         const double* __restrict__ gate) {
   __shared__ double sm4[4];
+  // (the gate is requested together with the break record: one round trip before a gated launch returns, not two)
+  const double gate0 = GATE ? gate[0] : 1.0;
   if (broken(brk)) return;
-  if (GATE && gate[0] == 0.0) return;   // partial re-orthogonalisation: the dots pass did not run on this step
+  if (GATE && gate0 == 0.0) return;     // partial re-orthogonalisation: the dots pass did not run on this step
   const int j = blockIdx.x;
   const double* __restrict__ row = P + (int64_t)j * pstride;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -296,10 +298,11 @@ __global__ __launch_bounds__(256) void k_axpy_norm(const double* __restrict__ Q,
   const int lane = threadIdx.x & 63;
   const int64_t widx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (widx >= nw) return;
+  const double sel0 = SEL ? sel[0] : 1.0;      // (requested together with the break record)
   if (broken(brk)) return;
   // (SEL is a template parameter: the check, compiled into the default instantiation, cost the fp64 pass 5 % -- 231 -> 244 us
   // at n = 2^20, i = 199 -- through nothing but a different register allocation)
-  if (SEL && sel[0] == 0.0) {
+  if (SEL && sel0 == 0.0) {
     // partial re-orthogonalisation: no correction on this step; ||r||^2 is the dots pass's own c[i], handed on in the
     // partial-sum layout the consumer expects (first partial = the value, the others 0)
     if (MODE == 0 && lane == 0) P[widx] = (widx == 0) ? c[i] : 0.0;
@@ -420,8 +423,9 @@ __global__ __launch_bounds__(W * 64) void k_axpy_norm_split(const double* __rest
                                                             const double* __restrict__ brk,
                                                             const double* __restrict__ sel) {
   __shared__ double2 part[W][64];
+  const double sel0 = SEL ? sel[0] : 1.0;
   if (broken(brk)) return;
-  if (SEL && sel[0] == 0.0) {                   // partial re-orthogonalisation: see k_axpy_norm
+  if (SEL && sel0 == 0.0) {                     // partial re-orthogonalisation: see k_axpy_norm
     if (MODE == 0 && threadIdx.x == 0) P[blockIdx.x] = (blockIdx.x == 0) ? c[i] : 0.0;
     return;
   }
@@ -2261,15 +2265,18 @@ __global__ __launch_bounds__(256) void k_pro_update(const double* __restrict__ a
                                                     double eps1, double delta, const double* __restrict__ brk) {
   __shared__ double smax[256];
   __shared__ double sm5[5];
-  if (broken(brk)) return;
   // ||r_i||^2 before any correction: the dots kernel's per-block partials, summed here (no second-stage launch); the
-  // total is stored for the correction kernel, which hands it on as ||r||^2 on a step that is not re-orthogonalised
-  const double rr = sum_partials_block(rrP, rrCount, sm5);
-  if (threadIdx.x == 0) rr_store[0] = rr;
-  const double bcur = sqrt(rr);                            // = beta_{i-1} to rounding
+  // total is stored for the correction kernel, which hands it on as ||r||^2 on a step that is not re-orthogonalised.
+  // (Everything that does not depend on another load is requested before the break record is looked at: the kernel is a
+  // chain of dependent round trips, nothing else.)
   const double a = alphas[i - 1];
   const double bprev = (i >= 2) ? betas[i - 2] : 0.0;
-  const double anorm = fmax(state[1], fabs(a) + bcur + bprev);
+  const double anorm_prev = state[1];
+  const double rr = sum_partials_block(rrP, rrCount, sm5);
+  if (broken(brk)) return;
+  if (threadIdx.x == 0) rr_store[0] = rr;
+  const double bcur = sqrt(rr);                            // = beta_{i-1} to rounding
+  const double anorm = fmax(anorm_prev, fabs(a) + bcur + bprev);
   double* __restrict__ o1 = om + (size_t)((i - 1) & 1) * ld;   // omega_{i-1, .}
   double* __restrict__ o2 = om + (size_t)(i & 1) * ld;         // omega_{i-2, .}  -> omega_{i, .}
   double mx = 0.0;
