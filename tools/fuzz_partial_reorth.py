@@ -35,11 +35,11 @@ def planted(n):
 def make_case():
     kind = rng.choice(["tfim", "stencil", "sell", "csr-plain", "planted-dense", "planted-callable"])
     if kind == "tfim":
-        L = int(rng.randint(4, 15)); g = float(rng.choice([0.6, 0.9, 1.0, 1.3, 2.0]))
+        L = int(rng.randint(4, 18)); g = float(rng.choice([0.6, 0.9, 1.0, 1.3, 2.0]))     # (from L = 15 the bf16 shadow is in play)
         op = TFIMOperator(L, dev); op.g = torch.tensor([g], dtype=F64, device=dev)
         return kind + " L=%d g=%.1f" % (L, g), 1 << L, op, dict(sparse=True, dim=1 << L), L * (1.0 + g)
     if kind == "stencil":
-        n = int(rng.choice([64, 129, 300, 1000, int(rng.randint(65, 30000))]))
+        n = int(rng.choice([64, 129, 300, 1000, int(rng.randint(65, 30000)), int(rng.randint(32768, 140000))]))
         h = float(rng.choice([2.0 / n, 0.1, 1.0]))          # h = O(1): a well-conditioned operator whose Ritz values converge
         V = torch.from_numpy(rng.rand(n) * 3.0).to(dev)
         return kind + " n=%d h=%.3g" % (n, h), n, Stencil3Operator(n, h, V), dict(sparse=True, dim=n), 2.0 / h ** 2 + 3.0
