@@ -36,8 +36,9 @@ DENSE_SYMMETRIC_KERNEL = True
 REORTH_PASSES = 1
 # Partial re-orthogonalisation (``reorth="partial"`` of Lanczos.symeigLanczos / Lanczos.Lanczos; an option the reference
 # lacks): None = off (the reference's full re-orthogonalisation on every step), a float = the threshold on the estimated
-# loss of orthogonality that triggers a pair of full passes (0.0 = the default 1e-10; Simon's classical value is sqrt(eps)).  Device operators with a fused
-# tail (TFIM, SELL, stencil), row-partitioned operators on the library driver, and callables (one phase call per step).
+# loss of orthogonality that triggers a pair of full passes (0.0 = the default 1e-10; Simon's classical value is
+# sqrt(eps)).  Device operators with a fused tail (TFIM, SELL, stencil), row-partitioned operators on the library driver,
+# and callables / operands without a fused tail (one phase call per step).
 PARTIAL_REORTH = None
 last_reorth_steps = None       # steps of the last native run that were re-orthogonalised (partial mode), else None
 import os as _os
