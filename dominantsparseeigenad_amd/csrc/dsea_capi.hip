@@ -124,7 +124,7 @@ TileGeom Workspace::geom(int64_t n_rows) const {
 
 extern "C" {
 
-int dsea_version(void) { return 110; }
+int dsea_version(void) { return 120; }   // 120: partial re-orthogonalisation entry points, stream probe
 
 const char* dsea_error_string(int status) {
   switch (status) {
