@@ -62,6 +62,16 @@ def test_bench_line_carries_honest_extras():
     assert 0.0 < d["roofline"]["frac_of_measured_read_ceiling"] < 1.5
 
 
+def test_bench_line_of_the_partial_reorthogonalisation_option():
+    """--reorth partial: labelled as an option (not the reference's schedule), priced with its own bytes, steps in the line"""
+    d = _run(["--reorth", "partial", "--no-cpu-baseline", "--no-extras"])
+    assert "partial re-orthogonalisation option" in d["metric"] and "not the reference" in d["metric"]
+    c = d["config"]
+    assert c["lanczos_reorthogonalisation"] == "partial" and c["bf16_shadow_of_basis"] is False
+    assert 0 <= c["steps_reorthogonalised"] <= c["of"] and "OPTION's own bytes" in c["value_is"]
+    assert 0.0 < d["value"] <= 8000.0 and d["ms_per_step"] > 0
+
+
 def test_bench_line_partitioned_path():
     d = _run(["--force-partitioned", "--no-cpu-baseline"])
     assert REQUIRED <= set(d) and d["scaling"] == "weak"
