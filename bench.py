@@ -21,7 +21,7 @@ Workloads (what the K timed steps run, i.e. what `value` / `ms_per_step` are quo
     call and relays rank 0's JSON line; under torchrun (WORLD_SIZE set) it is a worker.
 
 value = HBM GB/s of the whole job: bytes the step's kernels move (traffic model below; at the headline size checked
-against rocprofv3 PMC counters, profiles/pmc_traffic.json) / step time.  It is bounded by N x 8 TB/s.  The figure of
+against rocprofv3 PMC counters, profiles/r<NN>_pmc_traffic.json) / step time.  It is bounded by N x 8 TB/s.  The figure of
 SURVEY.md 8d -- ALGORITHMIC bytes 8 n (k^2 + 12k + 11m + 17) of the reference's algorithm / step time (m = CG
 iterations actually run) -- is config.algorithmic_GBs; it may exceed the peak because the correction pass streams a
 bf16 storage shadow of the basis.  Prints ONE JSON line (rank 0) as the last line of stdout.
@@ -238,7 +238,7 @@ def live_pmc_traffic(timeout_s=240):
     MI355X_MICROARCH.md prescribes) over `bench.py --steps 1 --warmup 1` as CHILD processes.  Must be called before
     this process touches the GPU (a process that has initialised the GPU must not start other programs on this pool).
     Units: KiB -> x 1024; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads -> x 2.
-    Returns (dict in the format of profiles/pmc_traffic.json, None) or (None, reason)."""
+    Returns (dict in the format of profiles/r<NN>_pmc_traffic.json, None) or (None, reason)."""
     import collections
     import csv
     import glob
@@ -326,34 +326,135 @@ def launch_workers(n):
     raise SystemExit(proc.returncode if proc.returncode else (0 if final is not None else 1))
 
 
-# one-GPU anchors of the two multi-GPU curves as last measured on an MI355X by `bench.py --gpus 1` of this repository
-# (profiles/, with the commit of the run); the N = 1 line re-measures them live (config.one_gpu_anchors)
-STORED_ANCHORS = {
-    "strong_L28_k100_ms": 5128.10, "strong_source": "profiles/r03_bench.json config.one_gpu_anchors.strong_L28_k100 (commit 7c75263; other boxes of the round: 5086 ... 5317)",
-    "weak_2p25_rows_k200_ms": 1250.42, "weak_source": "profiles/r03_bench.json config.one_gpu_anchors.weak_2p25_rows_k200 (commit 7c75263; other boxes of the round: 1246 ... 1318)",
-}
+# ---------------------------------------------------------------------------------------------- one-GPU anchors
+# The multi-GPU lines quote speed-ups against ONE-GPU runs of the same workload ("anchors").  They are measured LIVE by
+# the default N = 1 invocation (config.one_gpu_anchors), which also leaves them in ANCHOR_CACHE so that the N = 2, 4, 8
+# lines of the same back-to-back sequence on the same node divide by what THAT node measured.  Resolution order of an
+# N > 1 line: --anchors-json PATH (an N = 1 line, or a driver record wrapping one under "parsed") > $DSEA_ANCHORS_JSON >
+# the cache of this node > the newest committed profiles/r<NN>_bench.json that carries anchors.  No hand-copied constants.
+ANCHOR_CACHE = os.path.join(os.environ.get("TMPDIR", "/tmp"), "dsea_one_gpu_anchors.json")
+# the anchors and the arithmetic of their correction pass ("shadow": bf16 storage shadow of the basis):
+#   weak_2p25_rows_k200     2^25 rows, k = 200, shadow on   (the per-GPU load of BASELINE configs[4]; fits one GPU with it)
+#   strong_L28_k100         L = 28, k = 100, fp64 basis     (215 GB basis: the shadow does NOT fit beside it on one GPU)
+#   strong_L28_k80_shadow   L = 28, k = 80, shadow on       (172 + 43 GB: the largest round k whose shadow fits one GPU)
+ANCHOR_SPECS = (("weak_2p25_rows_k200", 25, 200, 3, "on"), ("strong_L28_k100", 28, 100, 2, "off"),
+                ("strong_L28_k80_shadow", 28, 80, 2, "on"))
+STRONG_K, STRONG_K_SHADOW_MATCHED = 100, 80
 
 
+def _commit():
+    try:
+        return open(os.path.join(ROOT, ".commit")).read().strip() or "unknown"
+    except OSError:
+        pass
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True,
+                              text=True).stdout.strip() or "unknown"
+    except OSError:
+        return "unknown"
+
+
+def _anchors_of(path):
+    """(anchors dict, description) from a JSON file holding an N = 1 bench line (possibly among other lines, possibly
+    wrapped by the driver under "parsed"), or from the node cache written by ``store_anchors``; (None, reason) otherwise"""
+    try:
+        text = open(path).read()
+    except OSError as exc:
+        return None, "%s: %s" % (path, exc)
+    cands = []
+    try:
+        cands.append(json.loads(text))
+    except ValueError:
+        for ln in text.splitlines():
+            if ln.startswith("{"):
+                try:
+                    cands.append(json.loads(ln))
+                except ValueError:
+                    pass
+    for d in reversed(cands):
+        if not isinstance(d, dict):
+            continue
+        d = d.get("parsed", d) if isinstance(d.get("parsed", None), dict) else d
+        anchors = d.get("one_gpu_anchors") or d.get("config", {}).get("one_gpu_anchors")
+        if isinstance(anchors, dict) and any(isinstance(v, dict) and v.get("ms_per_step") for v in anchors.values()):
+            commit = d.get("commit") or d.get("config", {}).get("commit")
+            return anchors, "%s%s" % (os.path.relpath(path, ROOT) if path.startswith(ROOT) else path,
+                                      " (commit %s)" % commit if commit else "")
+    return None, "%s: no one_gpu_anchors with a measured ms_per_step" % path
+
+
+def load_anchors(args):
+    """resolution order documented at ANCHOR_CACHE; returns (anchors or {}, source description)"""
+    import glob
+    tried = []
+    for path in (args.anchors_json, os.environ.get("DSEA_ANCHORS_JSON"), ANCHOR_CACHE):
+        if path and os.path.exists(path):
+            anchors, src = _anchors_of(path)
+            if anchors:
+                if path == ANCHOR_CACHE:
+                    src = "this node's N = 1 run of the same sequence (%s)" % src
+                return anchors, src
+            tried.append(src)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench.json")), reverse=True):
+        anchors, src = _anchors_of(path)
+        if anchors:
+            return anchors, "committed %s (another box: the N = 1 line of this sequence re-measures it)" % src
+        tried.append(src)
+    return {}, "no anchors found (%s)" % "; ".join(tried[-3:])
+
+
+def store_anchors(anchors):
+    try:
+        with open(ANCHOR_CACHE, "w") as f:
+            json.dump({"one_gpu_anchors": anchors, "commit": _commit(), "host": socket.gethostname(),
+                       "unix_time": time.time()}, f)
+    except OSError:
+        pass
+
+
+def anchor_ms(anchors, tag, shadow):
+    """ms_per_step of anchor ``tag`` IF it ran with the arithmetic asked for (``shadow`` True / False), else None"""
+    a = anchors.get(tag)
+    if not isinstance(a, dict) or not a.get("ms_per_step"):
+        return None
+    if bool(a.get("bf16_shadow_of_basis")) != bool(shadow):
+        return None
+    return float(a["ms_per_step"])
+
+
+# ---------------------------------------------------------------------------------------------- the workload
 class Problem:
-    """One TFIM workload behind the reference API: operator, pinned draws, step() = forward + backward."""
+    """One TFIM workload behind the reference API: operator, pinned draws, step() = forward + backward.
+    ``shadow``: "auto" (on where the bf16 shadow fits beside the basis), "on" (must fit), "off" (all-fp64 correction)."""
 
-    def __init__(self, args, L, k, world, rank, dev, dry, partitioned_path, reorth="full"):
+    def __init__(self, ctx, L, k, partitioned_path, reorth="full", shadow="auto", operator="matrix-free"):
         from dominantsparseeigenad_amd import engine
         import dominantsparseeigenad_amd.symeig as symeig
         from dominantsparseeigenad_amd.synthetic import normal_vector
-        self.engine, self.symeig = engine, symeig
+        self.engine, self.symeig, self.ctx = engine, symeig, ctx
+        world, rank, dev, dry = ctx.world, ctx.rank, ctx.dev, ctx.dry
         self.L, self.k, self.world, self.rank, self.dev, self.dry = L, k, world, rank, dev, dry
         self.partitioned = partitioned_path
         self.reorth = reorth
+        self.operator = operator
         self.notes = {}
-        p = int(np.log2(world))
+        p = int(np.log2(world)) if partitioned_path else 0
         self.p, self.Lloc = p, L - p
         self.nloc, self.n = 1 << (L - p), 1 << L
-        off = rank * self.nloc
+        off = rank * self.nloc if partitioned_path else 0
         # one GPU cannot hold the fp64 basis AND its bf16 shadow at L = 28, k = 100 (215 + 54 GB of 288 GB)
         free_b, total_b = (0, 1 << 62) if dry else torch.cuda.mem_get_info(dev)
         need_shadow = 10.0 * self.nloc * k + 16 * 8.0 * self.nloc
-        self.use_shadow = not (need_shadow > 0.92 * total_b or reorth in ("none", "partial"))
+        fits = need_shadow <= 0.92 * total_b / (ctx.ranks_per_device if not dry else 1)
+        if reorth in ("none", "partial") or shadow == "off":
+            self.use_shadow = False
+        elif shadow == "on":
+            if not fits:
+                raise RuntimeError("--shadow on: basis + bf16 shadow need %.0f GB of %.0f GB" % (need_shadow / 1e9, total_b / 1e9))
+            self.use_shadow = True
+        else:
+            self.use_shadow = fits
+        self.shadow_policy = shadow
 
         def slab(seed):
             return torch.from_numpy(normal_vector(self.nloc, seed, offset=off)).to(dev)
@@ -367,36 +468,50 @@ class Problem:
             self.op = TFIMOperator(L, dev)
             self.op.g = self.g
             self.A_operand = self.op.H
-            if args.operator != "matrix-free":
-                self.A_operand = self.op.to_csr(layout=args.operator)      # explicit matrix (values fixed at the current g)
+            if operator != "matrix-free":
+                self.A_operand = self.op.to_csr(layout=operator)      # explicit matrix (values fixed at the current g)
             self.dot = torch.matmul
         else:
-            from dominantsparseeigenad_amd import partitioned
-            backend = None
-            if dry:   # the torch test double of the slab kernels (test infrastructure; never on the product path)
-                sys.path.insert(0, os.path.join(ROOT, "tests"))
-                from cpu_backend import CpuBackend
-                backend = CpuBackend(self.nloc)
-            # The library-side driver (RCCL calls issued by libdsea) needs its communicators; if creating them fails on
-            # ANY rank the decision to use the Python driver instead is taken collectively (an all-reduced flag)
-            import torch.distributed as dist
-            failed = torch.zeros(1, dtype=torch.float64, device=dev)
-            try:
-                self.op = partitioned.PartitionedTFIMOperator(L, self.g, dev, backend=backend, overlap=True if dry else "auto")
-            except Exception as exc:  # noqa: BLE001
-                failed[0] = 1.0
-                self.notes["partitioned_driver_fallback_reason"] = "%s: %s" % (type(exc).__name__, str(exc)[:160])
-            dist.all_reduce(failed)
-            if failed.item() > 0:
-                os.environ["DSEA_DRIVER"] = "python"
-                self.op = partitioned.PartitionedTFIMOperator(L, self.g, dev, backend=backend, overlap=True if dry else "auto")
-                self.notes["partitioned_driver_fallback"] = "library driver unavailable on %d rank(s): Python driver used" \
-                                                            % int(failed.item())
+            self.op = self._partitioned_operator()
             self.op.force_driver = True
             self.A_operand = self.op.H
             self.dot = self.op.dot
             self.tvec = tvec / self.op.dot(tvec, tvec).sqrt()
         self.last = {}
+
+    def _partitioned_operator(self):
+        """The row-partitioned operator on this stack.  The library-side driver (collectives issued by libdsea) needs its
+        communicators; if creating them fails on ANY rank the decision to use the Python driver instead is taken
+        collectively (an all-reduced flag)."""
+        import torch.distributed as dist
+        from dominantsparseeigenad_amd import partitioned
+        ctx = self.ctx
+        backend = comm = None
+        if self.dry:   # the torch test double of the slab kernels (test infrastructure; never on the product path)
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from cpu_backend import CpuBackend
+            backend = CpuBackend(self.nloc)
+        if ctx.staged:   # ranks sharing one GPU: gloo staged through the host (RCCL refuses two ranks on a device)
+            comm = partitioned.HostStagedComm()
+        overlap = True if (self.dry or ctx.staged) else "auto"
+
+        def make():
+            return partitioned.PartitionedTFIMOperator(self.L, self.g, self.dev, backend=backend, comm=comm, overlap=overlap)
+
+        failed = torch.zeros(1, dtype=torch.float64, device=ctx.ctrl_dev)
+        op = None
+        try:
+            op = make()
+        except Exception as exc:  # noqa: BLE001
+            failed[0] = 1.0
+            self.notes["partitioned_driver_fallback_reason"] = "%s: %s" % (type(exc).__name__, str(exc)[:160])
+        dist.all_reduce(failed)
+        if failed.item() > 0:
+            os.environ["DSEA_DRIVER"] = "python"
+            op = make()
+            self.notes["partitioned_driver_fallback"] = "library driver unavailable on %d rank(s): Python driver used" \
+                                                        % int(failed.item())
+        return op
 
     def barrier(self):
         if not self.dry:
@@ -437,7 +552,7 @@ class Problem:
         if not (self.partitioned and self.op.transposed):
             return
         import torch.distributed as dist
-        failed = torch.zeros(1, dtype=torch.float64, device=self.dev)
+        failed = torch.zeros(1, dtype=torch.float64, device=self.ctx.ctrl_dev)
         try:
             probe = torch.zeros(self.world * 8, dtype=torch.float64, device=self.dev)
             self.op.comm.all_to_all(probe, torch.empty_like(probe))
@@ -452,6 +567,30 @@ class Problem:
             self.notes["distributed_fallback"] = "transposed exchange unavailable on %d rank(s): pairwise slab " \
                                                  "exchange used" % int(failed.item())
 
+    def _self_check(self, E0):
+        """the overlapped exchange is verified before anything is timed; if the eigen-residual is not at the level the
+        sequential exchange reaches, the run falls back to the sequential exchange"""
+        op, notes = self.op, self.notes
+        resid = self.eigen_residual(E0, self.last["psi"])
+        notes["partitioned_driver"] = getattr(op, "driver", "python")
+        notes["slab_exchange"] = ("none (one rank)" if op.p == 0 else
+                                  ("transposed all-to-all form" if op.transposed else "pairwise hypercube partners")
+                                  + (", overlapped with the dots / correction passes" if op.overlap else ""))
+        if op.p > 0 and op.overlap:
+            op.overlap = False
+            E0s, _ = self.step()
+            resid_seq = self.eigen_residual(E0s, self.last["psi"])
+            op.overlap = True
+            if not (resid <= 10.0 * resid_seq + 1e-9):
+                op.overlap = False
+                notes["distributed_self_check"] = "overlapped exchange failed its self-check (residual %.2e vs " \
+                                                  "%.2e sequential): sequential exchange timed instead" % (resid, resid_seq)
+            else:
+                notes["distributed_self_check"] = "overlapped exchange verified: eigen-residual %.2e (sequential " \
+                                                  "%.2e), %d premise fallbacks" % (resid, resid_seq, op.overlap_fallbacks)
+        else:
+            notes["distributed_self_check"] = "eigen-residual %.2e" % resid
+
     def measure(self, steps, warmup):
         """W untimed steps, [distributed self-check], barrier, EXACTLY K timed steps, barrier; returns seconds
         (max over ranks), E0, dloss/dg"""
@@ -462,30 +601,9 @@ class Problem:
             E0, gl = self.step()
         self.barrier()
         if self.partitioned:
-            op, notes = self.op, self.notes
-            # the overlapped exchange is verified before anything is timed; if the eigen-residual is not at the
-            # level the sequential exchange reaches, the run falls back to the sequential exchange
             if warmup == 0:
                 E0, gl = self.step()
-            resid = self.eigen_residual(E0, self.last["psi"])
-            notes["partitioned_driver"] = getattr(op, "driver", "python")
-            notes["slab_exchange"] = ("none (one rank)" if op.p == 0 else
-                                      ("transposed all-to-all form" if op.transposed else "pairwise hypercube partners")
-                                      + (", overlapped with the dots / correction passes" if op.overlap else ""))
-            if op.p > 0 and op.overlap:
-                op.overlap = False
-                E0s, _ = self.step()
-                resid_seq = self.eigen_residual(E0s, self.last["psi"])
-                op.overlap = True
-                if not (resid <= 10.0 * resid_seq + 1e-9):
-                    op.overlap = False
-                    notes["distributed_self_check"] = "overlapped exchange failed its self-check (residual %.2e vs " \
-                                                      "%.2e sequential): sequential exchange timed instead" % (resid, resid_seq)
-                else:
-                    notes["distributed_self_check"] = "overlapped exchange verified: eigen-residual %.2e (sequential " \
-                                                      "%.2e), %d premise fallbacks" % (resid, resid_seq, op.overlap_fallbacks)
-            else:
-                notes["distributed_self_check"] = "eigen-residual %.2e" % resid
+            self._self_check(E0)
             self.barrier()
         # ---- timed region: exactly K steps, no instrumentation inside
         t0 = time.perf_counter()
@@ -495,16 +613,32 @@ class Problem:
         dt = time.perf_counter() - t0
         if self.partitioned:
             import torch.distributed as dist
-            tmax = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+            tmax = torch.tensor([dt], dtype=torch.float64, device=self.ctx.ctrl_dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = tmax.item()
         return dt, E0, gl
 
-    def describe(self, operator="matrix-free", scaling=None):
+    def time_steps(self, n):
+        """one untimed + n timed steps of the CURRENT settings, max over ranks, ms per step (extras beside the headline)"""
+        self.step()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            E0, gl = self.step()
+        self.barrier()
+        dt = time.perf_counter() - t0
+        if self.partitioned:
+            import torch.distributed as dist
+            tmax = torch.tensor([dt], dtype=torch.float64, device=self.ctx.ctrl_dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = tmax.item()
+        return dt / n * 1e3, E0, gl
+
+    def describe(self, scaling=None):
         mode = "row-partitioned over %d GPUs%s" % (self.world, ", %s scaling" % scaling if scaling else "") \
             if self.partitioned else "one GPU"
         return "TFIM L=%d (n=2^%d, %d rows/GPU) DominantSparseSymeig k=%d fwd+bwd, g=1.0, loss=E0+psi.t, " \
-               "operand=%s, %s" % (self.L, self.L, self.nloc, self.k, operator, mode)
+               "operand=%s, %s" % (self.L, self.L, self.nloc, self.k, self.operator, mode)
 
     def release(self):
         """drop the operator and the arena basis (the next problem of this process may need the memory)"""
@@ -517,19 +651,19 @@ class Problem:
             torch.cuda.empty_cache()
 
 
-def rank_evidence(world, rank, local_rank, dev, dry):
+def rank_evidence(ctx):
     """what proves the collectives span N distinct GPUs: every rank's device, gathered to rank 0"""
     import torch.distributed as dist
-    mine = {"rank": rank, "local_rank": local_rank, "host": socket.gethostname(), "pid": os.getpid()}
-    if not dry:
-        pr = torch.cuda.get_device_properties(dev)
+    mine = {"rank": ctx.rank, "local_rank": ctx.local_rank, "host": socket.gethostname(), "pid": os.getpid()}
+    if not ctx.dry:
+        pr = torch.cuda.get_device_properties(ctx.dev)
         mine.update(device=pr.name, pci="%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0),
                                                              getattr(pr, "pci_device_id", 0)),
                     uuid=str(getattr(pr, "uuid", "")), hbm_GB=round(pr.total_memory / 1e9, 1))
-    gathered = [None] * world
+    gathered = [None] * ctx.world
     dist.all_gather_object(gathered, mine)
     info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": gathered}
-    if not dry:
+    if not ctx.dry:
         try:
             info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:  # noqa: BLE001
@@ -538,7 +672,8 @@ def rank_evidence(world, rank, local_rank, dev, dry):
     return info
 
 
-def main():
+# ---------------------------------------------------------------------------------------------- command line
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
@@ -548,6 +683,14 @@ def main():
     ap.add_argument("--L", type=int, default=None, help="chain length (default: by --gpus / --scaling)")
     ap.add_argument("--L-local", type=int, default=None, help="log2 rows per GPU (weak scaling)")
     ap.add_argument("--k", type=int, default=None)
+    ap.add_argument("--shadow", choices=["auto", "on", "off"], default="auto",
+                    help="bf16 storage shadow of the basis for the correction pass (DESIGN.md 4): auto = on where it fits "
+                         "beside the fp64 basis (at L = 28, k = 100 on ONE GPU it does not), on = must fit, off = all-fp64 "
+                         "correction pass (the reference's arithmetic)")
+    ap.add_argument("--anchors-json", type=str, default=None,
+                    help="N > 1: file with the N = 1 line (bench.py --gpus 1 output, or a driver record wrapping it) whose "
+                         "config.one_gpu_anchors the speed-ups are quoted against (default: the cache the N = 1 run of this "
+                         "sequence left on this node, else the newest committed profiles/r<NN>_bench.json)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", action="store_true",
                     help="CPU baseline on a bounded sample (k = --cpu-k, CG capped at --cpu-cg-cap) instead of the FULL "
@@ -562,11 +705,14 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp64-basis batch and the config-3 figures")
     ap.add_argument("--no-anchors", action="store_true",
-                    help="N = 1: skip the live one-GPU anchors of the multi-GPU curves (L = 28, k = 100 and 2^25 rows, "
-                         "k = 200: ~40 s and 230 GB of HBM)")
+                    help="N = 1: skip the live one-GPU anchors of the multi-GPU curves (L = 28 with k = 100 / k = 80 and "
+                         "2^25 rows, k = 200: ~60 s and 230 GB of HBM)")
+    ap.add_argument("--anchors-only", action="store_true",
+                    help="N = 1: one headline step, then the live anchors (no CPU baseline, extras, PMC passes, kernel events)")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="N = 1 headline run: do not measure roofline.traffic / pmc_* live with two rocprofv3 --pmc child "
-                         "passes (~20 s each) before the timed run; the committed profiles/pmc_traffic.json is quoted instead")
+                         "passes (~20 s each) before the timed run; the newest committed profiles/r<NN>_pmc_traffic.json is "
+                         "quoted instead")
     ap.add_argument("--rpl", type=int, default=0)
     ap.add_argument("--operator", choices=["matrix-free", "sell", "csr"], default="matrix-free",
                     help="operand form of the TFIM operator at N=1: native matrix-free kernel (headline) or the "
@@ -585,449 +731,582 @@ def main():
                          "double of the slab kernels (tests/cpu_backend.py).  Without --L / --k the default two-point "
                          "schedule of N > 1 runs at toy sizes.  The line it prints is labelled as a dry run and carries "
                          "no roofline / cpu_baseline.")
+    ap.add_argument("--host-staged", action="store_true",
+                    help="REHEARSAL, no measurement: the REAL N > 1 branch of this script -- self-launch, row-partitioned "
+                         "operator on the HIP slab kernels and the library-side driver, collective fallback decisions, "
+                         "overlapped-exchange self-check, strong point + matched extras + weak point, rank evidence, final "
+                         "line -- with the N ranks SHARING GPU 0 and the collectives over gloo staged through the host "
+                         "(RCCL refuses two ranks on one device), at toy sizes.  It is how a one-GPU box executes the "
+                         "P = 2 / 4 / 8 geometry end to end; the line is labelled as a rehearsal.")
     args = ap.parse_args()
-    dry = args.dry_run_cpu
+    if args.anchors_only:
+        args.steps = args.steps or 1
+        args.warmup = 1 if args.warmup is None else args.warmup
+        args.no_cpu_baseline = args.no_extras = args.no_live_pmc = args.no_kernel_events = True
+    return args
 
+
+def init_process(args):
+    """process-level state: ranks, device, process group, the live PMC passes (which must run BEFORE this process touches
+    the GPU).  Returns a namespace ``ctx``."""
+    import types
+    ctx = types.SimpleNamespace()
+    ctx.dry, ctx.staged = args.dry_run_cpu, args.host_staged
+    if ctx.dry and ctx.staged:
+        raise SystemExit("--dry-run-cpu and --host-staged exclude each other")
     env_world = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and env_world is None:
         launch_workers(args.gpus)          # does not return
-    world = int(env_world or "1")
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    live_pmc, live_pmc_note = None, None
-    headline_defaults = (world == 1 and not dry and not args.force_partitioned and args.L is None and args.L_local is None
-                         and args.k is None and args.operator == "matrix-free" and args.reorth == "full")
+    ctx.world = int(env_world or "1")
+    ctx.rank = int(os.environ.get("RANK", "0"))
+    ctx.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != ctx.world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, ctx.world))
+    ctx.p = int(np.log2(ctx.world))
+    assert (1 << ctx.p) == ctx.world, "world size must be a power of two"
+    ctx.ranks_per_device = ctx.world if ctx.staged else 1
+    ctx.live_pmc, ctx.live_pmc_note = None, None
+    headline_defaults = (ctx.world == 1 and not ctx.dry and not ctx.staged and not args.force_partitioned and args.L is None
+                         and args.L_local is None and args.k is None and args.operator == "matrix-free"
+                         and args.reorth == "full" and args.shadow == "auto")
     # never from under a profiler: its preloaded library may already have initialised the GPU in THIS process, and a
     # process that has done so must not start other programs on this pool
     under_profiler = any(kk.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "RPD_")) for kk in os.environ) or \
         "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or "roctracer" in os.environ.get("LD_PRELOAD", "").lower()
     if under_profiler and headline_defaults and not args.no_live_pmc:
-        live_pmc_note = "skipped: running under a profiler (committed profiles/pmc_traffic.json quoted)"
+        ctx.live_pmc_note = "skipped: running under a profiler (newest committed profiles/r<NN>_pmc_traffic.json quoted)"
     if headline_defaults and not args.no_live_pmc and not under_profiler and not torch.cuda.is_initialized() and \
             os.environ.get("DSEA_BENCH_CHILD", "") != "1":
         # child processes, BEFORE this process initialises the GPU
         t_pmc = time.time()
-        live_pmc, live_pmc_note = live_pmc_traffic()
-        live_pmc_note = live_pmc_note or "two rocprofv3 --pmc passes took %.0f s" % (time.time() - t_pmc)
-    if dry:
-        dev = torch.device("cpu")
+        ctx.live_pmc, ctx.live_pmc_note = live_pmc_traffic()
+        ctx.live_pmc_note = ctx.live_pmc_note or "two rocprofv3 --pmc passes took %.0f s" % (time.time() - t_pmc)
+    if ctx.dry:
+        ctx.dev = torch.device("cpu")
         torch.set_num_threads(1)
     else:
         assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU fallback for the product path"
-        torch.cuda.set_device(local_rank)
-        dev = torch.device("cuda", local_rank)
-
-    from dominantsparseeigenad_amd import _lib, engine
-    lib = None if dry else _lib.load()
-
-    p = int(np.log2(world))
-    assert (1 << p) == world, "world size must be a power of two"
-    partitioned_path = world > 1 or args.force_partitioned or dry
-    # ---- which point is timed
-    explicit = args.L is not None or args.L_local is not None
-    if world == 1:
-        scaling = args.scaling or "weak"
-    else:
-        scaling = args.scaling or ("weak" if explicit else "strong")
-    strong = scaling == "strong"
-    toy = dry and not explicit            # dry run of the default schedule: toy sizes
-    if args.L is not None:
-        L = args.L
-    elif strong:
-        L = 10 if toy else 28
-    elif args.L_local is not None:
-        L = args.L_local + p
-    elif toy:
-        L = 7 + p
-    else:
-        L = 20 if world == 1 else 25 + p
-    k = args.k if args.k is not None else ((80 if strong else 60) if toy else (100 if strong else 200))
-    # the weak point reported beside the timed strong one (default schedule of N > 1 only)
-    weak_extra = world > 1 and args.scaling is None and not explicit and args.reorth == "full"
-    nloc, n = 1 << (L - p), 1 << L
-    big = nloc >= (1 << 24)
-    steps = args.steps if args.steps is not None else (3 if big else 10)
-    warmup = args.warmup if args.warmup is not None else (1 if big else 2)
-
-    evidence = None
-    if partitioned_path:
+        dev_index = 0 if ctx.staged else ctx.local_rank
+        torch.cuda.set_device(dev_index)
+        ctx.dev = torch.device("cuda", dev_index)
+    # control-plane tensors (failure flags, max-over-ranks time): on the host whenever the backend is gloo
+    ctx.ctrl_dev = torch.device("cpu") if (ctx.dry or ctx.staged) else ctx.dev
+    ctx.partitioned_path = ctx.world > 1 or args.force_partitioned or ctx.dry or ctx.staged
+    ctx.evidence = None
+    if ctx.partitioned_path:
         import torch.distributed as dist
         if not dist.is_initialized():
-            if world == 1:
+            if ctx.world == 1:
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
                 os.environ.setdefault("MASTER_PORT", str(_free_port()))
-            if dry:
-                dist.init_process_group("gloo", rank=rank, world_size=world)
+            if ctx.dry or ctx.staged:
+                dist.init_process_group("gloo", rank=ctx.rank, world_size=ctx.world)
             else:
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        evidence = rank_evidence(world, rank, local_rank, dev, dry)
+                dist.init_process_group("nccl", rank=ctx.rank, world_size=ctx.world, device_id=ctx.dev)
+        ctx.evidence = rank_evidence(ctx)
+    return ctx
 
-    if os.environ.get("DSEA_PLACEMENT_TRIES"):
-        engine.BasisArena.PLACEMENT_TRIES = int(os.environ["DSEA_PLACEMENT_TRIES"])
 
-    prob = Problem(args, L, k, world, rank, dev, dry, partitioned_path, reorth=args.reorth)
-    ws = None if dry else engine.Workspace.get(nloc, k, dev)
-    if args.rpl and ws is not None:
-        ws.set_rows_per_lane(args.rpl)
-    dt, E0, gl = prob.measure(steps, warmup)
-    notes = prob.notes
-    m = prob.cg_iterations()
-    step, barrier = prob.step, prob.barrier
-    # ---- per-launch durations of the dominant kernels: the same K steps again, this time with a HIP event
-    # pair recorded on the launch stream around every reorth / mat-vec launch (the event records cost ~4 %
-    # of a step, which is why they are kept out of the timed region above)
-    use_events = not args.no_kernel_events and args.reorth == "full" and not dry   # rank 0's local kernels, also when partitioned
-    launches = (c_int64 * 3)()
-    total_ms = (c_double * 3)()
-    dt_instr = None
-    ev_steps = min(steps, 5) if big else steps
-    if use_events:
-        ws = engine.Workspace.get(nloc, k, dev)
-        _lib.check(lib.dsea_profile_begin(ws.handle, 3 * k * ev_steps + 8), "dsea_profile_begin")
-        t1 = time.perf_counter()
-        for _ in range(ev_steps):
-            step()
-        barrier()
-        dt_instr = time.perf_counter() - t1
-        _lib.check(lib.dsea_profile_end(ws.handle, launches, total_ms), "dsea_profile_end")
-    lp_stats = engine.lanczos_lp_stats(nloc, dev) if not partitioned_path else None
-    pr_timed_steps = engine.last_reorth_steps       # (partial option: steps the timed runs re-orthogonalised)
-    # ---- the same step with the all-fp64 correction pass (no bf16 shadow of the basis): the figure to hold
-    # against real HBM traffic
-    ms_fp64 = ms_basisfree = ms_partial = None
-    from dominantsparseeigenad_amd import Lanczos as _LZ
-    if not args.no_extras and not partitioned_path and args.reorth == "full" and not big:
-        # the same workload with the basis-free two-pass Lanczos (reorth='none'): a DIFFERENT forward algorithm (no
-        # full re-orthogonalisation, Lanczos.py:66), same eigenpair and gradient to rounding -- reported beside the
-        # headline, never as the headline
-        _LZ.REORTH_DEFAULT = "none"
-        step()
-        barrier()
-        t3 = time.perf_counter()
-        nb2 = min(steps, 5)
-        for _ in range(nb2):
-            E0bf, glbf = step()
-        barrier()
-        ms_basisfree = (time.perf_counter() - t3) / nb2 * 1e3
-        bf_dev = (abs(E0bf.item() - E0.item()) / abs(E0.item()), abs(float(glbf.reshape(-1)[0]) - float(gl.reshape(-1)[0])) / abs(float(gl.reshape(-1)[0])))
-        _LZ.REORTH_DEFAULT = "full"
-        # ... and the PARTIAL re-orthogonalisation option (SURVEY 8 f-4 "selective reorth"): the same Krylov process and
-        # stored basis, re-orthogonalised only when the omega recurrence asks for it -- also beside the headline only
-        _LZ.REORTH_DEFAULT = "partial"
-        try:
-            step()
-            barrier()
-            t3 = time.perf_counter()
-            for _ in range(nb2):
-                E0pr, glpr = step()
-            barrier()
-            ms_partial = (time.perf_counter() - t3) / nb2 * 1e3
-            pr_steps = engine.last_reorth_steps
-            pr_dev = (abs(E0pr.item() - E0.item()) / abs(E0.item()),
-                      abs(float(glpr.reshape(-1)[0]) - float(gl.reshape(-1)[0])) / abs(float(gl.reshape(-1)[0])))
-        except Exception as exc:  # noqa: BLE001
-            ms_partial, pr_steps, pr_dev = None, None, str(exc)
-        _LZ.REORTH_DEFAULT = "full"
-    if not args.no_extras and partitioned_path and args.reorth == "full" and not dry and \
-            (world == 1 or os.environ.get("DSEA_BENCH_PARTIAL_EXTRA", "") == "1"):
-        # row-partitioned run: the partial re-orthogonalisation option on the library driver (same collective sequence on
-        # every rank, one more scalar all-reduce per step) -- beside the timed figure, never in its place.  On more than
-        # one rank only on request (DSEA_BENCH_PARTIAL_EXTRA=1): an extra must not be able to cost the line its headline.
-        _LZ.REORTH_DEFAULT = "partial"
-        try:
-            step()
-            barrier()
-            t3 = time.perf_counter()
-            nb3 = 2
-            for _ in range(nb3):
-                E0pr, glpr = step()
-            barrier()
-            ms_partial = (time.perf_counter() - t3) / nb3 * 1e3
-            pr_steps = engine.last_reorth_steps
-            pr_dev = (abs(E0pr.item() - E0.item()) / abs(E0.item()),
-                      abs(float(glpr.reshape(-1)[0]) - float(gl.reshape(-1)[0])) / abs(float(gl.reshape(-1)[0])))
-        except Exception as exc:  # noqa: BLE001  (e.g. the Python step driver: the option needs the library driver)
-            ms_partial, pr_steps, pr_dev = None, None, str(exc)
-            if rank == 0:
-                print("[bench] partial re-orthogonalisation extra skipped: %s" % exc, file=sys.stderr)
-        _LZ.REORTH_DEFAULT = "full"
-    if not args.no_extras and engine.USE_SHADOW and not partitioned_path:
-        engine.USE_SHADOW = False
-        step()
-        barrier()
-        t2 = time.perf_counter()
-        nb = min(steps, 5)
-        for _ in range(nb):
-            step()
-        barrier()
-        ms_fp64 = (time.perf_counter() - t2) / nb * 1e3
-        engine.USE_SHADOW = True
-    ms_per_step = dt / steps * 1e3
-    alg_bytes = algorithmic_bytes(n, k, m)
-    if lp_stats is not None:
-        shadow_steps = int(lp_stats[0])
+def choose_point(args, ctx):
+    """which (L, k) the K timed steps run, and how many of them; returns a namespace ``pt``"""
+    import types
+    pt = types.SimpleNamespace()
+    world, p = ctx.world, ctx.p
+    pt.explicit = args.L is not None or args.L_local is not None
+    if world == 1:
+        pt.scaling = args.scaling or "weak"
     else:
-        shadow_steps = (k - 1) if (prob.use_shadow and k > 1) else 0
-    # the adjoint solve runs as one persistent launch for the full-space TFIM operator up to 2^20 rows
-    cg_persistent = (not partitioned_path) and args.operator == "matrix-free" and 14 <= L <= 20 and \
-        os.environ.get("DSEA_NO_PERSIST", "") != "1"
-    total_bytes = traffic_model_bytes(n, k, m, shadow_steps, 5.0 if cg_persistent else 11.0)
+        pt.scaling = args.scaling or ("weak" if pt.explicit else "strong")
+    pt.strong = pt.scaling == "strong"
+    # toy sizes: the default schedule in a dry run / rehearsal (no measurement is taken from either)
+    pt.toy = (ctx.dry or ctx.staged) and not pt.explicit
+    if ctx.dry:
+        pt.toy_strong, pt.toy_weak, pt.toy_matched_k = (10, 80), (7 + p, 60), 48
+    else:                       # rehearsal on the HIP kernels: slabs of >= 2^12 rows at 8 ranks
+        pt.toy_strong, pt.toy_weak, pt.toy_matched_k = (15, 80), (12 + p, 60), 48
+    if args.L is not None:
+        pt.L = args.L
+    elif pt.strong:
+        pt.L = pt.toy_strong[0] if pt.toy else 28
+    elif args.L_local is not None:
+        pt.L = args.L_local + p
+    elif pt.toy:
+        pt.L = pt.toy_weak[0]
+    else:
+        pt.L = 20 if world == 1 else 25 + p
+    if args.k is not None:
+        pt.k = args.k
+    elif pt.toy:
+        pt.k = pt.toy_strong[1] if pt.strong else pt.toy_weak[1]
+    else:
+        pt.k = STRONG_K if pt.strong else 200
+    # default schedule of N > 1: the strong point is timed; the same point with the all-fp64 correction pass, the
+    # shadow-matched k and the weak point are reported beside it
+    pt.default_schedule = world > 1 and args.scaling is None and not pt.explicit and args.k is None and \
+        args.reorth == "full" and args.shadow == "auto"
+    pt.nloc, pt.n = 1 << (pt.L - (p if ctx.partitioned_path else 0)), 1 << pt.L
+    pt.big = pt.nloc >= (1 << 24)
+    pt.steps = args.steps if args.steps is not None else (3 if pt.big else 10)
+    pt.warmup = args.warmup if args.warmup is not None else (1 if pt.big else 2)
+    return pt
+
+
+# ---------------------------------------------------------------------------------------------- measurements beside the headline
+def kernel_events(args, ctx, pt, prob, lib):
+    """per-launch durations of the dominant kernels: the same K steps again, this time with a HIP event pair recorded on
+    the launch stream around every reorth / mat-vec launch (the event records cost ~4 % of a step, which is why they are
+    kept out of the timed region).  Returns None or dict(launches, total_ms, steps, ms_per_step_instrumented)."""
+    from dominantsparseeigenad_amd import _lib, engine
+    if args.no_kernel_events or args.reorth != "full" or ctx.dry:
+        return None                  # (rank 0's local kernels, also when partitioned)
+    launches, total_ms = (c_int64 * 3)(), (c_double * 3)()
+    ev_steps = min(pt.steps, 5) if pt.big else pt.steps
+    ws = engine.Workspace.get(pt.nloc, pt.k, ctx.dev)
+    _lib.check(lib.dsea_profile_begin(ws.handle, 3 * pt.k * ev_steps + 8), "dsea_profile_begin")
+    t1 = time.perf_counter()
+    for _ in range(ev_steps):
+        prob.step()
+    prob.barrier()
+    dt_instr = time.perf_counter() - t1
+    _lib.check(lib.dsea_profile_end(ws.handle, launches, total_ms), "dsea_profile_end")
+    return {"launches": [int(v) for v in launches], "total_ms": [float(v) for v in total_ms], "steps": ev_steps,
+            "ms_per_step_instrumented": dt_instr / ev_steps * 1e3}
+
+
+def _rel_dev(a, b):
+    return abs(a - b) / abs(b)
+
+
+def option_extras(args, ctx, pt, prob, E0, gl):
+    """the same workload under the options the library offers beside the reference's schedule -- reported beside the
+    headline, never as the headline: basis-free two-pass Lanczos, partial re-orthogonalisation, all-fp64 correction pass"""
+    from dominantsparseeigenad_amd import Lanczos as _LZ, engine
+    out = {}
+    if args.no_extras or args.reorth != "full":
+        return out
+    E0v, glv = E0.item(), float(gl.reshape(-1)[0])
+    single = not ctx.partitioned_path
+    if single and not pt.big:
+        nb = min(pt.steps, 5)
+        for tag, mode, note in (
+                ("basisfree_two_pass_lanczos", "none",
+                 "reorth='none' option: no stored basis, no re-orthogonalisation; not the reference's algorithm"),
+                ("partial_reorth_lanczos", "partial",
+                 "reorth='partial' option (Simon's partial re-orthogonalisation, threshold 1e-10): same stored basis, "
+                 "re-orthogonalised only on the steps the omega recurrence selects; not the reference's schedule "
+                 "(Lanczos.py:66 re-orthogonalises on every step), never the headline")):
+            _LZ.REORTH_DEFAULT = mode
+            try:
+                ms, E0x, glx = prob.time_steps(nb)
+                rec = {"ms_per_step": round(ms, 4), "E0_rel_dev_vs_full_reorth": _rel_dev(E0x.item(), E0v),
+                       "dloss_dg_rel_dev_vs_full_reorth": _rel_dev(float(glx.reshape(-1)[0]), glv), "note": note}
+                if mode == "partial":
+                    rec.update(steps_reorthogonalised=engine.last_reorth_steps, of=pt.k - 1)
+                out[tag] = rec
+            except Exception as exc:  # noqa: BLE001
+                out[tag] = "failed: %s" % exc
+            finally:
+                _LZ.REORTH_DEFAULT = "full"
+    if ctx.partitioned_path and not ctx.dry and (ctx.world == 1 or os.environ.get("DSEA_BENCH_PARTIAL_EXTRA", "") == "1"):
+        # row-partitioned run: the partial re-orthogonalisation option on the library driver (same collective sequence on
+        # every rank, one more scalar all-reduce per step).  On more than one rank only on request
+        # (DSEA_BENCH_PARTIAL_EXTRA=1): an extra must not be able to cost the line its headline.
+        _LZ.REORTH_DEFAULT = "partial"
+        try:
+            ms, E0x, glx = prob.time_steps(2)
+            out["partial_reorth_lanczos"] = {
+                "ms_per_step": round(ms, 4), "steps_reorthogonalised": engine.last_reorth_steps, "of": pt.k - 1,
+                "E0_rel_dev_vs_full_reorth": _rel_dev(E0x.item(), E0v),
+                "dloss_dg_rel_dev_vs_full_reorth": _rel_dev(float(glx.reshape(-1)[0]), glv),
+                "note": "reorth='partial' option on the row-partitioned library driver; never the headline"}
+        except Exception as exc:  # noqa: BLE001  (e.g. the Python step driver: the option needs the library driver)
+            if ctx.rank == 0:
+                print("[bench] partial re-orthogonalisation extra skipped: %s" % exc, file=sys.stderr)
+        finally:
+            _LZ.REORTH_DEFAULT = "full"
+    if engine.USE_SHADOW and single:
+        # the same step with the all-fp64 correction pass (no bf16 shadow of the basis): the figure to hold against SURVEY
+        # 8d's algorithmic bytes
+        engine.USE_SHADOW = False
+        try:
+            ms, _, _ = prob.time_steps(min(pt.steps, 5))
+            out["ms_per_step_fp64_basis"] = round(ms, 4)
+        finally:
+            engine.USE_SHADOW = True
+    return out
+
+
+def _point_record(pw, ms, steps, warmup, E0, scaling):
+    m = pw.cg_iterations()
+    n, k = pw.n, pw.k
+    shadow_steps = (k - 1) if pw.use_shadow else 0
+    return {"workload": pw.describe(scaling), "ms_per_step": round(ms, 4), "steps": steps, "warmup": warmup,
+            "bf16_shadow_of_basis": bool(pw.use_shadow),
+            "GBs": round(traffic_model_bytes(n, k, m, shadow_steps) / (ms * 1e-3) / 1e9, 2),
+            "algorithmic_GBs": round(algorithmic_bytes(n, k, m) / (ms * 1e-3) / 1e9, 2), "cg_iterations": int(m),
+            "E0_per_site": E0.item() / pw.L, "E0_per_site_closed_form": analytic_E0_per_site(pw.L, 1.0)}
+
+
+def extra_point(ctx, L, k, shadow, steps, warmup, scaling):
+    """one more row-partitioned point of the N > 1 schedule, timed like the headline (W untimed, self-check, K timed, max
+    over ranks) -- every rank runs the same code, so an exception is collective"""
+    try:
+        pw = Problem(ctx, L, k, True, shadow=shadow)
+        dt, E0, _ = pw.measure(steps, warmup)
+        rec = _point_record(pw, dt / steps * 1e3, steps, warmup, E0, scaling)
+        rec.update(pw.notes)
+        pw.release()
+        return rec
+    except Exception as exc:  # noqa: BLE001
+        try:
+            from dominantsparseeigenad_amd import engine
+            engine.BasisArena.release()
+            if not ctx.dry:
+                torch.cuda.empty_cache()
+        except Exception:  # noqa: BLE001
+            pass
+        return "failed: %s: %s" % (type(exc).__name__, str(exc)[:200])
+
+
+def multi_gpu_extras(args, ctx, pt, prob, anchors):
+    """default schedule of N > 1, after the timed strong point (shadow: auto = on from two GPUs): the SAME point with the
+    all-fp64 correction pass, the shadow-matched k, and the weak point.  Returns (strong_fp64, strong_matched, weak)."""
+    if not pt.default_schedule:
+        return None, None, None
+    prob.release()
+    Ls = pt.L
+    sw = (2, 1)
+    k_m = pt.toy_matched_k if pt.toy else STRONG_K_SHADOW_MATCHED
+    strong_fp64 = extra_point(ctx, Ls, pt.k, "off", sw[0], sw[1], "strong")
+    strong_matched = extra_point(ctx, Ls, k_m, "auto", sw[0], sw[1], "strong")
+    Lw, kw = pt.toy_weak if pt.toy else (25 + ctx.p, 200)
+    weak = extra_point(ctx, Lw, kw, "auto", 2 if pt.toy else 3, 1, "weak")
+    if isinstance(weak, dict):
+        a = None if pt.toy else anchor_ms(anchors, "weak_2p25_rows_k200", weak["bf16_shadow_of_basis"])
+        weak["one_gpu_anchor_ms"] = a
+        weak["weak_efficiency_vs_anchor"] = round(a / weak["ms_per_step"], 4) if a else None
+    return strong_fp64, strong_matched, weak
+
+
+def one_gpu_anchors(args, ctx, pt, prob):
+    """N = 1, default workload: the live one-GPU anchors of the multi-GPU curves (outside the timed steps), each with the
+    arithmetic of its correction pass stated; also left in ANCHOR_CACHE for the N > 1 lines of the same sequence"""
+    from dominantsparseeigenad_amd import engine
+    default_headline = ctx.world == 1 and not ctx.partitioned_path and not pt.explicit and args.k is None and \
+        args.operator == "matrix-free" and args.reorth == "full" and args.shadow == "auto"
+    if not default_headline or args.no_anchors or ctx.dry:
+        return None
+    anchors = {}
+    free_b, total_b = torch.cuda.mem_get_info(ctx.dev)
+    for tag, La, ka, sa, shadow in ANCHOR_SPECS:
+        need = 8.0 * (1 << La) * (ka + 8) * (1.25 if shadow == "on" else 1.0)
+        if need > 0.9 * total_b:
+            anchors[tag] = "skipped: needs %.0f GB of %.0f GB" % (need / 1e9, total_b / 1e9)
+            continue
+        try:
+            engine.BasisArena.release()
+            engine.Workspace.clear_cache()
+            torch.cuda.empty_cache()
+            pa = Problem(ctx, La, ka, False, shadow=shadow)
+            dta, E0a, _ = pa.measure(sa, 1)
+            ma = pa.cg_iterations()
+            msa = dta / sa * 1e3
+            anchors[tag] = {"workload": pa.describe(), "ms_per_step": round(msa, 3), "steps": sa, "warmup": 1,
+                            "cg_iterations": int(ma), "bf16_shadow_of_basis": bool(pa.use_shadow),
+                            "GBs": round(traffic_model_bytes(1 << La, ka, ma, (ka - 1) if pa.use_shadow else 0) / (msa * 1e-3) / 1e9, 1),
+                            "algorithmic_GBs": round(algorithmic_bytes(1 << La, ka, ma) / (msa * 1e-3) / 1e9, 1),
+                            "E0_per_site_minus_closed_form": E0a.item() / La - analytic_E0_per_site(La, 1.0)}
+            pa.release()
+        except Exception as exc:  # noqa: BLE001
+            anchors[tag] = "failed: %s: %s" % (type(exc).__name__, str(exc)[:200])
+            engine.BasisArena.release()
+            torch.cuda.empty_cache()
+    prob.activate()          # module-global primitive, shadow flag and reorth default back to the headline problem
+    store_anchors(anchors)
+    return anchors
+
+
+# ---------------------------------------------------------------------------------------------- the JSON line
+def _metric_name(args, ctx):
+    if ctx.dry:
+        return "DRY RUN on CPU processes (gloo, torch test double of the slab kernels): control flow of the multi-rank " \
+               "bench only, not a measurement"
+    if ctx.staged:
+        return "REHEARSAL, not a measurement: the N > 1 branch on the HIP slab kernels with %d ranks SHARING ONE GPU, " \
+               "collectives over gloo staged through the host, toy sizes" % ctx.world
+    if args.reorth == "full":
+        return "DominantSparseSymeig fwd+bwd ms & HBM GB/s (TFIM, fp64)"
+    if args.reorth == "partial":
+        return "DominantSparseSymeig fwd+bwd GB/s, partial re-orthogonalisation option (TFIM, fp64; not the reference's " \
+               "schedule: it re-orthogonalises on every step)"
+    return "DominantSparseSymeig fwd+bwd GB/s, basis-free two-pass Lanczos option (TFIM, fp64; not the reference's " \
+           "full-reorthogonalisation algorithm)"
+
+
+def _priced_bytes(args, pt, m, shadow_steps, cg_persistent, pr_run_steps):
+    """(bytes `value` is quoted on, algorithmic bytes, description)"""
+    n, k = pt.n, pt.k
+    alg = algorithmic_bytes(n, k, m)
     if args.reorth == "none":
         # the basis-free two-pass option is a DIFFERENT algorithm: it is priced with ITS OWN algorithmic bytes, not with
         # SURVEY 8d's full-reorthogonalisation figure (which it does not move).  Per Lanczos step and pass: mat-vec 2 +
         # three-term 4 + scale/store 2 vectors; the second pass also updates psi (2): 18 k vectors in all.
-        total_bytes = alg_bytes = 8.0 * n * (18 * k + 11 * m + 24)
-    pr_run_steps = None
+        b = 8.0 * n * (18 * k + 11 * m + 24)
+        return b, b, "the OPTION's own bytes (18 k + 11 m + 24 vectors) / step time, all ranks"
     if args.reorth == "partial":
         # the partial re-orthogonalisation option, priced with ITS OWN bytes: every step mat-vec 2 + three-term 4 +
         # scale/store 2 vectors; a re-orthogonalised step i adds the two passes over the basis, (i + 1) + (i + 2) vectors --
         # R such steps, taken as spread evenly (mean i = k / 2); Ritz vector k + 1; backward as SURVEY 8d
-        pr_run_steps = int(pr_timed_steps or 0)
-        total_bytes = alg_bytes = 8.0 * n * (8 * k + pr_run_steps * (k + 3) + (k + 1) + 11 * m + 24)
+        b = 8.0 * n * (8 * k + pr_run_steps * (k + 3) + (k + 1) + 11 * m + 24)
+        return b, b, ("the OPTION's own bytes (every Lanczos step mat-vec 2 + three-term 4 + scale/store 2 vectors; each of "
+                      "the %d re-orthogonalised steps the two passes over the basis, taken at the mean step index; Ritz "
+                      "vector; backward as SURVEY 8d) / step time, all ranks" % pr_run_steps)
+    b = traffic_model_bytes(n, k, m, shadow_steps, 5.0 if cg_persistent else 11.0)
+    return b, alg, ("HBM bytes the step's kernels move (traffic model: SURVEY 8d per-phase count with the correction pass "
+                    "of %d Lanczos steps reading the bf16 shadow of the basis) / step time, all ranks" % shadow_steps)
+
+
+def _roofline(ctx, pt, prob, ev, pmc, lp_stats):
+    launches, total_ms = ev["launches"], ev["total_ms"]
+    if not (launches[0] > 0 and launches[1] > 0):
+        return None
+    k, nloc = pt.k, pt.nloc
+    dots_b, axpy_b = reorth_bytes_per_launch(nloc, k)
+    # the correction pass is priced with the bytes IT reads: bf16 shadow (2 bytes/element) when it is on
+    axpy_real = axpy_b if not prob.use_shadow else sum(2.0 * i + 16.0 for i in range(1, k)) / (k - 1) * nloc
+    per = {"k_rdots": (dots_b, total_ms[0] / launches[0], launches[0]),
+           "k_axpy_norm": (axpy_real, total_ms[1] / launches[1], launches[1])}
+    name = max(per, key=lambda kk: per[kk][1] * per[kk][2])
+    b, ms, cnt = per[name]
+    traffic = None
+    if pmc and pt.L == 20 and k == 200:
+        traffic = pmc.get(name, {}).get("hbm_bytes_per_launch")
+    lp, fb = lp_stats if lp_stats is not None else (launches[1] if prob.use_shadow else 0, 0)
+    return {
+        "kernel": name, "bound": "hbm", "achieved": round(b / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "traffic_commit": pmc.get("_commit") if (pmc and traffic) else None,
+        "avg_launch_ms": round(ms, 5), "launches": int(cnt), "launches_per_step": int(cnt) // max(ev["steps"], 1),
+        "algorithmic_bytes_per_launch": b,
+        "other": {kk: {"avg_launch_ms": round(v[1], 5), "achieved_GBs": round(v[0] / (v[1] * 1e-3) / 1e9, 1),
+                       "bytes_per_launch": v[0]} for kk, v in per.items() if kk != name},
+        "spmv_avg_launch_ms": round(total_ms[2] / max(launches[2], 1), 5),
+        "measured": "HIP events on the launch stream, %d instrumented steps run right after the timed region (%.3f "
+                    "ms/step with events)" % (ev["steps"], ev["ms_per_step_instrumented"]),
+        "note": ("k_axpy_norm streams the bf16 shadow of the basis on %d of %d steps (fp64 fallback %d) and is priced with "
+                 "the bytes it reads (2 per basis element + r in and out), not with SURVEY 8d's 8 per element"
+                 % (lp, lp + fb, fb)) if not ctx.partitioned_path else "rank 0's local kernels in the row-partitioned run"}
+
+
+def _cpu_baseline_block(args, pt):
+    ncpu = os.cpu_count() or 1
+    host = "%s, os.cpu_count()=%d" % (_cpu_model(), ncpu)
+    want = [min(int(t), ncpu) for t in args.cpu_threads.split(",") if t] or [min(8, ncpu)]
+    L, k = pt.L, pt.k
+    if args.cpu_sample:
+        # bounded sample of the same workload: same L, fewer Lanczos vectors, capped CG
+        _, r = cpu_baseline(L, args.cpu_k, args.cpu_cg_cap, want[0])
+        return {"value": r["GBs"], "unit": "GB/s", "cores": r["threads"], "kind": "port",
+                "sample": "oracle (torch-CPU port of reference Lanczos.py/CG.py/TFIM.H), TFIM L=%d, k=%d Lanczos "
+                          "vectors, CG capped at %d iterations (ran %d), fwd+bwd %.1f s, table build %.1f s not "
+                          "timed; GB/s of the algorithmic bytes (SURVEY 8d), which is what a CPU run moves; host: %s"
+                          % (L, r["k"], args.cpu_cg_cap, r["cg_iterations"], r["fwd_bwd_s"], r["table_build_s"], host)}
+    # SURVEY 8d: the FULL configuration (k as on the GPU, CG to the reference's tolerance)
+    model, runs = None, []
+    for th in want:
+        model, r = cpu_baseline(L, k, None, th, model=model)
+        runs.append(r)
+    best = max(runs, key=lambda r: r["GBs"])
+    return {"value": best["GBs"], "unit": "GB/s", "cores": best["threads"], "kind": "port",
+            "sample": "oracle (torch-CPU port of reference Lanczos.py/CG.py/TFIM.H incl. the gather-table "
+                      "mat-vec) on the FULL workload: TFIM L=%d, k=%d, CG to ||r||<1e-7 (%d iterations): fwd "
+                      "%.1f s + bwd %.1f s; GB/s of the algorithmic bytes (SURVEY 8d); host: %s"
+                      % (L, k, best["cg_iterations"], best["fwd_s"], best["bwd_s"], host),
+            "ms_per_step": round(best["fwd_bwd_s"] * 1e3, 1), "runs": runs}
+
+
+def _speedups(pt, ms_per_step, prob_shadow, strong_fp64, strong_matched, anchors, anchors_src):
+    """config.one_gpu_anchor of an N > 1 line: every speed-up divides LIKE BY LIKE (same k, same arithmetic of the
+    correction pass on both sides) and names its arithmetic; a pair whose one-GPU side is missing stays null"""
+    canonical = not pt.explicit and not pt.toy
+    rec = {"source": anchors_src,
+           "live": "the N = 1 line of the same sequence re-measures the anchors (config.one_gpu_anchors) and leaves them "
+                   "for the N > 1 lines of that sequence on the same node"}
+    if pt.strong:
+        k = pt.k
+        a_fp64 = anchor_ms(anchors, "strong_L28_k%d" % STRONG_K, False) if canonical and k == STRONG_K else None
+        a_m = anchor_ms(anchors, "strong_L28_k%d_shadow" % STRONG_K_SHADOW_MATCHED, True) if canonical else None
+        ms_fp64 = strong_fp64["ms_per_step"] if isinstance(strong_fp64, dict) else (None if prob_shadow else ms_per_step)
+        ms_m = strong_matched["ms_per_step"] if isinstance(strong_matched, dict) and strong_matched.get("bf16_shadow_of_basis") else None
+        rec.update({
+            "strong_k%d_fp64_basis_one_gpu_ms" % STRONG_K: a_fp64,
+            "strong_k%d_fp64_basis_ms" % STRONG_K: ms_fp64,
+            "speedup_vs_one_gpu_fp64_basis": round(a_fp64 / ms_fp64, 4) if (a_fp64 and ms_fp64) else None,
+            "speedup_vs_one_gpu_fp64_basis_is": "L = 28, k = %d, all-fp64 correction pass on BOTH sides (the one GPU cannot "
+                                                "hold the bf16 shadow beside its 215 GB basis)" % STRONG_K,
+            "strong_k%d_shadow_one_gpu_ms" % STRONG_K_SHADOW_MATCHED: a_m,
+            "strong_k%d_shadow_ms" % STRONG_K_SHADOW_MATCHED: ms_m,
+            "speedup_vs_one_gpu_k%d_shadow" % STRONG_K_SHADOW_MATCHED: round(a_m / ms_m, 4) if (a_m and ms_m) else None,
+            "speedup_vs_one_gpu_k%d_shadow_is" % STRONG_K_SHADOW_MATCHED:
+                "L = 28, k = %d, bf16 shadow of the basis on BOTH sides (the largest round k at which it fits one GPU)"
+                % STRONG_K_SHADOW_MATCHED,
+            "timed_point_note": "value / ms_per_step of this line: k = %d with the shadow %s -- NOT divided into the fp64 "
+                                "one-GPU anchor" % (k, "on" if prob_shadow else "off")})
+    else:
+        a = anchor_ms(anchors, "weak_2p25_rows_k200", prob_shadow) if canonical and pt.k == 200 and pt.nloc == (1 << 25) else None
+        rec.update({"weak_one_gpu_ms": a, "weak_efficiency": round(a / ms_per_step, 4) if a else None,
+                    "weak_efficiency_is": "2^25 rows per GPU, k = 200, bf16 shadow %s on both sides" % ("on" if prob_shadow else "off")})
+    return rec
+
+
+def main():
+    args = parse_args()
+    ctx = init_process(args)
+    dry, world, rank = ctx.dry, ctx.world, ctx.rank
+    from dominantsparseeigenad_amd import _lib, engine
+    lib = None if dry else _lib.load()
+    pt = choose_point(args, ctx)
+    L, k = pt.L, pt.k
+    if os.environ.get("DSEA_PLACEMENT_TRIES"):
+        engine.BasisArena.PLACEMENT_TRIES = int(os.environ["DSEA_PLACEMENT_TRIES"])
+
+    # ---- the timed point
+    prob = Problem(ctx, L, k, ctx.partitioned_path, reorth=args.reorth, shadow=args.shadow, operator=args.operator)
+    if args.rpl and not dry:
+        engine.Workspace.get(pt.nloc, k, ctx.dev).set_rows_per_lane(args.rpl)
+    dt, E0, gl = prob.measure(pt.steps, pt.warmup)
+    notes = dict(prob.notes)
+    m = prob.cg_iterations()
+    ms_per_step = dt / pt.steps * 1e3
+    ev = kernel_events(args, ctx, pt, prob, lib)
+    lp_stats = engine.lanczos_lp_stats(pt.nloc, ctx.dev) if not ctx.partitioned_path else None
+    pr_run_steps = int(engine.last_reorth_steps or 0) if args.reorth == "partial" else None
+    extras = option_extras(args, ctx, pt, prob, E0, gl)
+    shadow_steps = int(lp_stats[0]) if lp_stats is not None else ((k - 1) if (prob.use_shadow and k > 1) else 0)
+    # the adjoint solve runs as one persistent launch for the full-space TFIM operator up to 2^20 rows (DESIGN.md 3c)
+    cg_persistent = (not ctx.partitioned_path) and args.operator == "matrix-free" and 14 <= L <= 20 and \
+        os.environ.get("DSEA_NO_PERSIST", "") != "1"
+    total_bytes, alg_bytes, value_is = _priced_bytes(args, pt, m, shadow_steps, cg_persistent, pr_run_steps)
     value = total_bytes / (ms_per_step * 1e-3) / 1e9
-    workload = prob.describe(args.operator, scaling if world > 1 else None)
+    workload = prob.describe(pt.scaling if world > 1 else None)
     E0_site, gl0 = E0.item() / L, float(gl.reshape(-1)[0].item())
-    overlap_fb = prob.op.overlap_fallbacks if partitioned_path else None
+    overlap_fb = prob.op.overlap_fallbacks if ctx.partitioned_path else None
+    prob_shadow = bool(prob.use_shadow)
 
-    # ---- N > 1, default schedule: the weak point beside the timed strong one
-    weak_point = None
-    if weak_extra:
-        prob.release()
-        Lw, kw = ((7 + p, 60) if toy else (25 + p, 200))
-        try:
-            pw = Problem(args, Lw, kw, world, rank, dev, dry, True)
-            sw, ww = (2, 1) if toy else (3, 1)
-            dtw, E0w, _ = pw.measure(sw, ww)
-            mw = pw.cg_iterations()
-            msw = dtw / sw * 1e3
-            bw = traffic_model_bytes(1 << Lw, kw, mw, (kw - 1) if pw.use_shadow else 0)
-            weak_point = {"workload": pw.describe(args.operator, "weak"), "ms_per_step": round(msw, 4), "steps": sw,
-                          "warmup": ww, "GBs": round(bw / (msw * 1e-3) / 1e9, 2),
-                          "algorithmic_GBs": round(algorithmic_bytes(1 << Lw, kw, mw) / (msw * 1e-3) / 1e9, 2),
-                          "cg_iterations": int(mw), "E0_per_site": E0w.item() / Lw,
-                          "E0_per_site_closed_form": analytic_E0_per_site(Lw, 1.0),
-                          "one_gpu_anchor_ms": STORED_ANCHORS["weak_2p25_rows_k200_ms"],
-                          "weak_efficiency_vs_anchor": None if toy else round(STORED_ANCHORS["weak_2p25_rows_k200_ms"] / msw, 4)}
-            weak_point.update(pw.notes)
-            pw.release()
-        except Exception as exc:  # noqa: BLE001  (every rank runs the same code: the exception is collective)
-            weak_point = "failed: %s: %s" % (type(exc).__name__, str(exc)[:200])
-
-    # ---- N = 1, default workload: the live one-GPU anchors of the multi-GPU curves (outside the timed steps)
-    anchors = None
-    default_headline = world == 1 and not partitioned_path and not explicit and args.k is None and \
-        args.operator == "matrix-free" and args.reorth == "full"
-    if default_headline and not args.no_anchors and not dry:
-        prob_keep = prob
-        anchors = {}
-        free_b, total_b = torch.cuda.mem_get_info(dev)
-        for tag, La, ka, sa in (("weak_2p25_rows_k200", 25, 200, 3), ("strong_L28_k100", 28, 100, 2)):
-            need = 8.0 * (1 << La) * (ka + 8) * (1.25 if La == 25 else 1.0)
-            if need > 0.9 * total_b:
-                anchors[tag] = "skipped: needs %.0f GB of %.0f GB" % (need / 1e9, total_b / 1e9)
-                continue
-            try:
-                engine.BasisArena.release()
-                engine.Workspace.clear_cache()
-                torch.cuda.empty_cache()
-                pa = Problem(args, La, ka, 1, 0, dev, False, False)
-                dta, E0a, _ = pa.measure(sa, 1)
-                ma = pa.cg_iterations()
-                msa = dta / sa * 1e3
-                anchors[tag] = {"workload": pa.describe(), "ms_per_step": round(msa, 3), "steps": sa, "warmup": 1,
-                                "cg_iterations": int(ma), "bf16_shadow_of_basis": bool(pa.use_shadow),
-                                "GBs": round(traffic_model_bytes(1 << La, ka, ma, (ka - 1) if pa.use_shadow else 0) / (msa * 1e-3) / 1e9, 1),
-                                "algorithmic_GBs": round(algorithmic_bytes(1 << La, ka, ma) / (msa * 1e-3) / 1e9, 1),
-                                "E0_per_site_minus_closed_form": E0a.item() / La - analytic_E0_per_site(La, 1.0)}
-                pa.release()
-            except Exception as exc:  # noqa: BLE001
-                anchors[tag] = "failed: %s: %s" % (type(exc).__name__, str(exc)[:200])
-                engine.BasisArena.release()
-                torch.cuda.empty_cache()
-        prob = prob_keep
-        prob.activate()          # module-global primitive, shadow flag and reorth default back to the headline problem
+    # ---- beside the timed point: N > 1 default schedule / N = 1 anchors
+    anchors_in, anchors_src = load_anchors(args) if world > 1 else ({}, None)
+    strong_fp64, strong_matched, weak_point = multi_gpu_extras(args, ctx, pt, prob, anchors_in)
+    anchors = one_gpu_anchors(args, ctx, pt, prob)
 
     final_line = None
     if rank == 0:
-        out = {
-            "metric": "DRY RUN on CPU processes (gloo, torch test double of the slab kernels): control flow of the "
-                      "multi-rank bench only, not a measurement" if dry else
-                      "DominantSparseSymeig fwd+bwd ms & HBM GB/s (TFIM, fp64)" if args.reorth == "full" else
-                      "DominantSparseSymeig fwd+bwd GB/s, partial re-orthogonalisation option (TFIM, fp64; not the "
-                      "reference's schedule: it re-orthogonalises on every step)" if args.reorth == "partial" else
-                      "DominantSparseSymeig fwd+bwd GB/s, basis-free two-pass Lanczos option (TFIM, fp64; not the "
-                      "reference's full-reorthogonalisation algorithm)",
-            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling,
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": workload,
-                       "value_is": ("the OPTION's own bytes (every Lanczos step mat-vec 2 + three-term 4 + scale/store 2 "
-                                    "vectors; each of the %d re-orthogonalised steps the two passes over the basis, taken at "
-                                    "the mean step index; Ritz vector; backward as SURVEY 8d) / step time, all ranks"
-                                    % pr_run_steps) if args.reorth == "partial" else
-                                   ("the OPTION's own bytes (18 k + 11 m + 24 vectors) / step time, all ranks"
-                                    if args.reorth == "none" else
-                                    "HBM bytes the step's kernels move (traffic model: SURVEY 8d per-phase count with "
-                                    "the correction pass of %d Lanczos steps reading the bf16 shadow of the basis) / "
-                                    "step time, all ranks" % shadow_steps),
-                       "cg_iterations": int(m), "cg_form": "persistent single launch (x, r, d in registers)" if cg_persistent
-                       else "streaming (mat-vec, update, direction launches)",
-                       "traffic_model_bytes_per_step": total_bytes,
-                       "frac_of_hbm_peak": round(value / (HBM_PEAK_GBS * world), 4),
-                       "algorithmic_bytes_per_step": alg_bytes,
-                       "algorithmic_GBs": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 2),
-                       "algorithmic_GBs_note": "SURVEY 8d figure: bytes of the REFERENCE's algorithm (all-fp64 basis) / "
-                                               "step time; it may exceed the HBM peak because the implementation "
-                                               "moves fewer bytes -- not a roofline fraction",
-                       "ms_at_hbm_peak_for_algorithmic_bytes": round(alg_bytes / (HBM_PEAK_GBS * world * 1e9) * 1e3, 3),
-                       "bf16_shadow_of_basis": bool(prob.use_shadow), "lanczos_reorthogonalisation": args.reorth,
-                       **({"steps_reorthogonalised": pr_run_steps, "of": k - 1} if pr_run_steps is not None else {}),
-                       "E0_per_site": E0_site, "E0_per_site_closed_form": analytic_E0_per_site(L, 1.0),
-                       "dloss_dg": gl0,
-                       "adjoint_vs_reference_at_eps1e-7": ADJOINT_DEV_EPS7,
-                       "basis_placement_probe_us": [round(t, 1) for t in (engine.BasisArena.last_placement or [])]},
-        }
-        out["config"].update(notes)
-        if evidence is not None:
-            out["config"]["collectives"] = evidence
+        cfg = {"workload": workload, "value_is": value_is, "cg_iterations": int(m),
+               "cg_form": "persistent single launch (x, r, d in registers)" if cg_persistent
+               else "streaming (mat-vec, update, direction launches)",
+               "traffic_model_bytes_per_step": total_bytes,
+               "frac_of_hbm_peak": round(value / (HBM_PEAK_GBS * world), 4),
+               "algorithmic_bytes_per_step": alg_bytes,
+               "algorithmic_GBs": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 2),
+               "algorithmic_GBs_note": "SURVEY 8d figure: bytes of the REFERENCE's algorithm (all-fp64 basis) / step time; it "
+                                       "may exceed the HBM peak because the implementation moves fewer bytes -- not a "
+                                       "roofline fraction",
+               "ms_at_hbm_peak_for_algorithmic_bytes": round(alg_bytes / (HBM_PEAK_GBS * world * 1e9) * 1e3, 3),
+               "bf16_shadow_of_basis": prob_shadow, "shadow_policy": args.shadow,
+               "lanczos_reorthogonalisation": args.reorth,
+               **({"steps_reorthogonalised": pr_run_steps, "of": k - 1} if pr_run_steps is not None else {}),
+               "E0_per_site": E0_site, "E0_per_site_closed_form": analytic_E0_per_site(L, 1.0), "dloss_dg": gl0,
+               "adjoint_vs_reference_at_eps1e-7": ADJOINT_DEV_EPS7, "commit": _commit(),
+               "basis_placement_probe_us": [round(t, 1) for t in (engine.BasisArena.last_placement or [])]}
+        out = {"metric": _metric_name(args, ctx), "value": round(value, 2), "unit": "GB/s", "n_gpus": world,
+               "steps": pt.steps, "warmup": pt.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+               "scaling": pt.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": cfg}
+        cfg.update(notes)
+        if ctx.evidence is not None:
+            cfg["collectives"] = ctx.evidence
+            if ctx.staged:
+                cfg["collectives"]["note"] = "rehearsal: all ranks share GPU 0 (distinct_devices = 1 is expected)"
         if world > 1:
-            anchor_ms = STORED_ANCHORS["strong_L28_k100_ms"] if strong else STORED_ANCHORS["weak_2p25_rows_k200_ms"]
-            canonical = (not explicit and args.k is None and not dry)
-            out["config"]["one_gpu_anchor"] = {
-                "ms_per_step": anchor_ms, "source": STORED_ANCHORS["strong_source" if strong else "weak_source"],
-                "live": "the N = 1 line of the same sequence re-measures it (config.one_gpu_anchors)",
-                ("speedup_vs_one_gpu" if strong else "weak_efficiency"):
-                    round(anchor_ms / ms_per_step, 4) if canonical else None}
+            cfg["one_gpu_anchor"] = _speedups(pt, ms_per_step, prob_shadow, strong_fp64, strong_matched, anchors_in, anchors_src)
+            if strong_fp64 is not None:
+                cfg["strong_point_fp64_basis"] = strong_fp64
+            if strong_matched is not None:
+                cfg["strong_point_shadow_matched_k"] = strong_matched
             if weak_point is not None:
-                out["config"]["weak_scaling_point"] = weak_point
+                cfg["weak_scaling_point"] = weak_point
             if overlap_fb is not None:
-                out["config"]["overlap_premise_fallbacks"] = int(overlap_fb)
-        if world == 1 and not partitioned_path:
-            out["config"]["multi_gpu_schedule"] = (
-                "bench.py --gpus N (N > 1) times the STRONG point TFIM L=28, k=100 over N GPUs as value/ms_per_step and "
-                "reports the WEAK point (2^25 rows/GPU, k=200) as config.weak_scaling_point; their one-GPU anchors are "
-                "config.one_gpu_anchors of this line (speed-up at N = anchor ms / ms_per_step of the N-GPU line)")
+                cfg["overlap_premise_fallbacks"] = int(overlap_fb)
+        if world == 1 and not ctx.partitioned_path:
+            cfg["multi_gpu_schedule"] = (
+                "bench.py --gpus N (N > 1) times the STRONG point TFIM L=28, k=%d over N GPUs as value/ms_per_step (shadow "
+                "auto = on), then the same point with the all-fp64 correction pass, L=28 k=%d with the shadow, and the WEAK "
+                "point (2^25 rows/GPU, k=200); config.one_gpu_anchors of this line are their one-GPU sides, each with the "
+                "arithmetic of its correction pass -- speed-ups divide like by like only"
+                % (STRONG_K, STRONG_K_SHADOW_MATCHED))
         if anchors is not None:
-            out["config"]["one_gpu_anchors"] = anchors
-            out["config"]["one_gpu_anchors_stored"] = STORED_ANCHORS
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        pmc = live_pmc
-        if live_pmc_note:
-            out["config"]["pmc_live"] = live_pmc_note
+            cfg["one_gpu_anchors"] = anchors
+        import glob
+        stored = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+        tpath = stored[-1] if stored else ""       # the newest committed round file
+        pmc = ctx.live_pmc
+        if ctx.live_pmc_note:
+            cfg["pmc_live"] = ctx.live_pmc_note
         if pmc is None and os.path.exists(tpath):
             try:
                 pmc = json.load(open(tpath))
-            except Exception:
+            except Exception:  # noqa: BLE001
                 pmc = None
-        if not partitioned_path and L == 20 and k == 200 and args.operator == "matrix-free":
+        if not ctx.partitioned_path and L == 20 and k == 200 and args.operator == "matrix-free":
             # the traffic model against the counters: bytes that crossed the HBM interface in a profiled run of this step
             if pmc and pmc.get("_total_hbm_bytes_per_step"):
                 real = float(pmc["_total_hbm_bytes_per_step"])
-                out["config"]["pmc_hbm_bytes_per_step"] = real
-                out["config"]["pmc_source"] = ("rocprofv3 PMC FETCH_SIZE/WRITE_SIZE measured in THIS run (child processes, same box)"
-                                               if pmc.get("_commit") == "live" else
-                                               "rocprofv3 PMC FETCH_SIZE/WRITE_SIZE at commit %s (committed file)" % pmc.get("_commit", "?"))
-                out["config"]["pmc_GBs"] = round(real / (ms_per_step * 1e-3) / 1e9, 2)
-                out["config"]["frac_of_hbm_peak_pmc_traffic"] = round(real / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-        if ms_basisfree is not None:
-            out["config"]["basisfree_two_pass_lanczos"] = {
-                "ms_per_step": round(ms_basisfree, 4), "E0_rel_dev_vs_full_reorth": bf_dev[0],
-                "dloss_dg_rel_dev_vs_full_reorth": bf_dev[1],
-                "note": "reorth='none' option: no stored basis, no re-orthogonalisation; not the reference's algorithm"}
-        if ms_partial is not None:
-            out["config"]["partial_reorth_lanczos"] = {
-                "ms_per_step": round(ms_partial, 4), "steps_reorthogonalised": pr_steps, "of": k - 1,
-                "E0_rel_dev_vs_full_reorth": pr_dev[0], "dloss_dg_rel_dev_vs_full_reorth": pr_dev[1],
-                "note": "reorth='partial' option (Simon's partial re-orthogonalisation, threshold 1e-10): same stored "
-                        "basis, re-orthogonalised only on the steps the omega recurrence selects; not the reference's "
-                        "schedule (Lanczos.py:66 re-orthogonalises on every step), never the headline"}
-        if ms_fp64 is not None:
-            out["config"]["ms_per_step_fp64_basis"] = round(ms_fp64, 4)
-            out["config"]["GBs_fp64_basis"] = round(alg_bytes / (ms_fp64 * 1e-3) / 1e9, 2)
-        if use_events and launches[0] > 0 and launches[1] > 0:
-            dots_b, axpy_b = reorth_bytes_per_launch(nloc, k)
-            # the correction pass is priced with the bytes IT reads: bf16 shadow (2 bytes/element) when it is on
-            axpy_real = axpy_b if not prob.use_shadow else \
-                sum(2.0 * i + 16.0 for i in range(1, k)) / (k - 1) * nloc
-            per = {
-                "k_rdots": (dots_b, total_ms[0] / launches[0], launches[0]),
-                "k_axpy_norm": (axpy_real, total_ms[1] / launches[1], launches[1]),
-            }
-            name = max(per, key=lambda kk: per[kk][1] * per[kk][2])
-            b, ms, cnt = per[name]
-            traffic = None
-            if pmc and L == 20 and k == 200:
-                traffic = pmc.get(name, {}).get("hbm_bytes_per_launch")
-            lp, fb = lp_stats if lp_stats is not None else (launches[1] if prob.use_shadow else 0, 0)
-            out["roofline"] = {
-                "kernel": name, "bound": "hbm", "achieved": round(b / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_commit": pmc.get("_commit") if (pmc and traffic) else None,
-                "avg_launch_ms": round(ms, 5), "launches": int(cnt), "launches_per_step": int(cnt) // max(ev_steps, 1),
-                "algorithmic_bytes_per_launch": b,
-                "other": {kk: {"avg_launch_ms": round(v[1], 5), "achieved_GBs": round(v[0] / (v[1] * 1e-3) / 1e9, 1),
-                               "bytes_per_launch": v[0]}
-                          for kk, v in per.items() if kk != name},
-                "spmv_avg_launch_ms": round(total_ms[2] / max(launches[2], 1), 5),
-                "measured": "HIP events on the launch stream, %d instrumented steps run right after the timed "
-                            "region (%.3f ms/step with events)" % (ev_steps, dt_instr / ev_steps * 1e3),
-                "note": ("k_axpy_norm streams the bf16 shadow of the basis on %d of %d steps (fp64 fallback %d) and is "
-                         "priced with the bytes it reads (2 per basis element + r in and out), not with SURVEY 8d's "
-                         "8 per element" % (lp, lp + fb, fb)) if not partitioned_path
-                        else "rank 0's local kernels in the row-partitioned run",
-            }
-        if not args.no_extras and world == 1 and not partitioned_path and not big:
+                cfg["pmc_hbm_bytes_per_step"] = real
+                cfg["pmc_source"] = ("rocprofv3 PMC FETCH_SIZE/WRITE_SIZE measured in THIS run (child processes, same box)"
+                                     if pmc.get("_commit") == "live" else
+                                     "rocprofv3 PMC FETCH_SIZE/WRITE_SIZE at commit %s (committed file %s)"
+                                     % (pmc.get("_commit", "?"), os.path.basename(tpath)))
+                cfg["pmc_GBs"] = round(real / (ms_per_step * 1e-3) / 1e9, 2)
+                cfg["frac_of_hbm_peak_pmc_traffic"] = round(real / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        for key in ("basisfree_two_pass_lanczos", "partial_reorth_lanczos"):
+            if key in extras:
+                cfg[key] = extras[key]
+        if "ms_per_step_fp64_basis" in extras:
+            cfg["ms_per_step_fp64_basis"] = extras["ms_per_step_fp64_basis"]
+            cfg["GBs_fp64_basis"] = round(alg_bytes / (extras["ms_per_step_fp64_basis"] * 1e-3) / 1e9, 2)
+        if ev is not None:
+            roof = _roofline(ctx, pt, prob, ev, pmc, lp_stats)
+            if roof is not None:
+                out["roofline"] = roof
+        if not args.no_extras and world == 1 and not ctx.partitioned_path and not pt.big:
             try:
-                ceil = measured_ceilings(dev)
-                out["config"]["measured_ceilings"] = ceil
+                ceil = measured_ceilings(ctx.dev)
+                cfg["measured_ceilings"] = ceil
                 if "roofline" in out:
                     out["roofline"]["frac_of_measured_read_ceiling"] = round(out["roofline"]["achieved"] / ceil["read_GBs"], 4)
             except Exception as exc:  # noqa: BLE001
-                out["config"]["measured_ceilings"] = "failed: %s" % exc
+                cfg["measured_ceilings"] = "failed: %s" % exc
             try:
-                out["config"]["config3"] = c3_figures(dev)
+                cfg["config3"] = c3_figures(ctx.dev)
             except Exception as exc:  # noqa: BLE001
-                out["config"]["config3"] = "failed: %s" % exc
-        if not args.no_cpu_baseline and world == 1 and not big:
-            ncpu = os.cpu_count() or 1
-            host = "%s, os.cpu_count()=%d" % (_cpu_model(), ncpu)
-            want = [min(int(t), ncpu) for t in args.cpu_threads.split(",") if t] or [min(8, ncpu)]
-            if args.cpu_sample:
-                # bounded sample of the same workload: same L, fewer Lanczos vectors, capped CG
-                _, r = cpu_baseline(L, args.cpu_k, args.cpu_cg_cap, want[0])
-                out["cpu_baseline"] = {
-                    "value": r["GBs"], "unit": "GB/s", "cores": r["threads"], "kind": "port",
-                    "sample": "oracle (torch-CPU port of reference Lanczos.py/CG.py/TFIM.H), TFIM L=%d, k=%d Lanczos "
-                              "vectors, CG capped at %d iterations (ran %d), fwd+bwd %.1f s, table build %.1f s not "
-                              "timed; GB/s of the algorithmic bytes (SURVEY 8d), which is what a CPU run moves; host: %s"
-                              % (L, r["k"], args.cpu_cg_cap, r["cg_iterations"], r["fwd_bwd_s"], r["table_build_s"], host)}
-            else:
-                # the FULL configuration (k as on the GPU, CG to the reference's tolerance)
-                model, runs = None, []
-                for th in want:
-                    model, r = cpu_baseline(L, k, None, th, model=model)
-                    runs.append(r)
-                best = max(runs, key=lambda r: r["GBs"])
-                out["cpu_baseline"] = {
-                    "value": best["GBs"], "unit": "GB/s", "cores": best["threads"], "kind": "port",
-                    "sample": "oracle (torch-CPU port of reference Lanczos.py/CG.py/TFIM.H incl. the gather-table "
-                              "mat-vec) on the FULL workload: TFIM L=%d, k=%d, CG to ||r||<1e-7 (%d iterations): fwd "
-                              "%.1f s + bwd %.1f s; GB/s of the algorithmic bytes (SURVEY 8d); host: %s"
-                              % (L, k, best["cg_iterations"], best["fwd_s"], best["bwd_s"], host),
-                    "ms_per_step": round(best["fwd_bwd_s"] * 1e3, 1), "runs": runs}
+                cfg["config3"] = "failed: %s" % exc
+        if not args.no_cpu_baseline and world == 1 and not pt.big and not ctx.staged:
+            out["cpu_baseline"] = _cpu_baseline_block(args, pt)
         # RCCL / HIP runtime banners go through C stdio: flush them first so the JSON is the last line
         import ctypes
         try:
             ctypes.CDLL(None).fflush(None)
-        except Exception:
+        except Exception:  # noqa: BLE001
             pass
         sys.stdout.flush()
         final_line = json.dumps(out)
-    if partitioned_path:
+    if ctx.partitioned_path:
         import torch.distributed as dist
         dist.barrier()
+        prob.release()
+        try:
+            from dominantsparseeigenad_amd import partitioned
+            partitioned.NativeComm.release_all()
+        except Exception:  # noqa: BLE001
+            pass
         dist.destroy_process_group()
     if final_line is not None:
         print(final_line, flush=True)

@@ -140,6 +140,14 @@ def symeigLanczos(A, k, device=torch.device("cpu"), extreme="both", *, sparse=Fa
         # CGS2: the Gram-Schmidt pass of Lanczos.py:66 applied twice per step (an option the reference lacks; device
         # operators and callables on the GPU) -- same Krylov process, orthogonality of the basis at rounding level even
         # next to an invariant subspace
+        part = engine.native_of(A) if sparse else None
+        if torch.device(device).type != "cuda":
+            raise NotImplementedError("reorth='twice' runs on the GPU (native operators and callables); the host path "
+                                      "re-orthogonalises once per step like the reference")
+        if part is not None and getattr(part, "partitioned", False) and \
+                (part.world > 1 or part.force_driver or part._local_native() is None):
+            raise NotImplementedError("reorth='twice' is not implemented by the row-partitioned step drivers "
+                                      "(they re-orthogonalise once per step)")
         prev, engine.REORTH_PASSES = engine.REORTH_PASSES, 2
         try:
             return symeigLanczos(A, k, device, extreme, sparse=sparse, dim=dim, q0=q0, reorth="full")

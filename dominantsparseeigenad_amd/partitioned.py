@@ -267,6 +267,37 @@ class TorchDistComm:
         self.sendrecv([(src[j * chunk:(j + 1) * chunk], dst[j * chunk:(j + 1) * chunk], j) for j in range(P) if j != me])
 
 
+class HostStagedComm(TorchDistComm):
+    """The same collectives staged through the host around each call, for a process group whose backend is not
+    stream-ordered on device tensors (gloo): several ranks SHARING ONE GPU -- RCCL refuses two ranks on a device --
+    which is how the multi-rank paths (P = 2, 4, 8 geometry, library driver through the callback communicator) run on
+    real slab kernels on a one-GPU box: the tests of tests/test_gpu_partitioned.py and ``bench.py --host-staged``.
+    A transport for rehearsals, not for measurements."""
+
+    def allreduce(self, t):
+        h = t.cpu()
+        if self.world > 1:
+            dist.all_reduce(h, group=self.group)
+        t.copy_(h)
+
+    def sendrecv(self, items):
+        hs = [(s.cpu(), torch.empty(r.shape, dtype=r.dtype), peer) for s, r, peer in items]
+        super().sendrecv(hs)
+        for (_, dst, _), (_, src, _) in zip(items, hs):
+            dst.copy_(src)
+
+    def all_to_all(self, src, dst):
+        hs = src.cpu()
+        hd = torch.empty_like(hs)
+        super().all_to_all(hs, hd)
+        dst.copy_(hd)
+
+    def all_gather(self, slab, full):
+        hf = torch.empty(full.shape, dtype=full.dtype)
+        super().all_gather(slab.cpu(), hf)
+        full.copy_(hf)
+
+
 # =========================================================================== library-side communicator
 def _device_view(ptr, count, device):
     """zero-copy fp64 torch tensor over ``count`` doubles of device memory at ``ptr`` (used by the callback
@@ -290,11 +321,35 @@ class NativeComm:
         host-staged gloo communicator of the one-GPU tests, MPI wrappers ...) as blocking callbacks.
     """
 
-    def __init__(self, handle, rank, world, kind, keep=()):
+    # One communicator pair per (process group, device) for the life of the process: operators are built freely
+    # (replica operators, bench problems, sweeps) and must not each cost a process group and an RCCL communicator.
+    _cache = {}
+
+    def __init__(self, handle, rank, world, kind, keep=(), xgroup=None):
         self.handle, self.rank, self.world, self.kind = handle, rank, world, kind
         self._keep = keep            # ctypes callbacks / process groups that must outlive the handle
+        self._xgroup = xgroup        # exchange process group created HERE (close() destroys it), else None
+
+    def close(self):
+        """destroy the library handle and the exchange process group this object created (idempotent)"""
+        try:
+            if getattr(self, "handle", None):
+                from . import _lib
+                _lib.load().dsea_comm_destroy(self.handle)
+        except Exception:
+            pass
+        self.handle = None
+        xg, self._xgroup = getattr(self, "_xgroup", None), None
+        if xg is not None:
+            try:
+                if dist.is_initialized():
+                    dist.destroy_process_group(xg)
+            except Exception:
+                pass
 
     def __del__(self):
+        # the handle only: tearing a process group down from a finaliser (interpreter exit, arbitrary order across
+        # ranks) is not safe -- ``close()`` / ``release_all()`` do that explicitly
         try:
             if getattr(self, "handle", None):
                 from . import _lib
@@ -302,6 +357,18 @@ class NativeComm:
                 self.handle = None
         except Exception:
             pass
+
+    @classmethod
+    def release_all(cls):
+        """close every cached communicator pair (call before ``dist.destroy_process_group()``; operators built on
+        them must be gone)"""
+        for nc in list(cls._cache.values()):
+            nc.close()
+        cls._cache.clear()
+
+    @staticmethod
+    def _is_world(group):
+        return group is None or group is dist.group.WORLD
 
     @staticmethod
     def _torch_comm_ptr(group, device):
@@ -314,18 +381,31 @@ class NativeComm:
         return int(backend._comm_ptr())
 
     @classmethod
-    def adopt_torch(cls, group, device):
+    def adopt_torch(cls, group, device, exchange_group=None):
+        """``exchange_group``: a second process group over the same ranks for the slab exchange.  When omitted it is
+        created here -- ``dist.new_group`` is collective over the WHOLE world, so that is only done when ``group`` IS
+        the world; for a sub-group the caller passes one (or ``for_torch_group`` lets the library create its own pair,
+        which needs a broadcast inside the group only)."""
         from . import _lib
         lib = _lib.load()
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        ranks = dist.get_process_group_ranks(group if group is not None else dist.group.WORLD)
-        xgroup = dist.new_group(ranks=ranks, backend="nccl") if world > 1 else group
+        made = None
+        if world > 1:
+            if exchange_group is None:
+                if not cls._is_world(group):
+                    raise ValueError("adopt_torch on a sub-group needs exchange_group= (dist.new_group is collective "
+                                     "over the whole world)")
+                ranks = dist.get_process_group_ranks(dist.group.WORLD)
+                exchange_group = made = dist.new_group(ranks=ranks, backend="nccl")
+            xgroup = exchange_group
+        else:
+            xgroup = group
         coll = cls._torch_comm_ptr(group, device)
         xchg = cls._torch_comm_ptr(xgroup, device) if world > 1 else coll
         h = c_void_p()
         _lib.check(lib.dsea_comm_adopt(c_void_p(coll), c_void_p(xchg), rank, world, byref(h)), "dsea_comm_adopt")
         return cls(h, rank, world, "rccl (adopted from torch.distributed: %s)" %
-                   ("two communicators" if xchg != coll else "one communicator"), keep=(group, xgroup))
+                   ("two communicators" if xchg != coll else "one communicator"), keep=(group, xgroup), xgroup=made)
 
     @classmethod
     def own(cls, group, device):
@@ -347,17 +427,35 @@ class NativeComm:
         return cls(h, rank, world, "rccl (library-owned, two communicators)")
 
     @classmethod
-    def for_torch_group(cls, group, device):
-        """RCCL communicator pair for ``group``: adopted from torch where torch exposes its ncclComm_t, otherwise created
-        by the library (the choice depends only on the software stack, so every rank takes the same branch).
+    def for_torch_group(cls, group, device, exchange_group=None):
+        """RCCL communicator pair for ``group`` on ``device``, CACHED per (group, device): adopted from torch where torch
+        exposes its ncclComm_t and the exchange group is available (``exchange_group=``, or ``group`` is the world so
+        that it can be created collectively), otherwise created by the library from ids broadcast inside ``group``
+        (the choice depends only on the software stack and on the arguments, so every rank takes the same branch).
         ``DSEA_COMM=own|adopt`` forces one."""
         import os
+        device = torch.device(device)
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
         mode = os.environ.get("DSEA_COMM", "")
+        key = ("WORLD" if cls._is_world(group) else id(group), str(device), mode,
+               id(exchange_group) if exchange_group is not None else None)
+        hit = cls._cache.get(key)
+        if hit is not None and hit.handle:
+            return hit
         backend_cls = getattr(torch._C._distributed_c10d, "ProcessGroupNCCL", None)
         can_adopt = backend_cls is not None and hasattr(backend_cls, "_comm_ptr")
-        if mode == "own" or (mode != "adopt" and not can_adopt):
-            return cls.own(group, device)
-        return cls.adopt_torch(group, device)
+        adoptable = can_adopt and (exchange_group is not None or cls._is_world(group) or dist.get_world_size(group) == 1)
+        if mode == "own" or not adoptable:
+            if mode == "adopt":
+                raise RuntimeError("DSEA_COMM=adopt: torch's communicators cannot be adopted here (%s)" %
+                                   ("no ProcessGroupNCCL._comm_ptr in this torch build" if not can_adopt else
+                                    "sub-group without exchange_group="))
+            nc = cls.own(group, device)
+        else:
+            nc = cls.adopt_torch(group, device, exchange_group)
+        cls._cache[key] = nc
+        return nc
 
     @classmethod
     def from_python(cls, comm, device):
@@ -560,7 +658,7 @@ class PartitionedOperator:
             return NativeComm.from_python(comm, self.device)
         if type(comm) is TorchDistComm:
             if dist.get_backend(comm.group) == "nccl":
-                return NativeComm.for_torch_group(comm.group, self.device)
+                return NativeComm.for_torch_group(comm.group, self.device, getattr(self, "_exchange_group", None))
             return None      # gloo on device tensors is not stream-ordered: Python driver with explicit staging
         if all(hasattr(comm, a) for a in ("allreduce", "all_to_all", "sendrecv")):
             return NativeComm.from_python(comm, self.device)
@@ -820,8 +918,12 @@ class PartitionedTFIMOperator(PartitionedOperator):
     row-partitioned over the P = 2^p ranks of ``group``; ``g`` is the (1,) parameter tensor on this rank's
     device (same value on all ranks).  Attribute names follow the reference model class / ``TFIMOperator``."""
 
-    def __init__(self, L, g, device, backend=None, group=None, comm=None, overlap="auto"):
+    def __init__(self, L, g, device, backend=None, group=None, comm=None, overlap="auto", exchange_group=None):
+        """``exchange_group``: a second NCCL process group over the ranks of ``group`` for the slab exchange of the
+        library driver (needed only when ``group`` is a sub-group of the world and torch's communicators are to be
+        adopted; see ``NativeComm.for_torch_group``)."""
         comm = comm if comm is not None else TorchDistComm(group)
+        self._exchange_group = exchange_group
         p = int(round(np.log2(comm.world)))
         if (1 << p) != comm.world:
             raise ValueError("the TFIM row partition needs a power-of-two world size, got %d" % comm.world)
@@ -835,7 +937,7 @@ class PartitionedTFIMOperator(PartitionedOperator):
             backend = HipBackend(nloc, device)
         backend.attach_tfim(self.L, self.Lloc, comm.rank * nloc, g)
         super().__init__(1 << self.L, nloc, comm.rank * nloc, device, comm, backend)
-        self.g = g
+        self._g = g
         # Overlap of the slab exchange with the dots / correction passes (both exchange forms): the remote part
         # of u = A r' is then taken from the UN-corrected r (its exchange starts before the coefficients c are
         # known).  r - r' = Q c lies at the 1e-14 relative level per element while |c_j| <= ~1e-15 ||r||, the
@@ -860,13 +962,39 @@ class PartitionedTFIMOperator(PartitionedOperator):
         if self._ncomm is not None:
             self._create_pops()
 
+    # the parameter tensor (reference ``model.g``, TFIM.py; E0.py:95-96).  The kernels read g through its device
+    # pointer, so in-place updates are seen at once; REBINDING ``op.g = new_tensor`` (the reference's ``model.g = ...``
+    # pattern) rebuilds the slab operator and the library-side partitioned operators around the new tensor.
+    @property
+    def g(self):
+        return self._g
+
+    @g.setter
+    def g(self, value):
+        if value is self._g:
+            return
+        if not torch.is_tensor(value) or value.dtype != F64 or value.device != self._g.device:
+            raise ValueError("g must be a float64 tensor on %s" % self._g.device)
+        self._g = value
+        local = getattr(self.be, "op", None)
+        if local is not None and hasattr(type(local), "g"):
+            local.g = value                                  # operators.TFIMOperator: new handle on the new pointer
+        elif hasattr(self.be, "attach_tfim"):
+            self.be.attach_tfim(self.L, self.Lloc, self.rank * self.nloc, value)
+        if getattr(self, "_replica", None) is not None:
+            self._replica = None
+        if self._pop:
+            self._destroy_pops()
+            self._create_pops()
+
     def _create_pops(self):
         """library-side partitioned operators for H and dH/dg (they share the exchange scratch and the side stream)"""
         from . import _lib
         lib = self.be.lib
         nd = int(lib.dsea_pop_tfim_scratch_doubles(self.L, self.world)) if self.p > 0 else 0
-        self._scratch = self.be.empty(max(nd, 2))
-        self._side_stream = torch.cuda.Stream(device=self.device) if self.p > 0 else None
+        if getattr(self, "_scratch", None) is None:
+            self._scratch = self.be.empty(max(nd, 2))
+            self._side_stream = torch.cuda.Stream(device=self.device) if self.p > 0 else None
         side = c_void_p(self._side_stream.cuda_stream) if self._side_stream is not None else c_void_p(None)
         gdev = self.g.detach()
         self._g_keep = gdev
@@ -1081,8 +1209,9 @@ class PartitionedStencil3Operator(PartitionedOperator):
     examples/schrodinger1D.py:18-27) on a grid of n points cut into contiguous slabs; ``potential_slab`` is this
     rank's part of the parameter tensor.  One halo element travels to each neighbour per mat-vec."""
 
-    def __init__(self, n, h, potential_slab, device=None, backend=None, group=None, comm=None):
+    def __init__(self, n, h, potential_slab, device=None, backend=None, group=None, comm=None, exchange_group=None):
         comm = comm if comm is not None else TorchDistComm(group)
+        self._exchange_group = exchange_group
         rows, off = stencil_partition(n, comm.world, comm.rank)
         if rows < 1:
             raise ValueError("more ranks than grid points")

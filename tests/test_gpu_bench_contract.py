@@ -94,3 +94,63 @@ def test_headline_line_measures_its_pmc_traffic_live():
     assert 0.98 * r["algorithmic_bytes_per_launch"] < r["traffic"] < 1.05 * r["algorithmic_bytes_per_launch"]
     assert "THIS run" in c["pmc_source"] and 0.9 < c["pmc_hbm_bytes_per_step"] / c["traffic_model_bytes_per_step"] < 1.15
     assert d["value"] <= 8000.0 and 0 < r["frac"] <= 1.0
+
+
+def _bench(argv, env=None, timeout=1500):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + argv
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=e, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1 and out.stdout.strip().splitlines()[-1] == lines[0]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_bench_multi_gpu_branch_rehearsal_on_hip_kernels(world):
+    """``bench.py --gpus N --host-staged``: the REAL N > 1 branch of the script (self-launch of N workers, row-partitioned
+    operator on the HIP slab kernels with the library-side driver through the callback communicator, collective fallback
+    decisions, overlapped-exchange self-check, strong point + fp64 / shadow-matched extras + weak point, rank evidence,
+    one final JSON line) with the N ranks sharing the one GPU of this box at toy sizes.  N = 8 is the p = 3 geometry of
+    BASELINE configs[4]: transposed exchange with three far bits.  A rehearsal, labelled as such -- no measurement."""
+    d = _bench(["--gpus", str(world), "--host-staged", "--steps", "2", "--warmup", "1"])
+    assert d["metric"].startswith("REHEARSAL") and d["n_gpus"] == world and d["scaling"] == "strong"
+    assert "roofline" not in d or d["roofline"]["frac"] <= 1.0
+    cfg = d["config"]
+    assert cfg["partitioned_driver"].startswith("library (callbacks"), cfg["partitioned_driver"]
+    assert ("transposed" if world >= 4 else "pairwise") in cfg["slab_exchange"] and "overlapped" in cfg["slab_exchange"]
+    assert cfg["distributed_self_check"].startswith("overlapped exchange verified"), cfg["distributed_self_check"]
+    assert abs(cfg["E0_per_site"] - cfg["E0_per_site_closed_form"]) < 1e-9
+    col = cfg["collectives"]
+    assert col["world_size"] == world and sorted(r["rank"] for r in col["ranks"]) == list(range(world))
+    assert len({r["pid"] for r in col["ranks"]}) == world and col["distinct_devices"] == 1
+    for key in ("strong_point_fp64_basis", "strong_point_shadow_matched_k", "weak_scaling_point"):
+        rec = cfg[key]
+        assert isinstance(rec, dict), (key, rec)
+        assert rec["ms_per_step"] > 0 and abs(rec["E0_per_site"] - rec["E0_per_site_closed_form"]) < 1e-9, (key, rec)
+        assert rec["partitioned_driver"].startswith("library (callbacks") and "verified" in rec["distributed_self_check"]
+    assert cfg["strong_point_fp64_basis"]["bf16_shadow_of_basis"] is False and cfg["bf16_shadow_of_basis"] is True
+    anchor = cfg["one_gpu_anchor"]
+    assert "speedup_vs_one_gpu" not in anchor and "speedup_vs_one_gpu_fp64_basis" in anchor
+    assert "speedup_vs_one_gpu_k80_shadow" in anchor
+
+
+@pytest.mark.parametrize("mode,word", [("own", "library-owned"), ("adopt", "adopted")])
+def test_bench_partitioned_branch_with_library_owned_and_adopted_rccl_communicators(mode, word):
+    """DSEA_COMM=own|adopt through bench.py's partitioned branch (one rank over RCCL: the communicator pair is created by
+    dsea_comm_unique_id + dsea_comm_init_rank, or adopted from torch's ProcessGroupNCCL) -- the fallback a torch build
+    without ProcessGroupNCCL._comm_ptr would take must not be met first on the 8-GPU node."""
+    d = _bench(["--force-partitioned", "--L-local", "14", "--k", "48", "--steps", "2", "--warmup", "1",
+                "--no-cpu-baseline", "--no-extras"], env={"DSEA_COMM": mode})
+    cfg = d["config"]
+    assert word in cfg["partitioned_driver"] and cfg["partitioned_driver"].startswith("library (rccl"), cfg["partitioned_driver"]
+    assert abs(cfg["E0_per_site"] - cfg["E0_per_site_closed_form"]) < 1e-9
+
+
+def test_bench_shadow_switch():
+    """--shadow off: the all-fp64 correction pass is what is timed and what the line says"""
+    d = _bench(["--L-local", "14", "--k", "48", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras",
+                "--shadow", "off"])
+    assert d["config"]["bf16_shadow_of_basis"] is False and d["config"]["shadow_policy"] == "off"
+    assert "0 Lanczos steps reading the bf16 shadow" in d["config"]["value_is"]

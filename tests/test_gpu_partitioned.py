@@ -2,11 +2,13 @@
   * world_size 1 over "nccl" (= RCCL): the whole distributed code path with real kernels and real RCCL calls --
     at the FULL slab size of the headline configuration (2^20 rows, k = 200, bf16 shadow on, non-split kernels)
     against the reference-generated L = 20 scalars, through the reference API;
-  * world_size 2 and 4, all ranks on cuda:0, collectives over gloo staged through the host (RCCL refuses two
+  * world_size 2, 4 and 8, all ranks on cuda:0, collectives over gloo staged through the host (RCCL refuses two
     ranks on one device): real slab operators (L_local < L, row_offset != 0), real phase kernels; 2 ranks =
-    pairwise slab exchange, 4 ranks = transposed all-to-all form with the HIP flip-sum kernel; first and second
-    order through the reference API against the reference's fixtures; the 3-point stencil with halo exchange.
-The 8-GPU run itself is the driver's; its logic is also covered by tests/test_partitioned_gloo.py."""
+    pairwise slab exchange, 4 and 8 ranks = transposed all-to-all form with the HIP flip-sum kernel (8 ranks = the
+    p = 3 geometry of BASELINE configs[4]: three far bits, (max(3,p)+1)-slab scratch, overlapped exchange); first and
+    second order through the reference API against the reference's fixtures; the 3-point stencil with halo exchange.
+The 8-GPU run itself is the driver's; its logic is also covered by tests/test_partitioned_gloo.py and by the
+host-staged rehearsal of bench.py's N > 1 branch (tests/test_gpu_bench_contract.py)."""
 import os
 import socket
 import sys
@@ -37,31 +39,7 @@ def _free_port():
 
 def _host_staged_comm():
     """gloo is not stream-ordered for device tensors: stage through the host around each collective."""
-    from dominantsparseeigenad_amd.partitioned import TorchDistComm
-
-    class HostStagedComm(TorchDistComm):
-        def allreduce(self, t):
-            h = t.cpu()
-            dist.all_reduce(h)
-            t.copy_(h)
-
-        def sendrecv(self, items):
-            hs = [(s.cpu(), torch.empty(r.shape, dtype=r.dtype), peer) for s, r, peer in items]
-            super().sendrecv(hs)
-            for (_, dst, _), (_, src, _) in zip(items, hs):
-                dst.copy_(src)
-
-        def all_to_all(self, src, dst):
-            hs = src.cpu()
-            hd = torch.empty_like(hs)
-            super().all_to_all(hs, hd)
-            dst.copy_(hd)
-
-        def all_gather(self, slab, full):
-            hf = torch.empty(full.shape, dtype=full.dtype)
-            super().all_gather(slab.cpu(), hf)
-            full.copy_(hf)
-
+    from dominantsparseeigenad_amd.partitioned import HostStagedComm
     return HostStagedComm()
 
 
@@ -252,7 +230,8 @@ def _run(world, backend, case, *args):
 
 
 @pytest.mark.parametrize("world,backend,overlap", [(1, "nccl", False), (2, "gloo", False), (4, "gloo", False),
-                                                   (2, "gloo", True), (4, "gloo", True)])
+                                                   (2, "gloo", True), (4, "gloo", True), (8, "gloo", False),
+                                                   (8, "gloo", True)])
 def test_partitioned_hip_backend(world, backend, overlap):
     """overlap: the step that starts the slab exchange of the un-corrected r on the side stream before the dots pass
     (form_r snapshot, premise check, side-stream join) on the HIP slab kernels -- pairwise form at 2 ranks, transposed
@@ -293,9 +272,9 @@ def test_full_slab_world1_over_rccl_matches_reference_L20_scalars(force_driver):
     assert o["resid"] < 1e-9
 
 
-@pytest.mark.parametrize("world,tag", [(2, "L10_k300_g1.0"), (4, "L12_k200_g1.0")])
+@pytest.mark.parametrize("world,tag", [(2, "L10_k300_g1.0"), (4, "L12_k200_g1.0"), (8, "L12_k200_g1.0")])
 def test_reference_api_second_order_on_partitioned_hip_operator(world, tag):
-    """E0, psi, dE0, d2E0, loss gradient and chi_F (E0.py:53-67, chiF.py:40-53) with the vectors cut over 2 / 4
+    """E0, psi, dE0, d2E0, loss gradient and chi_F (E0.py:53-67, chiF.py:40-53) with the vectors cut over 2 / 4 / 8
     ranks: the re-entrant distributed backward against the reference's own outputs."""
     gd = np.load(os.path.join(GOLDEN, "tfim_" + tag + ".npz"))
     ret = _run(world, "gloo", "_case_api_tfim", tag, True, True)
@@ -338,7 +317,8 @@ def test_replicated_cg_on_hip_slabs_matches_partitioned_cg():
     assert abs(repl[0][3] - part[0][3]) <= 1                                # iteration counts (different summation orders)
 
 
-@pytest.mark.parametrize("world,backend,overlap", [(1, "nccl", False), (2, "gloo", True), (4, "gloo", True), (4, "gloo", False)])
+@pytest.mark.parametrize("world,backend,overlap", [(1, "nccl", False), (2, "gloo", True), (4, "gloo", True), (4, "gloo", False),
+                                                   (8, "gloo", True), (8, "gloo", False)])
 def test_library_driver_equals_python_driver(world, backend, overlap):
     """include/dsea.h "row-partitioned solvers": dsea_pop_lanczos_run / dsea_pop_cg_run issue the slab kernels AND the
     collectives from inside the library (RCCL at world size 1; caller-supplied callbacks -- host-staged gloo -- for
@@ -357,7 +337,7 @@ def test_library_driver_equals_python_driver(world, backend, overlap):
         assert "callbacks" in lib_run[0][4]
 
 
-@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (4, "gloo")])
+@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (4, "gloo"), (8, "gloo")])
 def test_library_driver_partial_reorthogonalisation(world, backend):
     """dsea_ws_set_partial_reorth on the row-partitioned library driver: the estimates take the GLOBAL norm (one more scalar
     all-reduce per step), every rank takes the same decisions, the collectives are issued on every step (zeros on the
@@ -410,7 +390,7 @@ def test_library_owned_rccl_communicators_world1():
     assert own[0][0] == adopt[0][0] and own[0][2] == adopt[0][2] and np.array_equal(own[0][1], adopt[0][1])
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_overlap_premise_is_checked_on_the_device_and_a_violation_repeats_the_run(world):
     """The overlapped exchange sends the UN-corrected r; its premise max|c_j| <= tau ||r|| is evaluated by a kernel each
     step and read ONCE after the run (dsea_pop_lanczos_status -> DSEA_ERR_PREMISE), not by a host round trip per step.

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Random configurations of the row-partitioned path on ONE GPU (ranks share the device, collectives staged through
-the host over gloo): world size, chain length, Krylov dimension (k = 40 INCLUDED), coupling, overlapped exchange,
+the host over gloo): world size (2, 4, 8), chain length, Krylov dimension (k = 40 INCLUDED), coupling, overlapped exchange,
 replicated CG -- against the single-device path on the same synthetic vectors, JUDGED AGAINST THE SINGLE-DEVICE PATH'S
 OWN SPREAD, at the reference's CG tolerance (eps = 1e-7, CG.py:25) and at the tight one (1e-12).
 
@@ -127,8 +127,10 @@ def main():
     rng = np.random.RandomState(args.seed)
     cases = []
     for _ in range(args.cases):
-        world = int(rng.choice([2, 4]))
+        world = int(rng.choice([2, 4, 8]))
         L = int(rng.randint(8, 14))
+        if world == 8:
+            L = max(L, 12)            # the p = 3 geometry of BASELINE configs[4] on slabs of at least 512 rows
         k = int(rng.choice([40, 90, 120, 150]))
         k = min(k, (1 << L) // 2)
         g0 = float(rng.choice([0.8, 1.0, 1.4]))
@@ -136,7 +138,7 @@ def main():
         replicate = [("auto"), True, False][int(rng.randint(0, 3))]
         cases.append((world, L, k, g0, overlap, replicate))
     results, drivers = {}, {}
-    for world in (2, 4):
+    for world in (2, 4, 8):
         sub = [(i, c) for i, c in enumerate(cases) if c[0] == world]
         if not sub:
             continue

@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs as MI355X_MICROARCH.md
-prescribes) into HBM bytes per launch of each dsea kernel and write profiles/pmc_traffic.json.
+prescribes) into HBM bytes per launch of each dsea kernel (profiles/r<NN>_pmc_traffic.json format).
 
 Units / corrections (MI355X_MICROARCH.md, section HBM):
   * FETCH_SIZE, WRITE_SIZE are in KiB  -> x 1024;
   * on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read -> x 2
     (all dsea kernels read with 16-byte-per-lane coalesced loads); WRITE_SIZE is used uncorrected.
-   python tools/pmc_traffic.py gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv
+   python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> [steps profiled] [out.json]
+The result goes to out.json (default gpurun_out/pmc_traffic.json); the copy to keep is committed as
+profiles/r<round>_pmc_traffic.json -- bench.py quotes the newest of those when it cannot measure live.
 """
 import csv, json, os, sys, collections
 
@@ -49,7 +51,9 @@ try:
                                     text=True).stdout.strip() or os.environ.get("DSEA_COMMIT", "unknown")
 except Exception:
     out["_commit"] = os.environ.get("DSEA_COMMIT", "unknown")
-with open(os.path.join(root, "profiles", "pmc_traffic.json"), "w") as f:
+dest = sys.argv[4] if len(sys.argv) > 4 else os.path.join(root, "gpurun_out", "pmc_traffic.json")
+os.makedirs(os.path.dirname(os.path.abspath(dest)), exist_ok=True)
+with open(dest, "w") as f:
     json.dump(out, f, indent=1)
 for k, v in out.items():
     if not k.startswith("_"):
