@@ -124,7 +124,7 @@ TileGeom Workspace::geom(int64_t n_rows) const {
 
 extern "C" {
 
-int dsea_version(void) { return 120; }   // 120: partial re-orthogonalisation entry points, stream probe
+int dsea_version(void) { return 130; }   // 130: mid-size single-launch Lanczos, fused tail of the overlapped partitioned step
 
 const char* dsea_error_string(int status) {
   switch (status) {
@@ -191,6 +191,10 @@ int dsea_ws_create(void* device_buffer, size_t bytes, int64_t n, int kmax, dsea_
   ws->w.shadow_ld = 0;
   ws->w.shadow_rows = 0;
   ws->w.lp_tau = 1e-12;
+  ws->w.defer_norm = 0;
+  ws->w.pend_P = nullptr;
+  ws->w.pend_count = 0;
+  ws->w.pend_out = nullptr;
   ws->w.partials = reinterpret_cast<double*>(base + L.partials_off);
   ws->w.aux = reinterpret_cast<double*>(base + L.aux_off);
   ws->w.coef = reinterpret_cast<double*>(base + L.coef_off);
@@ -315,6 +319,10 @@ int dsea_ws_set_rows_per_lane(dsea_ws_t ws, int rpl) {
 
 int dsea_ws_set_persist(dsea_ws_t ws, int mode) {
   if (!ws) return DSEA_ERR_ARG;
+  if (mode == 200) {     // TFIM, 2^14 ... 2^20 rows: the two-exchange persistent form (iterates bit-identical to the streaming
+    ws->w.persist_override = mode;   // kernels) instead of the default one-exchange form; other operands: as -1
+    return DSEA_OK;
+  }
   const int geo = mode >= 100 ? mode - 100 : mode;     // >= 100: merged-reduction form with geometry code mode - 100
   if (geo != -1 && geo != 0 && geo != 1 && geo != 2 && geo != 11 && geo != 12 && geo != 21 && geo != 22)
     return DSEA_ERR_ARG;
@@ -343,7 +351,9 @@ int dsea_ws_set_partial_reorth(dsea_ws_t ws, int on, double delta) {
 }
 
 int dsea_ws_set_lanczos_persist(dsea_ws_t ws, int mode) {
-  if (!ws || (mode != -1 && mode != 0 && mode != 1)) return DSEA_ERR_ARG;
+  // -1 automatic, 0 off, 1 forced wherever a single-launch form applies, 2 = only the README-sized form (the mid-size
+  // form of dsea_lanczos_persist_mid.hip off: A/B measurements)
+  if (!ws || (mode != -1 && mode != 0 && mode != 1 && mode != 2)) return DSEA_ERR_ARG;
   ws->w.lz_persist = mode;
   return DSEA_OK;
 }
@@ -508,7 +518,15 @@ int dsea_spmv(dsea_op_t op, dsea_ws_t ws, const double* x, double* y, const doub
   double* P = dot_out ? ws->w.partials : nullptr;
   int nb = launch_spmv(op->d, x, y, shift, skip_flag, P, st);
   if (nb < 0) return DSEA_ERR_UNSUPPORTED;
-  if (dot_out) launch_finalize_slot(P, nb, dot_out, skip_flag, st);
+  if (dot_out) {
+    Workspace& w = ws->w;
+    if (w.pend_P) {   // the row-partitioned step: the deferred ||r||^2 of dsea_plz_correct is closed in the same launch
+      launch_finalize_pair(w.pend_P, w.pend_count, w.pend_out, P, nb, dot_out, skip_flag, st);
+      w.pend_P = nullptr;
+    } else {
+      launch_finalize_slot(P, nb, dot_out, skip_flag, st);
+    }
+  }
   return check_launch();
 }
 
@@ -700,8 +718,10 @@ int dsea_axpy_multi_dot(dsea_ws_t ws, double a_host, const double* a_dev, const 
     REQUIRE(xs[b] != nullptr, DSEA_ERR_ARG);
     REQUIRE(aligned16(xs[b]), DSEA_ERR_ALIGN);
   }
-  launch_axpy_multi_dot(a_host, a_dev, xs, count, shift, skip_flag, x, y, n, ws->w.aux + 2 * DSEA_MAX_WAVE_TILES,
-                        dot_out, static_cast<hipStream_t>(stream));
+  Workspace& w = ws->w;
+  launch_axpy_multi_dot(a_host, a_dev, xs, count, shift, skip_flag, x, y, n, w.aux + 2 * DSEA_MAX_WAVE_TILES,
+                        dot_out, static_cast<hipStream_t>(stream), w.pend_P, w.pend_count, w.pend_out);
+  w.pend_P = nullptr;
   return check_launch();
 }
 
@@ -751,7 +771,13 @@ int dsea_plz_correct(dsea_ws_t ws, const double* Q, int64_t ldq, int64_t n, int 
       const int rps = lp_rows_per_step(n, false);
       int nn = launch_axpy_norm_lp(n, rps, Q, ldq, w.shadow, w.shadow_ld, row, c, w.lp_tau, r, nP, w.scal + 16, st,
                                    w.prof ? w.prof->next(PROF_AXPY) : nullptr);
-      launch_finalize1(nP, nn, pair_out, st);
+      if (w.defer_norm) {     // (library driver: summed together with the mat-vec's dot, see Workspace::defer_norm)
+        w.pend_P = nP;
+        w.pend_count = nn;
+        w.pend_out = pair_out;
+      } else {
+        launch_finalize1(nP, nn, pair_out, st);
+      }
     } else {
       TileGeom g = w.geom(n);
       launch_axpy_norm(g, Q, ldq, n, row, c, r, w.partials, pair_out, st, w.prof ? w.prof->next(PROF_AXPY) : nullptr);
@@ -834,6 +860,20 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
   if (w.lz_persist != 0 && w.reorth_passes == 1 && !w.partial_reorth && (w.lz_persist == 1 || n <= 4096) && !prof && lanczos_persist_applicable(op->d, n, k) &&
       lanczos_persist_comm_bytes(n, k) <= (size_t)DSEA_MAX_WAVE_TILES * (size_t)((w.kmax < 1 ? 1 : w.kmax) + 1) * sizeof(double)) {
     const int pr = launch_lanczos_persist(op->d, k, q0, Q, ldq, alphas, betas, brk, w.scal + DSEA_SCAL_LZ_FAIL, P, st, w.lose_peer);
+    if (pr == -2) {
+      g_last_hip = (int)hipGetLastError();
+      return DSEA_ERR_HIP;
+    }
+    if (pr == 0) return check_launch();
+  }
+  // Mid-size halo-1 operators (3-point stencil, 8192 < n <= 131072 rows: BASELINE configs[2]): ONE launch that keeps a
+  // third of the basis in registers and LDS and streams the rest (dsea_lanczos_persist_mid.hip).  mode 2 = off for this
+  // form only (A/B measurements).
+  if (w.lz_persist != 0 && w.lz_persist != 2 && w.reorth_passes == 1 && !w.partial_reorth && !prof &&
+      lanczos_persist_mid_applicable(op->d, n, k) &&
+      lanczos_persist_mid_comm_bytes(n, k) <= (size_t)DSEA_MAX_WAVE_TILES * (size_t)((w.kmax < 1 ? 1 : w.kmax) + 1) * sizeof(double)) {
+    const int pr = launch_lanczos_persist_mid(op->d, k, q0, Q, ldq, Qs, lds, w.lp_tau, alphas, betas, brk,
+                                              w.scal + DSEA_SCAL_LZ_FAIL, lp_count, P, st, w.lose_peer);
     if (pr == -2) {
       g_last_hip = (int)hipGetLastError();
       return DSEA_ERR_HIP;
@@ -1188,10 +1228,13 @@ int dsea_cg_run(dsea_op_t op, dsea_ws_t ws, const double* shift, const double* b
                         cg_persist_tfim_big_comm_bytes(n) <= (size_t)4 * DSEA_MAX_WAVE_TILES * sizeof(double);
   if (tfim_big || tfim_persist ||
       (w.persist_override != 0 && persist_comm_bytes(n) <= (size_t)4 * DSEA_MAX_WAVE_TILES * sizeof(double))) {
-    const int pr = tfim_big ? launch_cg_persist_tfim_big(op->d, shift, b, x, state, eps, maxiter, w.aux, d, Ad, st, w.lose_peer)
+    // (persist_override 200 = the two-exchange form whose iterates are bit-identical to the streaming kernels; default: the
+    //  one-exchange form, csrc/dsea_cg_persist_tfim_big.hip MERGED)
+    const int pr = tfim_big ? launch_cg_persist_tfim_big(op->d, shift, b, x, state, eps, maxiter, w.aux, d, Ad, st, w.lose_peer,
+                                                         w.persist_override != 200)
                    : tfim_persist ? launch_cg_persist_tfim(op->d, shift, b, x, state, eps, maxiter, P, st, w.lose_peer)
                                   : launch_cg_persist(op->d, shift, b, x, state, eps, maxiter, w.aux,
-                                                      w.persist_override > 0 ? w.persist_override : 0, st, w.lose_peer);
+                                                      (w.persist_override > 0 && w.persist_override != 200) ? w.persist_override : 0, st, w.lose_peer);
     if (pr == -2) {
       g_last_hip = (int)hipGetLastError();
       return DSEA_ERR_HIP;

@@ -24,6 +24,18 @@
 //     (S1) all-to-all: tile partials of d.A'd -> alpha ;  (S2) all-to-all: canonical-tile partials of r'.r' -> beta, stop.
 //   State zeroed per launch, spins bounded by a 3 s wall-clock timeout (-> DSEA_ERR_TIMEOUT, the host falls back to
 //   the streaming form).  G = 2^(L-11) / NVB <= 256 workgroups: one per compute unit.
+//
+// MERGED = true (round 4, the default from 2^14 rows): ONE all-to-all per iteration instead of two.  Each of the two
+// exchanges above costs ~6 us at 256 workgroups (gather + arrival skew) -- more than the mat-vec (6.6 us).  The two
+// scalars of CG.py:31-40 are dependent (alpha = rr / d.A'd, then r'.r' of the UPDATED residual), so merging them needs the
+// Chronopoulos-Gear recurrences: w = A'r is formed once per iteration, gamma = r.r and delta = r.w are reduced TOGETHER,
+// and s = A'p is carried by s <- w + beta s:
+//     p <- r + beta p ; s <- w + beta s ; x <- x + alpha p ; r <- r - alpha s ; [publish r] w <- A'r ; [gamma', delta]
+//     beta = gamma'/gamma ; alpha = gamma' / (delta - beta gamma'/alpha)
+// The same iteration in exact arithmetic, not the rounding sequence of CG.py's recurrences: iterates agree with the
+// streaming form / the CPU oracle to ~1e-13 relative after 50 iterations, converged runs take the same number of
+// iterations (tests/test_gpu_persistent.py).  Partials are per WORKGROUP (256 x 2 doubles gathered instead of 2048 + 512).
+// dsea_ws_set_persist(200) selects the bit-identical two-exchange form.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -77,11 +89,13 @@ struct CgbArgs {
 struct CgbSm {
   double red[2][4];
   double red4[2][CGB_PER][4];
+  double red2[8][2];     // merged form: per-wave partials of (r.r, r.w)
+  double tot2[2];
   double bcast;
   double fail;
 };
 
-template <int NVB>
+template <int NVB, bool MERGED>
 __global__ __launch_bounds__(256 * NVB) void k_cg_persist_tfim_big(CgbArgs a) {
   __shared__ double2 tile2[NVB][CGB_TILE / 2];
   __shared__ CgbSm sm;
@@ -269,6 +283,130 @@ __global__ __launch_bounds__(256 * NVB) void k_cg_persist_tfim_big(CgbArgs a) {
 #else
 #define CGB_TICK(k)
 #endif
+  if constexpr (MERGED) {
+    // ---- one exchange per iteration (Chronopoulos-Gear recurrences, see the header)
+    // workgroup sums of two values, then all workgroups' pairs gathered and summed in a fixed order (thread t of the first
+    // virtual block takes workgroup t): the totals are identical in every workgroup
+    auto exchange2 = [&](double v0, double v1, unsigned epoch, bool& fail, double& out0, double& out1) {
+      v0 = wave_sum(v0);
+      v1 = wave_sum(v1);
+      __syncthreads();
+      if (lane == 0) {
+        sm.red2[wave][0] = v0;
+        sm.red2[wave][1] = v1;
+      }
+      __syncthreads();
+      if (tid < 2) {
+        double tot = sm.red2[0][tid];
+#pragma unroll
+        for (int w = 1; w < 4 * NVB; ++w) tot += sm.red2[w][tid];
+        granule_put(PA + 2 * ((int64_t)blockIdx.x * 2 + tid), epoch, tot);
+      }
+      double g0 = 0.0, g1 = 0.0;
+      if (vb == 0) {
+        const int G = (int)gridDim.x;
+        if (t < G) {
+          const long long t0 = wall_clock64();
+          for (;;) {
+            const bool ok0 = granule_try_get(PA + 2 * ((int64_t)t * 2), epoch, g0);
+            const bool ok1 = granule_try_get(PA + 2 * ((int64_t)t * 2 + 1), epoch, g1);
+            if (ok0 && ok1) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > CGB_TIMEOUT_TICKS) {
+              sm.fail = 1.0;
+              break;
+            }
+          }
+        }
+        g0 = wave_sum(g0);
+        g1 = wave_sum(g1);
+      }
+      __syncthreads();
+      if (vb == 0 && lane == 0) {
+        sm.red2[wv4][0] = g0;
+        sm.red2[wv4][1] = g1;
+      }
+      __syncthreads();
+      out0 = ((sm.red2[0][0] + sm.red2[1][0]) + sm.red2[2][0]) + sm.red2[3][0];
+      out1 = ((sm.red2[0][1] + sm.red2[1][1]) + sm.red2[2][1]) + sm.red2[3][1];
+      fail = sm.fail != 0.0;
+    };
+    double2 xv[CGB_PER], rv[CGB_PER], pv[CGB_PER], sv[CGB_PER], wv[CGB_PER];
+#pragma unroll
+    for (int m = 0; m < CGB_PER; ++m) xv[m] = *reinterpret_cast<const double2*>(a.x + base + 2 * (int64_t)(t + 256 * m));
+    bool fail = false;
+    (void)matvec(xv, a.x, wv);                                                          // r = b - A'x0   (CG.py:26)
+#pragma unroll
+    for (int m = 0; m < CGB_PER; ++m) {
+      const double2 bv = *reinterpret_cast<const double2*>(a.b + base + 2 * (int64_t)(t + 256 * m));
+      rv[m].x = __dsub_rn(bv.x, wv[m].x);
+      rv[m].y = __dsub_rn(bv.y, wv[m].y);
+      pv[m] = make_double2(0.0, 0.0);
+      sv[m] = make_double2(0.0, 0.0);
+    }
+    unsigned epoch = 1;
+    auto rr_chain = [&]() -> double {
+      double acc = 0.0;
+#pragma unroll
+      for (int m = 0; m < CGB_PER; ++m) {
+        acc = fma(rv[m].x, rv[m].x, acc);
+        acc = fma(rv[m].y, rv[m].y, acc);
+      }
+      return acc;
+    };
+    publish_d(rv, 0, epoch);
+    wait_partners(epoch, fail);
+    double gam = 0.0, del = 0.0;
+    if (!fail) {
+      const double accw = matvec(rv, a.dbuf[0], wv);                                    // w = A'r, local r.w
+      exchange2(rr_chain(), accw, epoch, fail, gam, del);
+    }
+    double rn = sqrt(gam);
+    long long iters = 0;
+    bool done = !fail && rn < a.eps;
+    double alpha = gam / del, beta = 0.0;
+    while (!done && !fail && iters < a.maxiter) {
+#pragma unroll
+      for (int m = 0; m < CGB_PER; ++m) {
+        pv[m].x = __dadd_rn(rv[m].x, __dmul_rn(beta, pv[m].x));
+        pv[m].y = __dadd_rn(rv[m].y, __dmul_rn(beta, pv[m].y));
+        sv[m].x = __dadd_rn(wv[m].x, __dmul_rn(beta, sv[m].x));
+        sv[m].y = __dadd_rn(wv[m].y, __dmul_rn(beta, sv[m].y));
+        xv[m].x = __dadd_rn(xv[m].x, __dmul_rn(alpha, pv[m].x));
+        xv[m].y = __dadd_rn(xv[m].y, __dmul_rn(alpha, pv[m].y));
+        rv[m].x = __dsub_rn(rv[m].x, __dmul_rn(alpha, sv[m].x));
+        rv[m].y = __dsub_rn(rv[m].y, __dmul_rn(alpha, sv[m].y));
+      }
+      ++epoch;
+      const int which = (int)((iters + 1) & 1);
+      publish_d(rv, which, epoch);
+      wait_partners(epoch, fail);
+      if (fail) break;
+      const double accw = matvec(rv, a.dbuf[which], wv);
+      double gam2 = 0.0, del2 = 0.0;
+      exchange2(rr_chain(), accw, epoch, fail, gam2, del2);
+      if (fail) break;
+      ++iters;
+      rn = sqrt(gam2);
+      if (rn < a.eps) {
+        gam = gam2;
+        done = true;
+        break;
+      }
+      beta = gam2 / gam;
+      alpha = gam2 / (del2 - beta * gam2 / alpha);
+      gam = gam2;
+    }
+#pragma unroll
+    for (int m = 0; m < CGB_PER; ++m) *reinterpret_cast<double2*>(a.x + base + 2 * (int64_t)(t + 256 * m)) = xv[m];
+    if (blockIdx.x == 0 && tid == 0) {
+      a.state[DSEA_CG_RR] = gam;
+      a.state[DSEA_CG_RESNORM] = rn;
+      a.state[DSEA_CG_ITERS] = (double)iters;
+      a.state[DSEA_CG_DONE] = fail ? -1.0 : (done ? 1.0 : 0.0);
+    }
+    return;
+  }
   double2 xv[CGB_PER], rv[CGB_PER], dv[CGB_PER], Ad[CGB_PER];
 #pragma unroll
   for (int m = 0; m < CGB_PER; ++m) xv[m] = *reinterpret_cast<const double2*>(a.x + base + 2 * (int64_t)(t + 256 * m));
@@ -378,7 +516,7 @@ size_t cg_persist_tfim_big_comm_bytes(int64_t n) {
 // returns 0 if launched, -1 if not applicable, -2 on a HIP error.  dbuf0 / dbuf1: two scratch vectors of n doubles.
 int launch_cg_persist_tfim_big(const OpDesc& op, const double* shift, const double* b, double* x, double* state,
                                double eps, int64_t maxiter, void* comm, double* dbuf0, double* dbuf1, hipStream_t st,
-                               int lose_peer) {
+                               int lose_peer, bool merged) {
   if (!cg_persist_tfim_big_applicable(op)) return -1;
   const int64_t n = op.n;
   const int ntiles = (int)(n / CGB_TILE);
@@ -408,10 +546,13 @@ int launch_cg_persist_tfim_big(const OpDesc& op, const double* shift, const doub
   a.dbuf[1] = dbuf1;
   a.ntiles = ntiles;
   a.lose_peer = lose_peer;
-  if (nvb == 2)
-    hipLaunchKernelGGL((k_cg_persist_tfim_big<2>), dim3(G), dim3(512), 0, st, a);
-  else
-    hipLaunchKernelGGL((k_cg_persist_tfim_big<1>), dim3(G), dim3(256), 0, st, a);
+  if (nvb == 2) {
+    if (merged) hipLaunchKernelGGL((k_cg_persist_tfim_big<2, true>), dim3(G), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k_cg_persist_tfim_big<2, false>), dim3(G), dim3(512), 0, st, a);
+  } else {
+    if (merged) hipLaunchKernelGGL((k_cg_persist_tfim_big<1, true>), dim3(G), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_cg_persist_tfim_big<1, false>), dim3(G), dim3(256), 0, st, a);
+  }
   return 0;
 }
 

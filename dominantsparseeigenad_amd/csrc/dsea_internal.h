@@ -136,6 +136,12 @@ struct Workspace {
   int64_t shadow_ld;
   int shadow_rows;
   double lp_tau;     // low-precision pass allowed while max|c_j| <= lp_tau * ||r||
+  // row-partitioned library driver: dsea_plz_correct leaves its ||r||^2 partials un-summed (defer_norm) and the NEXT
+  // dot-closing call of the step sums both in one launch (k_finalize_pair) -- bit-identical, one launch fewer per step
+  int defer_norm;
+  const double* pend_P;
+  int pend_count;
+  double* pend_out;
   TileGeom geom(int64_t n_rows) const;
 };
 
@@ -187,12 +193,17 @@ void launch_cg_check(double* state, double eps, hipStream_t st);
 void launch_cg_direction(const double* r, double* d, const double* state, int64_t n, hipStream_t st);
 void launch_axpy_multi_dot(double a_host, const double* a_dev, const double* const* xs, int count,
                            const double* shift, const double* skip, const double* x, double* y, int64_t n,
-                           double* P, double* dot_out, hipStream_t st);
+                           double* P, double* dot_out, hipStream_t st, const double* pendP = nullptr, int pendN = 0,
+                           double* pendOut = nullptr);
 void launch_form_r(const double* u, const double* q1, const double* q2, const double* alpha, const double* beta,
                    double* r, double* r_copy, int64_t n, hipStream_t st);
 void launch_hypercube_flipsum(const double* xT, double* zT, int P, int p, int64_t chunk, hipStream_t st);
 void launch_plz_finish(const double* r, const double* y, const double* pair, double* q, uint16_t* qs, double* u,
                        double* alpha_out, double* beta_out, int64_t n, hipStream_t st);
+void launch_plz_finish_form(double* r, const double* y, const double* pair, double* q, uint16_t* qs, const double* qprev,
+                            double* alpha_out, double* beta_out, double* r_copy, int64_t n, hipStream_t st);
+void launch_finalize_pair(const double* PA, int na, double* outA, const double* PB, int nb, double* outB,
+                          const double* skipB, hipStream_t st);
 // dsea_krylov.hip
 bool blas_available();
 int blas_apply(const OpDesc& op, const double* x, double* y, hipStream_t st);
@@ -219,7 +230,7 @@ bool cg_persist_tfim_big_applicable(const OpDesc& op);
 size_t cg_persist_tfim_big_comm_bytes(int64_t n);
 int launch_cg_persist_tfim_big(const OpDesc& op, const double* shift, const double* b, double* x, double* state,
                                double eps, int64_t maxiter, void* comm, double* dbuf0, double* dbuf1, hipStream_t st,
-                               int lose_peer = 0);
+                               int lose_peer = 0, bool merged = true);
 // dsea_cg_persist_tfim.hip
 bool cg_persist_tfim_applicable(const OpDesc& op);
 size_t cg_persist_tfim_comm_bytes(int64_t n);
@@ -230,6 +241,13 @@ bool lanczos_persist_applicable(const OpDesc& op, int64_t n, int k);
 size_t lanczos_persist_comm_bytes(int64_t n, int k);
 int launch_lanczos_persist(const OpDesc& op, int k, const double* q0, double* Q, int64_t ldq, double* alphas,
                            double* betas, double* brk, double* fail, void* comm, hipStream_t st, int lose_peer = 0);
+
+// dsea_lanczos_persist_mid.hip
+bool lanczos_persist_mid_applicable(const OpDesc& op, int64_t n, int k);
+size_t lanczos_persist_mid_comm_bytes(int64_t n, int k);
+int launch_lanczos_persist_mid(const OpDesc& op, int k, const double* q0, double* Q, int64_t ldq, uint16_t* Qs, int64_t lds,
+                               double tau, double* alphas, double* betas, double* brk, double* fail, double* lp_count,
+                               void* comm, hipStream_t st, int lose_peer = 0);
 
 }  // namespace dsea
 

@@ -34,6 +34,22 @@ __global__ __launch_bounds__(256) void k_finalize1(const double* __restrict__ pa
   if (threadIdx.x == 0) out[0] = t;
 }
 
+// two independent sums in ONE launch (block 0: outA[0] = sum PA, block 1: outB[0] = sum PB), each in the order of
+// k_finalize1 / k_cg_finalize_slot -- the row-partitioned step closes ||r||^2 and r.Ar together before their all-reduce
+__global__ __launch_bounds__(256) void k_finalize_pair(const double* __restrict__ PA, int na, double* __restrict__ outA,
+                                                       const double* __restrict__ PB, int nb, double* __restrict__ outB,
+                                                       const double* __restrict__ skipB) {
+  __shared__ double sm4[4];
+  const bool second = blockIdx.x == 1;
+  if (second && skipB && skipB[0] != 0.0) return;
+  const double* __restrict__ P = second ? PB : PA;
+  const int count = second ? nb : na;
+  double acc = 0.0;
+  for (int b = threadIdx.x; b < count; b += 256) acc += P[b];
+  double t = block_sum(acc, sm4);
+  if (threadIdx.x == 0) (second ? outB : outA)[0] = t;
+}
+
 // c[j] = sum_{w<nw} P[j*pstride + w]   (one 256-thread block per j, 4 independent loads in flight per lane)
 template <bool GATE>
 __global__ __launch_bounds__(256) void k_finalize_multi(const double* __restrict__ P, int64_t pstride,
@@ -898,6 +914,42 @@ __global__ __launch_bounds__(256) void k_plz_finish(const double* __restrict__ r
     st2<true>(q, row, n, rv);
     if (qs) st_bf16x2(qs, row, n, rv);
     st2<true>(u, row, n, yv);
+  }
+}
+
+// k_plz_finish of step i and k_form_r of step i + 1 in ONE pass (the overlapped row-partitioned step, where the
+// three-term vector must exist as a stand-alone snapshot before the dots pass): q = r/beta (+ shadow), u = y/beta is NOT
+// stored, r' = u - alpha q - beta q_prev written over r and into r_copy.  The same rounded operations in the same order
+// as the two kernels it replaces -- bit-identical -- with three vector passes and a launch fewer per step.
+__global__ __launch_bounds__(256) void k_plz_finish_form(double* __restrict__ r, const double* __restrict__ y,
+                                                         const double* __restrict__ pair, double* __restrict__ q,
+                                                         uint16_t* __restrict__ qs, const double* __restrict__ qprev,
+                                                         double* __restrict__ alpha_out, double* __restrict__ beta_out,
+                                                         double* __restrict__ r_copy, int64_t n) {
+  const double nrm2 = pair[0];
+  const double beta = sqrt(nrm2);
+  const double a = pair[1] / nrm2;
+  const double b = qprev ? beta : 0.0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    alpha_out[0] = a;
+    if (beta_out) beta_out[0] = beta;
+  }
+  const int64_t stride = (int64_t)gridDim.x * 512;
+  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; row < n; row += stride) {
+    double2 rv = ld2<true>(r, row, n), yv = ld2<true>(y, row, n);
+    double2 qb = make_double2(0.0, 0.0);
+    if (qprev) qb = ld2<true>(qprev, row, n);
+    rv.x = rv.x / beta;
+    rv.y = rv.y / beta;
+    yv.x = yv.x / beta;
+    yv.y = yv.y / beta;
+    st2<true>(q, row, n, rv);
+    if (qs) st_bf16x2(qs, row, n, rv);
+    double2 nv;
+    nv.x = __dsub_rn(__dsub_rn(yv.x, __dmul_rn(a, rv.x)), __dmul_rn(b, qb.x));
+    nv.y = __dsub_rn(__dsub_rn(yv.y, __dmul_rn(a, rv.y)), __dmul_rn(b, qb.y));
+    st2<true>(r, row, n, nv);
+    if (r_copy) st2<true>(r_copy, row, n, nv);
   }
 }
 
@@ -2727,13 +2779,16 @@ void launch_cg_direction_fused(const double* r, double* d, double* state, int pa
 
 void launch_axpy_multi_dot(double a_host, const double* a_dev, const double* const* xs, int count,
                            const double* shift, const double* skip, const double* x, double* y, int64_t n,
-                           double* P, double* dot_out, hipStream_t st) {
+                           double* P, double* dot_out, hipStream_t st, const double* pendP, int pendN, double* pendOut) {
   MultiSrc ms;
   ms.count = count;
   for (int b = 0; b < 6; ++b) ms.p[b] = b < count ? xs[b] : nullptr;
   const int nb = ew_blocks(n);
   hipLaunchKernelGGL(k_axpy_multi_dot, dim3(nb), dim3(256), 0, st, a_host, a_dev, ms, shift, skip, x, y, n, P);
-  hipLaunchKernelGGL(k_cg_finalize_slot, dim3(1), dim3(256), 0, st, (const double*)P, nb, dot_out, skip);
+  if (pendP)
+    hipLaunchKernelGGL(k_finalize_pair, dim3(2), dim3(256), 0, st, pendP, pendN, pendOut, (const double*)P, nb, dot_out, skip);
+  else
+    hipLaunchKernelGGL(k_cg_finalize_slot, dim3(1), dim3(256), 0, st, (const double*)P, nb, dot_out, skip);
 }
 
 void launch_form_r(const double* u, const double* q1, const double* q2, const double* alpha, const double* beta,
@@ -2752,6 +2807,17 @@ void launch_plz_finish(const double* r, const double* y, const double* pair, dou
                        double* alpha_out, double* beta_out, int64_t n, hipStream_t st) {
   hipLaunchKernelGGL(k_plz_finish, dim3(ew_blocks(n)), dim3(256), 0, st, r, y, pair, q, qs, u, alpha_out,
                      beta_out, n);
+}
+
+void launch_plz_finish_form(double* r, const double* y, const double* pair, double* q, uint16_t* qs, const double* qprev,
+                            double* alpha_out, double* beta_out, double* r_copy, int64_t n, hipStream_t st) {
+  hipLaunchKernelGGL(k_plz_finish_form, dim3(ew_blocks(n)), dim3(256), 0, st, r, y, pair, q, qs, qprev, alpha_out, beta_out,
+                     r_copy, n);
+}
+
+void launch_finalize_pair(const double* PA, int na, double* outA, const double* PB, int nb, double* outB,
+                          const double* skipB, hipStream_t st) {
+  hipLaunchKernelGGL(k_finalize_pair, dim3(2), dim3(256), 0, st, PA, na, outA, PB, nb, outB, skipB);
 }
 
 int launch_three_term(const double* u, const double* q1, const double* q2, const double* aP, int aCount,

@@ -500,6 +500,12 @@ int dsea_pop_lanczos_run(dsea_pop_t P, dsea_ws_t ws, int k, const double* q0, do
   double* pro_om = w.aux + 4 * DSEA_MAX_WAVE_TILES;
   const double pro_eps1 = 64.0 * 2.220446049250313e-16;
   const TileGeom g = w.geom(n);
+  // the step's two local sums (||r||^2 from the correction pass, r.Ar from the mat-vec) are closed by ONE launch
+  struct DeferNorm {
+    Workspace& w;
+    explicit DeferNorm(Workspace& ww) : w(ww) { w.defer_norm = 1; w.pend_P = nullptr; }
+    ~DeferNorm() { w.defer_norm = 0; w.pend_P = nullptr; }
+  } defer_guard(w);
   HIP_TRY(hipMemsetAsync(w.scal + DSEA_SCAL_PRO, 0, 5 * sizeof(double), st));
   HIP_TRY(hipMemsetAsync(w.scal + 32, 0, 4 * sizeof(double), st));
   HIP_TRY(hipMemsetAsync(w.scal + 16, 0, 2 * sizeof(double), st));      // shadow-path statistics of this run
@@ -513,8 +519,8 @@ int dsea_pop_lanczos_run(dsea_pop_t P, dsea_ws_t ws, int k, const double* q0, do
         DSEA_TRY(tfim_exchange_start(P, P->r_send, st));
       }
     } else if (overlap) {
-      // the exchange of the UN-corrected r runs behind the dots and correction passes
-      DSEA_TRY(dsea_lanczos_form_r(ws, Q, ldq, n, i, u, a_prev, b_prev, r, P->r_send, stream));
+      // the exchange of the UN-corrected r runs behind the dots and correction passes; r and its snapshot were formed by
+      // the fused tail of the previous step (k_plz_finish_form = k_plz_finish + k_form_r, bit-identical)
       DSEA_TRY(tfim_exchange_start(P, P->r_send, st));
       // alpha = 0: r is rewritten with its own values (read from the snapshot, so that input and output of the
       // kernel do not alias), c = Q^T r, c[i] = r.r
@@ -553,9 +559,19 @@ int dsea_pop_lanczos_run(dsea_pop_t P, dsea_ws_t ws, int k, const double* q0, do
       DSEA_TRY(stencil_halo_exchange(P, r, st));
       DSEA_TRY(dsea_spmv(&P->local, ws, r, y, nullptr, pair + 1, nullptr, stream));
     }
+    if (w.pend_P) {     // (no dot-closing call consumed the deferred ||r||^2 on this path: close it now)
+      launch_finalize1(w.pend_P, w.pend_count, w.pend_out, st);
+      w.pend_P = nullptr;
+    }
     DSEA_TRY(comm_allreduce(P->comm, pair, 2, st));
-    DSEA_TRY(dsea_plz_finish(ws, r, y, pair, Q + (int64_t)i * ldq, i, u, alphas + i, i >= 1 ? betas + (i - 1) : nullptr, n,
-                             stream));
+    if (overlap && i + 1 < k) {
+      uint16_t* qs = (w.shadow && w.shadow_rows > i && w.shadow_ld >= n) ? w.shadow + (int64_t)i * w.shadow_ld : nullptr;
+      launch_plz_finish_form(r, y, pair, Q + (int64_t)i * ldq, qs, i >= 1 ? Q + (int64_t)(i - 1) * ldq : nullptr, alphas + i,
+                             i >= 1 ? betas + (i - 1) : nullptr, P->r_send, n, st);
+    } else {
+      DSEA_TRY(dsea_plz_finish(ws, r, y, pair, Q + (int64_t)i * ldq, i, u, alphas + i, i >= 1 ? betas + (i - 1) : nullptr, n,
+                               stream));
+    }
   }
   return hipGetLastError() == hipSuccess ? DSEA_OK : DSEA_ERR_HIP;
 }

@@ -30,7 +30,9 @@ DENSE_SYMMETRIC_KERNEL = True
 # README-sized problems (full-space TFIMOperator, Stencil3Operator; k <= 512): the whole Lanczos loop as ONE launch
 # (csrc/dsea_lanczos_persist.hip).  Same algorithm and expressions, T equal to the multi-launch form to rounding (not bit
 # for bit).  True = automatic (n <= 4096, where it is measured to win), "force" = wherever it applies (n <= 8192),
-# False keeps every workspace on the multi-launch kernels.
+# False keeps every workspace on the multi-launch kernels.  The same switch governs the MID-SIZE single-launch form for
+# halo-1 operators (csrc/dsea_lanczos_persist_mid.hip: 3-point stencil, 8192 < n <= 131072 rows -- BASELINE configs[2]):
+# on with True / "force", off with False or "small" (= only the README-sized form).
 # Gram-Schmidt passes per Lanczos step: 1 = the reference (Lanczos.py:66); 2 = CGS2 option (``reorth="twice"`` of
 # Lanczos.symeigLanczos / Lanczos.Lanczos): the pass is repeated on the corrected vector.
 REORTH_PASSES = 1
@@ -410,7 +412,7 @@ def lanczos(A, k, n, device, q0, native=None, callable_A=None, arena=False):
                           "dsea_ws_set_partial_reorth")
                     ws.partial_reorth = PARTIAL_REORTH
                 want = 0 if (not LANCZOS_PERSIST or getattr(ws, "lanczos_persist_lost", False)) else \
-                    (1 if LANCZOS_PERSIST == "force" else -1)
+                    (1 if LANCZOS_PERSIST == "force" else (2 if LANCZOS_PERSIST == "small" else -1))
                 if ws.lanczos_persist_mode != want:
                     ws.set_lanczos_persist(want)
                 rc0 = lib.dsea_lanczos_run(native.handle, ws.handle, int(k), _ptr(q0), _ptr(Q), ldq, _ptr(alphas),
@@ -641,6 +643,11 @@ last_cg = CGInfo()
 # CG.py:31-40 (measured: 6e-14 relative after 40 iterations, same iteration counts on converged runs), hence off
 # by default; ``cg(..., merged_reductions=True)`` selects it per call.
 CG_MERGED_REDUCTIONS = False
+# Full-space TFIM operator at 2^14 ... 2^20 rows (the adjoint solve of BASELINE configs[1]): the single-launch CG makes ONE
+# grid-wide exchange per iteration by default (Chronopoulos-Gear recurrences; same iteration in exact arithmetic, iterates
+# within ~1e-13 of the reference's recurrences, same iteration counts).  True selects the two-exchange form whose iterates
+# are BIT-IDENTICAL to the streaming kernels / CG.py:31-40 evaluated in fp64 (23 instead of ~15 us per iteration at L = 20).
+CG_TFIM_REFERENCE_RECURRENCES = _os.environ.get("DSEA_CG_REFERENCE_RECURRENCES", "") == "1"
 
 
 def cg(b, x0, *, native=None, callable_A=None, shift=None, eps=1e-7, maxiter=None, poll_every=8,
@@ -670,6 +677,8 @@ def cg(b, x0, *, native=None, callable_A=None, shift=None, eps=1e-7, maxiter=Non
         with ws.owned_by("CG (native operator)"):
             if merged and prev_mode == -1:
                 ws.set_persist(100)
+            elif CG_TFIM_REFERENCE_RECURRENCES and prev_mode == -1:
+                ws.set_persist(200)
             try:
                 rc = lib.dsea_cg_run(native.handle, ws.handle, _ptr(shift_t), _ptr(b), _ptr(x), _ptr(state), float(eps),
                                      cap, int(poll_every), byref(iters), byref(res), st)
@@ -689,7 +698,7 @@ def cg(b, x0, *, native=None, callable_A=None, shift=None, eps=1e-7, maxiter=Non
                     rc = lib.dsea_cg_run(native.handle, ws.handle, _ptr(shift_t), _ptr(b), _ptr(x), _ptr(state),
                                          float(eps), cap, int(poll_every), byref(iters), byref(res), st)
             finally:
-                if merged and prev_mode == -1:
+                if (merged or CG_TFIM_REFERENCE_RECURRENCES) and prev_mode == -1:
                     ws.set_persist(-1)
         check(rc, "dsea_cg_run", allow=(_lib.ERR_NOT_CONVERGED,))
         last_cg.iters, last_cg.resnorm, last_cg.converged = iters.value, res.value, rc == 0

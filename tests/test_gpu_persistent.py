@@ -242,6 +242,104 @@ def test_single_launch_lanczos_is_the_default_and_deterministic_and_reports_brea
     assert abs(lo.item() + 6.0) < 1e-12 and torch.isfinite(v).all()
 
 
+# ------------------------------------------------------------------ mid-size single-launch Lanczos (BASELINE configs[2] regime)
+@pytest.mark.parametrize("N,k", [(8193, 40), (8200, 130), (20000, 120), (33001, 200), (65536, 96), (100000, 300),
+                                 (100001, 64), (131072, 150), (131072, 2)])
+def test_mid_size_single_launch_lanczos_matches_streaming_form(N, k):
+    """csrc/dsea_lanczos_persist_mid.hip (3-point stencil, 8192 < N <= 131072: one launch, a slab per workgroup, the first
+    vectors of the basis in LDS and registers, the rest streamed -- fp64 for the dots, bf16 shadow for the correction)
+    against the multi-launch kernels on the same start vector: leading block of T, extreme Ritz values, orthonormal
+    basis.  Ragged slabs (N not a multiple of the slab rows, odd N), the smallest and the largest slab, k = 2."""
+    op, V, h, b, x0 = _problem(N, seed=70)
+    (Qp, Tp), (Qs, Ts) = _lanczos_both(op, k, N, b)
+    m = min(k, 12)
+    assert float((Tp[:m, :m] - Ts[:m, :m]).abs().max()) < 1e-10 * float(Ts[:m, :m].abs().max())
+    wp, ws_ = torch.linalg.eigvalsh(Tp), torch.linalg.eigvalsh(Ts)
+    assert abs(wp[0] - ws_[0]) < 1e-11 * abs(ws_[-1]) and abs(wp[-1] - ws_[-1]) < 1e-12 * abs(ws_[-1])
+    assert float((Qp.T @ Qp - torch.eye(k, dtype=F64, device=cuda)).abs().max()) < 1e-11
+    # the stored basis satisfies the three-term recurrence with the stored T (A Q = Q T + beta_k q_{k+1} e_k^T): columns < k - 1
+    AQ = torch.stack([op.H(Qp[:, j].contiguous()) for j in range(min(k - 1, 6))], dim=1)
+    QT = Qp @ Tp[:, :AQ.shape[1]]
+    assert float((AQ - QT).abs().max()) < 1e-9 * float(Tp.abs().max())
+
+
+@pytest.mark.parametrize("shadow,tau", [(True, None), (False, None), (True, 0.0)])
+def test_mid_size_single_launch_lanczos_streamed_part_with_and_without_the_shadow(shadow, tau):
+    """N = 1e5, k = 300 (config 3): 200+ vectors are streamed.  With the bf16 shadow (premise holds on every step), with
+    the all-fp64 correction pass, and with tau = 0 (premise violated on every step -> fp64 fallback inside the launch):
+    the same Ritz values and an orthonormal basis each time; the step counters say which path ran."""
+    from dominantsparseeigenad_amd.Lanczos import Lanczos
+    N, k = 100000, 300
+    op, V, h, b, x0 = _problem(N, seed=71)
+    old = engine.USE_SHADOW, engine.SHADOW_TAU
+    engine.USE_SHADOW = shadow
+    if tau is not None:
+        engine.SHADOW_TAU = tau
+    try:
+        Qk, T = Lanczos(op, k, cuda, sparse=True, dim=N, q0=b)
+        lp, fb = engine.lanczos_lp_stats(N, cuda)
+        engine.LANCZOS_PERSIST = False
+        Qr, Tr = Lanczos(op, k, cuda, sparse=True, dim=N, q0=b)
+    finally:
+        engine.USE_SHADOW, engine.SHADOW_TAU = old
+        engine.LANCZOS_PERSIST = True
+    assert lp + fb == k - 1
+    if shadow and tau is None:
+        assert fb == 0
+    else:
+        assert fb > 150 and lp < 150            # the steps that stream anything took the fp64 path
+    w, wr = torch.linalg.eigvalsh(T), torch.linalg.eigvalsh(Tr)
+    assert abs(w[0] - wr[0]) < 1e-11 * abs(wr[-1]) and abs(w[-1] - wr[-1]) < 1e-12 * abs(wr[-1])
+    G = Qk.T @ Qk
+    assert float((G - torch.eye(k, dtype=F64, device=cuda)).abs().max()) < 1e-11
+
+
+def test_mid_size_single_launch_lanczos_is_deterministic_reports_breakdown_and_survives_a_lost_peer():
+    import time
+    import warnings
+    from dominantsparseeigenad_amd import _lib
+    from dominantsparseeigenad_amd.Lanczos import Lanczos, symeigLanczos
+    N, k = 40000, 90
+    op, V, h, b, x0 = _problem(N, seed=72)
+    Q1, T1 = Lanczos(op, k, cuda, sparse=True, dim=N, q0=b)
+    Q2, T2 = Lanczos(op, k, cuda, sparse=True, dim=N, q0=b)
+    assert torch.equal(T1, T2) and torch.equal(Q1, Q2)
+    # breakdown: with h = 1e200 the stencil coefficient -0.5 / h^2 is exactly zero and the operator is diag(V); a start vector
+    # supported on rows of three distinct potential values spans a 3-dimensional Krylov space -> beta_3 = 0 exactly
+    Vd = torch.zeros(N, dtype=F64, device=cuda)
+    Vd[5], Vd[20000], Vd[39999] = 1.0, 2.0, 4.0
+    opd = Stencil3Operator(N, 1e200, Vd)
+    q = torch.zeros(N, dtype=F64, device=cuda)
+    q[5], q[20000], q[39999] = 1.0, -2.0, 0.5
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        lo, v = symeigLanczos(opd, 12, cuda, extreme="min", sparse=True, dim=N, q0=q)
+    assert 1 <= engine.last_break <= 3 and any("breakdown" in str(w.message) for w in rec)
+    assert torch.isfinite(v).all() and abs(lo.item() - 1.0) < 1e-12
+    # lost peer: the launch ends, the host repeats the run on the multi-launch kernels and stays there
+    lib = _lib.load()
+    engine.LANCZOS_PERSIST = False
+    try:
+        ref_lo, ref_v = symeigLanczos(op, k, cuda, extreme="min", sparse=True, dim=N, q0=b)
+    finally:
+        engine.LANCZOS_PERSIST = True
+    ws = engine.Workspace.get(N, k, cuda)
+    ws.lanczos_persist_lost = False
+    _lib.check(lib.dsea_ws_set_fault_injection(ws.handle, 1), "dsea_ws_set_fault_injection")
+    try:
+        t0 = time.time()
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            lo, v = symeigLanczos(op, k, cuda, extreme="min", sparse=True, dim=N, q0=b)
+        assert any("single-launch Lanczos timed out" in str(w.message) for w in rec)
+        assert 2.0 < time.time() - t0 < 20.0
+        assert lo.item() == ref_lo.item() and torch.equal(v, ref_v)
+        assert ws.lanczos_persist_lost and ws.lanczos_persist_mode == 0
+    finally:
+        lib.dsea_ws_set_fault_injection(ws.handle, 0)
+        ws.lanczos_persist_lost = False
+
+
 # ------------------------------------------------------------------ single-launch CG for the TFIM operator (README sizes)
 @pytest.mark.parametrize("L", [1, 2, 3, 6, 7, 8, 10, 12, 13])
 def test_persistent_tfim_cg_matches_streaming_form_and_oracle(L):
@@ -301,11 +399,11 @@ def test_persistent_tfim_cg_without_shift_and_zero_rhs_and_maxiter_zero():
 # ------------------------------------------------------------------ single-launch TFIM CG at 2^14 ... 2^20 rows
 @pytest.mark.parametrize("L", [14, 15, 17, 19, 20])
 def test_persistent_tfim_cg_large_is_bit_identical_to_streaming_form(L):
-    """csrc/dsea_cg_persist_tfim_big.hip (x / r / d in registers for the whole solve, d exchanged through device-coherent
-    buffer stores / loads, partial sums reproduced per mat-vec tile and per 512-row tile in the streaming kernels' order):
-    the iterates are BIT-IDENTICAL to the mat-vec + update + direction launches (torch.equal), with the same iteration
-    counts and residual norms -- fixed-iteration and converged runs, with and without shift.  L = 20 is BASELINE
-    configs[1]'s adjoint solve."""
+    """csrc/dsea_cg_persist_tfim_big.hip, TWO-exchange form (dsea_ws_set_persist(200); x / r / d in registers for the whole
+    solve, d exchanged through device-coherent buffer stores / loads, partial sums reproduced per mat-vec tile and per
+    512-row tile in the streaming kernels' order): the iterates are BIT-IDENTICAL to the mat-vec + update + direction
+    launches (torch.equal), with the same iteration counts and residual norms -- fixed-iteration and converged runs, with
+    and without shift.  L = 20 is BASELINE configs[1]'s adjoint solve."""
     from dominantsparseeigenad_amd.operators import TFIMOperator
     n = 1 << L
     op = TFIMOperator(L, cuda, g=torch.tensor([1.0], dtype=F64, device=cuda))
@@ -314,18 +412,63 @@ def test_persistent_tfim_cg_large_is_bit_identical_to_streaming_form(L):
     shift = torch.tensor(-1.3 * L - 1.0, dtype=F64, device=cuda)       # below the spectrum: A - s is SPD
     for sh in (shift, None):
         ref = _solve(op, b, x0, sh, 0, eps=0.0, maxiter=30)
-        got = _solve(op, b, x0, sh, -1, eps=0.0, maxiter=30)
+        got = _solve(op, b, x0, sh, 200, eps=0.0, maxiter=30)
         assert got[1] == ref[1] == 30 and got[2] == ref[2], (got[1:], ref[1:])
         assert torch.equal(got[0], ref[0]), float((got[0] - ref[0]).abs().max())
     ref = _solve(op, b, x0, shift, 0, eps=1e-8, maxiter=None)
-    got = _solve(op, b, x0, shift, -1, eps=1e-8, maxiter=None)
+    got = _solve(op, b, x0, shift, 200, eps=1e-8, maxiter=None)
     assert ref[3] and got[3] and got[1] == ref[1] and got[2] == ref[2] and torch.equal(got[0], ref[0])
     # early out and maxiter = 0
     bb = op.H(x0) - shift * x0
-    got = _solve(op, bb, x0, shift, -1, eps=1e-6, maxiter=None)
+    got = _solve(op, bb, x0, shift, 200, eps=1e-6, maxiter=None)
     assert got[1] == 0 and got[3] and torch.equal(got[0], x0)
-    got = _solve(op, b, x0, shift, -1, eps=1e-30, maxiter=0)
+    got = _solve(op, b, x0, shift, 200, eps=1e-30, maxiter=0)
     assert got[1] == 0 and not got[3] and torch.equal(got[0], x0)
+
+
+@pytest.mark.parametrize("L", [14, 15, 17, 19, 20])
+def test_persistent_tfim_cg_large_one_exchange_form_follows_the_reference_iteration(L):
+    """The DEFAULT single-launch form at 2^14 ... 2^20 rows makes ONE grid-wide exchange per iteration (Chronopoulos-Gear
+    recurrences: gamma = r.r and delta = r.A'r reduced together, s = A'p carried by a recurrence) -- the same iteration as
+    CG.py:31-40 in exact arithmetic, not its rounding sequence.  Held to the streaming kernels (which reproduce CG.py's
+    recurrences): the first 50 iterates to 1e-11 relative, residual norms alike, converged runs with the same number of
+    iterations (+-1) and a true residual below eps; to the CPU ORACLE at L = 14: 50 iterates at 1e-10; early-out paths."""
+    from dominantsparseeigenad_amd.operators import TFIMOperator
+    n = 1 << L
+    op = TFIMOperator(L, cuda, g=torch.tensor([1.0], dtype=F64, device=cuda))
+    b = torch.from_numpy(normal_vector(n, 500 + L)).to(cuda)
+    x0 = torch.from_numpy(normal_vector(n, 600 + L)).to(cuda)
+    shift = torch.tensor(-1.3 * L - 1.0, dtype=F64, device=cuda)       # below the spectrum: A - s is SPD
+    for sh in (shift, None):
+        for its in (1, 2, 50):
+            ref = _solve(op, b, x0, sh, 0, eps=0.0, maxiter=its)
+            got = _solve(op, b, x0, sh, -1, eps=0.0, maxiter=its)
+            scale = float(ref[0].abs().max())
+            assert got[1] == ref[1] == its
+            assert float((got[0] - ref[0]).abs().max()) < 1e-11 * scale, (its, float((got[0] - ref[0]).abs().max()) / scale)
+            assert abs(got[2] - ref[2]) <= 1e-8 * ref[2]
+    for eps in (1e-8, 1e-12):
+        ref = _solve(op, b, x0, shift, 0, eps=eps, maxiter=None)
+        got = _solve(op, b, x0, shift, -1, eps=eps, maxiter=None)
+        assert ref[3] and got[3] and abs(got[1] - ref[1]) <= 1 and got[2] < eps
+        res = op.H(got[0]) - shift * got[0] - b
+        assert float(res.norm()) < 10 * eps * max(1.0, float(b.norm()) * 1e-3) + 1e-11
+        assert float((got[0] - ref[0]).abs().max()) < 100 * eps + 1e-12 * float(ref[0].abs().max())
+    again = _solve(op, b, x0, shift, -1, eps=1e-12, maxiter=None)
+    assert torch.equal(again[0], got[0]) and again[1] == got[1]            # deterministic: fixed summation orders
+    # early out and maxiter = 0
+    bb = op.H(x0) - shift * x0
+    e0 = _solve(op, bb, x0, shift, -1, eps=1e-6, maxiter=None)
+    assert e0[1] == 0 and e0[3] and torch.equal(e0[0], x0)
+    e1 = _solve(op, b, x0, shift, -1, eps=1e-30, maxiter=0)
+    assert e1[1] == 0 and not e1[3] and torch.equal(e1[0], x0)
+    if L == 14:
+        model = oracle.TFIMTables(L, g=torch.tensor([1.0], dtype=F64))
+        st = {}
+        xo = oracle.cg_solve(lambda v: model.H(v) - shift.cpu() * v, b.cpu(), x0.cpu(), sparse=True, eps=0.0, maxiter=50, stats=st)
+        got = _solve(op, b, x0, shift, -1, eps=0.0, maxiter=50)
+        assert got[1] == st["iters"] == 50
+        assert float((got[0].cpu() - xo).abs().max()) <= 1e-10 * float(xo.abs().max())
 
 
 # ------------------------------------------------------------------ a lost peer workgroup: time out, fall back, stay there
