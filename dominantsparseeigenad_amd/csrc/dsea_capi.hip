@@ -869,8 +869,10 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
   // Mid-size halo-1 operators (3-point stencil, 8192 < n <= 131072 rows: BASELINE configs[2]): ONE launch that keeps a
   // third of the basis in registers and LDS and streams the rest (dsea_lanczos_persist_mid.hip).  mode 2 = off for this
   // form only (A/B measurements).
-  if (w.lz_persist != 0 && w.lz_persist != 2 && w.reorth_passes == 1 && !w.partial_reorth && !prof &&
-      lanczos_persist_mid_applicable(op->d, n, k) &&
+  // automatic where it is measured to win (n >= 49152 rows, k <= 400: profiles/r04_lanczos_mid_size.txt); mode 1 forces it
+  // wherever it applies
+  if (w.lz_persist != 0 && w.lz_persist != 2 && (w.lz_persist == 1 || (n >= 49152 && k <= 400)) && w.reorth_passes == 1 &&
+      !w.partial_reorth && !prof && lanczos_persist_mid_applicable(op->d, n, k) &&
       lanczos_persist_mid_comm_bytes(n, k) <= (size_t)DSEA_MAX_WAVE_TILES * (size_t)((w.kmax < 1 ? 1 : w.kmax) + 1) * sizeof(double)) {
     const int pr = launch_lanczos_persist_mid(op->d, k, q0, Q, ldq, Qs, lds, w.lp_tau, alphas, betas, brk,
                                               w.scal + DSEA_SCAL_LZ_FAIL, lp_count, P, st, w.lose_peer);

@@ -54,10 +54,17 @@ typedef gran_u64 lzm_gu64;
 #define LZM_NCH 4                 /* 128-row chunks of a slab held per lane: R <= 512 rows */
 #ifndef LZM_NR
 #define LZM_NR 10                 /* register-cache slots per wave (8 doubles per lane each).  The wave is alone on its SIMD:
-                                     256 VGPRs + 256 AGPRs; the compiler parks the slots in the AGPR half on its own (no MFMA
-                                     here).  10 is what fits without scratch (resource-usage: 256 + 237); explicit
-                                     v_accvgpr_read/write residency was tried and gained nothing -- AV-class values still
-                                     take VGPRs first */
+                                     256 VGPRs + 256 AGPRs, and the compiler parks the slots in the AGPR half on its own (no
+                                     MFMA here).  10 is what fits without scratch (resource-usage: 256 + 237).  Tried and
+                                     measured with -Rpass-analysis=kernel-resource-usage: explicit v_accvgpr_write / _read
+                                     residency ("a" constraints; volatile writes so that the conditional slot update is not
+                                     if-converted into VGPR selects; tied "+a" operands; an unconditional shift-register
+                                     form) -- the allocator keeps TWO registers per loop-carried dword in every form, i.e.
+                                     32 row-pair slots fill the 256 AGPRs: no more capacity than the compiler finds itself.
+                                     A wave-partitioned layout (each wave a quarter of the slab, 124-VGPR loop body, no
+                                     cross-wave combine) was built and measured as well: 17.8 instead of 19.4 us per step with
+                                     everything on chip, but its quarter-row streams (784-byte fp64 and 196-byte bf16 loads
+                                     per wave) ran slower than this form's: 46.5 vs 43.5 us per step at N = 1e5, k = 300. */
 #endif
 //                  /* register-cache slots per wave (one slot = this wave's copy of a slab of one vector) */
 #define LZM_LDS_BYTES 163840      /* 160 KiB per CU */
@@ -170,6 +177,12 @@ __global__ __launch_bounds__(LZM_THREADS, LZM_WAVES / 4) void k_lanczos_persist_
   int lp_steps = 0, fb_steps = 0;
   __syncthreads();
 
+#ifdef DSEA_LZM_TIMING
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = wall_clock64();
+#define LZM_TICK(k) { const long long tn = wall_clock64(); tacc[k] += tn - tprev; tprev = tn; }
+#else
+#define LZM_TICK(k)
+#endif
   const int lane_fixed = lane;
   for (int s = 0; s < a.k; ++s) {
     const unsigned epoch = (unsigned)(s + 1);
@@ -244,6 +257,7 @@ __global__ __launch_bounds__(LZM_THREADS, LZM_WAVES / 4) void k_lanczos_persist_
       if (lane == 63) s_b[24 + m] = rec[3];       // r_last of workgroup 64 m + 63
     }
     __syncthreads();                                                             // B1
+    LZM_TICK(0)
     if (s_b[1] != 0.0) {
       if (tid == 0) a.fail[0] = 1.0;
       return;
@@ -334,6 +348,7 @@ __global__ __launch_bounds__(LZM_THREADS, LZM_WAVES / 4) void k_lanczos_persist_
         }
     }
     if (s == a.k - 1) break;
+    LZM_TICK(1)
     // ---------------------------------------------------------------- partial c_j = q_j . r'  (j <= s), ||r'||^2
     {
       // (a) this wave's register slots (zeros where nothing is cached yet: harmless)
@@ -382,22 +397,21 @@ __global__ __launch_bounds__(LZM_THREADS, LZM_WAVES / 4) void k_lanczos_persist_
       for (int cc = wv; M + 4 * cc < s; cc += LZM_WAVES) {
         const int j0 = M + 4 * cc;
         double acc[4];
+        {                                           // four vectors (16 loads of 16 bytes per lane) in flight at a time
+          double2 qq[4][LZM_NCH];
 #pragma unroll
-        for (int h = 0; h < 4; h += 2) {            // two vectors (8 loads of 16 bytes per lane) in flight at a time
-          double2 qq[2][LZM_NCH];
-#pragma unroll
-          for (int v = 0; v < 2; ++v)
+          for (int v = 0; v < 4; ++v)
 #pragma unroll
             for (int c = 0; c < LZM_NCH; ++c) {
               const int lr = 128 * c + 2 * lane;
               qq[v][c] = make_double2(0.0, 0.0);
-              if (j0 + h + v < s && vx[c]) qq[v][c] = ld2<true>(a.Q + (int64_t)(j0 + h + v) * a.ldq + base, lr, Rg);
+              if (j0 + v < s && vx[c]) qq[v][c] = ld2<true>(a.Q + (int64_t)(j0 + v) * a.ldq + base, lr, Rg);
             }
 #pragma unroll
-          for (int v = 0; v < 2; ++v) {
-            acc[h + v] = 0.0;
+          for (int v = 0; v < 4; ++v) {
+            acc[v] = 0.0;
 #pragma unroll
-            for (int c = 0; c < LZM_NCH; ++c) acc[h + v] = fma(qq[v][c].x, rn[c].x, fma(qq[v][c].y, rn[c].y, acc[h + v]));
+            for (int c = 0; c < LZM_NCH; ++c) acc[v] = fma(qq[v][c].x, rn[c].x, fma(qq[v][c].y, rn[c].y, acc[v]));
           }
         }
         const double bsum = wave_sum4_rows(acc[0], acc[1], acc[2], acc[3]);
@@ -421,6 +435,7 @@ __global__ __launch_bounds__(LZM_THREADS, LZM_WAVES / 4) void k_lanczos_persist_
       }
     }
     __syncthreads();                                                             // B2
+    LZM_TICK(2)
     // ---------------------------------------------------------------- X2a: partials to their owners, X2b: reduced values to all
     const int nvec = s + 2;
     for (int t = tid; t < nvec; t += LZM_THREADS) granule_put(X2a + ((int64_t)t * G + g) * 2, epoch, s_cpart[t]);
@@ -431,6 +446,7 @@ __global__ __launch_bounds__(LZM_THREADS, LZM_WAVES / 4) void k_lanczos_persist_
       tot = wave_sum(tot);
       if (lane == 0) granule_put(X2b + (int64_t)j * 2, epoch, tot);
     }
+    LZM_TICK(3)
     for (int t = tid; t < nvec; t += LZM_THREADS) {
       double v = 0.0;
       while (!granule_try_get(X2b + (int64_t)t * 2, epoch, v)) {
@@ -444,6 +460,7 @@ __global__ __launch_bounds__(LZM_THREADS, LZM_WAVES / 4) void k_lanczos_persist_
     }
     if (tid == 0) s_b[5] = 0.0;
     __syncthreads();                                                             // B3
+    LZM_TICK(4)
     if (s_b[1] != 0.0) {
       if (tid == 0) a.fail[0] = 1.0;
       return;
@@ -459,6 +476,7 @@ __global__ __launch_bounds__(LZM_THREADS, LZM_WAVES / 4) void k_lanczos_persist_
       use_shadow = s_b[5] == 0.0;
     }
     if (stream_any && !use_shadow) ++fb_steps; else ++lp_steps;
+    LZM_TICK(5)
     // ---------------------------------------------------------------- r = r' - sum_{j<=s} c_j q_j
     {
       double2 w[LZM_NCH];
@@ -508,12 +526,12 @@ __global__ __launch_bounds__(LZM_THREADS, LZM_WAVES / 4) void k_lanczos_persist_
 #pragma unroll
         for (int e = 0; e < 8; ++e) ws8[e] = 0.0;
         const bool act = 8 * lane < Rg;          // (R and the slab bases are multiples of 8; a ragged tail reads zeros... see launcher)
-        for (int cc = wv; M + 4 * cc < s; cc += LZM_WAVES) {
-          const int j0 = M + 4 * cc;
-          uint4 pk[4];
-          double cj[4];
+        for (int cc = wv; M + 8 * cc < s; cc += LZM_WAVES) {
+          const int j0 = M + 8 * cc;
+          uint4 pk[8];
+          double cj[8];
 #pragma unroll
-          for (int v = 0; v < 4; ++v) {
+          for (int v = 0; v < 8; ++v) {
             pk[v] = make_uint4(0u, 0u, 0u, 0u);
             cj[v] = 0.0;
             if (j0 + v < s) {
@@ -522,7 +540,7 @@ __global__ __launch_bounds__(LZM_THREADS, LZM_WAVES / 4) void k_lanczos_persist_
             }
           }
 #pragma unroll
-          for (int v = 0; v < 4; ++v) {
+          for (int v = 0; v < 8; ++v) {
             ws8[0] = fma(cj[v], bf16lo_to_f64(pk[v].x), ws8[0]);
             ws8[1] = fma(cj[v], bf16hi_to_f64(pk[v].x), ws8[1]);
             ws8[2] = fma(cj[v], bf16lo_to_f64(pk[v].y), ws8[2]);
@@ -580,6 +598,7 @@ __global__ __launch_bounds__(LZM_THREADS, LZM_WAVES / 4) void k_lanczos_persist_
         const int lr = 128 * c + 2 * lane;
         if (lr < R) *reinterpret_cast<double2*>(mine + lr) = w[c];
       }
+      LZM_TICK(6)
       __syncthreads();                                                           // B4
 #pragma unroll
       for (int c = 0; c < LZM_NCH; ++c) {
@@ -598,9 +617,14 @@ __global__ __launch_bounds__(LZM_THREADS, LZM_WAVES / 4) void k_lanczos_persist_
         r[c].y = vy[c] ? rn[c].y - tot.y : 0.0;
       }
     }
+    LZM_TICK(7)
     // no barrier here: s_part / s_c are next written behind B1..B3 of the next step, s_r / s_y by wave 0 after it has
     // passed B4 (every wave is then beyond its reads of them), s_b by wave 1 likewise
   }
+#ifdef DSEA_LZM_TIMING
+  if (g == 7 % G && tid == 0)
+    for (int q = 0; q < 8; ++q) a.alphas[q] = (double)tacc[q] * 0.01 / (double)a.k;   // us per step (overwrites alphas!)
+#endif
   if (g == 0 && tid == 0) {
     a.brk[1] = scale;
     if (a.lp_count) {

@@ -301,6 +301,14 @@ def test_mid_size_single_launch_lanczos_is_deterministic_reports_breakdown_and_s
     from dominantsparseeigenad_amd.Lanczos import Lanczos, symeigLanczos
     N, k = 40000, 90
     op, V, h, b, x0 = _problem(N, seed=72)
+    engine.LANCZOS_PERSIST = "force"        # (the automatic choice starts at 49152 rows, where the form is measured to win)
+    try:
+        _mid_size_checks(op, N, k, b, Lanczos, symeigLanczos, _lib, warnings, time)
+    finally:
+        engine.LANCZOS_PERSIST = True
+
+
+def _mid_size_checks(op, N, k, b, Lanczos, symeigLanczos, _lib, warnings, time):
     Q1, T1 = Lanczos(op, k, cuda, sparse=True, dim=N, q0=b)
     Q2, T2 = Lanczos(op, k, cuda, sparse=True, dim=N, q0=b)
     assert torch.equal(T1, T2) and torch.equal(Q1, Q2)
@@ -308,7 +316,7 @@ def test_mid_size_single_launch_lanczos_is_deterministic_reports_breakdown_and_s
     # supported on rows of three distinct potential values spans a 3-dimensional Krylov space -> beta_3 = 0 exactly
     Vd = torch.zeros(N, dtype=F64, device=cuda)
     Vd[5], Vd[20000], Vd[39999] = 1.0, 2.0, 4.0
-    opd = Stencil3Operator(N, 1e200, Vd)
+    opd = Stencil3Operator(N, 1e150, Vd)          # coefficient -0.5e-300: negligible beside V, no overflow in h ** 2
     q = torch.zeros(N, dtype=F64, device=cuda)
     q[5], q[20000], q[39999] = 1.0, -2.0, 0.5
     with warnings.catch_warnings(record=True) as rec:
@@ -322,7 +330,7 @@ def test_mid_size_single_launch_lanczos_is_deterministic_reports_breakdown_and_s
     try:
         ref_lo, ref_v = symeigLanczos(op, k, cuda, extreme="min", sparse=True, dim=N, q0=b)
     finally:
-        engine.LANCZOS_PERSIST = True
+        engine.LANCZOS_PERSIST = "force"
     ws = engine.Workspace.get(N, k, cuda)
     ws.lanczos_persist_lost = False
     _lib.check(lib.dsea_ws_set_fault_injection(ws.handle, 1), "dsea_ws_set_fault_injection")
