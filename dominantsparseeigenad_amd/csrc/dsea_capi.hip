@@ -883,10 +883,13 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
     if (pr == 0) return check_launch();
   }
   const int rps = lp_rows_per_step(n, g.split_w != 0);   // 0 = split form
-  launch_dot(q0, q0, n, P, nrm2, st);
-  launch_scale_store(q0, nrm2, Q, nullptr, n, st, Qs);
   const bool has_fused_tail = (op->d.kind == OP_TFIM && op->d.tfim.L_local >= 1) || op->d.kind == OP_SELL ||
                               op->d.kind == OP_STENCIL3;
+  // (operators without a fused tail: full re-orthogonalisation only -- refused BEFORE anything is enqueued; the partial
+  //  option reaches them through dsea_lanczos_partial_step)
+  if (w.partial_reorth && !has_fused_tail) return DSEA_ERR_UNSUPPORTED;
+  launch_dot(q0, q0, n, P, nrm2, st);
+  launch_scale_store(q0, nrm2, Q, nullptr, n, st, Qs);
   if (has_fused_tail) {
     // Fused sequence, 4 launches per step and no stand-alone scalar reductions: the mat-vec leaves
     // per-block partials of alpha (aP), the dots kernel sums them in its prologue; the axpy kernel leaves

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256 * NVB) void k_cg_persist_tfim_big(CgbArgs a) {
     fail = sm.fail != 0.0;
   };
 
-#ifdef DSEA_CGB_TIMING
+  #ifdef DSEA_CGB_TIMING
   long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = wall_clock64();
 #define CGB_TICK(k) { const long long tn = wall_clock64(); tacc[k] += tn - tprev; tprev = tn; }
 #else
@@ -379,13 +379,18 @@ __global__ __launch_bounds__(256 * NVB) void k_cg_persist_tfim_big(CgbArgs a) {
       }
       ++epoch;
       const int which = (int)((iters + 1) & 1);
+      CGB_TICK(4)
       publish_d(rv, which, epoch);
+      CGB_TICK(0)
       wait_partners(epoch, fail);
       if (fail) break;
+      CGB_TICK(1)
       const double accw = matvec(rv, a.dbuf[which], wv);
+      CGB_TICK(2)
       double gam2 = 0.0, del2 = 0.0;
       exchange2(rr_chain(), accw, epoch, fail, gam2, del2);
       if (fail) break;
+      CGB_TICK(3)
       ++iters;
       rn = sqrt(gam2);
       if (rn < a.eps) {
@@ -399,6 +404,10 @@ __global__ __launch_bounds__(256 * NVB) void k_cg_persist_tfim_big(CgbArgs a) {
     }
 #pragma unroll
     for (int m = 0; m < CGB_PER; ++m) *reinterpret_cast<double2*>(a.x + base + 2 * (int64_t)(t + 256 * m)) = xv[m];
+#ifdef DSEA_CGB_TIMING
+    if (blockIdx.x == 7 && tid == 0)
+      for (int q = 0; q < 6; ++q) a.dbuf[0][q] = (double)tacc[q] * 0.01 / (double)(iters > 0 ? iters : 1);   // us per iteration
+#endif
     if (blockIdx.x == 0 && tid == 0) {
       a.state[DSEA_CG_RR] = gam;
       a.state[DSEA_CG_RESNORM] = rn;

@@ -45,7 +45,8 @@ namespace dsea {
 
 namespace {
 typedef gran_u64 lzp_gu64;
-#define LZP_TIMEOUT_TICKS DSEA_GRANULE_TIMEOUT_TICKS
+#define LZP_TIMEOUT_TICKS 30000000ll   /* 0.3 s of the 100 MHz wall clock: a healthy step takes ~10 us, a lost peer must not hold
+                                          up to 64 CUs for seconds before the host falls back to the multi-launch kernels */
 #define LZP_ROWS 128
 #define LZP_MAX_K 512
 #define LZP_MAX_G 64
@@ -380,7 +381,9 @@ int launch_lanczos_persist(const OpDesc& op, int k, const double* q0, double* Q,
   if (!lanczos_persist_applicable(op, n, k)) return -1;
   const int G = (int)((n + LZP_ROWS - 1) / LZP_ROWS);
   {
-    // all G workgroups (one per CU: 1024 threads, ~50 KB of LDS) must be resident together
+    // all G workgroups must be resident together: 1024 threads and ~153 KB of static LDS each (s_cache 112 KB, s_part 16 KB,
+    // s_red 8 KB, s_c / s_cpart 8 KB, s_nb 6 KB ...), i.e. one per CU and nothing else holding LDS there -- the occupancy
+    // query below refuses the form otherwise (the host then takes the multi-launch kernels at once instead of timing out)
     static thread_local int cu_dev = -1, cu_count = 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -2;
@@ -389,6 +392,12 @@ int launch_lanczos_persist(const OpDesc& op, int k, const double* q0, double* Q,
       cu_dev = dev;
     }
     if (G > cu_count) return -1;
+    static thread_local int occ_dev = -1, occ = 0;
+    if (dev != occ_dev) {
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_lanczos_persist, 1024, 0) != hipSuccess) return -2;
+      occ_dev = dev;
+    }
+    if (occ < 1) return -1;
   }
   if (hipMemsetAsync(comm, 0, lanczos_persist_comm_bytes(n, k), st) != hipSuccess) return -2;
   LzpArgs a;

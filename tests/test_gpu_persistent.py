@@ -447,8 +447,10 @@ def test_persistent_tfim_cg_large_one_exchange_form_follows_the_reference_iterat
     b = torch.from_numpy(normal_vector(n, 500 + L)).to(cuda)
     x0 = torch.from_numpy(normal_vector(n, 600 + L)).to(cuda)
     shift = torch.tensor(-1.3 * L - 1.0, dtype=F64, device=cuda)       # below the spectrum: A - s is SPD
+    # (without the shift the operator is indefinite: CG is then no convergent process and any two rounding-different
+    #  evaluations drift apart after a few iterations -- only the first steps are compared there)
     for sh in (shift, None):
-        for its in (1, 2, 50):
+        for its in ((1, 2, 50) if sh is not None else (1, 2, 5)):
             ref = _solve(op, b, x0, sh, 0, eps=0.0, maxiter=its)
             got = _solve(op, b, x0, sh, -1, eps=0.0, maxiter=its)
             scale = float(ref[0].abs().max())
@@ -511,7 +513,7 @@ def test_lost_peer_times_out_and_the_host_falls_back_to_the_multi_launch_kernels
             lo, v = symeigLanczos(op, k, cuda, extreme="min", sparse=True, dim=n, q0=q0)
         waited = time.time() - t0
         assert any("single-launch Lanczos timed out" in str(w.message) for w in rec)
-        assert 2.0 < waited < 20.0, waited
+        assert 0.2 < waited < 20.0, waited        # (0.3 s spin bound of the README-sized form)
         assert lo.item() == ref_lo.item() and torch.equal(v, ref_v)
         assert ws.lanczos_persist_lost and ws.lanczos_persist_mode == 0
         t0 = time.time()

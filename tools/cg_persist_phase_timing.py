@@ -28,5 +28,9 @@ for L in (16, 20):
     npad = (ws.n + 255) // 256 * 256
     vec_off = buf.numel() - 4 * npad
     dbg = buf[vec_off + 2 * npad: vec_off + 2 * npad + 6].cpu().numpy()
-    print("L=%d: %.2f us/iteration total | wait partners %.2f  matvec %.2f  S1 (d.Ad) %.2f  update+S2 (r.r) %.2f  direction+publish d %.2f  loop top %.2f" % (
-        L, dt / 400 * 1e6, dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5]))
+    if engine.CG_TFIM_REFERENCE_RECURRENCES:
+        print("L=%d two-exchange form: %.2f us/iteration total | wait partners %.2f  matvec %.2f  S1 (d.Ad) %.2f  update+S2 (r.r) %.2f  direction+publish d %.2f  loop top %.2f" % (
+            L, dt / 400 * 1e6, dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5]))
+    else:
+        print("L=%d one-exchange form: %.2f us/iteration total | publish r %.2f  wait partners %.2f  matvec %.2f  exchange (gamma, delta) %.2f  vector updates %.2f" % (
+            L, dt / 400 * 1e6, dbg[0], dbg[1], dbg[2], dbg[3], dbg[4]))
