@@ -480,7 +480,7 @@ int dsea_op_create_transfer(int D, int d, const double* A_dev, int transpose, do
                             dsea_op_t* out) {
   if (!out || D < 1 || d < 1 || !A_dev || !work || (int64_t)d * D > 2147483647ll) return DSEA_ERR_ARG;
   if (!aligned16(A_dev) || !aligned16(work)) return DSEA_ERR_ALIGN;
-  if (!blas_available()) return DSEA_ERR_UNSUPPORTED;
+  if (!blas_available() && !(D >= 64 && D % 64 == 0)) return DSEA_ERR_UNSUPPORTED;   // (hand-written kernels cover D % 64 == 0)
   dsea_op_s* op = new (std::nothrow) dsea_op_s;
   if (!op) return DSEA_ERR_ARG;
   memset(&op->d, 0, sizeof(op->d));

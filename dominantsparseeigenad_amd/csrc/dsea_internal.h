@@ -242,6 +242,9 @@ size_t lanczos_persist_comm_bytes(int64_t n, int k);
 int launch_lanczos_persist(const OpDesc& op, int k, const double* q0, double* Q, int64_t ldq, double* alphas,
                            double* betas, double* brk, double* fail, void* comm, hipStream_t st, int lose_peer = 0);
 
+// dsea_transfer_mfma.hip
+bool transfer_mfma_applicable(const OpDesc& op);
+int launch_transfer_mfma(const OpDesc& op, const double* x, double* y, hipStream_t st);
 // dsea_lanczos_persist_mid.hip
 bool lanczos_persist_mid_applicable(const OpDesc& op, int64_t n, int k);
 size_t lanczos_persist_mid_comm_bytes(int64_t n, int k);

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <rocblas/rocblas.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <mutex>
 
@@ -174,6 +175,10 @@ __global__ __launch_bounds__(256) void k_sum_slices(const double* __restrict__ Y
 // y = op x for the GEMM-shaped operands (row-major data, rocBLAS is column-major: a row-major product C = A B
 // is the column-major product C^T = B^T A^T on the same memory).  Returns 0 or -1.
 int blas_apply(const OpDesc& op, const double* x, double* y, hipStream_t st) {
+  // the transfer operand at D a multiple of 64 also has two hand-written fp64 MFMA kernels (dsea_transfer_mfma.hip): opt-in
+  // (DSEA_TRANSFER_MFMA=1) -- measured slower than the library GEMMs below -- and the only path where rocBLAS is absent
+  if (op.kind == OP_TRANSFER && (getenv("DSEA_TRANSFER_MFMA") || !blas_available()) && launch_transfer_mfma(op, x, y, st) == 0)
+    return 0;
   if (!blas_available()) return -1;
   const double one = 1.0, zero = 0.0;
   rocblas_handle hd = handle_for(st);

@@ -129,6 +129,35 @@ def test_transfer_and_dense_operators_match_einsum(D, d):
     assert float((DenseOperator(G, transpose=True)(v) - G.T @ v).abs().max()) < 1e-13 * scale * D
 
 
+@pytest.mark.parametrize("D,d", [(64, 1), (128, 3), (192, 2), (512, 2)])
+def test_transfer_matvec_on_the_fp64_matrix_cores_matches_the_contraction_and_the_library_gemm_path(D, d):
+    """csrc/dsea_transfer_mfma.hip (opt-in, DSEA_TRANSFER_MFMA=1; D a multiple of 64: two hand-written v_mfma_f64_16x16x4
+    kernels -- T = [B_s] X as one stacked product, y = sum_s T_s B_s^T as ONE product over the inner dimension d D, no
+    transpose, no slice sum) against the contraction of general.py:59-66 and against the default rocBLAS path, both
+    orientations; an ASYMMETRIC operand so that a transposed tile or fragment cannot pass."""
+    import os
+    from dominantsparseeigenad_amd.operators import TransferOperator
+    rng = np.random.RandomState(1000 + D)
+    A = torch.from_numpy(rng.randn(d, D, D) + np.arange(D)[None, :, None] * 0.01).to(cuda)
+    v = torch.from_numpy(rng.randn(D * D)).to(cuda)
+    X = v.reshape(D, D)
+    fr = sum(A[s] @ X @ A[s].T for s in range(d)).reshape(-1)                  # general.py:59-61
+    fl = sum(A[s].T @ X @ A[s] for s in range(d)).reshape(-1)                  # general.py:62-64
+    opr, opl = TransferOperator(A), TransferOperator(A, transpose=True)
+    zr, zl = opr(v).clone(), opl(v).clone()                                    # default path
+    os.environ["DSEA_TRANSFER_MFMA"] = "1"
+    try:
+        yr, yl = opr(v).clone(), opl(v).clone()
+        again = opr(v).clone()
+    finally:
+        del os.environ["DSEA_TRANSFER_MFMA"]
+    sr, sl = float(fr.abs().max()), float(fl.abs().max())
+    assert float((yr - fr).abs().max()) < 1e-13 * sr * D, float((yr - fr).abs().max()) / sr
+    assert float((yl - fl).abs().max()) < 1e-13 * sl * D
+    assert float((yr - zr).abs().max()) < 1e-13 * sr * D and float((yl - zl).abs().max()) < 1e-13 * sl * D
+    assert torch.equal(again, yr)                                               # deterministic
+
+
 def test_dominant_eig_device_matches_reference_fixture():
     """reference tests/test_gradient.py:5-22 case: outputs of the REFERENCE's DominantEig (ARPACK + scipy gmres,
     eig.py:27-62) stored by tests/golden/make_golden.py, reproduced by the library Arnoldi / GMRES on the GPU."""
