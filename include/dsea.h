@@ -79,7 +79,12 @@ int dsea_ws_set_split(dsea_ws_t ws, int waves);
  * 100 + g (g = 0 automatic geometry, or one of the codes above): the MERGED-REDUCTION form -- one grid-wide exchange
  * per iteration instead of two (r.r and r.Ar reduced together, A p carried by a recurrence: Chronopoulos-Gear).  The
  * same iteration in exact arithmetic, NOT the rounding sequence of reference CG.py:31-40: an option for
- * latency-bound solves, never selected automatically.                                                           */
+ * latency-bound solves on the STENCIL operand, never selected automatically there.
+ * Full-space matrix-free TFIM operand at 2^14 ... 2^20 rows (the adjoint solve of BASELINE configs[1]): the single-launch
+ * form makes ONE grid-wide exchange per iteration by default (the same Chronopoulos-Gear recurrences; measured within
+ * 1e-15 of the two-exchange form on SPD systems, same iteration counts: profiles/r04_cg_one_exchange_check.txt);
+ * mode 200 selects the TWO-exchange form there, whose iterates are bit-identical to the streaming kernels, i.e. to
+ * reference CG.py:31-40 evaluated in fp64 (other operands treat 200 as -1).                                       */
 int dsea_ws_set_persist(dsea_ws_t ws, int mode);
 /* tuning knob: single-launch Lanczos of dsea_lanczos_run for README-sized problems (full-space matrix-free TFIM with
  * L <= 13, 3-point stencil without halo pointers with n <= 8192; k <= 512): the whole k-step loop is ONE launch of
@@ -88,7 +93,12 @@ int dsea_ws_set_persist(dsea_ws_t ws, int mode);
  * sums are combined in a different order (per 128-row slab): T agrees with the multi-launch form to rounding, not bit
  * for bit.  -1 = automatic (on up to n = 4096, where it is measured to win), 0 = off, 1 = on wherever it applies.  A lost
  * peer workgroup (bounded spins) makes
- * dsea_lanczos_status return DSEA_ERR_TIMEOUT; the caller then repeats the run with the knob off.                 */
+ * dsea_lanczos_status return DSEA_ERR_TIMEOUT; the caller then repeats the run with the knob off.
+ * The same knob governs the MID-SIZE single-launch form (3-point stencil without halo pointers, 8192 < n <= 131072 rows,
+ * k <= 505: BASELINE configs[2]; csrc/dsea_lanczos_persist_mid.hip): one workgroup per CU owns a slab of rows and keeps
+ * its rows of the first ~80 basis vectors in LDS and registers, the rest is streamed (fp64 dots, bf16 shadow correction
+ * when a shadow is set).  Automatic from 49152 rows up to k = 400 (where it is measured to win), mode 1 forces it
+ * wherever it applies, mode 2 = only the README-sized form (this one off).                                         */
 int dsea_ws_set_lanczos_persist(dsea_ws_t ws, int mode);
 /* Gram-Schmidt passes per step of dsea_lanczos_run: 1 = the reference (single-pass classical Gram-Schmidt against all
  * previous vectors, Lanczos.py:66), 2 = the pass is repeated on the corrected vector ("CGS2": orthogonality at rounding
@@ -178,7 +188,11 @@ int dsea_op_set_tuning(dsea_op_t op, int key, int value);
  *                 transpose == 0:  y = sum_s A_s x A_s^T        ("Gong",  general.py:59-61)
  *                 transpose != 0:  y = sum_s A_s^T x A_s        ("GongT", general.py:62-64)
  *             as two strided-batched GEMMs in the "X Y^T" shape (the transposed form is the same contraction on
- *             the slice-wise transposed tensor, copied once) + a transpose and a slice-sum kernel.  `work`:
+ *             the slice-wise transposed tensor, copied once) + a transpose and a slice-sum kernel.  For D a multiple
+ *             of 64 two hand-written fp64 MFMA kernels exist as well (csrc/dsea_transfer_mfma.hip: one stacked product
+ *             and one product over the inner dimension d D -- no transpose, no slice sum): measured SLOWER than the
+ *             library GEMMs (53 vs 33 us at D = 512), hence opt-in (environment DSEA_TRANSFER_MFMA=1) and the path taken
+ *             when rocBLAS is not available.  `work`:
  *             caller-owned scratch of dsea_op_transfer_work_bytes(D, d); dsea_op_create_transfer fills part of it
  *             on `stream`.                                                                                    */
 int dsea_op_create_dense(int64_t n, const double *A_dev, int64_t lda, int transpose, dsea_op_t *out);

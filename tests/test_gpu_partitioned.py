@@ -7,8 +7,10 @@
     pairwise slab exchange, 4 and 8 ranks = transposed all-to-all form with the HIP flip-sum kernel (8 ranks = the
     p = 3 geometry of BASELINE configs[4]: three far bits, (max(3,p)+1)-slab scratch, overlapped exchange); first and
     second order through the reference API against the reference's fixtures; the 3-point stencil with halo exchange.
-The 8-GPU run itself is the driver's; its logic is also covered by tests/test_partitioned_gloo.py and by the
-host-staged rehearsal of bench.py's N > 1 branch (tests/test_gpu_bench_contract.py)."""
+The 8-rank cases of every test below live in tests/test_gpu_0_world8.py, which runs FIRST: the GPU serves eight compute
+processes at a time, and eight workers beside a pytest process that already holds a GPU context are time-sliced (measured:
+10 s -> 100-375 s per test).  The 8-GPU run itself is the driver's; its logic is also covered by
+tests/test_partitioned_gloo.py and by the host-staged rehearsal of bench.py's N > 1 branch (tests/test_gpu_bench_contract.py)."""
 import os
 import socket
 import sys
@@ -222,6 +224,9 @@ def _worker(rank, world, port, backend, case, args, ret):
 
 
 def _run(world, backend, case, *args):
+    if world >= 8 and torch.cuda.is_initialized():
+        pytest.skip("eight workers beside a parent that holds a GPU context exceed the eight compute processes the GPU "
+                    "serves at a time (time-sliced: minutes per test); the 8-rank cases run first, in test_gpu_0_world8.py")
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), backend, case, args, ret), nprocs=world, join=True)
@@ -230,8 +235,7 @@ def _run(world, backend, case, *args):
 
 
 @pytest.mark.parametrize("world,backend,overlap", [(1, "nccl", False), (2, "gloo", False), (4, "gloo", False),
-                                                   (2, "gloo", True), (4, "gloo", True), (8, "gloo", False),
-                                                   (8, "gloo", True)])
+                                                   (2, "gloo", True), (4, "gloo", True)])
 def test_partitioned_hip_backend(world, backend, overlap):
     """overlap: the step that starts the slab exchange of the un-corrected r on the side stream before the dots pass
     (form_r snapshot, premise check, side-stream join) on the HIP slab kernels -- pairwise form at 2 ranks, transposed
@@ -272,7 +276,7 @@ def test_full_slab_world1_over_rccl_matches_reference_L20_scalars(force_driver):
     assert o["resid"] < 1e-9
 
 
-@pytest.mark.parametrize("world,tag", [(2, "L10_k300_g1.0"), (4, "L12_k200_g1.0"), (8, "L12_k200_g1.0")])
+@pytest.mark.parametrize("world,tag", [(2, "L10_k300_g1.0"), (4, "L12_k200_g1.0")])
 def test_reference_api_second_order_on_partitioned_hip_operator(world, tag):
     """E0, psi, dE0, d2E0, loss gradient and chi_F (E0.py:53-67, chiF.py:40-53) with the vectors cut over 2 / 4 / 8
     ranks: the re-entrant distributed backward against the reference's own outputs."""
@@ -317,8 +321,7 @@ def test_replicated_cg_on_hip_slabs_matches_partitioned_cg():
     assert abs(repl[0][3] - part[0][3]) <= 1                                # iteration counts (different summation orders)
 
 
-@pytest.mark.parametrize("world,backend,overlap", [(1, "nccl", False), (2, "gloo", True), (4, "gloo", True), (4, "gloo", False),
-                                                   (8, "gloo", True), (8, "gloo", False)])
+@pytest.mark.parametrize("world,backend,overlap", [(1, "nccl", False), (2, "gloo", True), (4, "gloo", True), (4, "gloo", False)])
 def test_library_driver_equals_python_driver(world, backend, overlap):
     """include/dsea.h "row-partitioned solvers": dsea_pop_lanczos_run / dsea_pop_cg_run issue the slab kernels AND the
     collectives from inside the library (RCCL at world size 1; caller-supplied callbacks -- host-staged gloo -- for
@@ -337,7 +340,7 @@ def test_library_driver_equals_python_driver(world, backend, overlap):
         assert "callbacks" in lib_run[0][4]
 
 
-@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (4, "gloo"), (8, "gloo")])
+@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (4, "gloo")])
 def test_library_driver_partial_reorthogonalisation(world, backend):
     """dsea_ws_set_partial_reorth on the row-partitioned library driver: the estimates take the GLOBAL norm (one more scalar
     all-reduce per step), every rank takes the same decisions, the collectives are issued on every step (zeros on the
@@ -390,7 +393,7 @@ def test_library_owned_rccl_communicators_world1():
     assert own[0][0] == adopt[0][0] and own[0][2] == adopt[0][2] and np.array_equal(own[0][1], adopt[0][1])
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("world", [2, 4])
 def test_overlap_premise_is_checked_on_the_device_and_a_violation_repeats_the_run(world):
     """The overlapped exchange sends the UN-corrected r; its premise max|c_j| <= tau ||r|| is evaluated by a kernel each
     step and read ONCE after the run (dsea_pop_lanczos_status -> DSEA_ERR_PREMISE), not by a host round trip per step.
