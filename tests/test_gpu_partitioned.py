@@ -174,6 +174,27 @@ def _case_api_tfim(rank, world, backend, dev, tag, second_order, force_driver):
     return out
 
 
+def _case_g_rebind(rank, world, backend, dev):
+    """op.g = new_tensor on the LIBRARY driver (dsea_pop_* handles hold a device pointer to g): the setter rebuilds the slab
+    operator and the partitioned-operator handles, so the next solve uses the new coupling (the stale pointer was
+    read silently)"""
+    from dominantsparseeigenad_amd.partitioned import PartitionedTFIMOperator
+    p = world.bit_length() - 1
+    nloc = 1 << (L - p)
+    off = rank * nloc
+    q0 = torch.from_numpy(normal_vector(nloc, 5100, offset=off)).to(dev)
+    op = PartitionedTFIMOperator(L, torch.tensor([1.0], dtype=torch.float64, device=dev), dev, comm=_comm(backend))
+    op.force_driver = True
+    _, _, a1, _ = op.lanczos(40, q0)
+    op.g = torch.tensor([1.6], dtype=torch.float64, device=dev)
+    _, _, a2, _ = op.lanczos(40, q0)
+    fresh = PartitionedTFIMOperator(L, torch.tensor([1.6], dtype=torch.float64, device=dev), dev, comm=_comm(backend))
+    fresh.force_driver = True
+    _, _, a3, _ = fresh.lanczos(40, q0)
+    torch.cuda.synchronize()
+    return (bool(torch.equal(a2, a3)), float((a1 - a2).abs().max()), op.driver)
+
+
 def _case_api_stencil(rank, world, backend, dev):
     from helpers import PatchRandn
     import dominantsparseeigenad_amd.symeig as symeig
@@ -382,6 +403,13 @@ def test_library_driver_partial_reorthogonalisation_on_the_stencil(world, backen
     assert np.max(np.abs(psi_f - sgn * psi_p)) < 1e-8
     assert abs(full[0]["loss"] - part[0]["loss"]) < 1e-8
     assert np.max(np.abs(g_f - g_p)) < 1e-6 * np.max(np.abs(g_f))
+
+
+@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo")])
+def test_rebinding_g_rebuilds_the_library_side_operators(world, backend):
+    ret = _run(world, backend, "_case_g_rebind")
+    for same, moved, driver in ret:
+        assert same and moved > 1e-3 and driver.startswith("library"), ret
 
 
 def test_library_owned_rccl_communicators_world1():

@@ -50,6 +50,23 @@ def _case_driver(rank, world, overlap=False, tau=None, replicate="auto"):
     return (E0.item(), psi.numpy().copy(), grad.item(), solver.last_cg_iters, solver.op.overlap_fallbacks)
 
 
+def _case_g_rebind(rank, world):
+    """op.g = new_tensor (the reference's ``model.g = ...`` pattern) must be SEEN by the slab operator: H with the new g"""
+    from cpu_backend import CpuBackend
+    from dominantsparseeigenad_amd.partitioned import PartitionedTFIMOperator
+    p = world.bit_length() - 1
+    nloc = 1 << (L - p)
+    off = rank * nloc
+    v = torch.from_numpy(normal_vector(nloc, 6000, offset=off))
+    op = PartitionedTFIMOperator(L, torch.tensor([1.0], dtype=torch.float64), "cpu", backend=CpuBackend(nloc))
+    y1 = op.H(v).clone()
+    op.g = torch.tensor([1.7], dtype=torch.float64)
+    y2 = op.H(v).clone()
+    fresh = PartitionedTFIMOperator(L, torch.tensor([1.7], dtype=torch.float64), "cpu", backend=CpuBackend(nloc))
+    y3 = fresh.H(v).clone()
+    return (bool(torch.equal(y2, y3)), float((y1 - y2).abs().max()))
+
+
 def _case_partial_on_python_driver(rank, world):
     """the partial re-orthogonalisation option needs the library driver: the Python step driver says so on every rank (same
     condition everywhere, no collective has been issued yet) instead of silently re-orthogonalising on every step"""
@@ -318,6 +335,11 @@ def test_bench_anchor_resolution_and_like_by_like_speedups(tmp_path):
     rec = bench._speedups(pt, 700.0, True, {"ms_per_step": 1000.0, "bf16_shadow_of_basis": False},
                           {"ms_per_step": 600.0, "bf16_shadow_of_basis": True}, anchors, src)
     assert rec["speedup_vs_one_gpu_k80_shadow"] is None and rec["speedup_vs_one_gpu_fp64_basis"] == 5.0
+
+
+def test_rebinding_g_on_a_partitioned_operator_is_seen():
+    ret = _run(2, "_case_g_rebind")
+    assert all(same and moved > 1e-3 for same, moved in ret), ret
 
 
 def test_partial_reorthogonalisation_needs_the_library_driver():
