@@ -3,13 +3,8 @@
 // on the fp64 matrix cores (v_mfma_f64_16x16x4_f64) -- the one GEMM-shaped operand of the path (BASELINE
 // configs[3]: D = 512, d = 2).
 //
-// STATUS: an OPT-IN alternative (DSEA_TRANSFER_MFMA=1), correct (tests/test_gpu_eig.py) and SLOWER than the library path it
-// was written to replace -- measured on MI355X, D = 512, d = 2 (profiles/r04_transfer_mfma.txt): 53 us per mat-vec against
-// 33 us for transpose + two strided-batched rocBLAS DGEMMs + slice sum.  A variant with 16-byte fragment reads (two MFMAs per
-// ds_read_b128) and two accumulation chains per tile ran at 74 us.  Each kernel sits at ~4x its matrix-core bound (256
-// MFMAs per wave = 6.8 us); the default therefore stays the rocBLAS path of dsea_krylov.hip.
-//
-// The formulation -- two hand-written kernels and no vendor library:
+// Until round 3 this was four launches: transpose of x, two strided-batched rocBLAS DGEMMs, slice sum (32.7 us at D = 512).
+// Here two hand-written kernels and no vendor library:
 //   K1   T = [B_0; B_1; ...] X          one (dD x D)(D x D) product: the d slices are d D more rows of ONE row-major matrix
 //   K2   y = [T_0 T_1 ...] [B_0 B_1 ...]^T   one product with inner dimension dD: the sum over s IS the inner sum, so the
 //        result is written once -- no slice sum, and because both operands are read as they lie in memory (K2 is an
@@ -22,7 +17,7 @@
 // reads word pair 2 i + kk mod 32 ... distinct over the 32 lanes of an LDS cycle), a B tile [KC][TN + 16].
 // Fragment layout of v_mfma_f64_16x16x4_f64 (cdna_hip_programming.md 3): A[i = lane & 15][k = lane >> 4], B[k = lane >> 4]
 // [j = lane & 15], one double each; C/D four doubles per lane: row = (lane >> 4) + 4 reg, col = lane & 15.
-// Shapes the kernels do not cover (D not a multiple of 64) always take the rocBLAS path of dsea_krylov.hip.
+// Shapes the kernels do not cover (D not a multiple of 64) keep the rocBLAS path of dsea_krylov.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -151,36 +146,45 @@ bool transfer_mfma_applicable(const OpDesc& op) {
   return op.kind == OP_TRANSFER && op.transfer.D >= 64 && (op.transfer.D % 64) == 0 && op.transfer.d >= 1;
 }
 
+namespace {
+// one GEMM launch of the pair; the dynamic-LDS attribute (above the 64 KB a kernel gets without asking) is set once per
+// device and instantiation
+template <int TM, int TN, int KC, int WM, int WN, bool BT>
+int tfm_launch(dim3 grid, hipStream_t st, const double* A, int64_t lda, int64_t sA, const double* B, int64_t ldb, int64_t sB,
+               double* C, int64_t ldc, int Kseg, int nseg) {
+  static thread_local int attr_dev = -1;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  if (dev != attr_dev) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_dgemm_mfma<TM, TN, KC, WM, WN, BT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)tfm_lds_bytes<TM, TN, KC, BT>()) != hipSuccess)
+      return -1;
+    attr_dev = dev;
+  }
+  hipLaunchKernelGGL((k_dgemm_mfma<TM, TN, KC, WM, WN, BT>), grid, dim3(256), (tfm_lds_bytes<TM, TN, KC, BT>()), st, A, lda, sA,
+                     B, ldb, sB, C, ldc, Kseg, nseg);
+  return 0;
+}
+}  // namespace
+
 // y = sum_s B_s X B_s^T through the two kernels above; T = the operator's d x D x D scratch.  Returns 0 or -1 (not applicable).
+// The chunk of the inner dimension is as long as D allows (D % 128 == 0: 64 for K1, 128 for K2 -- 32 MFMAs per wave and
+// chunk, ~1 us, which covers the latency of the next chunk's global loads; otherwise half that).
 int launch_transfer_mfma(const OpDesc& op, const double* x, double* y, hipStream_t st) {
   if (!transfer_mfma_applicable(op)) return -1;
   const TransferParams& p = op.transfer;
   const int D = p.D, d = p.d;
   const int64_t DD = (int64_t)D * D;
-  {
-    // K1: T (dD x D) = B (dD x D, the d slices stacked) X (D x D): tile 64 x 32, chunk 32, waves 4 x 1
-    constexpr int TM = 64, TN = 32, KC = 32;
-    const dim3 grid((unsigned)(D / TN), (unsigned)((int64_t)d * D / TM));
-    hipLaunchKernelGGL((k_dgemm_mfma<TM, TN, KC, 4, 1, false>), grid, dim3(256), (tfm_lds_bytes<TM, TN, KC, false>()), st, p.B,
-                       (int64_t)D, (int64_t)0, x, (int64_t)D, (int64_t)0, p.T, (int64_t)D, D, 1);
-  }
-  {
-    // K2: y (D x D) = sum_s T_s B_s^T: inner dimension in d segments of D; tile 32 x 32, chunk 64, waves 2 x 2
-    constexpr int TM = 32, TN = 32, KC = 64;
-    static thread_local int attr_dev = -1;      // (66 KB of dynamic LDS: above the 64 KB a kernel gets without asking)
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return -1;
-    if (dev != attr_dev) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_dgemm_mfma<TM, TN, KC, 2, 2, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)tfm_lds_bytes<TM, TN, KC, true>()) != hipSuccess)
-        return -1;
-      attr_dev = dev;
-    }
-    const dim3 grid((unsigned)(D / TN), (unsigned)(D / TM));
-    hipLaunchKernelGGL((k_dgemm_mfma<TM, TN, KC, 2, 2, true>), grid, dim3(256), (tfm_lds_bytes<TM, TN, KC, true>()), st,
-                       (const double*)p.T, (int64_t)D, DD, p.B, (int64_t)D, DD, y, (int64_t)D, D, d);
-  }
-  return 0;
+  const bool longc = (D % 128) == 0;
+  // K1: T (dD x D) = B (dD x D, the d slices stacked) X (D x D): tile 64 x 32, waves 4 x 1
+  const dim3 g1((unsigned)(D / 32), (unsigned)((int64_t)d * D / 64));
+  int rc = longc ? tfm_launch<64, 32, 64, 4, 1, false>(g1, st, p.B, D, 0, x, D, 0, p.T, D, D, 1)
+                 : tfm_launch<64, 32, 32, 4, 1, false>(g1, st, p.B, D, 0, x, D, 0, p.T, D, D, 1);
+  if (rc != 0) return rc;
+  // K2: y (D x D) = sum_s T_s B_s^T: inner dimension in d segments of D; tile 32 x 32, waves 2 x 2
+  const dim3 g2((unsigned)(D / 32), (unsigned)(D / 32));
+  return longc ? tfm_launch<32, 32, 128, 2, 2, true>(g2, st, p.T, D, DD, p.B, D, DD, y, D, D, d)
+               : tfm_launch<32, 32, 64, 2, 2, true>(g2, st, p.T, D, DD, p.B, D, DD, y, D, D, d);
 }
 
 }  // namespace dsea
