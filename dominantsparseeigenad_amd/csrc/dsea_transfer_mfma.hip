@@ -23,6 +23,9 @@
 
 #include "dsea_internal.h"
 
+#ifndef TFM_DIAG
+#define TFM_DIAG 0
+#endif
 namespace dsea {
 
 namespace {
@@ -32,7 +35,7 @@ typedef double tfm_v4d __attribute__((ext_vector_type(4)));
 // and B' either (BT = false) a K' x N row-major matrix in segments B + s * segB (row stride ldb), or (BT = true) the
 // TRANSPOSE of an N x K' matrix given the same way (rows j, contiguous along the inner index).
 template <int TM, int TN, int KC, int WM, int WN, bool BT>
-__global__ __launch_bounds__(256) void k_dgemm_mfma(const double* __restrict__ A, int64_t lda, int64_t segA,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_dgemm_mfma(const double* __restrict__ A, int64_t lda, int64_t segA,
                                                     const double* __restrict__ B, int64_t ldb, int64_t segB,
                                                     double* __restrict__ C, int64_t ldc, int Kseg, int nseg) {
   static_assert(WM * WN == 4, "four waves");
@@ -116,8 +119,22 @@ __global__ __launch_bounds__(256) void k_dgemm_mfma(const double* __restrict__ A
   }
   for (int c = 0; c + 1 < nchunks; ++c) {
     const int buf = c & 1;
+#if TFM_DIAG != 1
     TFM_LOAD_CHUNK(c + 1)                                  // in flight while this chunk is multiplied
+#endif
+#if TFM_DIAG != 2
     TFM_COMPUTE(buf)
+#endif
+    // Pin the order loads -> MFMAs -> LDS stores: left alone, the scheduler either sinks the loads next to their stores
+    // (saving registers) or hoists the stores above the MFMAs -- both expose the load latency once per chunk.  The empty
+    // asm makes every staged value depend on the last accumulator of the chunk.
+    {
+      const double dep_ = acc[NT - 1][3];
+#pragma unroll
+      for (int p_ = 0; p_ < A_V2; ++p_) asm volatile("" : "+v"(ra[p_].x), "+v"(ra[p_].y) : "v"(dep_));
+#pragma unroll
+      for (int p_ = 0; p_ < B_V2; ++p_) asm volatile("" : "+v"(rb[p_].x), "+v"(rb[p_].y) : "v"(dep_));
+    }
     TFM_STORE_CHUNK(buf ^ 1)                               // (last read in iteration c - 1: every wave is past that barrier)
     __syncthreads();
   }

@@ -1,5 +1,6 @@
-cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-O=gpurun_out/r4o; mkdir -p $O
-timeout 1200 python -m pytest tests/test_gpu_0_world8.py tests/test_gpu_bench_contract.py tests/test_gpu_config5.py tests/test_gpu_partitioned.py -m gpu -q -rs --durations=5 -k "world8 or rehearsal or config5 or anchor or rebinding" > $O/pytest_a.log 2>&1; echo "rc=$?"; tail -16 $O/pytest_a.log | cut -c1-250
-ps aux | grep -i python | grep -v grep | wc -l; rocm-smi --showpids 2>/dev/null | head -20
+cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
+R=$PWD
+for v in "" _D1 _D2; do
+cd /tmp; rm -rf /tmp/tp; DSEA_LIB=$R/dominantsparseeigenad_amd/csrc/libdsea$v.so DSEA_TRANSFER_MFMA=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tp -o t -- python3 $R/tools/kbench_transfer.py > /dev/null 2>&1
+S=$(find /tmp/tp -name "*kernel_stats.csv" | head -1); echo "== variant '$v'"; grep -i "dgemm_mfma" $S | sed 's/.*k_dgemm_mfma\(<[^>]*>\)[^"]*"/\1/' | cut -c1-100
+done
