@@ -175,10 +175,17 @@ __global__ __launch_bounds__(256) void k_sum_slices(const double* __restrict__ Y
 // y = op x for the GEMM-shaped operands (row-major data, rocBLAS is column-major: a row-major product C = A B
 // is the column-major product C^T = B^T A^T on the same memory).  Returns 0 or -1.
 int blas_apply(const OpDesc& op, const double* x, double* y, hipStream_t st) {
-  // the transfer operand at D a multiple of 64 also has two hand-written fp64 MFMA kernels (dsea_transfer_mfma.hip): opt-in
-  // (DSEA_TRANSFER_MFMA=1) -- measured slower than the library GEMMs below -- and the only path where rocBLAS is absent
-  if (op.kind == OP_TRANSFER && (getenv("DSEA_TRANSFER_MFMA") || !blas_available()) && launch_transfer_mfma(op, x, y, st) == 0)
-    return 0;
+  // the transfer operand at D a multiple of 64 has two hand-written fp64 MFMA kernels (dsea_transfer_mfma.hip).  They are the
+  // default where they are measured faster than the library GEMMs below (profiles/r04_transfer_mfma.txt: D = 64 ... 256 and
+  // 384: 9-25 us against 20-40; equal at 512, slower beyond) and the only path where rocBLAS is absent.
+  // DSEA_TRANSFER_MFMA=0 -> library GEMMs always; =1 / =lds -> the hand-written kernels wherever they apply.
+  if (op.kind == OP_TRANSFER) {
+    const char* env = getenv("DSEA_TRANSFER_MFMA");
+    const int D = op.transfer.D;
+    const bool by_size = D <= 256 || ((D % 128) == 0 && D <= 384);
+    const bool want = env ? env[0] != '0' : by_size;
+    if ((want || !blas_available()) && launch_transfer_mfma(op, x, y, st) == 0) return 0;
+  }
   if (!blas_available()) return -1;
   const double one = 1.0, zero = 0.0;
   rocblas_handle hd = handle_for(st);

@@ -20,6 +20,7 @@
 // Shapes the kernels do not cover (D not a multiple of 64) keep the rocBLAS path of dsea_krylov.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "dsea_internal.h"
 
@@ -153,6 +154,134 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef TFM_STORE_CHUNK
 }
 
+// ---- second form (round 4, later): the four waves split the INNER dimension, fragments come straight from global memory --------
+// Every wave owns the whole TMT x TNT block of 16 x 16 tiles of the workgroup's output tile and every fourth 16-wide block of
+// the inner dimension.  No LDS and no barrier inside the loop: the k index of v_mfma_f64_16x16x4_f64 may be permuted (the
+// instruction sums over it), so MFMA step s of a block takes k = block + 4 (lane >> 4) + s -- a lane's four A values (and its
+// four B values when B' is given transposed) are 32 contiguous bytes of ONE row, two 16-byte loads.  Fragment reads per MFMA:
+// (TMT + TNT) / (TMT TNT) instead of 1.5 through LDS; the next block's fragments are requested before this block's MFMAs.  The
+// four partial tiles meet once, at the end, through LDS (fixed order: deterministic).
+template <int TMT, int TNT, bool BT, bool SWZ>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_dgemm_mfma_ksplit(
+    const double* __restrict__ A, int64_t lda, int64_t segA, const double* __restrict__ B, int64_t ldb, int64_t segB,
+    double* __restrict__ C, int64_t ldc, int Kseg, int nseg) {
+  constexpr int NW = 4;                                    // waves (8 = two per SIMD measured no faster: profiles/r04_transfer_mfma.txt)
+  extern __shared__ __attribute__((aligned(16))) double tfm_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int fi = lane & 15, kq = lane >> 4;
+  // tile of this workgroup.  Workgroups go to the 8 XCDs round robin by their linear index and every XCD has its own L2: left
+  // as (x, y) = (column tile, row tile), an XCD owns column tiles x = c mod 8 and EVERY row tile, i.e. pulls the whole A'
+  // through the fabric.  SWZ gives an XCD a compact (rows / 4) x (columns / 2) block of tiles instead (measured: -2 % on K2,
+  // +6 % on K1 whose A' is read once per row tile anyway -- so K2 only).
+  int tr = blockIdx.y, tc = blockIdx.x;
+  if (SWZ) {
+    const int TR = gridDim.y, TC = gridDim.x;
+    if ((TR % 4) == 0 && (TC % 2) == 0) {
+      const int lin = blockIdx.y * TC + blockIdx.x, xcd = lin & 7, idx = lin >> 3;
+      const int br = TR / 4, bc = TC / 2;                  // tiles per XCD block: br x bc (br * bc = TR * TC / 8 = number of idx)
+      tr = (xcd >> 1) * br + idx / bc;
+      tc = (xcd & 1) * bc + idx % bc;
+    }
+  }
+  const int64_t row0 = (int64_t)tr * (16 * TMT), col0 = (int64_t)tc * (16 * TNT);
+  const int bps = Kseg / 16;                               // 16-wide blocks per segment
+  const int nb = bps * nseg / NW;                          // blocks of this wave: global block index NW b + wv
+  tfm_v4d acc[TMT][TNT];
+#pragma unroll
+  for (int tm = 0; tm < TMT; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TNT; ++tn) acc[tm][tn] = (tfm_v4d){0.0, 0.0, 0.0, 0.0};
+  const double* __restrict__ Arow = A + (row0 + fi) * lda + 4 * kq;
+  const double* __restrict__ Bbase = BT ? B + (col0 + fi) * ldb + 4 * kq : B + (int64_t)(4 * kq) * ldb + col0 + fi;
+  tfm_v4d fa[TMT], fb[TNT], ga[TMT], gb[TNT];              // current / next block's fragments (element s = MFMA step s)
+
+#define TFM_KS_LOAD(bidx, FA, FB)                                                                                 \
+  {                                                                                                               \
+    const int gbk_ = NW * (bidx) + wv, sg_ = gbk_ / bps, kc_ = (gbk_ - sg_ * bps) * 16;                              \
+    const double* __restrict__ ap_ = Arow + (int64_t)sg_ * segA + kc_;                                            \
+    _Pragma("unroll") for (int tm = 0; tm < TMT; ++tm) {                                                          \
+      const double2 lo_ = *reinterpret_cast<const double2*>(ap_ + (int64_t)(16 * tm) * lda);                      \
+      const double2 hi_ = *reinterpret_cast<const double2*>(ap_ + (int64_t)(16 * tm) * lda + 2);                  \
+      FA[tm] = (tfm_v4d){lo_.x, lo_.y, hi_.x, hi_.y};                                                             \
+    }                                                                                                             \
+    if (BT) {                                                                                                     \
+      const double* __restrict__ bp_ = Bbase + (int64_t)sg_ * segB + kc_;                                         \
+      _Pragma("unroll") for (int tn = 0; tn < TNT; ++tn) {                                                        \
+        const double2 lo_ = *reinterpret_cast<const double2*>(bp_ + (int64_t)(16 * tn) * ldb);                    \
+        const double2 hi_ = *reinterpret_cast<const double2*>(bp_ + (int64_t)(16 * tn) * ldb + 2);                \
+        FB[tn] = (tfm_v4d){lo_.x, lo_.y, hi_.x, hi_.y};                                                           \
+      }                                                                                                           \
+    } else {                                                                                                      \
+      const double* __restrict__ bp_ = Bbase + (int64_t)sg_ * segB + (int64_t)kc_ * ldb;                          \
+      _Pragma("unroll") for (int tn = 0; tn < TNT; ++tn)                                                          \
+        FB[tn] = (tfm_v4d){bp_[16 * tn], bp_[ldb + 16 * tn], bp_[2 * ldb + 16 * tn], bp_[3 * ldb + 16 * tn]};    \
+    }                                                                                                             \
+  }
+#define TFM_KS_MMA(FA, FB)                                                                                        \
+  _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4)                                                                \
+    _Pragma("unroll") for (int tm = 0; tm < TMT; ++tm)                                                            \
+      _Pragma("unroll") for (int tn = 0; tn < TNT; ++tn)                                                          \
+        acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[tm][s4], FB[tn][s4], acc[tm][tn], 0, 0, 0);
+
+  TFM_KS_LOAD(0, fa, fb)
+  int b = 0;
+#if TFM_DIAG == 1                                           /* timing diagnostics: no loads inside the loop */
+  TFM_KS_LOAD(1, ga, gb)
+  for (; b + 2 < nb; b += 2) {
+    TFM_KS_MMA(fa, fb)
+    TFM_KS_MMA(ga, gb)
+  }
+  TFM_KS_MMA(fa, fb)
+  TFM_KS_MMA(ga, gb)
+#elif TFM_DIAG == 2                                         /* timing diagnostics: one MFMA step per block instead of four */
+  for (; b + 2 < nb; b += 2) {
+    TFM_KS_LOAD(b + 1, ga, gb)
+    _Pragma("unroll") for (int tm = 0; tm < TMT; ++tm) _Pragma("unroll") for (int tn = 0; tn < TNT; ++tn)
+      acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[tm][0] + fa[tm][1] + fa[tm][2] + fa[tm][3], fb[tn][0] + fb[tn][1] + fb[tn][2] + fb[tn][3], acc[tm][tn], 0, 0, 0);
+    TFM_KS_LOAD(b + 2, fa, fb)
+    _Pragma("unroll") for (int tm = 0; tm < TMT; ++tm) _Pragma("unroll") for (int tn = 0; tn < TNT; ++tn)
+      acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[tm][0] + ga[tm][1] + ga[tm][2] + ga[tm][3], gb[tn][0] + gb[tn][1] + gb[tn][2] + gb[tn][3], acc[tm][tn], 0, 0, 0);
+  }
+  TFM_KS_LOAD(b + 1, ga, gb)
+  TFM_KS_MMA(fa, fb)
+  TFM_KS_MMA(ga, gb)
+#else
+  for (; b + 2 < nb; b += 2) {                             // (nb is even: the inner dimension is a multiple of 32 NW)
+    TFM_KS_LOAD(b + 1, ga, gb)
+    TFM_KS_MMA(fa, fb)
+    TFM_KS_LOAD(b + 2, fa, fb)
+    TFM_KS_MMA(ga, gb)
+  }
+  TFM_KS_LOAD(b + 1, ga, gb)
+  TFM_KS_MMA(fa, fb)
+  TFM_KS_MMA(ga, gb)
+#endif
+#undef TFM_KS_LOAD
+#undef TFM_KS_MMA
+
+  // the NW waves' partial tiles: [wave][tile][reg][lane] in LDS, then wave w sums tiles w, w + NW, ... over the waves in
+  // the order 0, 1, 2, ... and writes them (C/D layout: row = (lane >> 4) + 4 reg, col = lane & 15)
+  constexpr int NTILE = TMT * TNT;
+#pragma unroll
+  for (int tm = 0; tm < TMT; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TNT; ++tn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tfm_smem[((wv * NTILE + tm * TNT + tn) * 4 + r) * 64 + lane] = acc[tm][tn][r];
+  __syncthreads();
+#pragma unroll
+  for (int t = wv; t < NTILE; t += NW) {
+    const int tm = t / TNT, tn = t % TNT;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double v = tfm_smem[((0 * NTILE + t) * 4 + r) * 64 + lane];
+#pragma unroll
+      for (int w2 = 1; w2 < NW; ++w2) v += tfm_smem[((w2 * NTILE + t) * 4 + r) * 64 + lane];
+      C[(row0 + 16 * tm + 4 * r + kq) * ldc + col0 + 16 * tn + fi] = v;
+    }
+  }
+}
+
 template <int TM, int TN, int KC, bool BT>
 constexpr size_t tfm_lds_bytes() {
   return (size_t)2 * ((size_t)TM * (KC + 2) + (BT ? (size_t)TN * (KC + 2) : (size_t)KC * (TN + 16))) * sizeof(double);
@@ -182,24 +311,41 @@ int tfm_launch(dim3 grid, hipStream_t st, const double* A, int64_t lda, int64_t 
                      B, ldb, sB, C, ldc, Kseg, nseg);
   return 0;
 }
+
+template <int TMT, int TNT, bool BT, bool SWZ>
+int tfm_launch_ksplit(dim3 grid, hipStream_t st, const double* A, int64_t lda, int64_t sA, const double* B, int64_t ldb,
+                      int64_t sB, double* C, int64_t ldc, int Kseg, int nseg) {
+  constexpr size_t lds = (size_t)4 * TMT * TNT * 4 * 64 * sizeof(double);
+  static_assert(lds <= 65536, "partial tiles fit the default LDS allowance");
+  hipLaunchKernelGGL((k_dgemm_mfma_ksplit<TMT, TNT, BT, SWZ>), grid, dim3(256), lds, st, A, lda, sA, B, ldb, sB, C, ldc, Kseg,
+                     nseg);
+  return 0;
+}
 }  // namespace
 
-// y = sum_s B_s X B_s^T through the two kernels above; T = the operator's d x D x D scratch.  Returns 0 or -1 (not applicable).
-// The chunk of the inner dimension is as long as D allows (D % 128 == 0: 64 for K1, 128 for K2 -- 32 MFMAs per wave and
-// chunk, ~1 us, which covers the latency of the next chunk's global loads; otherwise half that).
+// y = sum_s B_s X B_s^T through two launches; T = the operator's d x D x D scratch.  Returns 0 or -1 (not applicable).
+// D % 128 == 0: the k-split kernels (fragments from global memory, no LDS in the loop); otherwise the LDS-staged kernels with
+// chunks of 32 / 64.  DSEA_TRANSFER_MFMA=lds forces the LDS-staged form (A/B measurements).
 int launch_transfer_mfma(const OpDesc& op, const double* x, double* y, hipStream_t st) {
   if (!transfer_mfma_applicable(op)) return -1;
   const TransferParams& p = op.transfer;
   const int D = p.D, d = p.d;
   const int64_t DD = (int64_t)D * D;
   const bool longc = (D % 128) == 0;
-  // K1: T (dD x D) = B (dD x D, the d slices stacked) X (D x D): tile 64 x 32, waves 4 x 1
+  const char* env = getenv("DSEA_TRANSFER_MFMA");
+  const bool force_lds = env && env[0] == 'l';
+  // K1: T (dD x D) = B (dD x D, the d slices stacked) X (D x D): tile 64 x 32
   const dim3 g1((unsigned)(D / 32), (unsigned)((int64_t)d * D / 64));
+  // K2: y (D x D) = sum_s T_s B_s^T: inner dimension in d segments of D; tile 32 x 32
+  const dim3 g2((unsigned)(D / 32), (unsigned)(D / 32));
+  if (longc && !force_lds) {
+    int rc = tfm_launch_ksplit<4, 2, false, false>(g1, st, p.B, D, 0, x, D, 0, p.T, D, D, 1);
+    if (rc != 0) return rc;
+    return tfm_launch_ksplit<2, 2, true, true>(g2, st, p.T, D, DD, p.B, D, DD, y, D, D, d);
+  }
   int rc = longc ? tfm_launch<64, 32, 64, 4, 1, false>(g1, st, p.B, D, 0, x, D, 0, p.T, D, D, 1)
                  : tfm_launch<64, 32, 32, 4, 1, false>(g1, st, p.B, D, 0, x, D, 0, p.T, D, D, 1);
   if (rc != 0) return rc;
-  // K2: y (D x D) = sum_s T_s B_s^T: inner dimension in d segments of D; tile 32 x 32, waves 2 x 2
-  const dim3 g2((unsigned)(D / 32), (unsigned)(D / 32));
   return longc ? tfm_launch<32, 32, 128, 2, 2, true>(g2, st, p.T, D, DD, p.B, D, DD, y, D, D, d)
                : tfm_launch<32, 32, 64, 2, 2, true>(g2, st, p.T, D, DD, p.B, D, DD, y, D, D, d);
 }

@@ -188,11 +188,12 @@ int dsea_op_set_tuning(dsea_op_t op, int key, int value);
  *                 transpose == 0:  y = sum_s A_s x A_s^T        ("Gong",  general.py:59-61)
  *                 transpose != 0:  y = sum_s A_s^T x A_s        ("GongT", general.py:62-64)
  *             as two strided-batched GEMMs in the "X Y^T" shape (the transposed form is the same contraction on
- *             the slice-wise transposed tensor, copied once) + a transpose and a slice-sum kernel.  For D a multiple
- *             of 64 two hand-written fp64 MFMA kernels exist as well (csrc/dsea_transfer_mfma.hip: one stacked product
- *             and one product over the inner dimension d D -- no transpose, no slice sum): measured SLOWER than the
- *             library GEMMs (53 vs 33 us at D = 512), hence opt-in (environment DSEA_TRANSFER_MFMA=1) and the path taken
- *             when rocBLAS is not available.  `work`:
+ *             the slice-wise transposed tensor, copied once) + a transpose and a slice-sum kernel (rocBLAS), or -- for D a
+ *             multiple of 64 -- as two hand-written fp64 MFMA kernels (csrc/dsea_transfer_mfma.hip: one stacked product
+ *             and one product over the inner dimension d D; no transpose, no slice sum, no vendor library).  The hand-written
+ *             pair is the default where it is measured faster (D = 64 ... 256 and 384: 9-25 us against 20-40), the library
+ *             GEMMs from D = 512 on (33 us either way at 512); environment DSEA_TRANSFER_MFMA=1 / =0 forces one or the other;
+ *             the hand-written pair is also the path taken when rocBLAS is not available.  `work`:
  *             caller-owned scratch of dsea_op_transfer_work_bytes(D, d); dsea_op_create_transfer fills part of it
  *             on `stream`.                                                                                    */
 int dsea_op_create_dense(int64_t n, const double *A_dev, int64_t lda, int transpose, dsea_op_t *out);

@@ -129,11 +129,13 @@ def test_transfer_and_dense_operators_match_einsum(D, d):
     assert float((DenseOperator(G, transpose=True)(v) - G.T @ v).abs().max()) < 1e-13 * scale * D
 
 
-@pytest.mark.parametrize("D,d", [(64, 1), (128, 3), (192, 2), (512, 2)])
-def test_transfer_matvec_on_the_fp64_matrix_cores_matches_the_contraction_and_the_library_gemm_path(D, d):
-    """csrc/dsea_transfer_mfma.hip (opt-in, DSEA_TRANSFER_MFMA=1; D a multiple of 64: two hand-written v_mfma_f64_16x16x4
+@pytest.mark.parametrize("D,d,form", [(64, 1, "1"), (128, 3, "1"), (128, 3, "lds"), (192, 2, "1"), (256, 1, "1"), (384, 2, "1"), (512, 2, "1"),
+                                      (512, 2, "lds")])
+def test_transfer_matvec_on_the_fp64_matrix_cores_matches_the_contraction_and_the_library_gemm_path(D, d, form):
+    """csrc/dsea_transfer_mfma.hip (default for D = 64 ... 256 and 384, DSEA_TRANSFER_MFMA=1 forces it, =0 the library GEMMs; D a multiple of 64: two hand-written v_mfma_f64_16x16x4
     kernels -- T = [B_s] X as one stacked product, y = sum_s T_s B_s^T as ONE product over the inner dimension d D, no
-    transpose, no slice sum) against the contraction of general.py:59-66 and against the default rocBLAS path, both
+    transpose, no slice sum; D a multiple of 128: the form whose waves split the inner dimension and take their fragments
+    straight from global memory, "lds" = the LDS-staged form) against the contraction of general.py:59-66 and against the default rocBLAS path, both
     orientations; an ASYMMETRIC operand so that a transposed tile or fragment cannot pass."""
     import os
     from dominantsparseeigenad_amd.operators import TransferOperator
@@ -144,13 +146,18 @@ def test_transfer_matvec_on_the_fp64_matrix_cores_matches_the_contraction_and_th
     fr = sum(A[s] @ X @ A[s].T for s in range(d)).reshape(-1)                  # general.py:59-61
     fl = sum(A[s].T @ X @ A[s] for s in range(d)).reshape(-1)                  # general.py:62-64
     opr, opl = TransferOperator(A), TransferOperator(A, transpose=True)
-    zr, zl = opr(v).clone(), opl(v).clone()                                    # default path
-    os.environ["DSEA_TRANSFER_MFMA"] = "1"
+    dr = opr(v).clone()                                                        # default: chosen by size
+    os.environ["DSEA_TRANSFER_MFMA"] = "0"
     try:
+        zr, zl = opr(v).clone(), opl(v).clone()                                # the library-GEMM path
+        os.environ["DSEA_TRANSFER_MFMA"] = form
         yr, yl = opr(v).clone(), opl(v).clone()
         again = opr(v).clone()
     finally:
         del os.environ["DSEA_TRANSFER_MFMA"]
+    # the default is the hand-written pair up to D = 256 and at 384, the library GEMMs from 512 (csrc/dsea_krylov.hip)
+    if form == "1":
+        assert torch.equal(dr, yr if D <= 384 else zr)
     sr, sl = float(fr.abs().max()), float(fl.abs().max())
     assert float((yr - fr).abs().max()) < 1e-13 * sr * D, float((yr - fr).abs().max()) / sr
     assert float((yl - fl).abs().max()) < 1e-13 * sl * D
