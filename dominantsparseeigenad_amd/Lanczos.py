@@ -131,11 +131,9 @@ def symeigLanczos(A, k, device=torch.device("cpu"), extreme="both", *, sparse=Fa
         if torch.device(device).type != "cuda":
             raise NotImplementedError("reorth='partial' runs on the GPU (native operators, row-partitioned operators on "
                                       "the library driver, callables)")
-        prev, engine.PARTIAL_REORTH = engine.PARTIAL_REORTH, (0.0 if engine.PARTIAL_REORTH is None else engine.PARTIAL_REORTH)
-        try:
+        cur = engine.partial_reorth()                    # (a threshold set process-wide stays the threshold)
+        with engine.reorth_options(partial=0.0 if cur is None else cur):   # this thread only
             return symeigLanczos(A, k, device, extreme, sparse=sparse, dim=dim, q0=q0, reorth="full")
-        finally:
-            engine.PARTIAL_REORTH = prev
     if reorth == "twice":
         # CGS2: the Gram-Schmidt pass of Lanczos.py:66 applied twice per step (an option the reference lacks; device
         # operators and callables on the GPU) -- same Krylov process, orthogonality of the basis at rounding level even
@@ -148,11 +146,8 @@ def symeigLanczos(A, k, device=torch.device("cpu"), extreme="both", *, sparse=Fa
                 (part.world > 1 or part.force_driver or part._local_native() is None):
             raise NotImplementedError("reorth='twice' is not implemented by the row-partitioned step drivers "
                                       "(they re-orthogonalise once per step)")
-        prev, engine.REORTH_PASSES = engine.REORTH_PASSES, 2
-        try:
+        with engine.reorth_options(passes=2):            # this thread only
             return symeigLanczos(A, k, device, extreme, sparse=sparse, dim=dim, q0=q0, reorth="full")
-        finally:
-            engine.REORTH_PASSES = prev
     if reorth == "none":
         native = engine.native_of(A) if sparse else None
         if native is None or getattr(native, "partitioned", False) or torch.device(device).type != "cuda":

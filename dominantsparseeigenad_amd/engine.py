@@ -43,6 +43,37 @@ REORTH_PASSES = 1
 # and callables / operands without a fused tail (one phase call per step).
 PARTIAL_REORTH = None
 last_reorth_steps = None       # steps of the last native run that were re-orthogonalised (partial mode), else None
+# The two module attributes above are the process-wide defaults.  A call that asks for an option (``reorth=`` of
+# Lanczos.symeigLanczos) sets it for ITS thread only (``reorth_options``), so the left / right worker threads of eig.py
+# and concurrent callers do not see each other's choice; every driver reads the option through the two accessors.
+import contextlib as _contextlib
+import threading as _threading
+_tls = _threading.local()
+_UNSET = object()
+
+
+def reorth_passes():
+    v = getattr(_tls, "reorth_passes", None)
+    return int(REORTH_PASSES if v is None else v)
+
+
+def partial_reorth():
+    v = getattr(_tls, "partial_reorth", _UNSET)
+    return PARTIAL_REORTH if v is _UNSET else v
+
+
+@_contextlib.contextmanager
+def reorth_options(passes=None, partial=_UNSET):
+    """Thread-local override of REORTH_PASSES / PARTIAL_REORTH for the duration of the block."""
+    prev = (getattr(_tls, "reorth_passes", None), getattr(_tls, "partial_reorth", _UNSET))
+    if passes is not None:
+        _tls.reorth_passes = int(passes)
+    if partial is not _UNSET:
+        _tls.partial_reorth = partial
+    try:
+        yield
+    finally:
+        _tls.reorth_passes, _tls.partial_reorth = prev
 import os as _os
 _NO_PERSIST = _os.environ.get("DSEA_NO_PERSIST", "") == "1"
 LANCZOS_PERSIST = not _NO_PERSIST
@@ -391,6 +422,7 @@ def lanczos(A, k, n, device, q0, native=None, callable_A=None, arena=False):
     alphas = torch.empty(k, dtype=F64, device=device)
     betas = torch.empty(max(k - 1, 1), dtype=F64, device=device)
     q0 = as_vector(q0, n)
+    PARTIAL_REORTH, REORTH_PASSES = partial_reorth(), reorth_passes()      # (this thread's view of the two options)
     partial = PARTIAL_REORTH is not None
     if partial and REORTH_PASSES != 1:
         raise NotImplementedError("reorth='partial' and reorth='twice' exclude each other")

@@ -684,7 +684,8 @@ class PartitionedOperator:
         alphas, betas = be.zeros(k), be.zeros(max(k - 1, 1))
         q0 = _vec(q0_slab)
         # partial re-orthogonalisation option (engine.PARTIAL_REORTH, reorth="partial"): fp64 basis, no overlapped exchange
-        partial = _engine_mod.PARTIAL_REORTH is not None
+        pro = _engine_mod.partial_reorth()               # (this thread's view of the option)
+        partial = pro is not None
         _engine_mod.last_reorth_steps = None
         use_shadow = self.use_shadow and _engine_mod.USE_SHADOW and k > 1 and not partial and \
             _engine_mod.shadow_fits(self.device, k, ldq, n, arena)
@@ -692,10 +693,10 @@ class PartitionedOperator:
         with ws.owned_by("row-partitioned Lanczos (library driver)"):
             if use_shadow:
                 be.set_shadow(k, ldq, arena)
-            if getattr(ws, "partial_reorth", None) != _engine_mod.PARTIAL_REORTH:
-                _lib.check(lib.dsea_ws_set_partial_reorth(ws.handle, 1 if partial else 0,
-                                                          float(_engine_mod.PARTIAL_REORTH or 0.0)), "dsea_ws_set_partial_reorth")
-                ws.partial_reorth = _engine_mod.PARTIAL_REORTH
+            if getattr(ws, "partial_reorth", None) != pro:
+                _lib.check(lib.dsea_ws_set_partial_reorth(ws.handle, 1 if partial else 0, float(pro or 0.0)),
+                           "dsea_ws_set_partial_reorth")
+                ws.partial_reorth = pro
             try:
                 for attempt in (0, 1):
                     _lib.check(lib.dsea_pop_set_flags(self._pop, flags), "dsea_pop_set_flags")
@@ -789,7 +790,7 @@ class PartitionedOperator:
             return _engine_mod.lanczos(native, k, self.nloc, self.device, q0_slab, native=native, arena=arena)
         if self._pop:
             return self._lanczos_library(k, q0_slab, arena)
-        if _engine_mod.PARTIAL_REORTH is not None:
+        if _engine_mod.partial_reorth() is not None:
             raise NotImplementedError("reorth='partial' on a row-partitioned operator needs the library driver "
                                       "(dsea_pop_lanczos_run); the Python step driver re-orthogonalises on every step")
         be, n = self.be, self.nloc

@@ -343,3 +343,45 @@ def test_arnoldi_stage_schedule():
         if j >= m:
             break
     assert j == m
+
+
+def test_reorth_options_are_per_thread():
+    """``reorth="twice"`` / ``"partial"`` used to mutate engine.REORTH_PASSES / PARTIAL_REORTH for the whole
+    process -- visible to the left / right worker threads of eig.py and to concurrent callers.  The call-level option is
+    now a thread-local override (engine.reorth_options); the module attributes stay the process-wide defaults."""
+    import threading
+    from dominantsparseeigenad_amd import engine
+    assert engine.reorth_passes() == 1 and engine.partial_reorth() is None
+    seen, inside, go = {}, threading.Event(), threading.Event()
+
+    def other():
+        inside.wait(10)
+        seen["passes"], seen["partial"] = engine.reorth_passes(), engine.partial_reorth()
+        go.set()
+
+    t = threading.Thread(target=other)
+    t.start()
+    with engine.reorth_options(passes=2, partial=1e-9):
+        assert engine.reorth_passes() == 2 and engine.partial_reorth() == 1e-9
+        with engine.reorth_options(partial=None):           # nested: only what is named changes
+            assert engine.reorth_passes() == 2 and engine.partial_reorth() is None
+        assert engine.partial_reorth() == 1e-9
+        inside.set()
+        assert go.wait(10)
+    t.join()
+    assert seen == {"passes": 1, "partial": None}
+    assert engine.reorth_passes() == 1 and engine.partial_reorth() is None
+    engine.PARTIAL_REORTH = 0.0                              # the process-wide default is what an un-overridden thread sees
+    try:
+        assert engine.partial_reorth() == 0.0
+    finally:
+        engine.PARTIAL_REORTH = None
+    # the host path still refuses the options it would silently ignore
+    import torch
+    import pytest as _pytest
+    from dominantsparseeigenad_amd.Lanczos import symeigLanczos
+    A = torch.eye(8, dtype=torch.float64)
+    for opt in ("twice", "partial"):
+        with _pytest.raises(NotImplementedError):
+            symeigLanczos(A, 4, torch.device("cpu"), "min", reorth=opt)
+    assert engine.reorth_passes() == 1 and engine.partial_reorth() is None
