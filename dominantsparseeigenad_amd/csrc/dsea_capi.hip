@@ -473,7 +473,8 @@ int dsea_op_create_symdense(int64_t n, const void* A_dev, int elem_bytes, int64_
 }
 
 size_t dsea_op_transfer_work_bytes(int D, int d) {
-  return D < 1 || d < 1 ? 0 : (size_t)(1 + 3 * (size_t)d) * (size_t)D * (size_t)D * sizeof(double);
+  // x^T, T, Y, the slice-wise transposed tensor, the fragment-packed tensor
+  return D < 1 || d < 1 ? 0 : (size_t)(1 + 4 * (size_t)d) * (size_t)D * (size_t)D * sizeof(double);
 }
 
 int dsea_op_create_transfer(int D, int d, const double* A_dev, int transpose, double* work, void* stream,
@@ -492,8 +493,10 @@ int dsea_op_create_transfer(int D, int d, const double* A_dev, int transpose, do
   double* T = work + DD;
   double* Y = T + slab;
   double* AT = Y + slab;
-  op->d.transfer = TransferParams{D, d, transpose ? AT : A_dev, xT, T, Y, transpose ? 1 : 0};
+  double* Bp = (D % 128) == 0 ? AT + slab : nullptr;
+  op->d.transfer = TransferParams{D, d, transpose ? AT : A_dev, xT, T, Y, transpose ? 1 : 0, Bp};
   if (transpose) launch_transpose_sq(A_dev, AT, D, d, static_cast<hipStream_t>(stream));   // B_k = A_k^T, once
+  if (Bp) launch_pack_fragments(op->d.transfer.B, Bp, D, d, static_cast<hipStream_t>(stream));   // (MFMA fragment order, once)
   *out = op;
   return check_launch();
 }

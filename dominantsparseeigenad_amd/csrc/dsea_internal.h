@@ -63,6 +63,7 @@ struct TransferParams {
   double* T;        // d * D * D  scratch: B_k x
   double* Y;        // d * D * D  scratch: (B_k x) B_k^T
   int transpose;
+  const double* Bp; // d * D * D: B in fragment-packed order (dsea_transfer_mfma.hip), D a multiple of 128; else nullptr
 };
 struct SymDenseParams {
   int64_t n, lda, npad;
@@ -245,6 +246,7 @@ int launch_lanczos_persist(const OpDesc& op, int k, const double* q0, double* Q,
 // dsea_transfer_mfma.hip
 bool transfer_mfma_applicable(const OpDesc& op);
 int launch_transfer_mfma(const OpDesc& op, const double* x, double* y, hipStream_t st);
+void launch_pack_fragments(const double* B, double* Bp, int D, int d, hipStream_t st);
 // dsea_lanczos_persist_mid.hip
 bool lanczos_persist_mid_applicable(const OpDesc& op, int64_t n, int k);
 size_t lanczos_persist_mid_comm_bytes(int64_t n, int k);

@@ -161,7 +161,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // four B values when B' is given transposed) are 32 contiguous bytes of ONE row, two 16-byte loads.  Fragment reads per MFMA:
 // (TMT + TNT) / (TMT TNT) instead of 1.5 through LDS; the next block's fragments are requested before this block's MFMAs.  The
 // four partial tiles meet once, at the end, through LDS (fixed order: deterministic).
-template <int TMT, int TNT, bool BT, bool SWZ>
+//
+// FRAGMENT-PACKED operands (PKA / PKB / PKC).  A lane's 32 bytes sit in a row of the matrix, so one 16-byte load
+// instruction of a wave touches 16 rows = 16 cache lines and uses half of each; measured, the fragment loads then take as long as the
+// whole kernel (profiles/r04_transfer_mfma.txt).  A packed operand stores every (16-row tile, 16-wide k block) as one 2 KB
+// chunk in the order the loads want it: [plane p = 0, 1][lane][2 doubles], lane (i, kq) holding columns 4 kq + 2 p, + 1 of
+// row i -- a wave's load instruction is then 1 KB of consecutive bytes.  Chunks of a segment are ordered [tile][k block],
+// segments segA / segB doubles apart (a D x D slice packs into exactly D * D doubles).  The tensor's slices are packed once
+// at operator creation (k_pack_fragments); K1 WRITES T packed (PKC: its LDS reduction gathers in packed order, every store
+// instruction 1 KB of consecutive bytes) for K2 to read.
+template <int TMT, int TNT, bool BT, bool SWZ, bool PKA, bool PKB, bool PKC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_dgemm_mfma_ksplit(
     const double* __restrict__ A, int64_t lda, int64_t segA, const double* __restrict__ B, int64_t ldb, int64_t segB,
     double* __restrict__ C, int64_t ldc, int Kseg, int nseg) {
@@ -197,18 +206,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 #define TFM_KS_LOAD(bidx, FA, FB)                                                                                 \
   {                                                                                                               \
-    const int gbk_ = NW * (bidx) + wv, sg_ = gbk_ / bps, kc_ = (gbk_ - sg_ * bps) * 16;                              \
-    const double* __restrict__ ap_ = Arow + (int64_t)sg_ * segA + kc_;                                            \
+    const int gbk_ = NW * (bidx) + wv, sg_ = gbk_ / bps, kb_ = gbk_ - sg_ * bps, kc_ = kb_ * 16;                    \
+    const double* __restrict__ ap_ = PKA ? A + (int64_t)sg_ * segA + ((row0 / 16) * bps + kb_) * 256 + 2 * lane  \
+                                         : Arow + (int64_t)sg_ * segA + kc_;                                      \
     _Pragma("unroll") for (int tm = 0; tm < TMT; ++tm) {                                                          \
-      const double2 lo_ = *reinterpret_cast<const double2*>(ap_ + (int64_t)(16 * tm) * lda);                      \
-      const double2 hi_ = *reinterpret_cast<const double2*>(ap_ + (int64_t)(16 * tm) * lda + 2);                  \
+      const double* __restrict__ fa_ = PKA ? ap_ + (int64_t)tm * bps * 256 : ap_ + (int64_t)(16 * tm) * lda;     \
+      const double2 lo_ = *reinterpret_cast<const double2*>(fa_);                                                 \
+      const double2 hi_ = *reinterpret_cast<const double2*>(fa_ + (PKA ? 128 : 2));                               \
       FA[tm] = (tfm_v4d){lo_.x, lo_.y, hi_.x, hi_.y};                                                             \
     }                                                                                                             \
     if (BT) {                                                                                                     \
-      const double* __restrict__ bp_ = Bbase + (int64_t)sg_ * segB + kc_;                                         \
+      const double* __restrict__ bp_ = PKB ? B + (int64_t)sg_ * segB + ((col0 / 16) * bps + kb_) * 256 + 2 * lane \
+                                           : Bbase + (int64_t)sg_ * segB + kc_;                                   \
       _Pragma("unroll") for (int tn = 0; tn < TNT; ++tn) {                                                        \
-        const double2 lo_ = *reinterpret_cast<const double2*>(bp_ + (int64_t)(16 * tn) * ldb);                    \
-        const double2 hi_ = *reinterpret_cast<const double2*>(bp_ + (int64_t)(16 * tn) * ldb + 2);                \
+        const double* __restrict__ fb_ = PKB ? bp_ + (int64_t)tn * bps * 256 : bp_ + (int64_t)(16 * tn) * ldb;   \
+        const double2 lo_ = *reinterpret_cast<const double2*>(fb_);                                               \
+        const double2 hi_ = *reinterpret_cast<const double2*>(fb_ + (PKB ? 128 : 2));                             \
         FB[tn] = (tfm_v4d){lo_.x, lo_.y, hi_.x, hi_.y};                                                           \
       }                                                                                                           \
     } else {                                                                                                      \
@@ -259,27 +272,61 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef TFM_KS_LOAD
 #undef TFM_KS_MMA
 
-  // the NW waves' partial tiles: [wave][tile][reg][lane] in LDS, then wave w sums tiles w, w + NW, ... over the waves in
-  // the order 0, 1, 2, ... and writes them (C/D layout: row = (lane >> 4) + 4 reg, col = lane & 15)
+  // the NW waves' partial tiles meet in LDS: [wave][tile][reg r][kq][fi, row padded to 18] (C/D layout: row = kq + 4 r,
+  // col = fi).  Wave w then sums tiles w, w + NW, ... over the waves in the order 0, 1, 2, ... and writes them.
   constexpr int NTILE = TMT * TNT;
 #pragma unroll
   for (int tm = 0; tm < TMT; ++tm)
 #pragma unroll
     for (int tn = 0; tn < TNT; ++tn)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tfm_smem[((wv * NTILE + tm * TNT + tn) * 4 + r) * 64 + lane] = acc[tm][tn][r];
+      for (int r = 0; r < 4; ++r) tfm_smem[(((wv * NTILE + tm * TNT + tn) * 4 + r) * 4 + kq) * 18 + fi] = acc[tm][tn][r];
   __syncthreads();
 #pragma unroll
   for (int t = wv; t < NTILE; t += NW) {
     const int tm = t / TNT, tn = t % TNT;
+    if (PKC) {
+      // packed store: C is the A-type operand of the next product -- rows are its rows, columns its k.  Chunk of (row tile,
+      // k block); position [plane p][lane' = (i, kq')][2]: row i = lane' & 15, columns 4 (lane' >> 4) + 2 p, + 1.
+      const int64_t grow = row0 + 16 * tm, seg = grow / Kseg, rt = (grow - seg * Kseg) / 16;     // (C's segments: Kseg rows each)
+      const int64_t kb = (col0 + 16 * tn) / 16, cbps = ldc / 16;
+      double* __restrict__ cp = C + seg * ((int64_t)Kseg * ldc) + (rt * cbps + kb) * 256 + 2 * lane;
+      const int i16 = lane & 15, r = i16 >> 2, q = i16 & 3;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      double v = tfm_smem[((0 * NTILE + t) * 4 + r) * 64 + lane];
+      for (int pl = 0; pl < 2; ++pl) {
+        const int f0 = 4 * (lane >> 4) + 2 * pl;
+        double2 v = *reinterpret_cast<const double2*>(&tfm_smem[(((0 * NTILE + t) * 4 + r) * 4 + q) * 18 + f0]);
 #pragma unroll
-      for (int w2 = 1; w2 < NW; ++w2) v += tfm_smem[((w2 * NTILE + t) * 4 + r) * 64 + lane];
-      C[(row0 + 16 * tm + 4 * r + kq) * ldc + col0 + 16 * tn + fi] = v;
+        for (int w2 = 1; w2 < NW; ++w2) {
+          const double2 u = *reinterpret_cast<const double2*>(&tfm_smem[(((w2 * NTILE + t) * 4 + r) * 4 + q) * 18 + f0]);
+          v.x += u.x;
+          v.y += u.y;
+        }
+        *reinterpret_cast<double2*>(cp + 128 * pl) = v;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double v = tfm_smem[(((0 * NTILE + t) * 4 + r) * 4 + kq) * 18 + fi];
+#pragma unroll
+        for (int w2 = 1; w2 < NW; ++w2) v += tfm_smem[(((w2 * NTILE + t) * 4 + r) * 4 + kq) * 18 + fi];
+        C[(row0 + 16 * tm + 4 * r + kq) * ldc + col0 + 16 * tn + fi] = v;
+      }
     }
   }
+}
+
+// one-off packing of the tensor's slices (d x D x D row-major, D a multiple of 16) into fragment chunks; one wave per chunk
+__global__ __launch_bounds__(256) void k_pack_fragments(const double* __restrict__ B, double* __restrict__ Bp, int D, int64_t nchunks) {
+  const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (chunk >= nchunks) return;
+  const int lane = threadIdx.x & 63, bps = D / 16;
+  const int64_t per_slice = (int64_t)bps * bps, s = chunk / per_slice, rem = chunk - s * per_slice;
+  const int64_t rt = rem / bps, kb = rem - rt * bps;
+  const double* __restrict__ src = B + s * (int64_t)D * D + (rt * 16 + (lane & 15)) * (int64_t)D + kb * 16 + 4 * (lane >> 4);
+  double* __restrict__ dst = Bp + chunk * 256 + 2 * lane;
+  *reinterpret_cast<double2*>(dst) = *reinterpret_cast<const double2*>(src);
+  *reinterpret_cast<double2*>(dst + 128) = *reinterpret_cast<const double2*>(src + 2);
 }
 
 template <int TM, int TN, int KC, bool BT>
@@ -312,16 +359,32 @@ int tfm_launch(dim3 grid, hipStream_t st, const double* A, int64_t lda, int64_t 
   return 0;
 }
 
-template <int TMT, int TNT, bool BT, bool SWZ>
+template <int TMT, int TNT, bool BT, bool SWZ, bool PKA, bool PKB, bool PKC>
 int tfm_launch_ksplit(dim3 grid, hipStream_t st, const double* A, int64_t lda, int64_t sA, const double* B, int64_t ldb,
                       int64_t sB, double* C, int64_t ldc, int Kseg, int nseg) {
-  constexpr size_t lds = (size_t)4 * TMT * TNT * 4 * 64 * sizeof(double);
-  static_assert(lds <= 65536, "partial tiles fit the default LDS allowance");
-  hipLaunchKernelGGL((k_dgemm_mfma_ksplit<TMT, TNT, BT, SWZ>), grid, dim3(256), lds, st, A, lda, sA, B, ldb, sB, C, ldc, Kseg,
-                     nseg);
+  constexpr size_t lds = (size_t)4 * TMT * TNT * 4 * 4 * 18 * sizeof(double);
+  if (lds > 65536) {
+    static thread_local int attr_dev = -1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (dev != attr_dev) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_dgemm_mfma_ksplit<TMT, TNT, BT, SWZ, PKA, PKB, PKC>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return -1;
+      attr_dev = dev;
+    }
+  }
+  hipLaunchKernelGGL((k_dgemm_mfma_ksplit<TMT, TNT, BT, SWZ, PKA, PKB, PKC>), grid, dim3(256), lds, st, A, lda, sA, B, ldb, sB, C,
+                     ldc, Kseg, nseg);
   return 0;
 }
 }  // namespace
+
+// fragment-packed copy of the slices (dsea_op_create_transfer, once): Bp must hold d * D * D doubles
+void launch_pack_fragments(const double* B, double* Bp, int D, int d, hipStream_t st) {
+  const int64_t nchunks = (int64_t)d * (D / 16) * (D / 16);
+  hipLaunchKernelGGL(k_pack_fragments, dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0, st, B, Bp, D, nchunks);
+}
 
 // y = sum_s B_s X B_s^T through two launches; T = the operator's d x D x D scratch.  Returns 0 or -1 (not applicable).
 // D % 128 == 0: the k-split kernels (fragments from global memory, no LDS in the loop); otherwise the LDS-staged kernels with
@@ -338,10 +401,11 @@ int launch_transfer_mfma(const OpDesc& op, const double* x, double* y, hipStream
   const dim3 g1((unsigned)(D / 32), (unsigned)((int64_t)d * D / 64));
   // K2: y (D x D) = sum_s T_s B_s^T: inner dimension in d segments of D; tile 32 x 32
   const dim3 g2((unsigned)(D / 32), (unsigned)(D / 32));
-  if (longc && !force_lds) {
-    int rc = tfm_launch_ksplit<4, 2, false, false>(g1, st, p.B, D, 0, x, D, 0, p.T, D, D, 1);
+  if (longc && !force_lds && p.Bp) {
+    // K1 reads the packed slices and writes T packed; K2 reads T packed and the packed slices
+    int rc = tfm_launch_ksplit<4, 2, false, false, true, false, true>(g1, st, p.Bp, D, 0, x, D, 0, p.T, D, D, 1);
     if (rc != 0) return rc;
-    return tfm_launch_ksplit<2, 2, true, true>(g2, st, p.T, D, DD, p.B, D, DD, y, D, D, d);
+    return tfm_launch_ksplit<2, 2, true, true, true, true, false>(g2, st, p.T, D, DD, p.Bp, D, DD, y, D, D, d);
   }
   int rc = longc ? tfm_launch<64, 32, 64, 4, 1, false>(g1, st, p.B, D, 0, x, D, 0, p.T, D, D, 1)
                  : tfm_launch<64, 32, 32, 4, 1, false>(g1, st, p.B, D, 0, x, D, 0, p.T, D, D, 1);
