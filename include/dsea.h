@@ -195,7 +195,7 @@ int dsea_op_set_tuning(dsea_op_t op, int key, int value);
  *             multiples of 64 up to 256), the library GEMMs beyond; environment DSEA_TRANSFER_MFMA=1 / =0 forces one or the other;
  *             the hand-written pair is also the path taken when rocBLAS is not available.  `work`:
  *             caller-owned scratch of dsea_op_transfer_work_bytes(D, d) = (1 + 4 d) D^2 doubles; dsea_op_create_transfer
-  *             fills part of it on `stream` (slice-wise transpose, MFMA-fragment-packed copy of the slices).   */
+ *             fills part of it on `stream` (slice-wise transpose, MFMA-fragment-packed copy of the slices).   */
 int dsea_op_create_dense(int64_t n, const double *A_dev, int64_t lda, int transpose, dsea_op_t *out);
 /* dense SYMMETRIC operand (reference symeig.py:15-31 DominantSymeig; Lanczos.py:46-49 applies torch.matmul(A, v)):
  * hand-written mat-vec that reads only the UPPER triangle of the row-major matrix -- every 64 x 64 tile is loaded
