@@ -176,7 +176,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     double* __restrict__ C, int64_t ldc, int Kseg, int nseg) {
   constexpr int NW = 4;                                    // waves (8 = two per SIMD measured no faster: profiles/r04_transfer_mfma.txt)
   extern __shared__ __attribute__((aligned(16))) double tfm_smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: the block / segment arithmetic stays on the scalar unit)
   const int fi = lane & 15, kq = lane >> 4;
   // tile of this workgroup.  Workgroups go to the 8 XCDs round robin by their linear index and every XCD has its own L2: left
   // as (x, y) = (column tile, row tile), an XCD owns column tiles x = c mod 8 and EVERY row tile, i.e. pulls the whole A'
@@ -194,7 +195,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   const int64_t row0 = (int64_t)tr * (16 * TMT), col0 = (int64_t)tc * (16 * TNT);
   const int bps = Kseg / 16;                               // 16-wide blocks per segment
+#if TFM_DIAG == 4                                           /* timing diagnostics: two blocks only = the kernel's fixed cost */
+  const int nb = 2;
+#else
   const int nb = bps * nseg / NW;                          // blocks of this wave: global block index NW b + wv
+#endif
   tfm_v4d acc[TMT][TNT];
 #pragma unroll
   for (int tm = 0; tm < TMT; ++tm)
