@@ -232,6 +232,62 @@ def c3_figures(dev):
                        "in exact arithmetic, 6e-14 relative deviation after 40 iterations), off by default"}
 
 
+def c4_figures(dev):
+    """BASELINE configs[3]: dominant eigen-triple of the MPS transfer matrix at bond dimension D = 512 (n = 262144),
+    DominantSparseEig k = 200 (examples/TFIM_vumps/general.py:59-66, eig.py:115-149) -- the one MFMA-shaped operand of the path."""
+    import dominantsparseeigenad_amd.eig as eig
+    from dominantsparseeigenad_amd.operators import TransferOperator
+    from dominantsparseeigenad_amd.synthetic import normal_vector
+    D, d, k = 512, 2, 200
+    n = D * D
+    A = (torch.from_numpy(normal_vector(d * n, 11)).reshape(d, D, D) / D ** 0.5).to(dev).requires_grad_(True)
+    Ad = A.detach()
+    op, opT = TransferOperator(Ad), TransferOperator(Ad, transpose=True)
+
+    def hook(pieces):                                        # dA of sum_s A_s r A_s^T (general.py:66-76 counterpart)
+        gA = torch.zeros_like(Ad)
+        for u, v in pieces:
+            um, vm = u.reshape(D, D), v.reshape(D, D)
+            gA = gA + torch.matmul(torch.matmul(um, Ad), vm.T) + torch.matmul(torch.matmul(um.T, Ad), vm)
+        return gA
+
+    v = torch.from_numpy(normal_vector(n, 12)).to(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(20):
+        op(v)
+    reps = 200
+    e0.record()
+    for _ in range(reps):
+        op(v)
+    e1.record()
+    torch.cuda.synchronize()
+    mv_us = e0.elapsed_time(e1) / reps * 1e3
+    eig.setDominantSparseEig(op, opT, hook)
+    tv1, tv2 = torch.from_numpy(normal_vector(n, 13)).to(dev), torch.from_numpy(normal_vector(n, 14)).to(dev)
+    best_f = best_b = 1e30
+    lam = None
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        lam, l, r = eig.DominantSparseEig.apply(A, k)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        loss = lam.sum() + (l * tv1).sum() * (r * tv2).sum()
+        torch.autograd.grad(loss, A)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        best_f, best_b = min(best_f, t1 - t0), min(best_b, t2 - t1)
+    res = float((op(r.detach()) - lam.detach() * r.detach()).norm())
+    flops = 4.0 * d * D ** 3                                 # two products of d D^3 multiply-adds
+    return {"workload": "MPS transfer matrix D=512, d=2 (n=262144), DominantSparseEig k=200: forward = two Arnoldi solves, "
+                        "backward = two GMRES solves",
+            "forward_ms": round(best_f * 1e3, 2), "backward_ms": round(best_b * 1e3, 2),
+            "matvec_us": round(mv_us, 2), "matvec_TFLOPs_fp64": round(flops / (mv_us * 1e-6) / 1e12, 1),
+            "matvec_form": "two hand-written v_mfma_f64_16x16x4_f64 kernels on fragment-packed operands "
+                           "(csrc/dsea_transfer_mfma.hip); DSEA_TRANSFER_MFMA=0 selects two rocBLAS GEMMs",
+            "eigen_residual": res}
+
+
 def live_pmc_traffic(timeout_s=240):
     """HBM bytes per launch of every kernel of ONE step of the headline workload, from the PMC counters, measured NOW on
     this box: two rocprofv3 passes (FETCH_SIZE, WRITE_SIZE: separate passes, --kernel-trace only, as
@@ -1288,6 +1344,10 @@ def main():
                 cfg["config3"] = c3_figures(ctx.dev)
             except Exception as exc:  # noqa: BLE001
                 cfg["config3"] = "failed: %s" % exc
+            try:
+                cfg["config4"] = c4_figures(ctx.dev)
+            except Exception as exc:  # noqa: BLE001
+                cfg["config4"] = "failed: %s" % exc
         if not args.no_cpu_baseline and world == 1 and not pt.big and not ctx.staged:
             out["cpu_baseline"] = _cpu_baseline_block(args, pt)
         # RCCL / HIP runtime banners go through C stdio: flush them first so the JSON is the last line

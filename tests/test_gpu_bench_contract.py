@@ -56,6 +56,10 @@ def test_bench_line_carries_honest_extras():
     assert d["config"]["ms_per_step_fp64_basis"] > 0 and d["config"]["bf16_shadow_of_basis"] is True
     c3 = d["config"]["config3"]
     assert c3["cg_iterations"] == 1000 and c3["cg_us_per_iteration"] > 0 and c3["lanczos_k300_ms"] > 0
+    # BASELINE configs[3] (transfer matrix D = 512, DominantSparseEig k = 200): the mat-vec on the fp64 matrix cores
+    c4 = d["config"]["config4"]
+    assert 0 < c4["matvec_us"] < 200 and c4["forward_ms"] > 0 and c4["backward_ms"] > 0 and c4["eigen_residual"] < 1e-10
+    assert 0 < c4["matvec_TFLOPs_fp64"] < 80.0               # (dense fp64 MFMA peak of the chip)
     # the box's own copy / read ceilings beside the spec peak; the dominant kernel cannot beat a read-only stream by much
     ceil = d["config"]["measured_ceilings"]
     assert 2000.0 < ceil["copy_GBs"] <= 8000.0 and 2000.0 < ceil["read_GBs"] <= 8000.0
