@@ -23,6 +23,7 @@ ERR_BREAKDOWN = -7
 ERR_TIMEOUT = -8
 ERR_COMM = -9
 ERR_PREMISE = -10
+ERR_SECOND_PASS = -11
 ERR_UNSUPPORTED = -6
 COMM_ID_BYTES = 128
 POP_OVERLAP, POP_PAIRWISE = 1, 2
@@ -129,6 +130,8 @@ _SIGNATURES = {
     "dsea_arnoldi_extend": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int,
                                     c_void_p]),
     "dsea_arnoldi_second_passes": (c_int, [c_void_p, POINTER(c_int64), c_void_p]),
+    "dsea_ws_set_arnoldi_optimistic": (c_int, [c_void_p, c_int]),
+    "dsea_arnoldi_status": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), c_void_p]),
     "dsea_arnoldi_orth": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int,
                                   c_void_p]),
     "dsea_gmres_work_doubles": (c_size_t, [c_int]),

@@ -124,7 +124,7 @@ TileGeom Workspace::geom(int64_t n_rows) const {
 
 extern "C" {
 
-int dsea_version(void) { return 130; }   // 130: mid-size single-launch Lanczos, fused tail of the overlapped partitioned step
+int dsea_version(void) { return 140; }   // 140: fp64-MFMA transfer mat-vec on packed operands, optimistic Arnoldi second pass
 
 const char* dsea_error_string(int status) {
   switch (status) {
@@ -139,6 +139,7 @@ const char* dsea_error_string(int status) {
     case DSEA_ERR_BREAKDOWN: return "Lanczos breakdown: the Krylov space is smaller than k";
     case DSEA_ERR_COMM: return "a collective (RCCL call or caller-supplied callback) failed";
     case DSEA_ERR_PREMISE: return "overlapped slab exchange: the premise max|c_j| <= tau ||r|| failed at some step";
+    case DSEA_ERR_SECOND_PASS: return "optimistic Arnoldi extension: a step needs its second Gram-Schmidt pass (repeat it with the option off)";
     default: return "unknown status";
   }
 }
@@ -182,6 +183,7 @@ int dsea_ws_create(void* device_buffer, size_t bytes, int64_t n, int kmax, dsea_
   ws->w.split_override = -1;
   ws->w.persist_override = -1;
   ws->w.lz_persist = -1;
+  ws->w.arnoldi_optimistic = 0;
   ws->w.reorth_passes = 1;
   ws->w.partial_reorth = 0;
   ws->w.pro_delta = DSEA_PRO_DELTA_DEFAULT;
@@ -1058,10 +1060,40 @@ int dsea_arnoldi_extend(dsea_op_t op, dsea_ws_t ws, const double* shift, double*
   }
   for (int j = j0; j < j1; ++j) {
     if (arnoldi_step(op->d, w, shift ? shift : w.zero, V, ldv, j, H + (int64_t)j * ldh, brk, w.scal + 24, w.scal + 26,
-                     w.scal + 27, st) != 0)
+                     w.scal + 27, st, w.arnoldi_optimistic != 0) != 0)
       return DSEA_ERR_UNSUPPORTED;
   }
   return check_launch();
+}
+
+int dsea_ws_set_arnoldi_optimistic(dsea_ws_t ws, int on) {
+  if (!ws || (on != 0 && on != 1)) return DSEA_ERR_ARG;
+  ws->w.arnoldi_optimistic = on;
+  return DSEA_OK;
+}
+
+int dsea_arnoldi_status(dsea_ws_t ws, int* break_step, int* redo_step, void* stream) {
+  if (!ws) return DSEA_ERR_ARG;
+  double h = 0.0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  double* brk = ws->w.scal + DSEA_SCAL_BREAK;
+  if (hipMemcpyAsync(&h, brk, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+    g_last_hip = (int)hipGetLastError();
+    return DSEA_ERR_HIP;
+  }
+  if (break_step) *break_step = h > 0.0 ? (int)h : 0;
+  if (redo_step) *redo_step = -1;
+  if (h < 0.0) {
+    // optimistic mode: step -h - 1 needs its second Gram-Schmidt pass.  The record is cleared here so that the caller
+    // can continue: repeat that step with the option off, then go on.
+    if (redo_step) *redo_step = (int)(-h) - 1;
+    if (hipMemsetAsync(brk, 0, sizeof(double), st) != hipSuccess) {
+      g_last_hip = (int)hipGetLastError();
+      return DSEA_ERR_HIP;
+    }
+    return DSEA_ERR_SECOND_PASS;
+  }
+  return h != 0.0 ? DSEA_ERR_BREAKDOWN : DSEA_OK;
 }
 
 int dsea_arnoldi_orth(dsea_ws_t ws, const double* u, const double* shift, double* V, int64_t ldv, int64_t n, int j,

@@ -121,6 +121,7 @@ struct Workspace {
   int split_override;  // -1 automatic, 0 off, 4/8/16 forced
   int persist_override;  // persistent single-launch CG: -1 automatic, 0 off, 1/2/4 = row pairs per thread forced
   int lz_persist;        // single-launch Lanczos for small problems: -1 automatic (on where it applies), 0 off
+  int arnoldi_optimistic;  // dsea_arnoldi_extend: 1 = the second Gram-Schmidt pass is not enqueued; a step failing the DGKS test records itself
   int lose_peer;         // TEST HOOK (dsea_ws_set_fault_injection): the last workgroup of a persistent launch exits at once
   int reorth_passes;     // Gram-Schmidt passes per Lanczos step: 1 (the reference, Lanczos.py:66) or 2 (CGS2 option)
   int partial_reorth;    // 1 = re-orthogonalise only when the omega recurrence says so (option; dsea_ws_set_partial_reorth)
@@ -210,9 +211,11 @@ bool blas_available();
 int blas_apply(const OpDesc& op, const double* x, double* y, hipStream_t st);
 void launch_transpose_sq(const double* in, double* out, int D, int batch, hipStream_t st);
 void arnoldi_orth(Workspace& w, int64_t n, const double* u, const double* shift_or_zero, double* V, int64_t ldv, int j,
-                  double* hcol, double* brk, double* skip, double* nrm1, double* nrm2, hipStream_t st);
+                  double* hcol, double* brk, double* skip, double* nrm1, double* nrm2, hipStream_t st,
+                  bool optimistic = false);
 int arnoldi_step(const OpDesc& op, Workspace& w, const double* shift_or_zero, double* V, int64_t ldv, int j,
-                 double* hcol, double* brk, double* skip, double* nrm1, double* nrm2, hipStream_t st);
+                 double* hcol, double* brk, double* skip, double* nrm1, double* nrm2, hipStream_t st,
+                 bool optimistic = false);
 void launch_residual(const double* b, const double* u, double* r, int64_t n, double* P, double* nrm2_out,
                      hipStream_t st);
 void launch_gmres_begin(const double* nrm2, double target, double* g, int m, double* state, double* brk,

@@ -283,6 +283,52 @@ __global__ __launch_bounds__(256) void k_arnoldi_finish(const double* __restrict
   }
 }
 
+// The same with the DGKS test inside (optimistic mode of dsea_arnoldi_extend: no second pass is enqueued).  Every block sums
+// the correction pass's `count` partials of ||w1||^2 in the order of k_dgks_decide (same value in every block, bit for
+// bit what the two-kernel sequence computes) and tests it; a step that NEEDS the second pass is not finished: block 0
+// records brk[0] = -(j + 1) -- every later launch of the run is then a no-op (broken()) -- and dsea_arnoldi_status hands
+// the step back to the caller, who repeats it with the second pass enqueued.
+__global__ __launch_bounds__(256) void k_arnoldi_finish_opt(const double* __restrict__ c1, const double* __restrict__ P,
+                                                            int count, int j, double* __restrict__ hcol,
+                                                            const double* __restrict__ w1, double* __restrict__ v_out,
+                                                            int64_t n, double* __restrict__ brk,
+                                                            double* __restrict__ counter) {
+  __shared__ double sm4[4];
+  __shared__ double s_nrm1;
+  if (broken(brk)) return;
+  double acc = 0.0;
+  for (int b = threadIdx.x; b < count; b += 256) acc += P[b];
+  const double t0 = block_sum(acc, sm4);  // (the total is thread 0's)
+  if (threadIdx.x == 0) s_nrm1 = t0;
+  __syncthreads();
+  const double nrm1 = s_nrm1;
+  const double ww = c1[j + 1];            // ||A v_j - shift v_j||^2
+  if (!(nrm1 >= 0.5 * ww)) {              // DGKS: the first pass lost too much -- this step needs the second pass
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      brk[0] = -(double)(j + 1);
+      if (counter) counter[0] += 1.0;
+    }
+    return;
+  }
+  const double beta = sqrt(nrm1);
+  const bool dead = !(beta > DSEA_BREAK_TOL * sqrt(ww));
+  if (blockIdx.x == 0) {
+    for (int t = threadIdx.x; t <= j; t += 256) hcol[t] = c1[t];
+    if (threadIdx.x == 0) {
+      hcol[j + 1] = beta;
+      if (dead && brk) brk[0] = (double)(j + 1);
+    }
+  }
+  if (dead) return;
+  const int64_t stride = (int64_t)gridDim.x * 512;
+  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; row < n; row += stride) {
+    double2 v = ld2<true>(w1, row, n);
+    v.x = v.x / beta;
+    v.y = v.y / beta;
+    st2<true>(v_out, row, n, v);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // GMRES cycle scalars (restart length m <= 64): one thread each, all on the stream
 // gw = device work: H (m+1) x m column-major | cs[m] | sn[m] | g[m+1] | y[m]
@@ -379,18 +425,18 @@ static inline int kr_blocks(int64_t n) {
 // One Arnoldi step j -> j+1 on (A - shift I):  w = A v_j - shift v_j, orthogonalised against V[0..j] (CGS + DGKS
 // second pass), column j of H, v_{j+1}.  brk: break / skip record of the run (2 doubles), skip: DGKS flag (1 double).
 int arnoldi_step(const OpDesc& op, Workspace& w, const double* shift_or_zero, double* V, int64_t ldv, int j,
-                 double* hcol, double* brk, double* skip, double* nrm1, double* nrm2, hipStream_t st) {
+                 double* hcol, double* brk, double* skip, double* nrm1, double* nrm2, hipStream_t st, bool optimistic) {
   double* u = w.vec[0];
   const double* vj = V + (int64_t)j * ldv;
   int nb = launch_spmv(op, vj, u, nullptr, brk, nullptr, st);
   if (nb < 0) return -1;
-  arnoldi_orth(w, op.n, u, shift_or_zero, V, ldv, j, hcol, brk, skip, nrm1, nrm2, st);
+  arnoldi_orth(w, op.n, u, shift_or_zero, V, ldv, j, hcol, brk, skip, nrm1, nrm2, st, optimistic);
   return 0;
 }
 
 // the step without its mat-vec: u = A v_j is given (generic-callable mode: the mat-vec is the caller's code)
 void arnoldi_orth(Workspace& w, int64_t n, const double* u, const double* shift_or_zero, double* V, int64_t ldv, int j,
-                  double* hcol, double* brk, double* skip, double* nrm1, double* nrm2, hipStream_t st) {
+                  double* hcol, double* brk, double* skip, double* nrm1, double* nrm2, hipStream_t st, bool optimistic) {
   double* w1 = w.vec[1];
   double* w2 = w.vec[2];
   double* c1 = w.coef;
@@ -400,6 +446,14 @@ void arnoldi_orth(Workspace& w, int64_t n, const double* u, const double* shift_
   // pass 1: w1 = u - shift v_j ; c1 = V^T w1 ; c1[i] = ||w1||^2 ; w1 -= V c1 ; nrm1 = ||w1||^2
   launch_rdots(g, V, ldv, n, i, u, shift_or_zero, nullptr, w1, w.partials, c1, st, nullptr, nullptr, 0, nullptr, true, brk);
   launch_axpy_norm(g, V, ldv, n, i, c1, w1, w.partials, nullptr, st, nullptr, brk);
+  if (optimistic) {
+    // six launches per step instead of eleven: the DGKS test rides in the finish kernel, the second pass (needed on 0 of 200
+    // steps of the D = 512 transfer matrix) is not enqueued; a step that needs it hands itself back (k_arnoldi_finish_opt)
+    hipLaunchKernelGGL(k_arnoldi_finish_opt, dim3(kr_blocks(n)), dim3(256), 0, st, (const double*)c1,
+                       (const double*)w.partials, g.nw, j, hcol, (const double*)w1, V + (int64_t)(j + 1) * ldv, n, brk,
+                       w.scal + 31);
+    return;
+  }
   hipLaunchKernelGGL(k_dgks_decide, dim3(1), dim3(256), 0, st, (const double*)c1, i, (const double*)w.partials, g.nw,
                      nrm1, skip, (const double*)brk, w.scal + 31);
   // pass 2 (skipped on the device unless the DGKS test failed): w2 = w1 - V (V^T w1)

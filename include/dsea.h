@@ -466,6 +466,19 @@ int dsea_arnoldi_extend(dsea_op_t op, dsea_ws_t ws, const double *shift, double 
 /* diagnostics (synchronises): how many steps since the last j0 == 0 call needed the second Gram-Schmidt pass */
 int dsea_arnoldi_second_passes(dsea_ws_t ws, int64_t *count, void *stream);
 
+/* OPTIMISTIC second pass (round 4; off by default).  The second Gram-Schmidt pass of dsea_arnoldi_extend is needed rarely
+ * (0 of 200 steps on BASELINE configs[3]'s transfer matrix) but its three launches and the two scalar kernels around
+ * them are enqueued on every step -- 11 launches, 5 of them returning at once.  With the option on, a step is 6 launches:
+ * the DGKS test runs inside the finish kernel, and a step that FAILS it is not finished -- it records itself, every later
+ * launch of the run is a no-op, and dsea_arnoldi_status returns DSEA_ERR_SECOND_PASS with *redo_step = that step (the
+ * record is cleared by the call).  The caller then repeats the step with the option off -- dsea_arnoldi_extend(..., j, j + 1,
+ * ...) -- and continues from j + 1.  Columns of H and vectors of V are bit-identical to the default mode either way.
+ * dsea_arnoldi_status SYNCHRONISES: DSEA_OK, DSEA_ERR_BREAKDOWN (*break_step = invariant subspace reached at that step)
+ * or DSEA_ERR_SECOND_PASS.  Without the option it reports what dsea_lanczos_status reports for an Arnoldi run.          */
+#define DSEA_ERR_SECOND_PASS (-11)
+int dsea_ws_set_arnoldi_optimistic(dsea_ws_t ws, int on);
+int dsea_arnoldi_status(dsea_ws_t ws, int *break_step, int *redo_step, void *stream);
+
 /* the orthogonalisation of ONE Arnoldi step when the mat-vec is the caller's code: u = A v_j given, writes column j
  * of H (entries 0..j+1) and V[j+1]; (*shift) v_j is subtracted from u inside the first pass.                    */
 int dsea_arnoldi_orth(dsea_ws_t ws, const double *u, const double *shift, double *V, int64_t ldv, int64_t n, int j,

@@ -340,3 +340,42 @@ def test_staged_convergence_test_finds_the_same_pair_with_fewer_columns():
         assert float((s * x - x_full).abs().max()) < 1e-10
         assert float((op(x) - lam_st * x).norm()) <= 1e-12 * abs(lam_st)
     print("staged Arnoldi: converged with %d of %d columns" % (cols, k))
+
+
+def test_optimistic_second_pass_hands_failing_steps_back_and_changes_nothing():
+    """include/dsea.h dsea_ws_set_arnoldi_optimistic / dsea_arnoldi_status: with the option on (krylov's default for native
+    operands) the second Gram-Schmidt pass is not enqueued -- 6 launches per Arnoldi step instead of 11 -- and a step that fails
+    the DGKS test on the device is handed back and repeated with the pass.  On a matrix that is a rank-one term plus 1e-6 noise
+    almost every step after the first fails the test (A v_j lies in the span of the basis up to 1e-6): the factorisation, and so
+    the Ritz pair, must come out bit for bit as in the default mode; on the well-conditioned D = 16 transfer matrix no step
+    comes back."""
+    from dominantsparseeigenad_amd.operators import DenseOperator, TransferOperator
+    rng = np.random.RandomState(77)
+    n = 2048
+    u, v = rng.randn(n), rng.randn(n)
+    v = v + 0.5 * u                                          # (u.v > 0: the dominant eigenvalue is real)
+    G = torch.from_numpy(np.outer(u, v) / n + 1e-6 * rng.randn(n, n)).to(cuda)
+    op = DenseOperator(G)
+    v0 = torch.from_numpy(rng.randn(n)).to(cuda)
+    out = {}
+    old = krylov.OPTIMISTIC_SECOND_PASS
+    try:
+        for mode in (False, True):
+            krylov.OPTIMISTIC_SECOND_PASS = mode
+            theta, x = krylov.arnoldi_dominant(op, n, 24, cuda, v0=v0)
+            out[mode] = (theta, x.clone(), krylov.last("arnoldi_second_pass_redos"), krylov.last("arnoldi_columns"))
+    finally:
+        krylov.OPTIMISTIC_SECOND_PASS = old
+    assert out[False][2] == 0 and out[True][2] >= 3, (out[False][2], out[True][2])
+    assert out[True][0] == out[False][0] and torch.equal(out[True][1], out[False][1]) and out[True][3] == out[False][3]
+    lam = float((v @ u) / n)
+    assert abs(out[True][0] - lam) < 1e-4 * abs(lam)
+    res = float((G @ out[True][1] - out[True][0] * out[True][1]).norm())
+    assert res < 1e-10 * abs(lam)
+    # the usual case: nothing comes back
+    A = torch.from_numpy(rng.randn(2, 16, 16) / 4.0).to(cuda)
+    assert krylov.OPTIMISTIC_SECOND_PASS is True
+    theta, x = krylov.arnoldi_dominant(TransferOperator(A), 256, 40, cuda)
+    assert krylov.last("arnoldi_second_pass_redos") == 0
+    Gd = torch.einsum("kij,kmn->imjn", A, A).reshape(256, 256)
+    assert float((Gd @ x - theta * x).norm()) < 1e-10 * abs(theta)
