@@ -321,7 +321,7 @@ int dsea_ws_set_rows_per_lane(dsea_ws_t ws, int rpl) {
 
 int dsea_ws_set_persist(dsea_ws_t ws, int mode) {
   if (!ws) return DSEA_ERR_ARG;
-  if (mode == 200) {     // TFIM, 2^14 ... 2^20 rows: the two-exchange persistent form (iterates bit-identical to the streaming
+  if (mode == 200) {     // TFIM, 2^11 ... 2^20 rows: the two-exchange persistent form (iterates bit-identical to the streaming
     ws->w.persist_override = mode;   // kernels) instead of the default one-exchange form; other operands: as -1
     return DSEA_OK;
   }
@@ -1262,7 +1262,7 @@ int dsea_cg_run(dsea_op_t op, dsea_ws_t ws, const double* shift, const double* b
   const bool tfim_persist = w.persist_override != 0 && cg_persist_tfim_applicable(op->d) &&
                             cg_persist_tfim_comm_bytes(n) <=
                                 (size_t)DSEA_MAX_WAVE_TILES * (size_t)((w.kmax < 1 ? 1 : w.kmax) + 1) * sizeof(double);
-  // 2^14 ... 2^20 rows: k_cg_persist_tfim_big (iterates bit-identical to the streaming form; d double-buffered in the
+  // 2^11 ... 2^20 rows: k_cg_persist_tfim_big (iterates bit-identical to the streaming form; d double-buffered in the
   // workspace vectors the streaming form uses for d and A'd, granules in w.aux)
   const bool tfim_big = w.persist_override != 0 && cg_persist_tfim_big_applicable(op->d) &&
                         cg_persist_tfim_big_comm_bytes(n) <= (size_t)4 * DSEA_MAX_WAVE_TILES * sizeof(double);

@@ -1,5 +1,5 @@
 // dsea_cg_persist_tfim_big.hip -- conjugate gradients (reference CG.py:24-41 with A' = A - shift, CG.py:120) for the
-// full-space matrix-free TFIM operator at 2^14 ... 2^20 rows (BASELINE configs[1] is L = 20) as ONE persistent launch
+// full-space matrix-free TFIM operator at 2^11 ... 2^20 rows (BASELINE configs[1] is L = 20) as ONE persistent launch
 // whose iterates are BIT-IDENTICAL to the streaming form (mat-vec + update + direction launches).
 //
 // Streaming form at L = 20: 25.6 us per iteration for 92 MB of algorithmic traffic -- three dependent launches, x / r /
@@ -25,7 +25,8 @@
 //   State zeroed per launch, spins bounded by a 3 s wall-clock timeout (-> DSEA_ERR_TIMEOUT, the host falls back to
 //   the streaming form).  G = 2^(L-11) / NVB <= 256 workgroups: one per compute unit.
 //
-// MERGED = true (round 4, the default from 2^14 rows): ONE all-to-all per iteration instead of two.  Each of the two
+// MERGED = true (round 4, the default from 2^11 rows = one tile: measured faster than the small-problem kernel of
+// dsea_cg_persist_tfim.hip from there on -- L = 12: 6.8 -> 4.9 us, L = 13: 9.1 -> 5.0 us per iteration): ONE all-to-all per iteration instead of two.  Each of the two
 // exchanges above costs ~6 us at 256 workgroups (gather + arrival skew) -- more than the mat-vec (6.6 us).  The two
 // scalars of CG.py:31-40 are dependent (alpha = rr / d.A'd, then r'.r' of the UPDATED residual), so merging them needs the
 // Chronopoulos-Gear recurrences: w = A'r is formed once per iteration, gamma = r.r and delta = r.w are reduced TOGETHER,
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(256 * NVB) void k_cg_persist_tfim_big(CgbArgs a) {
 }
 
 bool cg_persist_tfim_big_applicable(const OpDesc& op) {
-  return op.kind == OP_TFIM && op.tfim.L_local == op.tfim.L && op.tfim.row_offset == 0 && op.tfim.L >= 14 &&
+  return op.kind == OP_TFIM && op.tfim.L_local == op.tfim.L && op.tfim.row_offset == 0 && op.tfim.L >= 11 &&
          op.tfim.L <= 20 && op.tune_tile_log2 == CGB_T;
 }
 size_t cg_persist_tfim_big_comm_bytes(int64_t n) {

@@ -675,7 +675,7 @@ last_cg = CGInfo()
 # CG.py:31-40 (measured: 6e-14 relative after 40 iterations, same iteration counts on converged runs), hence off
 # by default; ``cg(..., merged_reductions=True)`` selects it per call.
 CG_MERGED_REDUCTIONS = False
-# Full-space TFIM operator at 2^14 ... 2^20 rows (the adjoint solve of BASELINE configs[1]): the single-launch CG makes ONE
+# Full-space TFIM operator at 2^11 ... 2^20 rows (the adjoint solve of BASELINE configs[1]): the single-launch CG makes ONE
 # grid-wide exchange per iteration by default (Chronopoulos-Gear recurrences; same iteration in exact arithmetic, iterates
 # within ~1e-13 of the reference's recurrences, same iteration counts).  True selects the two-exchange form whose iterates
 # are BIT-IDENTICAL to the streaming kernels / CG.py:31-40 evaluated in fp64 (23 instead of ~15 us per iteration at L = 20).

@@ -80,7 +80,7 @@ int dsea_ws_set_split(dsea_ws_t ws, int waves);
  * per iteration instead of two (r.r and r.Ar reduced together, A p carried by a recurrence: Chronopoulos-Gear).  The
  * same iteration in exact arithmetic, NOT the rounding sequence of reference CG.py:31-40: an option for
  * latency-bound solves on the STENCIL operand, never selected automatically there.
- * Full-space matrix-free TFIM operand at 2^14 ... 2^20 rows (the adjoint solve of BASELINE configs[1]): the single-launch
+ * Full-space matrix-free TFIM operand at 2^11 ... 2^20 rows (the adjoint solve of BASELINE configs[1]): the single-launch
  * form makes ONE grid-wide exchange per iteration by default (the same Chronopoulos-Gear recurrences; measured within
  * 1e-15 of the two-exchange form on SPD systems, same iteration counts: profiles/r04_cg_one_exchange_check.txt);
  * mode 200 selects the TWO-exchange form there, whose iterates are bit-identical to the streaming kernels, i.e. to

@@ -349,7 +349,7 @@ def _mid_size_checks(op, N, k, b, Lanczos, symeigLanczos, _lib, warnings, time):
 
 
 # ------------------------------------------------------------------ single-launch CG for the TFIM operator (README sizes)
-@pytest.mark.parametrize("L", [1, 2, 3, 6, 7, 8, 10, 12, 13])
+@pytest.mark.parametrize("L", [1, 2, 3, 6, 7, 8, 10, 11, 12, 13])
 def test_persistent_tfim_cg_matches_streaming_form_and_oracle(L):
     """csrc/dsea_cg_persist_tfim.hip (n = 2^L <= 8192: one launch per solve, x / r / d in registers, two grid
     exchanges per iteration) against the 3-launches-per-iteration kernels and the CPU oracle on the shifted system
@@ -404,8 +404,8 @@ def test_persistent_tfim_cg_without_shift_and_zero_rhs_and_maxiter_zero():
     assert got[1] == 0 and not got[3] and torch.equal(got[0], x0)
 
 
-# ------------------------------------------------------------------ single-launch TFIM CG at 2^14 ... 2^20 rows
-@pytest.mark.parametrize("L", [14, 15, 17, 19, 20])
+# ------------------------------------------------------------------ single-launch TFIM CG at 2^11 ... 2^20 rows
+@pytest.mark.parametrize("L", [11, 12, 13, 14, 15, 17, 19, 20])
 def test_persistent_tfim_cg_large_is_bit_identical_to_streaming_form(L):
     """csrc/dsea_cg_persist_tfim_big.hip, TWO-exchange form (dsea_ws_set_persist(200); x / r / d in registers for the whole
     solve, d exchanged through device-coherent buffer stores / loads, partial sums reproduced per mat-vec tile and per
@@ -434,9 +434,9 @@ def test_persistent_tfim_cg_large_is_bit_identical_to_streaming_form(L):
     assert got[1] == 0 and not got[3] and torch.equal(got[0], x0)
 
 
-@pytest.mark.parametrize("L", [14, 15, 17, 19, 20])
+@pytest.mark.parametrize("L", [11, 12, 13, 14, 15, 17, 19, 20])
 def test_persistent_tfim_cg_large_one_exchange_form_follows_the_reference_iteration(L):
-    """The DEFAULT single-launch form at 2^14 ... 2^20 rows makes ONE grid-wide exchange per iteration (Chronopoulos-Gear
+    """The DEFAULT single-launch form at 2^11 ... 2^20 rows makes ONE grid-wide exchange per iteration (Chronopoulos-Gear
     recurrences: gamma = r.r and delta = r.A'r reduced together, s = A'p carried by a recurrence) -- the same iteration as
     CG.py:31-40 in exact arithmetic, not its rounding sequence.  Held to the streaming kernels (which reproduce CG.py's
     recurrences): the first 50 iterates to 1e-11 relative, residual norms alike, converged runs with the same number of

@@ -11,7 +11,7 @@ from dominantsparseeigenad_amd.synthetic import normal_vector
 dev = torch.device("cuda:0")
 iters = 400
 cases = [("TFIM L=%d" % L, TFIMOperator(L, dev, g=torch.tensor([1.0], dtype=torch.float64, device=dev)), 1 << L)
-         for L in (8, 10, 12, 13, 14, 16, 18, 19, 20)]
+         for L in (8, 10, 11, 12, 13, 14, 16, 18, 19, 20)]
 for N in (300, 1000, 4096):
     x = torch.from_numpy(np.linspace(-1.0, 1.0, num=N, endpoint=False)).to(dev)
     cases.append(("stencil N=%d" % N, Stencil3Operator(N, 2.0 / N, 0.5 * x ** 2), N))
