@@ -1175,7 +1175,7 @@ int dsea_gmres_step(dsea_op_t op, dsea_ws_t ws, const double* shift, const doubl
   const double* sh = shift ? shift : w.zero;
   if (op) {
     if (arnoldi_step(op->d, w, sh, V, ldv, j, gw.H + (size_t)j * gw.ldh, brk, w.scal + 24, w.scal + 26, w.scal + 27,
-                     st) != 0)
+                     st, w.arnoldi_optimistic != 0) != 0)
       return DSEA_ERR_UNSUPPORTED;
   } else {
     REQUIRE(aligned16(u), DSEA_ERR_ALIGN);

@@ -347,6 +347,7 @@ __global__ void k_gmres_begin(const double* __restrict__ nrm2, double target, do
   const bool conv = beta0 <= target;
   state[1] = conv ? 1.0 : 0.0;
   state[4] = conv ? 1.0 : 0.0;
+  state[5] = 0.0;              // (optimistic mode: a step of this cycle needed the second Gram-Schmidt pass)
   brk[0] = conv ? 1.0 : 0.0;   // converged already: every step kernel of the cycle returns at once
   brk[1] = 0.0;
 }
@@ -356,6 +357,14 @@ __global__ void k_gmres_givens(double* __restrict__ H, int ldh, int j, double* _
                                double* __restrict__ sn, double* __restrict__ g, double target,
                                double* __restrict__ state, double* __restrict__ brk) {
   if (state[4] != 0.0) return;
+  if (brk[0] < 0.0) {
+    // optimistic mode (dsea_ws_set_arnoldi_optimistic): step j failed the DGKS test and was not finished -- column j does
+    // not exist.  The cycle ends here with the j columns it has (a restart, always valid); state[5] tells the caller to
+    // run the next cycle with the second pass enqueued.
+    state[4] = 1.0;
+    state[5] = 1.0;
+    return;
+  }
   double* h = H + (int64_t)j * ldh;
   for (int t = 0; t < j; ++t) {
     const double a = h[t], b = h[t + 1];

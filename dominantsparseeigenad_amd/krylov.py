@@ -348,10 +348,20 @@ def gmres(A, b, shift=None, rtol=1e-12, atol=1e-12, restart=20, maxiter=None):
     target = max(rtol * bnorm, atol)
     cycles = 10 * n if maxiter is None else int(maxiter)
     info = None
+    optimistic = lp.native is not None and OPTIMISTIC_SECOND_PASS
+    DIAG.gmres_second_pass_fallbacks = 0
     for c in range(cycles):
         if lp.native is not None:
-            check(lib.dsea_gmres_cycle(lp.native.handle, ws.handle, _ptr(sh), _ptr(b), _ptr(x), _ptr(V), ldv, m,
-                                       _ptr(work), float(target), _ptr(state), int(c == 0), st()), "dsea_gmres_cycle")
+            # optimistic second pass (see OPTIMISTIC_SECOND_PASS): a step that needs it ends its cycle early (= a restart)
+            # and the rest of the solve runs with the pass enqueued
+            if optimistic:
+                check(lib.dsea_ws_set_arnoldi_optimistic(ws.handle, 1), "dsea_ws_set_arnoldi_optimistic")
+            try:
+                check(lib.dsea_gmres_cycle(lp.native.handle, ws.handle, _ptr(sh), _ptr(b), _ptr(x), _ptr(V), ldv, m,
+                                           _ptr(work), float(target), _ptr(state), int(c == 0), st()), "dsea_gmres_cycle")
+            finally:
+                if optimistic:
+                    check(lib.dsea_ws_set_arnoldi_optimistic(ws.handle, 0), "dsea_ws_set_arnoldi_optimistic")
         else:
             Ax = None
             if c > 0:
@@ -370,6 +380,9 @@ def gmres(A, b, shift=None, rtol=1e-12, atol=1e-12, restart=20, maxiter=None):
         info = state.cpu()
         if info[1].item() != 0.0:
             break
+        if optimistic and info[5].item() != 0.0:
+            optimistic = False
+            DIAG.gmres_second_pass_fallbacks += 1
     DIAG.gmres_cycles = c + 1
     DIAG.gmres_residual = float(info[0].item()) if info is not None else float("nan")
     return x

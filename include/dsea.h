@@ -474,7 +474,10 @@ int dsea_arnoldi_second_passes(dsea_ws_t ws, int64_t *count, void *stream);
  * record is cleared by the call).  The caller then repeats the step with the option off -- dsea_arnoldi_extend(..., j, j + 1,
  * ...) -- and continues from j + 1.  Columns of H and vectors of V are bit-identical to the default mode either way.
  * dsea_arnoldi_status SYNCHRONISES: DSEA_OK, DSEA_ERR_BREAKDOWN (*break_step = invariant subspace reached at that step)
- * or DSEA_ERR_SECOND_PASS.  Without the option it reports what dsea_lanczos_status reports for an Arnoldi run.          */
+ * or DSEA_ERR_SECOND_PASS.  Without the option it reports what dsea_lanczos_status reports for an Arnoldi run.
+ * dsea_gmres_cycle / dsea_gmres_step (native operand) honour the option too: a step that fails the test ends the CYCLE
+ * early with the columns it has -- a restart, always valid -- and sets state[5] = 1; the caller runs the following
+ * cycle(s) with the option off.                                                                                      */
 #define DSEA_ERR_SECOND_PASS (-11)
 int dsea_ws_set_arnoldi_optimistic(dsea_ws_t ws, int on);
 int dsea_arnoldi_status(dsea_ws_t ws, int *break_step, int *redo_step, void *stream);
