@@ -396,3 +396,60 @@ def test_optimistic_second_pass_hands_failing_steps_back_and_changes_nothing():
     theta, x = krylov.arnoldi_dominant(top, 1024, 30, cuda)
     assert krylov.last("arnoldi_second_pass_redos") == 0
     assert float((top(x) - theta * x).norm()) < 1e-10 * abs(theta)
+
+
+def test_arnoldi_status_protocol_through_the_c_abi():
+    """include/dsea.h, the optimistic-second-pass protocol step by step through ctypes: extend with the option on -> the
+    first step that fails the DGKS test stops the run and dsea_arnoldi_status returns DSEA_ERR_SECOND_PASS with that step
+    (and clears the record: the next status call is DSEA_OK) -> that step repeated with the option off -> the rest with
+    the option on again; H and V equal the default mode's bit for bit.  Bad arguments are refused."""
+    import ctypes
+    from dominantsparseeigenad_amd import _lib, engine
+    from dominantsparseeigenad_amd.engine import _ptr
+    from dominantsparseeigenad_amd.operators import DenseOperator
+    lib = _lib.load()
+    rng = np.random.RandomState(78)
+    n, m = 1024, 6
+    u, v = rng.randn(n), rng.randn(n)
+    G = torch.from_numpy(np.outer(u, v + 0.5 * u) / n + 1e-6 * rng.randn(n, n)).to(cuda)
+    op = DenseOperator(G)
+    lp = krylov._Loop(op, n, cuda, m + 2)
+    ws, ldv, st = lp.ws, lp.ldv, lp.st
+    v0 = torch.from_numpy(rng.randn(n)).to(cuda)
+    v0 = v0 / v0.norm()
+
+    def run(optimistic):
+        V = torch.zeros((m + 1, ldv), dtype=F64, device=cuda)
+        H = torch.zeros((m, m + 1), dtype=F64, device=cuda)
+        V[0, :n] = v0
+        brk, redo, log, j = ctypes.c_int(0), ctypes.c_int(-1), [], 0
+        while j < m:
+            _lib.check(lib.dsea_ws_set_arnoldi_optimistic(ws.handle, 1 if optimistic else 0))
+            try:
+                _lib.check(lib.dsea_arnoldi_extend(op.handle, ws.handle, None, _ptr(V), ldv, j, m, _ptr(H), m + 1, st()))
+            finally:
+                _lib.check(lib.dsea_ws_set_arnoldi_optimistic(ws.handle, 0))
+            rc = lib.dsea_arnoldi_status(ws.handle, ctypes.byref(brk), ctypes.byref(redo), st())
+            log.append((rc, brk.value, redo.value))
+            if rc != _lib.ERR_SECOND_PASS:
+                assert rc == 0, rc
+                break
+            assert optimistic and j <= redo.value < m and brk.value == 0
+            # the record was cleared by the status call
+            assert lib.dsea_arnoldi_status(ws.handle, ctypes.byref(brk), ctypes.byref(redo), st()) == 0 and redo.value == -1
+            _lib.check(lib.dsea_arnoldi_extend(op.handle, ws.handle, None, _ptr(V), ldv, log[-1][2], log[-1][2] + 1, _ptr(H),
+                                               m + 1, st()))
+            j = log[-1][2] + 1
+        torch.cuda.synchronize()
+        return V.clone(), H.clone(), log
+
+    Vd, Hd, logd = run(False)
+    Vo, Ho, logo = run(True)
+    assert logd == [(0, 0, -1)]
+    assert [e[0] for e in logo].count(_lib.ERR_SECOND_PASS) >= 2 and logo[0][2] == 1, logo   # step 0 passes, step 1 comes back
+    assert torch.equal(Vo, Vd) and torch.equal(Ho, Hd)
+    Vh = Vd[:m + 1, :n]
+    assert float((Vh @ Vh.T - torch.eye(m + 1, dtype=F64, device=cuda)).abs().max()) < 1e-12     # second passes did their work
+    assert lib.dsea_ws_set_arnoldi_optimistic(ws.handle, 2) == _lib.ERR_ARG
+    assert lib.dsea_ws_set_arnoldi_optimistic(None, 1) == _lib.ERR_ARG and lib.dsea_arnoldi_status(None, None, None, None) == _lib.ERR_ARG
+    assert b"second Gram-Schmidt" in lib.dsea_error_string(_lib.ERR_SECOND_PASS)
