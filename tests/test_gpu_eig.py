@@ -377,13 +377,14 @@ def test_optimistic_second_pass_hands_failing_steps_back_and_changes_nothing():
     b = torch.from_numpy(rng.randn(n)).to(cuda)
     sigma = torch.tensor([2.0 * lam], dtype=F64, device=cuda)
     sols = {}
+    assert krylov.OPTIMISTIC_SECOND_PASS_GMRES is False          # (off by default: no gain measured on the adjoint systems)
     try:
         for mode in (False, True):
-            krylov.OPTIMISTIC_SECOND_PASS = mode
+            krylov.OPTIMISTIC_SECOND_PASS_GMRES = mode
             xs = krylov.gmres(op, b, shift=sigma)
             sols[mode] = (xs, krylov.last("gmres_second_pass_fallbacks"), krylov.last("gmres_cycles"))
     finally:
-        krylov.OPTIMISTIC_SECOND_PASS = old
+        krylov.OPTIMISTIC_SECOND_PASS_GMRES = False
     assert sols[False][1] == 0 and sols[True][1] == 1, (sols[False][1:], sols[True][1:])
     for mode in (False, True):
         r = G @ sols[mode][0] - sigma * sols[mode][0] - b
