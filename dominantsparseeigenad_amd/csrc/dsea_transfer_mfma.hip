@@ -10,14 +10,19 @@
 //        result is written once -- no slice sum, and because both operands are read as they lie in memory (K2 is an
 //        "A B^T" product: rows of T_s and rows of B_s are both contiguous along the inner index) no transpose either.
 // Tiling for 256 CUs, not for a big-GEMM library shape: the output has only D^2 = 2^18 elements, so a workgroup takes a
-// 64 x 32 (K1: 16 x 16 = 256 workgroups) / 32 x 32 (K2: 256 workgroups) tile -- one workgroup per CU, one wave per SIMD,
-// each wave 16 x 32 / 16 x 16 of it as 16 x 16 x 4 MFMA tiles.  Inner dimension in chunks of KC staged through LDS (double
-// buffered: the next chunk's global loads are in flight while the current one is multiplied; one barrier per chunk).
-// LDS rows are padded so that the 8-byte fragment reads are conflict-free: an A-type tile [rows][KC + 2] (lane (i, kk)
-// reads word pair 2 i + kk mod 32 ... distinct over the 32 lanes of an LDS cycle), a B tile [KC][TN + 16].
+// 64 x 32 (K1: 16 x 16 = 256 workgroups) / 32 x 32 (K2: 256 workgroups) tile -- one workgroup per CU, one wave per SIMD.
+// Two forms of the kernels (measurements: profiles/r04_transfer_mfma.txt):
+//   k_dgemm_mfma_ksplit  (D a multiple of 128; 25.5 us per mat-vec at D = 512, the library GEMM path 33): the four waves split
+//       the INNER dimension, fragments come straight from global memory out of FRAGMENT-PACKED operands -- no LDS and no
+//       barrier inside the loop; see the comment at the kernel.
+//   k_dgemm_mfma         (other multiples of 64): each wave 16 x 32 / 16 x 16 of the tile; inner dimension in chunks of KC
+//       staged through LDS (double buffered: the next chunk's global loads are in flight while the current one is
+//       multiplied; one barrier per chunk).  LDS rows are padded so that the 8-byte fragment reads are conflict-free: an
+//       A-type tile [rows][KC + 2], a B tile [KC][TN + 16].
 // Fragment layout of v_mfma_f64_16x16x4_f64 (cdna_hip_programming.md 3): A[i = lane & 15][k = lane >> 4], B[k = lane >> 4]
 // [j = lane & 15], one double each; C/D four doubles per lane: row = (lane >> 4) + 4 reg, col = lane & 15.
-// Shapes the kernels do not cover (D not a multiple of 64) keep the rocBLAS path of dsea_krylov.hip.
+// Shapes the kernels do not cover (D not a multiple of 64), and by default D > 512, keep the rocBLAS path of dsea_krylov.hip.
+// -DTFM_DIAG=1/2/4: timing diagnostics only (no loads in the loop / a quarter of the MFMAs / two k blocks), wrong results.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
