@@ -495,7 +495,7 @@ int dsea_op_create_transfer(int D, int d, const double* A_dev, int transpose, do
   double* T = work + DD;
   double* Y = T + slab;
   double* AT = Y + slab;
-  double* Bp = (D % 128) == 0 ? AT + slab : nullptr;
+  double* Bp = (D % 64) == 0 ? AT + slab : nullptr;
   op->d.transfer = TransferParams{D, d, transpose ? AT : A_dev, xT, T, Y, transpose ? 1 : 0, Bp};
   if (transpose) launch_transpose_sq(A_dev, AT, D, d, static_cast<hipStream_t>(stream));   // B_k = A_k^T, once
   if (Bp) launch_pack_fragments(op->d.transfer.B, Bp, D, d, static_cast<hipStream_t>(stream));   // (MFMA fragment order, once)

@@ -191,8 +191,8 @@ int dsea_op_set_tuning(dsea_op_t op, int key, int value);
  *             the slice-wise transposed tensor, copied once) + a transpose and a slice-sum kernel (rocBLAS), or -- for D a
  *             multiple of 64 -- as two hand-written fp64 MFMA kernels (csrc/dsea_transfer_mfma.hip: one stacked product
  *             and one product over the inner dimension d D; no transpose, no slice sum, no vendor library).  The hand-written
- *             pair is the default where it is measured faster (multiples of 128 up to D = 512: 10-27 us against 26-40;
- *             multiples of 64 up to 256), the library GEMMs beyond; environment DSEA_TRANSFER_MFMA=1 / =0 forces one or the other;
+ *             pair is the default where it is measured faster (every multiple of 64 up to D = 512: 9-25 us against 20-41),
+ *             the library GEMMs beyond; environment DSEA_TRANSFER_MFMA=1 / =0 forces one or the other;
  *             the hand-written pair is also the path taken when rocBLAS is not available.  `work`:
  *             caller-owned scratch of dsea_op_transfer_work_bytes(D, d) = (1 + 4 d) D^2 doubles; dsea_op_create_transfer
  *             fills part of it on `stream` (slice-wise transpose, MFMA-fragment-packed copy of the slices).   */

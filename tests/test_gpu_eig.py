@@ -129,13 +129,13 @@ def test_transfer_and_dense_operators_match_einsum(D, d):
     assert float((DenseOperator(G, transpose=True)(v) - G.T @ v).abs().max()) < 1e-13 * scale * D
 
 
-@pytest.mark.parametrize("D,d,form", [(64, 1, "1"), (128, 3, "1"), (128, 3, "lds"), (192, 2, "1"), (256, 1, "1"), (384, 2, "1"), (512, 2, "1"), (640, 1, "1"),
-                                      (512, 2, "lds")])
+@pytest.mark.parametrize("D,d,form", [(64, 1, "1"), (64, 3, "1"), (128, 3, "1"), (192, 2, "1"), (256, 1, "1"), (320, 2, "1"), (384, 2, "1"),
+                                      (512, 2, "1"), (640, 1, "1")])
 def test_transfer_matvec_on_the_fp64_matrix_cores_matches_the_contraction_and_the_library_gemm_path(D, d, form):
     """csrc/dsea_transfer_mfma.hip (default up to D = 512, DSEA_TRANSFER_MFMA=1 forces it, =0 the library GEMMs; D a multiple of 64: two hand-written v_mfma_f64_16x16x4
     kernels -- T = [B_s] X as one stacked product, y = sum_s T_s B_s^T as ONE product over the inner dimension d D, no
-    transpose, no slice sum; D a multiple of 128: the form whose waves split the inner dimension and take their fragments
-    straight from global memory, "lds" = the LDS-staged form) against the contraction of general.py:59-66 and against the default rocBLAS path, both
+    transpose, no slice sum; the waves split the inner dimension and take their fragments straight from global memory out of
+    fragment-packed operands -- odd and even numbers of k blocks per wave) against the contraction of general.py:59-66 and against the default rocBLAS path, both
     orientations; an ASYMMETRIC operand so that a transposed tile or fragment cannot pass."""
     import os
     from dominantsparseeigenad_amd.operators import TransferOperator
@@ -155,7 +155,7 @@ def test_transfer_matvec_on_the_fp64_matrix_cores_matches_the_contraction_and_th
         again = opr(v).clone()
     finally:
         del os.environ["DSEA_TRANSFER_MFMA"]
-    # the default is the hand-written pair up to D = 512 (multiples of 128; of 64 up to 256), the library GEMMs beyond
+    # the default is the hand-written pair up to D = 512, the library GEMMs beyond
     if form == "1":
         assert torch.equal(dr, yr if D <= 512 else zr)
     sr, sl = float(fr.abs().max()), float(fl.abs().max())
