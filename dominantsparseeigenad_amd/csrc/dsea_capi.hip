@@ -475,15 +475,17 @@ int dsea_op_create_symdense(int64_t n, const void* A_dev, int elem_bytes, int64_
 }
 
 size_t dsea_op_transfer_work_bytes(int D, int d) {
-  // x^T, T, Y, the slice-wise transposed tensor, the fragment-packed tensor
-  return D < 1 || d < 1 ? 0 : (size_t)(1 + 4 * (size_t)d) * (size_t)D * (size_t)D * sizeof(double);
+  // x^T, T, Y, the slice-wise transposed tensor (D^2 each per slice); the fragment-packed tensor and the packed T of the
+  // matrix-core path (Dp^2 each per slice, Dp = D rounded up to a multiple of 64)
+  if (D < 1 || d < 1) return 0;
+  const size_t Dp = ((size_t)D + 63) / 64 * 64;
+  return ((1 + 3 * (size_t)d) * (size_t)D * (size_t)D + 1 + 2 * (size_t)d * Dp * Dp) * sizeof(double);   // (+1: 16-byte alignment of the packed part)
 }
 
 int dsea_op_create_transfer(int D, int d, const double* A_dev, int transpose, double* work, void* stream,
                             dsea_op_t* out) {
   if (!out || D < 1 || d < 1 || !A_dev || !work || (int64_t)d * D > 2147483647ll) return DSEA_ERR_ARG;
   if (!aligned16(A_dev) || !aligned16(work)) return DSEA_ERR_ALIGN;
-  if (!blas_available() && !(D >= 64 && D % 64 == 0)) return DSEA_ERR_UNSUPPORTED;   // (hand-written kernels cover D % 64 == 0)
   dsea_op_s* op = new (std::nothrow) dsea_op_s;
   if (!op) return DSEA_ERR_ARG;
   memset(&op->d, 0, sizeof(op->d));
@@ -495,8 +497,10 @@ int dsea_op_create_transfer(int D, int d, const double* A_dev, int transpose, do
   double* T = work + DD;
   double* Y = T + slab;
   double* AT = Y + slab;
-  double* Bp = (D % 64) == 0 ? AT + slab : nullptr;
-  op->d.transfer = TransferParams{D, d, transpose ? AT : A_dev, xT, T, Y, transpose ? 1 : 0, Bp};
+  const size_t Dp = ((size_t)D + 63) / 64 * 64;
+  double* Bp = AT + slab + ((DD + 3 * slab) & 1);      // (16-byte aligned: the packed chunks are read 16 bytes per lane)
+  double* Tp = Bp + (size_t)d * Dp * Dp;
+  op->d.transfer = TransferParams{D, d, transpose ? AT : A_dev, xT, T, Y, transpose ? 1 : 0, Bp, Tp};
   if (transpose) launch_transpose_sq(A_dev, AT, D, d, static_cast<hipStream_t>(stream));   // B_k = A_k^T, once
   if (Bp) launch_pack_fragments(op->d.transfer.B, Bp, D, d, static_cast<hipStream_t>(stream));   // (MFMA fragment order, once)
   *out = op;

@@ -63,7 +63,8 @@ struct TransferParams {
   double* T;        // d * D * D  scratch: B_k x
   double* Y;        // d * D * D  scratch: (B_k x) B_k^T
   int transpose;
-  const double* Bp; // d * D * D: B in fragment-packed order (dsea_transfer_mfma.hip), D a multiple of 128; else nullptr
+  const double* Bp; // d * Dp * Dp (Dp = D rounded up to a multiple of 64): B zero-padded, in fragment-packed order (dsea_transfer_mfma.hip)
+  double* Tp;       // d * Dp * Dp scratch: B_k x, written and read in fragment-packed order
 };
 struct SymDenseParams {
   int64_t n, lda, npad;

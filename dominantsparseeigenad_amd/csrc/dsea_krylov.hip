@@ -175,9 +175,9 @@ __global__ __launch_bounds__(256) void k_sum_slices(const double* __restrict__ Y
 // y = op x for the GEMM-shaped operands (row-major data, rocBLAS is column-major: a row-major product C = A B
 // is the column-major product C^T = B^T A^T on the same memory).  Returns 0 or -1.
 int blas_apply(const OpDesc& op, const double* x, double* y, hipStream_t st) {
-  // the transfer operand at D a multiple of 64 has two hand-written fp64 MFMA kernels (dsea_transfer_mfma.hip).  They are the
-  // default where they are measured faster than the library GEMMs below (profiles/r04_transfer_mfma.txt: every multiple of 64
-  // up to D = 512 -- 9-26 us against 20-41; equal at 576 / 640, mixed beyond) and the only path where rocBLAS is absent.
+  // the transfer operand has two hand-written fp64 MFMA kernels (dsea_transfer_mfma.hip; any D, zero-padded to a multiple of 64).
+  // They are the default where they are measured faster than the library GEMMs below (profiles/r04_transfer_mfma.txt: up to
+  // D = 512 -- 9-26 us against 20-41; equal at 576 / 640, mixed beyond) and the only path where rocBLAS is absent.
   // DSEA_TRANSFER_MFMA=0 -> library GEMMs always; =1 -> the hand-written kernels wherever they apply.
   if (op.kind == OP_TRANSFER) {
     const char* env = getenv("DSEA_TRANSFER_MFMA");

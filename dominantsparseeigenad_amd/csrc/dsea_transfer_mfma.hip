@@ -11,13 +11,13 @@
 //        "A B^T" product: rows of T_s and rows of B_s are both contiguous along the inner index) no transpose either.
 // Tiling for 256 CUs, not for a big-GEMM library shape: the output has only D^2 = 2^18 elements, so a workgroup takes a
 // 64 x 32 (K1: 16 x 16 = 256 workgroups) / 32 x 32 (K2: 256 workgroups) tile -- one workgroup per CU, one wave per SIMD.
-// k_dgemm_mfma_ksplit (D a multiple of 64; 25.5 us per mat-vec at D = 512, the library GEMM path 33; measurements and the forms
+// k_dgemm_mfma_ksplit (any D, zero-padded to a multiple of 64; 25.0 us per mat-vec at D = 512, the library GEMM path 33; measurements and the forms
 // tried before it -- an LDS-staged kernel, 40-53 us -- in profiles/r04_transfer_mfma.txt): the four waves split
 // the INNER dimension, fragments come straight from global memory out of FRAGMENT-PACKED operands -- no LDS and no barrier
 // inside the loop; see the comment at the kernel.
 // Fragment layout of v_mfma_f64_16x16x4_f64 (cdna_hip_programming.md 3): A[i = lane & 15][k = lane >> 4], B[k = lane >> 4]
 // [j = lane & 15], one double each; C/D four doubles per lane: row = (lane >> 4) + 4 reg, col = lane & 15.
-// Shapes the kernels do not cover (D not a multiple of 64), and by default D > 512, keep the rocBLAS path of dsea_krylov.hip.
+// By default D > 512 keeps the rocBLAS path of dsea_krylov.hip.
 // -DTFM_DIAG=1/4: timing diagnostics only (no loads in the loop / two k blocks), wrong results.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -52,10 +52,14 @@ typedef double tfm_v4d __attribute__((ext_vector_type(4)));
 // segments segA / segB doubles apart (a D x D slice packs into exactly D * D doubles).  The tensor's slices are packed once
 // at operator creation (k_pack_fragments); K1 WRITES T packed (PKC: its LDS reduction gathers in packed order, every store
 // instruction 1 KB of consecutive bytes) for K2 to read.
-template <int TMT, int TNT, bool BT, bool SWZ, bool PKA, bool PKB, bool PKC>
+//
+// GUARD (D not a multiple of 64 -- the reference's own examples run D = 20 and D = 80): the packed operands are zero-padded to
+// the next multiple of 64, the PLAIN ones are not: a plain B' is read, and a plain C written, only inside `valid` x `valid`
+// (reads outside give 0), with scalar accesses (no alignment assumption on an odd leading dimension).
+template <int TMT, int TNT, bool BT, bool SWZ, bool PKA, bool PKB, bool PKC, bool GUARD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_dgemm_mfma_ksplit(
     const double* __restrict__ A, int64_t lda, int64_t segA, const double* __restrict__ B, int64_t ldb, int64_t segB,
-    double* __restrict__ C, int64_t ldc, int Kseg, int nseg) {
+    double* __restrict__ C, int64_t ldc, int Kseg, int nseg, int valid) {
   constexpr int NW = 4;                                    // waves (8 = two per SIMD measured no faster: profiles/r04_transfer_mfma.txt)
   extern __shared__ __attribute__((aligned(16))) double tfm_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -113,8 +117,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }                                                                                                           \
     } else {                                                                                                      \
       const double* __restrict__ bp_ = Bbase + (int64_t)sg_ * segB + (int64_t)kc_ * ldb;                          \
-      _Pragma("unroll") for (int tn = 0; tn < TNT; ++tn)                                                          \
-        FB[tn] = (tfm_v4d){bp_[16 * tn], bp_[ldb + 16 * tn], bp_[2 * ldb + 16 * tn], bp_[3 * ldb + 16 * tn]};    \
+      _Pragma("unroll") for (int tn = 0; tn < TNT; ++tn) {                                                        \
+        if (GUARD) {                                                                                              \
+          const bool cok_ = col0 + fi + 16 * tn < valid;                                                          \
+          const int k0_ = kc_ + 4 * kq;                                                                           \
+          FB[tn] = (tfm_v4d){cok_ && k0_ < valid ? bp_[16 * tn] : 0.0, cok_ && k0_ + 1 < valid ? bp_[ldb + 16 * tn] : 0.0, \
+                             cok_ && k0_ + 2 < valid ? bp_[2 * ldb + 16 * tn] : 0.0,                              \
+                             cok_ && k0_ + 3 < valid ? bp_[3 * ldb + 16 * tn] : 0.0};                             \
+        } else {                                                                                                  \
+          FB[tn] = (tfm_v4d){bp_[16 * tn], bp_[ldb + 16 * tn], bp_[2 * ldb + 16 * tn], bp_[3 * ldb + 16 * tn]};  \
+        }                                                                                                         \
+      }                                                                                                           \
     }                                                                                                             \
   }
 #define TFM_KS_MMA(FA, FB)                                                                                        \
@@ -191,73 +204,85 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         double v = tfm_smem[(((0 * NTILE + t) * 4 + r) * 4 + kq) * 18 + fi];
 #pragma unroll
         for (int w2 = 1; w2 < NW; ++w2) v += tfm_smem[(((w2 * NTILE + t) * 4 + r) * 4 + kq) * 18 + fi];
-        C[(row0 + 16 * tm + 4 * r + kq) * ldc + col0 + 16 * tn + fi] = v;
+        const int64_t crow = row0 + 16 * tm + 4 * r + kq, ccol = col0 + 16 * tn + fi;
+        if (!GUARD || (crow < valid && ccol < valid)) C[crow * ldc + ccol] = v;
       }
     }
   }
 }
 
-// one-off packing of the tensor's slices (d x D x D row-major, D a multiple of 16) into fragment chunks; one wave per chunk
-__global__ __launch_bounds__(256) void k_pack_fragments(const double* __restrict__ B, double* __restrict__ Bp, int D, int64_t nchunks) {
+// one-off packing of the tensor's slices (d x D x D row-major) into fragment chunks of the zero-padded d x Dp x Dp tensor
+// (Dp = D rounded up to a multiple of 64); one wave per chunk
+__global__ __launch_bounds__(256) void k_pack_fragments(const double* __restrict__ B, double* __restrict__ Bp, int D, int Dp,
+                                                        int64_t nchunks) {
   const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (chunk >= nchunks) return;
-  const int lane = threadIdx.x & 63, bps = D / 16;
+  const int lane = threadIdx.x & 63, bps = Dp / 16;
   const int64_t per_slice = (int64_t)bps * bps, s = chunk / per_slice, rem = chunk - s * per_slice;
   const int64_t rt = rem / bps, kb = rem - rt * bps;
-  const double* __restrict__ src = B + s * (int64_t)D * D + (rt * 16 + (lane & 15)) * (int64_t)D + kb * 16 + 4 * (lane >> 4);
+  const int64_t row = rt * 16 + (lane & 15), c0 = kb * 16 + 4 * (lane >> 4);
+  const double* __restrict__ src = B + s * (int64_t)D * D + row * (int64_t)D + c0;
+  double v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = (row < D && c0 + e < D) ? src[e] : 0.0;
   double* __restrict__ dst = Bp + chunk * 256 + 2 * lane;
-  *reinterpret_cast<double2*>(dst) = *reinterpret_cast<const double2*>(src);
-  *reinterpret_cast<double2*>(dst + 128) = *reinterpret_cast<const double2*>(src + 2);
+  *reinterpret_cast<double2*>(dst) = make_double2(v[0], v[1]);
+  *reinterpret_cast<double2*>(dst + 128) = make_double2(v[2], v[3]);
 }
 
 }  // namespace
 
 bool transfer_mfma_applicable(const OpDesc& op) {
-  return op.kind == OP_TRANSFER && op.transfer.D >= 64 && (op.transfer.D % 64) == 0 && op.transfer.d >= 1 && op.transfer.Bp;
+  return op.kind == OP_TRANSFER && op.transfer.D >= 1 && op.transfer.d >= 1 && op.transfer.Bp && op.transfer.Tp;
 }
 
 namespace {
-template <int TMT, int TNT, bool BT, bool SWZ, bool PKA, bool PKB, bool PKC>
+template <int TMT, int TNT, bool BT, bool SWZ, bool PKA, bool PKB, bool PKC, bool GUARD>
 int tfm_launch_ksplit(dim3 grid, hipStream_t st, const double* A, int64_t lda, int64_t sA, const double* B, int64_t ldb,
-                      int64_t sB, double* C, int64_t ldc, int Kseg, int nseg) {
+                      int64_t sB, double* C, int64_t ldc, int Kseg, int nseg, int valid) {
   constexpr size_t lds = (size_t)4 * TMT * TNT * 4 * 4 * 18 * sizeof(double);
   if (lds > 65536) {
     static thread_local int attr_dev = -1;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;
     if (dev != attr_dev) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_dgemm_mfma_ksplit<TMT, TNT, BT, SWZ, PKA, PKB, PKC>),
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_dgemm_mfma_ksplit<TMT, TNT, BT, SWZ, PKA, PKB, PKC, GUARD>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return -1;
       attr_dev = dev;
     }
   }
-  hipLaunchKernelGGL((k_dgemm_mfma_ksplit<TMT, TNT, BT, SWZ, PKA, PKB, PKC>), grid, dim3(256), lds, st, A, lda, sA, B, ldb, sB, C,
-                     ldc, Kseg, nseg);
+  hipLaunchKernelGGL((k_dgemm_mfma_ksplit<TMT, TNT, BT, SWZ, PKA, PKB, PKC, GUARD>), grid, dim3(256), lds, st, A, lda, sA, B, ldb,
+                     sB, C, ldc, Kseg, nseg, valid);
   return 0;
 }
 }  // namespace
 
-// fragment-packed copy of the slices (dsea_op_create_transfer, once): Bp must hold d * D * D doubles
+// fragment-packed, zero-padded copy of the slices (dsea_op_create_transfer, once): Bp must hold d * Dp * Dp doubles
 void launch_pack_fragments(const double* B, double* Bp, int D, int d, hipStream_t st) {
-  const int64_t nchunks = (int64_t)d * (D / 16) * (D / 16);
-  hipLaunchKernelGGL(k_pack_fragments, dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0, st, B, Bp, D, nchunks);
+  const int Dp = (D + 63) / 64 * 64;
+  const int64_t nchunks = (int64_t)d * (Dp / 16) * (Dp / 16);
+  hipLaunchKernelGGL(k_pack_fragments, dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0, st, B, Bp, D, Dp, nchunks);
 }
 
-// y = sum_s B_s X B_s^T through two launches; T = the operator's d x D x D scratch (written and read in packed order), Bp = the
-// fragment-packed slices.  Returns 0 or -1 (not applicable).
+// y = sum_s B_s X B_s^T through two launches; Tp = the operator's d x Dp x Dp scratch (written and read in packed order), Bp =
+// the fragment-packed slices, Dp = D rounded up to a multiple of 64.  Returns 0 or -1 (not applicable).
 int launch_transfer_mfma(const OpDesc& op, const double* x, double* y, hipStream_t st) {
   if (!transfer_mfma_applicable(op)) return -1;
   const TransferParams& p = op.transfer;
-  const int D = p.D, d = p.d;
-  const int64_t DD = (int64_t)D * D;
-  // K1: T (dD x D) = B (dD x D, the d slices stacked) X (D x D): tile 64 x 32; reads the packed slices, writes T packed
-  const dim3 g1((unsigned)(D / 32), (unsigned)((int64_t)d * D / 64));
-  int rc = tfm_launch_ksplit<4, 2, false, false, true, false, true>(g1, st, p.Bp, D, 0, x, D, 0, p.T, D, D, 1);
+  const int D = p.D, d = p.d, Dp = (D + 63) / 64 * 64;
+  const int64_t DDp = (int64_t)Dp * Dp;
+  const bool guard = Dp != D;
+  // K1: T (d Dp x Dp) = B (the d padded slices stacked) X (D x D, read as Dp x Dp with zeros outside): tile 64 x 32; reads the
+  // packed slices, writes T packed
+  const dim3 g1((unsigned)(Dp / 32), (unsigned)((int64_t)d * Dp / 64));
+  int rc = guard ? tfm_launch_ksplit<4, 2, false, false, true, false, true, true>(g1, st, p.Bp, Dp, 0, x, D, 0, p.Tp, Dp, Dp, 1, D)
+                 : tfm_launch_ksplit<4, 2, false, false, true, false, true, false>(g1, st, p.Bp, Dp, 0, x, D, 0, p.Tp, Dp, Dp, 1, D);
   if (rc != 0) return rc;
-  // K2: y (D x D) = sum_s T_s B_s^T: inner dimension in d segments of D; tile 32 x 32; reads T and the slices packed
-  const dim3 g2((unsigned)(D / 32), (unsigned)(D / 32));
-  return tfm_launch_ksplit<2, 2, true, true, true, true, false>(g2, st, p.T, D, DD, p.Bp, D, DD, y, D, D, d);
+  // K2: y (D x D) = sum_s T_s B_s^T: inner dimension in d segments of Dp; tile 32 x 32; reads T and the slices packed
+  const dim3 g2((unsigned)(Dp / 32), (unsigned)(Dp / 32));
+  return guard ? tfm_launch_ksplit<2, 2, true, true, true, true, false, true>(g2, st, p.Tp, Dp, DDp, p.Bp, Dp, DDp, y, D, Dp, d, D)
+               : tfm_launch_ksplit<2, 2, true, true, true, true, false, false>(g2, st, p.Tp, Dp, DDp, p.Bp, Dp, DDp, y, D, Dp, d, D);
 }
 
 }  // namespace dsea

@@ -188,13 +188,14 @@ int dsea_op_set_tuning(dsea_op_t op, int key, int value);
  *                 transpose == 0:  y = sum_s A_s x A_s^T        ("Gong",  general.py:59-61)
  *                 transpose != 0:  y = sum_s A_s^T x A_s        ("GongT", general.py:62-64)
  *             as two strided-batched GEMMs in the "X Y^T" shape (the transposed form is the same contraction on
- *             the slice-wise transposed tensor, copied once) + a transpose and a slice-sum kernel (rocBLAS), or -- for D a
- *             multiple of 64 -- as two hand-written fp64 MFMA kernels (csrc/dsea_transfer_mfma.hip: one stacked product
+ *             the slice-wise transposed tensor, copied once) + a transpose and a slice-sum kernel (rocBLAS), or -- any D,
+ *             zero-padded to a multiple of 64 inside -- as two hand-written fp64 MFMA kernels (csrc/dsea_transfer_mfma.hip: one stacked product
  *             and one product over the inner dimension d D; no transpose, no slice sum, no vendor library).  The hand-written
- *             pair is the default where it is measured faster (every multiple of 64 up to D = 512: 9-25 us against 20-41),
+ *             pair is the default where it is measured faster (D <= 512: 9-27 us against 20-52, e.g. the reference examples'
+ *             D = 80: 12.5 vs 20.8 us),
  *             the library GEMMs beyond; environment DSEA_TRANSFER_MFMA=1 / =0 forces one or the other;
  *             the hand-written pair is also the path taken when rocBLAS is not available.  `work`:
- *             caller-owned scratch of dsea_op_transfer_work_bytes(D, d) = (1 + 4 d) D^2 doubles; dsea_op_create_transfer
+ *             caller-owned scratch of dsea_op_transfer_work_bytes(D, d) (~ (1 + 3 d) D^2 + 2 d Dp^2 doubles, Dp = D rounded up to 64); dsea_op_create_transfer
  *             fills part of it on `stream` (slice-wise transpose, MFMA-fragment-packed copy of the slices).   */
 int dsea_op_create_dense(int64_t n, const double *A_dev, int64_t lda, int transpose, dsea_op_t *out);
 /* dense SYMMETRIC operand (reference symeig.py:15-31 DominantSymeig; Lanczos.py:46-49 applies torch.matmul(A, v)):

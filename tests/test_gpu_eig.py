@@ -129,10 +129,11 @@ def test_transfer_and_dense_operators_match_einsum(D, d):
     assert float((DenseOperator(G, transpose=True)(v) - G.T @ v).abs().max()) < 1e-13 * scale * D
 
 
-@pytest.mark.parametrize("D,d,form", [(64, 1, "1"), (64, 3, "1"), (128, 3, "1"), (192, 2, "1"), (256, 1, "1"), (320, 2, "1"), (384, 2, "1"),
-                                      (512, 2, "1"), (640, 1, "1")])
+@pytest.mark.parametrize("D,d,form", [(3, 2, "1"), (20, 2, "1"), (33, 3, "1"), (64, 1, "1"), (64, 3, "1"), (80, 2, "1"), (100, 3, "1"), (128, 3, "1"),
+                                      (192, 2, "1"), (256, 1, "1"), (320, 2, "1"), (384, 2, "1"), (500, 1, "1"), (512, 2, "1"), (640, 1, "1")])
 def test_transfer_matvec_on_the_fp64_matrix_cores_matches_the_contraction_and_the_library_gemm_path(D, d, form):
-    """csrc/dsea_transfer_mfma.hip (default up to D = 512, DSEA_TRANSFER_MFMA=1 forces it, =0 the library GEMMs; D a multiple of 64: two hand-written v_mfma_f64_16x16x4
+    """csrc/dsea_transfer_mfma.hip (default up to D = 512, DSEA_TRANSFER_MFMA=1 forces it, =0 the library GEMMs; any D -- the reference's examples run 20 and 80 --
+    zero-padded to a multiple of 64 with guarded reads of x and writes of y: two hand-written v_mfma_f64_16x16x4
     kernels -- T = [B_s] X as one stacked product, y = sum_s T_s B_s^T as ONE product over the inner dimension d D, no
     transpose, no slice sum; the waves split the inner dimension and take their fragments straight from global memory out of
     fragment-packed operands -- odd and even numbers of k blocks per wave) against the contraction of general.py:59-66 and against the default rocBLAS path, both
