@@ -399,13 +399,17 @@ STRONG_K, STRONG_K_SHADOW_MATCHED = 100, 80
 
 
 def _commit():
+    """the tree's commit: from git where the tree has its history, else the stamp __graft_entry__.build() leaves (.commit
+    travels to the GPU box, .git does not)"""
+    if os.path.isdir(os.path.join(ROOT, ".git")):
+        try:
+            out = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+            if out:
+                return out
+        except OSError:
+            pass
     try:
         return open(os.path.join(ROOT, ".commit")).read().strip() or "unknown"
-    except OSError:
-        pass
-    try:
-        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True,
-                              text=True).stdout.strip() or "unknown"
     except OSError:
         return "unknown"
 
