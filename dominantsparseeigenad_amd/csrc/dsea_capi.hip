@@ -440,7 +440,6 @@ int dsea_op_create_stencil3(int64_t n, double coef, const double* V_dev, const d
 
 int dsea_op_create_dense(int64_t n, const double* A_dev, int64_t lda, int transpose, dsea_op_t* out) {
   if (!out || n < 1 || !A_dev || lda < n || n > 2147483647ll || lda > 2147483647ll) return DSEA_ERR_ARG;
-  if (!blas_available()) return DSEA_ERR_UNSUPPORTED;
   dsea_op_s* op = new (std::nothrow) dsea_op_s;
   if (!op) return DSEA_ERR_ARG;
   memset(&op->d, 0, sizeof(op->d));

@@ -172,6 +172,109 @@ __global__ __launch_bounds__(256) void k_sum_slices(const double* __restrict__ Y
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// general dense operand (reference eig.py:28-30): hand-written GEMV, HBM-bound (n^2 doubles read once), deterministic
+// ------------------------------------------------------------------------------------------
+// y = A x, A row-major: a wave takes ROWS rows at a time, its lanes stride along the columns -- 16 bytes per lane and row
+// when everything is pair-aligned (VEC), scalar accesses otherwise (odd n or lda: the small matrices of the reference's
+// tests); x is read once per ROWS rows.  ROWS = 1 with two column steps in flight up to n = 8192 (n waves: enough of
+// them to cover the latency), 4 beyond (x re-read four times less).  Fixed summation order per row: two lane-strided fma
+// chains (even / odd column steps), their sum, then wave_sum.
+template <bool VEC, int ROWS>
+__global__ __launch_bounds__(256) void k_gemv_rows(const double* __restrict__ A, int64_t lda, int64_t n,
+                                                   const double* __restrict__ x, double* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  for (int64_t r0 = wave * ROWS; r0 < n; r0 += (int64_t)gridDim.x * 4 * ROWS) {
+    double acc[ROWS], acc2[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = acc2[r] = 0.0;
+    const double* __restrict__ a0 = A + r0 * lda;
+    if (VEC) {
+      int64_t c = 2 * lane;
+      for (; c + 128 < n; c += 256) {
+        const double2 x0 = *reinterpret_cast<const double2*>(x + c), x1 = *reinterpret_cast<const double2*>(x + c + 128);
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+          if (r0 + r < n) {
+            const double2 a0v = ld2_stream<false>(a0 + r * lda, c, n);          // (read once: non-temporal)
+            const double2 a1v = ld2_stream<false>(a0 + r * lda, c + 128, n);
+            acc[r] = fma(a0v.x, x0.x, acc[r]);
+            acc[r] = fma(a0v.y, x0.y, acc[r]);
+            acc2[r] = fma(a1v.x, x1.x, acc2[r]);
+            acc2[r] = fma(a1v.y, x1.y, acc2[r]);
+          }
+        }
+      }
+      if (c < n) {
+        const double2 x0 = *reinterpret_cast<const double2*>(x + c);
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+          if (r0 + r < n) {
+            const double2 a0v = ld2_stream<false>(a0 + r * lda, c, n);
+            acc[r] = fma(a0v.x, x0.x, acc[r]);
+            acc[r] = fma(a0v.y, x0.y, acc[r]);
+          }
+        }
+      }
+    } else {
+      for (int64_t c = lane; c < n; c += 64) {
+        const double xv = x[c];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+          if (r0 + r < n) acc[r] = fma(a0[r * lda + c], xv, acc[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const double t = wave_sum(acc[r] + acc2[r]);
+      if (lane == 0 && r0 + r < n) y[r0 + r] = t;
+    }
+  }
+}
+
+// y = A^T x without a transposed copy and without scratch: a block owns a strip of 64 columns, its four waves take every
+// fourth row (512 contiguous bytes per row and wave), the four partial strips meet in LDS in fixed order.  n / 64 blocks:
+// correct and deterministic, but it fills the chip only from n ~ 16 384 -- callers that apply A^T repeatedly hand in the
+// transposed matrix instead (operators.DenseOperator does).
+__global__ __launch_bounds__(256) void k_gemv_cols(const double* __restrict__ A, int64_t lda, int64_t n,
+                                                   const double* __restrict__ x, double* __restrict__ y) {
+  __shared__ double part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int64_t c0 = (int64_t)blockIdx.x * 64; c0 < n; c0 += (int64_t)gridDim.x * 64) {
+    const int64_t c = c0 + lane;
+    double acc = 0.0;
+    if (c < n)
+      for (int64_t r = w; r < n; r += 4) acc = fma(A[r * lda + c], x[r], acc);
+    part[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && c < n) y[c] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    __syncthreads();
+  }
+}
+
+int launch_gemv(const DenseParams& p, const double* x, double* y, hipStream_t st) {
+  if (p.transpose) {
+    int64_t nb = (p.n + 63) / 64;
+    if (nb > 65535) nb = 65535;
+    hipLaunchKernelGGL(k_gemv_cols, dim3((unsigned)nb), dim3(256), 0, st, p.A, p.lda, p.n, x, y);
+    return 0;
+  }
+  const bool vec = (p.n % 2) == 0 && (p.lda % 2) == 0 && (reinterpret_cast<uintptr_t>(p.A) & 15u) == 0 &&
+                   (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
+  if (p.n <= 8192) {
+    const int64_t nb = (p.n + 3) / 4;                       // one row per wave
+    if (vec) hipLaunchKernelGGL((k_gemv_rows<true, 1>), dim3((unsigned)nb), dim3(256), 0, st, p.A, p.lda, p.n, x, y);
+    else hipLaunchKernelGGL((k_gemv_rows<false, 1>), dim3((unsigned)nb), dim3(256), 0, st, p.A, p.lda, p.n, x, y);
+  } else {
+    int64_t nb = (p.n + 15) / 16;
+    if (nb > 4096) nb = 4096;
+    if (vec) hipLaunchKernelGGL((k_gemv_rows<true, 4>), dim3((unsigned)nb), dim3(256), 0, st, p.A, p.lda, p.n, x, y);
+    else hipLaunchKernelGGL((k_gemv_rows<false, 4>), dim3((unsigned)nb), dim3(256), 0, st, p.A, p.lda, p.n, x, y);
+  }
+  return 0;
+}
+
 // y = op x for the GEMM-shaped operands (row-major data, rocBLAS is column-major: a row-major product C = A B
 // is the column-major product C^T = B^T A^T on the same memory).  Returns 0 or -1.
 int blas_apply(const OpDesc& op, const double* x, double* y, hipStream_t st) {
@@ -185,6 +288,11 @@ int blas_apply(const OpDesc& op, const double* x, double* y, hipStream_t st) {
     const bool by_size = D <= 512;
     const bool want = env ? env[0] != '0' : by_size;
     if ((want || !blas_available()) && launch_transfer_mfma(op, x, y, st) == 0) return 0;
+  }
+  // the general dense operand: hand-written GEMV (DSEA_DENSE_GEMV=0 -> rocBLAS, for A/B measurements)
+  if (op.kind == OP_DENSE) {
+    const char* env = getenv("DSEA_DENSE_GEMV");
+    if (!(env && env[0] == '0' && blas_available())) return launch_gemv(op.dense, x, y, st);
   }
   if (!blas_available()) return -1;
   const double one = 1.0, zero = 0.0;

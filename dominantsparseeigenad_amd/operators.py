@@ -316,22 +316,24 @@ class CSROperator:
 # ------------------------------------------------------------------------------------------ GEMM-shaped operands
 class DenseOperator:
     """A dense real matrix (row-major device tensor) as a library operand of the NON-symmetric primitives
-    (reference eig.py:28-30 hands the matrix to ARPACK); ``transpose=True`` applies A^T.  The mat-vec is a rocBLAS
-    GEMV issued by libdsea (include/dsea.h: dsea_op_create_dense)."""
+    (reference eig.py:28-30 hands the matrix to ARPACK); ``transpose=True`` applies A^T.  The mat-vec is libdsea's
+    hand-written row-major GEMV (include/dsea.h: dsea_op_create_dense; HBM-bound, deterministic); for ``transpose=True`` the
+    transposed matrix is materialised once so that both orientations stream rows."""
 
     _native_methods = ("__call__", "matvec")
 
     def __init__(self, A, transpose=False):
         if A.device.type != "cuda" or A.dim() != 2 or A.shape[0] != A.shape[1]:
             raise ValueError("DenseOperator takes a square CUDA matrix")
-        self.A = A.detach().to(F64).contiguous()
+        self.transpose = bool(transpose)
+        A = A.detach().to(F64)
+        self.A = (A.T if self.transpose else A).contiguous()       # the matrix whose ROWS the kernel streams
         self.n = int(A.shape[0])
         self.shape = (self.n, self.n)
         self.device = self.A.device
-        self.transpose = bool(transpose)
         raw = c_void_p()
-        check(_lib.load().dsea_op_create_dense(self.n, c_void_p(self.A.data_ptr()), self.n, int(self.transpose),
-                                               byref(raw)), "dsea_op_create_dense")
+        check(_lib.load().dsea_op_create_dense(self.n, c_void_p(self.A.data_ptr()), self.n, 0, byref(raw)),
+              "dsea_op_create_dense")
         self._H = _NativeView(_Handle(raw, self.n, self.A))
 
     @property

@@ -180,9 +180,11 @@ int dsea_op_create_stencil3(int64_t n, double coef, const double *V_dev, const d
 int dsea_op_set_tuning(dsea_op_t op, int key, int value);
 
 /* GEMM-shaped operands of the NON-symmetric primitives (reference eig.py) -- the one place on this path where a matrix
- * core is the right unit.  The transfer operand runs on hand-written fp64 MFMA kernels up to D = 512 (below); the general
- * dense operand (a GEMV) and larger transfer operands go to rocBLAS, bound at run time from the copy already in the process
- * (dense: DSEA_ERR_UNSUPPORTED if there is none); rocBLAS may keep device memory of its own.
+ * core is the right unit.  The transfer operand runs on hand-written fp64 MFMA kernels up to D = 512 (below), the general
+ * dense operand on a hand-written row-streaming GEMV (HBM-bound: 6.2 TB/s from n = 4096; transpose != 0 uses a column-strip
+ * kernel that fills the chip only for large n -- callers that apply A^T repeatedly hand in the transposed matrix);
+ * only transfer operands beyond D = 512 go to rocBLAS, bound at run time from the copy already in the process (it may
+ * keep device memory of its own; without it the hand-written kernels run at every size).
  *   dense   : row-major n x n matrix (eig.py:28-30, DominantEig); transpose != 0 applies A^T.
  *   transfer: MPS transfer matrix of a rank-3 tensor A (d x D x D row-major), dimension D^2, vectors are D x D
  *             row-major (reference examples/TFIM_vumps/general.py:59-66):

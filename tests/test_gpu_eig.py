@@ -455,3 +455,41 @@ def test_arnoldi_status_protocol_through_the_c_abi():
     assert lib.dsea_ws_set_arnoldi_optimistic(ws.handle, 2) == _lib.ERR_ARG
     assert lib.dsea_ws_set_arnoldi_optimistic(None, 1) == _lib.ERR_ARG and lib.dsea_arnoldi_status(None, None, None, None) == _lib.ERR_ARG
     assert b"second Gram-Schmidt" in lib.dsea_error_string(_lib.ERR_SECOND_PASS)
+
+
+@pytest.mark.parametrize("n", [1, 2, 25, 1000, 1001, 2050, 9000])
+def test_dense_operand_gemv_kernels(n):
+    """include/dsea.h dsea_op_create_dense: the general dense operand of the non-symmetric primitives (eig.py:28-30) is a
+    hand-written row-streaming GEMV (k_gemv_rows: one row per wave up to n = 8192, four beyond; 16-byte accesses when n and
+    lda are even, scalar otherwise), A^T through a transposed copy made once by operators.DenseOperator or, at the C ABI,
+    through the column-strip kernel (k_gemv_cols) -- against torch.mv, deterministic, with the shift / dot tail of dsea_spmv."""
+    import ctypes
+    from dominantsparseeigenad_amd import _lib, engine
+    from dominantsparseeigenad_amd.engine import _ptr
+    from dominantsparseeigenad_amd.operators import DenseOperator
+    rng = np.random.RandomState(900 + n)
+    G = torch.from_numpy(rng.randn(n, n)).to(cuda)
+    v = torch.from_numpy(rng.randn(n)).to(cuda)
+    ref, refT = torch.mv(G, v), torch.mv(G.T, v)
+    tol = 1e-14 * max(n, 16) ** 0.5 * float(G.abs().max()) * float(v.abs().max()) * 8
+    op, opT = DenseOperator(G), DenseOperator(G, transpose=True)
+    y, yT = op(v), opT(v)
+    assert float((y - ref).abs().max()) <= tol and float((yT - refT).abs().max()) <= tol
+    assert torch.equal(op(v), y) and torch.equal(opT(v), yT)                    # deterministic
+    # the C entry point with transpose != 0 (no transposed copy): the column-strip kernel
+    lib = _lib.load()
+    raw = ctypes.c_void_p()
+    Gc = G.contiguous()
+    _lib.check(lib.dsea_op_create_dense(n, ctypes.c_void_p(Gc.data_ptr()), n, 1, ctypes.byref(raw)))
+    try:
+        ws = engine.Workspace.get(n, 8, cuda)
+        out = torch.empty(n, dtype=F64, device=cuda)
+        dot = torch.zeros(1, dtype=F64, device=cuda)
+        shift = torch.tensor([0.37], dtype=F64, device=cuda)
+        _lib.check(lib.dsea_spmv(raw, ws.handle, _ptr(v), _ptr(out), _ptr(shift), _ptr(dot), None, engine._stream(cuda)))
+        torch.cuda.synchronize()
+        want = refT - 0.37 * v
+        assert float((out - want).abs().max()) <= tol
+        assert abs(float(dot) - float(v @ want)) <= 1e-12 * max(1.0, float(v.abs().max()) * float(want.abs().max()) * n)
+    finally:
+        lib.dsea_op_destroy(raw)
