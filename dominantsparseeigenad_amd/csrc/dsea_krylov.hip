@@ -280,12 +280,12 @@ int launch_gemv(const DenseParams& p, const double* x, double* y, hipStream_t st
 int blas_apply(const OpDesc& op, const double* x, double* y, hipStream_t st) {
   // the transfer operand has two hand-written fp64 MFMA kernels (dsea_transfer_mfma.hip; any D, zero-padded to a multiple of 64).
   // They are the default where they are measured faster than the library GEMMs below (profiles/r04_transfer_mfma.txt: up to
-  // D = 512 -- 9-26 us against 20-41; equal at 576 / 640, mixed beyond) and the only path where rocBLAS is absent.
+  // D = 768 -- 9-89 us against 20-110; within +-3 % of each other beyond, up to 2048) and the only path where rocBLAS is absent.
   // DSEA_TRANSFER_MFMA=0 -> library GEMMs always; =1 -> the hand-written kernels wherever they apply.
   if (op.kind == OP_TRANSFER) {
     const char* env = getenv("DSEA_TRANSFER_MFMA");
     const int D = op.transfer.D;
-    const bool by_size = D <= 512;
+    const bool by_size = D <= 768;
     const bool want = env ? env[0] != '0' : by_size;
     if ((want || !blas_available()) && launch_transfer_mfma(op, x, y, st) == 0) return 0;
   }

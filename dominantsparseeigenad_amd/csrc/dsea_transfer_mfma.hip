@@ -21,6 +21,7 @@
 // -DTFM_DIAG=1/4: timing diagnostics only (no loads in the loop / two k blocks), wrong results.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "dsea_internal.h"
 
@@ -273,6 +274,21 @@ int launch_transfer_mfma(const OpDesc& op, const double* x, double* y, hipStream
   const int D = p.D, d = p.d, Dp = (D + 63) / 64 * 64;
   const int64_t DDp = (int64_t)Dp * Dp;
   const bool guard = Dp != D;
+  const char* env = getenv("DSEA_TRANSFER_TILE");          // (A/B measurements: "s" / "l" force the small / large tiles)
+  // 64 x 64 tiles for both products (0.5 fragment reads per MFMA instead of 0.75 / 1) where their workgroup count wastes no
+  // more of its last round of 256 CUs than the small tiles' does -- the rule that matches every size measured
+  // (profiles/r04_transfer_mfma.txt: D = 896, 1024, 2048 large; 512, 640, 768, 1280, 1536 small)
+  const auto waste = [](int64_t c) { return (double)((c + 255) / 256 * 256 - c) / (double)c; };
+  const int64_t ns = (int64_t)(Dp / 32) * (Dp / 32), nl = (int64_t)(Dp / 64) * (Dp / 64);
+  const bool large = env ? env[0] == 'l' : waste(nl) <= waste(ns);
+  if (large) {
+    const dim3 h1((unsigned)(Dp / 64), (unsigned)((int64_t)d * Dp / 64)), h2((unsigned)(Dp / 64), (unsigned)(Dp / 64));
+    int rc = guard ? tfm_launch_ksplit<4, 4, false, true, true, false, true, true>(h1, st, p.Bp, Dp, 0, x, D, 0, p.Tp, Dp, Dp, 1, D)
+                   : tfm_launch_ksplit<4, 4, false, true, true, false, true, false>(h1, st, p.Bp, Dp, 0, x, D, 0, p.Tp, Dp, Dp, 1, D);
+    if (rc != 0) return rc;
+    return guard ? tfm_launch_ksplit<4, 4, true, true, true, true, false, true>(h2, st, p.Tp, Dp, DDp, p.Bp, Dp, DDp, y, D, Dp, d, D)
+                 : tfm_launch_ksplit<4, 4, true, true, true, true, false, false>(h2, st, p.Tp, Dp, DDp, p.Bp, Dp, DDp, y, D, Dp, d, D);
+  }
   // K1: T (d Dp x Dp) = B (the d padded slices stacked) X (D x D, read as Dp x Dp with zeros outside): tile 64 x 32; reads the
   // packed slices, writes T packed
   const dim3 g1((unsigned)(Dp / 32), (unsigned)((int64_t)d * Dp / 64));

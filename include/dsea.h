@@ -180,10 +180,10 @@ int dsea_op_create_stencil3(int64_t n, double coef, const double *V_dev, const d
 int dsea_op_set_tuning(dsea_op_t op, int key, int value);
 
 /* GEMM-shaped operands of the NON-symmetric primitives (reference eig.py) -- the one place on this path where a matrix
- * core is the right unit.  The transfer operand runs on hand-written fp64 MFMA kernels up to D = 512 (below), the general
+ * core is the right unit.  The transfer operand runs on hand-written fp64 MFMA kernels up to D = 768 (below), the general
  * dense operand on a hand-written row-streaming GEMV (HBM-bound: 6.2 TB/s from n = 4096; transpose != 0 uses a column-strip
  * kernel that fills the chip only for large n -- callers that apply A^T repeatedly hand in the transposed matrix);
- * only transfer operands beyond D = 512 go to rocBLAS, bound at run time from the copy already in the process (it may
+ * only transfer operands beyond D = 768 go to rocBLAS, bound at run time from the copy already in the process (it may
  * keep device memory of its own; without it the hand-written kernels run at every size).
  *   dense   : row-major n x n matrix (eig.py:28-30, DominantEig); transpose != 0 applies A^T.
  *   transfer: MPS transfer matrix of a rank-3 tensor A (d x D x D row-major), dimension D^2, vectors are D x D
@@ -194,8 +194,8 @@ int dsea_op_set_tuning(dsea_op_t op, int key, int value);
  *             the slice-wise transposed tensor, copied once) + a transpose and a slice-sum kernel (rocBLAS), or -- any D,
  *             zero-padded to a multiple of 64 inside -- as two hand-written fp64 MFMA kernels (csrc/dsea_transfer_mfma.hip: one stacked product
  *             and one product over the inner dimension d D; no transpose, no slice sum, no vendor library).  The hand-written
- *             pair is the default where it is measured faster (D <= 512: 9-27 us against 20-52, e.g. the reference examples'
- *             D = 80: 12.5 vs 20.8 us),
+ *             pair is the default where it is measured faster (D <= 768: 9-89 us against 20-110, e.g. the reference examples'
+ *             D = 80: 12.5 vs 20.8 us; beyond, the two paths are within 3 % of each other),
  *             the library GEMMs beyond; environment DSEA_TRANSFER_MFMA=1 / =0 forces one or the other;
  *             the hand-written pair is also the path taken when rocBLAS is not available.  `work`:
  *             caller-owned scratch of dsea_op_transfer_work_bytes(D, d) (~ (1 + 3 d) D^2 + 2 d Dp^2 doubles, Dp = D rounded up to 64); dsea_op_create_transfer
