@@ -283,6 +283,9 @@ def c4_figures(dev):
                         "backward = two GMRES solves",
             "forward_ms": round(best_f * 1e3, 2), "backward_ms": round(best_b * 1e3, 2),
             "matvec_us": round(mv_us, 2), "matvec_TFLOPs_fp64": round(flops / (mv_us * 1e-6) / 1e12, 1),
+            "matvec_frac_of_fp64_matrix_peak": round(flops / (mv_us * 1e-6) / 1e12 / 78.6, 3),
+            "fp64_matrix_peak_note": "78.6 TFLOP/s = the vendor's dense fp64 matrix figure for MI355X (MI355X_MICROARCH.md has no fp64 "
+                                     "row); tools/probes/mfma_f64_probe.hip sustains 70-77 in a pure register loop",
             "matvec_form": "two hand-written v_mfma_f64_16x16x4_f64 kernels on fragment-packed operands "
                            "(csrc/dsea_transfer_mfma.hip); DSEA_TRANSFER_MFMA=0 selects two rocBLAS GEMMs",
             "eigen_residual": res}
