@@ -1125,8 +1125,15 @@ def _priced_bytes(args, pt, m, shadow_steps, cg_persistent, pr_run_steps):
                       "the %d re-orthogonalised steps the two passes over the basis, taken at the mean step index; Ritz "
                       "vector; backward as SURVEY 8d) / step time, all ranks" % pr_run_steps)
     b = traffic_model_bytes(n, k, m, shadow_steps, 5.0 if cg_persistent else 11.0)
-    return b, alg, ("HBM bytes the step's kernels move (traffic model: SURVEY 8d per-phase count with the correction pass "
-                    "of %d Lanczos steps reading the bf16 shadow of the basis) / step time, all ranks" % shadow_steps)
+    what = ("HBM bytes the step's kernels move (traffic model: SURVEY 8d per-phase count with the correction pass "
+            "of %d Lanczos steps reading the bf16 shadow of the basis) / step time, all ranks" % shadow_steps)
+    if args.operator != "matrix-free":
+        # explicit operand (the 21-nnz/row TFIM matrix, fp64 values + int32 columns): every mat-vec also
+        # streams the matrix -- k of them in the forward pass, m + 1 in the adjoint solve
+        operand = 12.0 * (pt.L + 1) * n * (k + m + 1)
+        b, alg = b + operand, alg + operand
+        what += "; plus the explicit operand, 12 B per non-zero (%d per row) in each of the %d mat-vecs" % (pt.L + 1, k + m + 1)
+    return b, alg, what
 
 
 def _roofline(ctx, pt, prob, ev, pmc, lp_stats):
@@ -1247,7 +1254,7 @@ def main():
     extras = option_extras(args, ctx, pt, prob, E0, gl)
     shadow_steps = int(lp_stats[0]) if lp_stats is not None else ((k - 1) if (prob.use_shadow and k > 1) else 0)
     # the adjoint solve runs as one persistent launch for the full-space TFIM operator up to 2^20 rows
-    cg_persistent = (not ctx.partitioned_path) and args.operator == "matrix-free" and 14 <= L <= 20 and \
+    cg_persistent = (not ctx.partitioned_path) and args.operator == "matrix-free" and 11 <= L <= 20 and \
         os.environ.get("DSEA_NO_PERSIST", "") != "1"
     total_bytes, alg_bytes, value_is = _priced_bytes(args, pt, m, shadow_steps, cg_persistent, pr_run_steps)
     value = total_bytes / (ms_per_step * 1e-3) / 1e9
