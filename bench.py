@@ -371,8 +371,21 @@ def launch_workers(n):
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
-    lines = proc.stdout.splitlines()
+    # the workers are SUPERVISORS (tools/bench_watchdog.py): each runs the measuring process as its child, notices a stall
+    # and walks the fallback ladder, so a line comes back well inside their budget; the limit here is the last resort
+    limit = float(os.environ.get("DSEA_BENCH_BUDGET_S", "1500")) + 240.0
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, start_new_session=True)
+    try:
+        stdout, _ = proc.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        import signal
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except OSError:
+            proc.kill()
+        stdout, _ = proc.communicate()
+        stdout = (stdout or "") + "\nbench.py: the worker group exceeded %.0f s and was killed\n" % limit
+    lines = stdout.splitlines()
     final = None
     for line in lines:
         if line.startswith("{") and '"metric"' in line:
@@ -383,6 +396,32 @@ def launch_workers(n):
     if final is not None:
         print(final, flush=True)
     raise SystemExit(proc.returncode if proc.returncode else (0 if final is not None else 1))
+
+
+def progress(event, **kw):
+    """one line into this rank's progress file (DSEA_BENCH_PROGRESS, set by the supervisor of tools/bench_watchdog.py):
+    the supervisor takes a file that stops growing for a stall"""
+    path = os.environ.get("DSEA_BENCH_PROGRESS")
+    if not path:
+        return
+    try:
+        with open(path, "a") as f:
+            f.write(json.dumps(dict(kw, event=event, t=round(time.time(), 3))) + "\n")
+    except OSError:
+        pass
+
+
+def _simulated_hang(ctx, where):
+    """DRY RUN only (tests of the watchdog on CPU processes): DSEA_BENCH_SIMULATE_HANG is set by the supervisor for the
+    stages an injected fault of that kind would hit; rank 0 then stops making progress in its second step"""
+    kind = os.environ.get("DSEA_BENCH_SIMULATE_HANG", "")
+    if ctx.dry and kind == "crash" and ctx.rank == 1 and where == "step 2":
+        raise RuntimeError("simulated failure of rank 1 (dry run)")
+    if ctx.dry and kind and ctx.rank == 0 and where == ("extras" if kind == "extras" else "step 2") and kind != "crash":
+        print("bench.py: simulated %s hang (dry run, stage %s)" % (os.environ["DSEA_BENCH_SIMULATE_HANG"],
+                                                                   os.environ.get("DSEA_BENCH_STAGE", "?")), flush=True)
+        while True:
+            time.sleep(3600)
 
 
 # ---------------------------------------------------------------------------------------------- one-GPU anchors
@@ -556,10 +595,21 @@ class Problem:
             backend = CpuBackend(self.nloc)
         if ctx.staged:   # ranks sharing one GPU: gloo staged through the host (RCCL refuses two ranks on a device)
             comm = partitioned.HostStagedComm()
+            if os.environ.get("DSEA_RCCL_LIB") and os.environ.get("DSEA_DRIVER", "") != "python":
+                # rehearsal of the RCCL branch: library-owned communicators over the stand-in RCCL of tests/fake_rccl
+                # (ids broadcast over the gloo group), cached for the problems of this process
+                if getattr(ctx, "stand_in_comm", None) is None:
+                    ctx.stand_in_comm = partitioned.NativeComm.own(None, self.dev)
+                comm.native_comm = ctx.stand_in_comm
         overlap = True if (self.dry or ctx.staged) else "auto"
+        if os.environ.get("DSEA_BENCH_OVERLAP", "") == "off":          # stages 2 and 3 of the watchdog's ladder
+            overlap = False
 
         def make():
-            return partitioned.PartitionedTFIMOperator(self.L, self.g, self.dev, backend=backend, comm=comm, overlap=overlap)
+            op = partitioned.PartitionedTFIMOperator(self.L, self.g, self.dev, backend=backend, comm=comm, overlap=overlap)
+            if os.environ.get("DSEA_BENCH_PAIRWISE", "") == "1" and op.p > 0:
+                op.use_pairwise_exchange()
+            return op
 
         failed = torch.zeros(1, dtype=torch.float64, device=ctx.ctrl_dev)
         op = None
@@ -660,20 +710,28 @@ class Problem:
         self.activate()
         self.first_contact()
         E0 = gl = None
-        for _ in range(warmup):
+        progress("first contact done", L=self.L, k=self.k)
+        for w in range(warmup):
+            _simulated_hang(self.ctx, "step %d" % (w + 1))
             E0, gl = self.step()
+            if not self.dry:
+                torch.cuda.synchronize()
+            progress("warm-up step", L=self.L, k=self.k)
         self.barrier()
         if self.partitioned:
             if warmup == 0:
                 E0, gl = self.step()
+            _simulated_hang(self.ctx, "step 2")
             self._self_check(E0)
             self.barrier()
+            progress("self-check done", L=self.L, k=self.k)
         # ---- timed region: exactly K steps, no instrumentation inside
         t0 = time.perf_counter()
         for _ in range(steps):
             E0, gl = self.step()
         self.barrier()
         dt = time.perf_counter() - t0
+        progress("timed steps done", L=self.L, k=self.k, steps=steps, seconds=round(dt, 4))
         if self.partitioned:
             import torch.distributed as dist
             tmax = torch.tensor([dt], dtype=torch.float64, device=self.ctx.ctrl_dev)
@@ -820,6 +878,17 @@ def init_process(args):
     env_world = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and env_world is None:
         launch_workers(args.gpus)          # does not return
+    if env_world is not None and int(env_world) > 1 and os.environ.get("DSEA_BENCH_CHILD", "") != "1" and \
+            os.environ.get("DSEA_BENCH_NO_WATCHDOG", "") != "1":
+        # a rank started by the launcher (the driver's torchrun line or launch_workers): supervise a child that does the
+        # measuring; this process never touches the GPU                                        (does not return)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_watchdog
+        anchors, _src = load_anchors(args)
+        describe = {"metric": "DominantSparseSymeig fwd+bwd ms & HBM GB/s (TFIM, fp64)", "unit": "GB/s", "n_gpus": int(env_world),
+                    "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": args.scaling or "strong",
+                    "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"commit": _commit()}}
+        bench_watchdog.supervise(os.path.abspath(__file__), sys.argv[1:], anchors, describe)
     ctx.world = int(env_world or "1")
     ctx.rank = int(os.environ.get("RANK", "0"))
     ctx.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -867,6 +936,7 @@ def init_process(args):
             else:
                 dist.init_process_group("nccl", rank=ctx.rank, world_size=ctx.world, device_id=ctx.dev)
         ctx.evidence = rank_evidence(ctx)
+    progress("process group up", world=ctx.world)
     return ctx
 
 
@@ -1014,6 +1084,8 @@ def extra_point(ctx, L, k, shadow, steps, warmup, scaling):
     """one more row-partitioned point of the N > 1 schedule, timed like the headline (W untimed, self-check, K timed, max
     over ranks) -- every rank runs the same code, so an exception is collective"""
     try:
+        progress("extra point", L=L, k=k, shadow=shadow, scaling=scaling)
+        _simulated_hang(ctx, "extras")
         pw = Problem(ctx, L, k, True, shadow=shadow)
         dt, E0, _ = pw.measure(steps, warmup)
         rec = _point_record(pw, dt / steps * 1e3, steps, warmup, E0, scaling)
@@ -1034,7 +1106,7 @@ def extra_point(ctx, L, k, shadow, steps, warmup, scaling):
 def multi_gpu_extras(args, ctx, pt, prob, anchors):
     """default schedule of N > 1, after the timed strong point (shadow: auto = on from two GPUs): the SAME point with the
     all-fp64 correction pass, the shadow-matched k, and the weak point.  Returns (strong_fp64, strong_matched, weak)."""
-    if not pt.default_schedule:
+    if not pt.default_schedule or os.environ.get("DSEA_BENCH_REDUCED", "") == "1":      # (fallback stages: timed point only)
         return None, None, None
     prob.release()
     Ls = pt.L
@@ -1262,6 +1334,16 @@ def main():
     E0_site, gl0 = E0.item() / L, float(gl.reshape(-1)[0].item())
     overlap_fb = prob.op.overlap_fallbacks if ctx.partitioned_path else None
     prob_shadow = bool(prob.use_shadow)
+    if rank == 0 and world > 1:
+        # the timed point is complete: leave it with the supervisor, so that a stall in what runs BESIDE it (extras, tear-down)
+        # cannot cost the number
+        progress("provisional_line", line={
+            "metric": _metric_name(args, ctx), "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": pt.steps,
+            "warmup": pt.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": pt.scaling,
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": dict(notes, workload=workload, value_is=value_is, cg_iterations=int(m), bf16_shadow_of_basis=prob_shadow,
+                           E0_per_site=E0_site, E0_per_site_closed_form=analytic_E0_per_site(L, 1.0), dloss_dg=gl0,
+                           commit=_commit(), collectives=ctx.evidence, provisional=True)})
 
     # ---- beside the timed point: N > 1 default schedule / N = 1 anchors
     anchors_in, anchors_src = load_anchors(args) if world > 1 else ({}, None)
@@ -1289,8 +1371,13 @@ def main():
                "basis_placement_probe_us": [round(t, 1) for t in (engine.BasisArena.last_placement or [])]}
         out = {"metric": _metric_name(args, ctx), "value": round(value, 2), "unit": "GB/s", "n_gpus": world,
                "steps": pt.steps, "warmup": pt.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-               "scaling": pt.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": cfg}
+               "scaling": pt.scaling if (world > 1 or ctx.partitioned_path) else "none", "vs_baseline": None, "dtype": "f64",
+               "data": "synthetic", "config": cfg}
         cfg.update(notes)
+        if os.environ.get("DSEA_BENCH_STAGE"):
+            cfg["ladder_stage_env"] = {kk: os.environ[kk] for kk in ("DSEA_BENCH_STAGE", "DSEA_COMM_SINGLE", "DSEA_BENCH_OVERLAP",
+                                                                    "DSEA_BENCH_PAIRWISE", "DSEA_DRIVER", "DSEA_BENCH_REDUCED")
+                                       if kk in os.environ}
         if ctx.evidence is not None:
             cfg["collectives"] = ctx.evidence
             if ctx.staged:
@@ -1379,6 +1466,8 @@ def main():
         try:
             from dominantsparseeigenad_amd import partitioned
             partitioned.NativeComm.release_all()
+            if getattr(ctx, "stand_in_comm", None) is not None:
+                ctx.stand_in_comm.close()
         except Exception:  # noqa: BLE001
             pass
         dist.destroy_process_group()

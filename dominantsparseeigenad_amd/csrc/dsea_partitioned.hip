@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -38,6 +40,16 @@ std::once_flag g_rccl_once;
 
 void rccl_init() {
   void* lib = nullptr;
+  // DSEA_RCCL_LIB=<path>: bind THAT library and nothing else (RTLD_LOCAL: its nccl* symbols do not interpose on the
+  // RCCL PyTorch uses).  What the tests use to run the RCCL branch with several ranks on one GPU (tests/fake_rccl).
+  const char* forced = getenv("DSEA_RCCL_LIB");
+  if (forced && *forced) {
+    lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+    if (!lib) {
+      fprintf(stderr, "libdsea: DSEA_RCCL_LIB=%s cannot be loaded (%s)\n", forced, dlerror());
+      return;
+    }
+  }
   const char* names[] = {"librccl.so", "librccl.so.1"};
   for (const char* nm : names)
     if (!lib) lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);      // the copy the process already uses (PyTorch's)

@@ -298,6 +298,24 @@ class HostStagedComm(TorchDistComm):
         full.copy_(hf)
 
 
+class RankOrderedHostStagedComm(HostStagedComm):
+    """HostStagedComm whose all-reduce adds the contributions in RANK ORDER (all-gather, then a left-to-right sum):
+    the order tests/fake_rccl uses, so that a run over the stand-in RCCL communicators and a run over the callback
+    communicator can be compared bit for bit at any world size (gloo's ring all-reduce associates differently from
+    P = 3 on)."""
+
+    def allreduce(self, t):
+        h = t.cpu()
+        if self.world > 1:
+            parts = [torch.empty_like(h) for _ in range(self.world)]
+            dist.all_gather(parts, h, group=self.group)
+            acc = parts[0].clone()
+            for q in parts[1:]:
+                acc += q
+            h = acc
+        t.copy_(h)
+
+
 # =========================================================================== library-side communicator
 def _device_view(ptr, count, device):
     """zero-copy fp64 torch tensor over ``count`` doubles of device memory at ``ptr`` (used by the callback
@@ -388,9 +406,12 @@ class NativeComm:
         which needs a broadcast inside the group only)."""
         from . import _lib
         lib = _lib.load()
+        import os
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         made = None
-        if world > 1:
+        if world > 1 and os.environ.get("DSEA_COMM_SINGLE", "") == "1":
+            xgroup = group          # one communicator for the all-reduces and the exchange (see ``own``)
+        elif world > 1:
             if exchange_group is None:
                 if not cls._is_world(group):
                     raise ValueError("adopt_torch on a sub-group needs exchange_group= (dist.new_group is collective "
@@ -408,11 +429,19 @@ class NativeComm:
                    ("two communicators" if xchg != coll else "one communicator"), keep=(group, xgroup), xgroup=made)
 
     @classmethod
-    def own(cls, group, device):
+    def own(cls, group, device, single=None):
+        """``group`` only carries the two unique ids from its rank 0 to the others (any backend: the ids travel as
+        Python objects).  ``single`` (default: ``DSEA_COMM_SINGLE=1``): ONE communicator for the all-reduces and the
+        slab exchange -- the exchange then queues behind the all-reduces of its own step (RCCL orders the operations of
+        one communicator), which costs the overlap and removes every cross-communicator ordering question: the second
+        stage of bench.py's N > 1 fallback ladder."""
         from . import _lib
         import ctypes
+        import os
         lib = _lib.load()
         rank, world = dist.get_rank(group), dist.get_world_size(group)
+        if single is None:
+            single = os.environ.get("DSEA_COMM_SINGLE", "") == "1"
         ids = [None, None]
         if rank == 0:
             for j in range(2):
@@ -420,11 +449,12 @@ class NativeComm:
                 _lib.check(lib.dsea_comm_unique_id(buf), "dsea_comm_unique_id")
                 ids[j] = bytes(buf.raw)
         dist.broadcast_object_list(ids, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        two = world > 1 and not single
         h = c_void_p()
         with torch.cuda.device(device):
-            _lib.check(lib.dsea_comm_init_rank(ids[0], ids[1] if world > 1 else None, rank, world, byref(h)),
+            _lib.check(lib.dsea_comm_init_rank(ids[0], ids[1] if two else None, rank, world, byref(h)),
                        "dsea_comm_init_rank")
-        return cls(h, rank, world, "rccl (library-owned, two communicators)")
+        return cls(h, rank, world, "rccl (library-owned, %s)" % ("two communicators" if two else "one communicator"))
 
     @classmethod
     def for_torch_group(cls, group, device, exchange_group=None):
@@ -439,7 +469,7 @@ class NativeComm:
             device = torch.device("cuda", torch.cuda.current_device())
         mode = os.environ.get("DSEA_COMM", "")
         key = ("WORLD" if cls._is_world(group) else id(group), str(device), mode,
-               id(exchange_group) if exchange_group is not None else None)
+               id(exchange_group) if exchange_group is not None else None, os.environ.get("DSEA_COMM_SINGLE", ""))
         hit = cls._cache.get(key)
         if hit is not None and hit.handle:
             return hit
@@ -654,6 +684,10 @@ class PartitionedOperator:
         if not isinstance(self.be, HipBackend) or os.environ.get("DSEA_DRIVER", "") == "python":
             return None
         comm = self.comm
+        if getattr(comm, "native_comm", None) is not None:
+            # the Python-level communicator carries the library-side one to use (e.g. library-owned RCCL communicators
+            # beside a gloo group that only serves the host-side collectives of the autograd wrappers)
+            return comm.native_comm
         if isinstance(comm, _SelfComm):
             return NativeComm.from_python(comm, self.device)
         if type(comm) is TorchDistComm:

@@ -39,3 +39,14 @@ def test_overlap_premise_is_checked_on_the_device_and_a_violation_repeats_the_ru
 
 def test_library_driver_partial_reorthogonalisation_world8():
     tp.test_library_driver_partial_reorthogonalisation(8, "gloo")
+
+
+@pytest.mark.parametrize("overlap,env", [(True, {}), (True, tp.ASYNC), (False, {})])
+def test_rccl_branch_of_the_library_driver_equals_the_callback_path_world8(overlap, env):
+    """the 8-rank geometry of BASELINE configs[4] through the RCCL branch (stand-in RCCL, tests/fake_rccl): 7 sends + 7
+    receives per all-to-all, two all-to-alls per mat-vec, on the second communicator"""
+    tp.test_rccl_branch_of_the_library_driver_equals_the_callback_path(8, overlap, env)
+
+
+def test_library_owned_communicators_over_the_rccl_stand_in_collectives_world8():
+    tp.test_library_owned_communicators_over_the_rccl_stand_in_collectives(8, {})

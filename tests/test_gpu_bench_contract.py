@@ -159,3 +159,33 @@ def test_bench_shadow_switch():
                 "--shadow", "off"])
     assert d["config"]["bf16_shadow_of_basis"] is False and d["config"]["shadow_policy"] == "off"
     assert "0 Lanczos steps reading the bf16 shadow" in d["config"]["value_is"]
+
+
+FAKE_RCCL = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+
+
+@pytest.mark.parametrize("inject,stage,driver", [(None, 1, "library (rccl (library-owned, two communicators"),
+                                                 ("exchange", 2, "library (rccl (library-owned, one communicator"),
+                                                 ("allreduce", 3, "python")])
+def test_bench_watchdog_on_the_rccl_branch_rehearsal(inject, stage, driver):
+    """The N > 1 branch of bench.py with the LIBRARY'S OWN RCCL calls executing (DSEA_RCCL_LIB = the stand-in of
+    tests/fake_rccl; two ranks sharing the GPU) under the watchdog of tools/bench_watchdog.py.  A hang injected INSIDE the
+    stand-in -- in the point-to-point traffic of the second communicator, or in the all-reduce -- is what a dead-locked
+    RCCL call would look like: no error, no return.  The supervisors notice the stall, kill both children and start fresh
+    ones at the next stage; the line arrives from stage 2 (one communicator) resp. stage 3 (Python driver)."""
+    assert os.path.exists(FAKE_RCCL), "build() compiles tests/fake_rccl/libfake_rccl.so"
+    env = {"DSEA_RCCL_LIB": FAKE_RCCL, "DSEA_BENCH_STALL_S": "30", "DSEA_BENCH_STARTUP_S": "300"}
+    if inject:
+        env["DSEA_BENCH_INJECT_HANG"] = inject
+    d = _bench(["--gpus", "2", "--host-staged", "--steps", "2", "--warmup", "1"], env=env)
+    cfg = d["config"]
+    assert cfg["fallback_stage"] == stage, cfg["watchdog"]
+    assert cfg["partitioned_driver"].startswith(driver), cfg["partitioned_driver"]
+    assert abs(cfg["E0_per_site"] - cfg["E0_per_site_closed_form"]) < 1e-9
+    wd = cfg["watchdog"]["stages"]
+    assert [r["stage"] for r in wd] == list(range(1, stage + 1)) and wd[-1]["outcome"] == "completed"
+    if inject:
+        assert "no progress" in cfg["fallback_reason"] and "overlapped" not in cfg["slab_exchange"]
+    else:
+        assert cfg["fallback_reason"] is None and "overlapped" in cfg["slab_exchange"]
+        assert isinstance(cfg["weak_scaling_point"], dict)

@@ -432,3 +432,164 @@ def test_overlap_premise_is_checked_on_the_device_and_a_violation_repeats_the_ru
     for r in range(world):
         assert forced[r][5] == 1 and plain[r][5] == 0
         assert forced[r][0] == plain[r][0] and forced[r][2] == plain[r][2] and np.array_equal(forced[r][1], plain[r][1])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The RCCL branch of the library driver (csrc/dsea_partitioned.hip: comm_alltoall's ncclGroupStart / ncclSend / ncclRecv /
+# ncclGroupEnd loop, comm_sendrecv's RCCL half, dsea_comm_unique_id -> broadcast -> dsea_comm_init_rank over > 1 rank, two
+# communicators on two streams) at world 2 / 4 / 8 on ONE GPU.  Real RCCL refuses two ranks on one device, so libdsea is
+# pointed (DSEA_RCCL_LIB) at tests/fake_rccl/libfake_rccl.so: the same ten entry points over POSIX shared memory, blocking
+# or (FAKE_RCCL_ASYNC=1) with a progress thread and a device-side wait per operation.  Test infrastructure only.
+FAKE_RCCL = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rccl", "libfake_rccl.so")
+
+
+def _fake_rccl_stats():
+    import ctypes
+    lib = ctypes.CDLL(FAKE_RCCL)
+    out = (ctypes.c_uint64 * 8)()
+    lib.fake_rccl_stats(out)
+    return [int(v) for v in out]
+
+
+def _rccl_branch_comm(dev, mode, env):
+    """Python-level communicator (gloo, host-staged, all-reduce in rank order) carrying, for mode "rccl", a pair of
+    LIBRARY-OWNED communicators created over the stand-in RCCL"""
+    from dominantsparseeigenad_amd.partitioned import NativeComm, RankOrderedHostStagedComm
+    os.environ.update(env)
+    comm = RankOrderedHostStagedComm()
+    if mode == "rccl":
+        os.environ["DSEA_RCCL_LIB"] = FAKE_RCCL
+        comm.native_comm = NativeComm.own(None, dev)
+    return comm
+
+
+def _case_rccl_branch(rank, world, backend, dev, overlap, mode, env):
+    from dominantsparseeigenad_amd.partitioned import PartitionedTFIM
+    comm = _rccl_branch_comm(dev, mode, env)
+    p = world.bit_length() - 1
+    nloc = 1 << (L - p)
+    off = rank * nloc
+    g = torch.tensor([G], dtype=torch.float64, device=dev)
+    solver = PartitionedTFIM(L, g, dev, eps=1e-12, comm=comm)
+    solver.overlap = overlap
+    solver.op.replicate_cg = False          # the row-partitioned CG: its exchange and its all-reduces are the point
+    q0 = torch.from_numpy(normal_vector(nloc, 5100, offset=off)).to(dev)
+    x0 = torch.from_numpy(normal_vector(nloc, 5102, offset=off)).to(dev)
+    t = torch.from_numpy(normal_vector(nloc, 5103, offset=off)).to(dev)
+    E0, psi, grad = solver.forward_backward(K, q0, x0, t)
+    torch.cuda.synchronize()
+    out = dict(E0=E0.item(), psi=psi.cpu().numpy().copy(), grad=grad.item(), iters=solver.last_cg_iters,
+               driver=solver.op.driver, fallbacks=solver.op.overlap_fallbacks, transposed=bool(solver.op.transposed),
+               stats=_fake_rccl_stats() if mode == "rccl" else None)
+    del solver
+    if mode == "rccl":
+        comm.native_comm.close()
+    return out
+
+
+def _case_rccl_collectives(rank, world, backend, dev, env):
+    """dsea_comm_allreduce / dsea_comm_alltoall on library-owned communicators, payloads longer than one mailbox slot"""
+    from ctypes import c_void_p
+    from dominantsparseeigenad_amd import _lib
+    comm = _rccl_branch_comm(dev, "rccl", env)
+    nc, lib = comm.native_comm, _lib.load()
+    chunk = 150001                                          # 1.2 MB per chunk: more than one 1 MiB mailbox slot
+    src = torch.empty(world * chunk, dtype=torch.float64, device=dev)
+    for j in range(world):
+        src[j * chunk:(j + 1) * chunk] = torch.arange(chunk, dtype=torch.float64, device=dev) + 1e6 * rank + 1e3 * j
+    dst = torch.zeros_like(src)
+    st = c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(lib.dsea_comm_alltoall(nc.handle, c_void_p(src.data_ptr()), c_void_p(dst.data_ptr()), chunk, st), "alltoall")
+    red = torch.arange(9001, dtype=torch.float64, device=dev) * (rank + 1) + 0.1 * rank     # 72 kB: two deposit rounds
+    _lib.check(lib.dsea_comm_allreduce(nc.handle, c_void_p(red.data_ptr()), red.numel(), st), "allreduce")
+    torch.cuda.synchronize()
+    ok_a2a = all(bool(torch.equal(dst[j * chunk:(j + 1) * chunk],
+                                  torch.arange(chunk, dtype=torch.float64, device=dev) + 1e6 * j + 1e3 * rank))
+                 for j in range(world))
+    want = torch.zeros(9001, dtype=torch.float64)
+    for r in range(world):                                   # the stand-in adds in rank order
+        want += torch.arange(9001, dtype=torch.float64) * (r + 1) + 0.1 * r
+    out = dict(a2a=ok_a2a, red=bool(torch.equal(red.cpu(), want)), kind=nc.kind, stats=_fake_rccl_stats())
+    nc.close()
+    return out
+
+
+def _case_rccl_stencil(rank, world, backend, dev, mode, env):
+    """_case_api_stencil with the halo exchange through the library driver's communicator: stand-in RCCL or callbacks"""
+    comm = _rccl_branch_comm(dev, mode, env)
+    orig = globals()["_comm"]
+    globals()["_comm"] = lambda backend: comm
+    try:
+        out = _case_api_stencil(rank, world, backend, dev)
+    finally:
+        globals()["_comm"] = orig
+    out["stats"] = _fake_rccl_stats() if mode == "rccl" else None
+    return out
+
+
+def _need_fake_rccl():
+    if not os.path.exists(FAKE_RCCL):
+        pytest.fail("tests/fake_rccl/libfake_rccl.so is missing: __graft_entry__.build() (or make -C tests/fake_rccl) builds it")
+
+
+ASYNC = {"FAKE_RCCL_ASYNC": "1"}
+
+
+@pytest.mark.parametrize("world,env", [(2, {}), (4, {}), (4, ASYNC)])
+def test_library_owned_communicators_over_the_rccl_stand_in_collectives(world, env):
+    """unique ids on rank 0 -> broadcast -> dsea_comm_init_rank on every rank (two communicators); the group of
+    point-to-point operations that IS the all-to-all; the all-reduce -- against closed-form payloads"""
+    _need_fake_rccl()
+    ret = _run(world, "gloo", "_case_rccl_collectives", env)
+    for r in range(world):
+        assert ret[r]["a2a"] and ret[r]["red"], ret[r]
+        assert "library-owned, two communicators" in ret[r]["kind"]
+        st = ret[r]["stats"]
+        assert st[4] == 2 and st[0] == 1 and st[1] == world - 1 and st[2] == world - 1 and st[3] == 1, st
+        assert (st[5] > 0) == bool(env), st
+
+
+@pytest.mark.parametrize("world,overlap,env", [(2, True, {}), (2, False, ASYNC), (4, True, {}), (4, True, ASYNC), (4, False, {})])
+def test_rccl_branch_of_the_library_driver_equals_the_callback_path(world, overlap, env):
+    """COMM_RCCL_OWNED at world 2 (pair exchange: comm_sendrecv's RCCL half) and 4 (transposed form: two all-to-alls per
+    mat-vec), exchange on the second communicator and the side stream, overlap on and off, blocking and asynchronous
+    stand-in -- bit-identical to the same driver over the callback communicator (same rank-ordered all-reduce)."""
+    _need_fake_rccl()
+    rccl = _run(world, "gloo", "_case_rccl_branch", overlap, "rccl", env)
+    cb = _run(world, "gloo", "_case_rccl_branch", overlap, "callbacks", {})
+    for r in range(world):
+        a, b = rccl[r], cb[r]
+        assert "rccl (library-owned, two communicators)" in a["driver"] and "callbacks" in b["driver"], (a["driver"], b["driver"])
+        assert a["E0"] == b["E0"] and a["grad"] == b["grad"] and a["iters"] == b["iters"], (a["E0"], b["E0"], a["grad"], b["grad"])
+        assert np.array_equal(a["psi"], b["psi"])
+        assert a["fallbacks"] == 0 and b["fallbacks"] == 0
+        assert a["transposed"] == (world >= 4)
+        st = a["stats"]
+        # every Lanczos step and CG iteration went through the stand-in: all-reduces, sends, receives, groups
+        assert st[0] > 2 * K and st[1] > K and st[2] == st[1] and st[3] > K and st[4] == 2, st
+    assert rccl[0]["E0"] == rccl[world - 1]["E0"]
+
+
+def test_rccl_branch_with_one_communicator():
+    """DSEA_COMM_SINGLE=1 (stage 2 of bench.py's N > 1 ladder): exchange and all-reduces on ONE communicator"""
+    _need_fake_rccl()
+    one = _run(2, "gloo", "_case_rccl_branch", True, "rccl", {"DSEA_COMM_SINGLE": "1"})
+    two = _run(2, "gloo", "_case_rccl_branch", True, "rccl", {})
+    for r in range(2):
+        assert "one communicator" in one[r]["driver"] and one[r]["stats"][4] == 1
+        assert one[r]["E0"] == two[r]["E0"] and one[r]["grad"] == two[r]["grad"] and np.array_equal(one[r]["psi"], two[r]["psi"])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rccl_branch_halo_exchange_of_the_stencil(world):
+    """the 3-point stencil's one-element halo exchange (comm_sendrecv with one or two peers, uneven slabs at 3 ranks)
+    through the stand-in, behind the reference API, against the callback path and the reference fixture"""
+    _need_fake_rccl()
+    gd = np.load(os.path.join(GOLDEN, "schrodinger.npz"))
+    rccl = _run(world, "gloo", "_case_rccl_stencil", "rccl", {})
+    cb = _run(world, "gloo", "_case_rccl_stencil", "callbacks", {})
+    for r in range(world):
+        assert rccl[r]["E"] == cb[r]["E"] and rccl[r]["loss"] == cb[r]["loss"]
+        assert np.array_equal(rccl[r]["psi"], cb[r]["psi"]) and np.array_equal(rccl[r]["grad"], cb[r]["grad"])
+        assert rccl[r]["stats"][1] > 100 and rccl[r]["stats"][0] > 100
+    assert abs(rccl[0]["E"] - float(gd["E"])) < 1e-10 * abs(float(gd["E"]))

@@ -359,3 +359,37 @@ def test_replicated_cg_equals_partitioned_cg(world):
         assert repl[r][0] == part[r][0] and torch.equal(torch.from_numpy(repl[r][1]), torch.from_numpy(part[r][1]))
     assert repl[0][3] == part[0][3]
     assert abs(repl[0][2] - part[0][2]) < 1e-10 * abs(part[0][2])
+
+
+@pytest.mark.parametrize("inject,stage", [("exchange", 2), ("allreduce", 3), ("crash", 2), ("extras", 1)])
+def test_bench_watchdog_walks_the_fallback_ladder(inject, stage):
+    """tools/bench_watchdog.py: every launched rank supervises a child; a child that stops making progress (or dies) is
+    killed on ALL ranks together and a fresh one started at the next stage -- library driver with the exchange on its
+    own communicator -> one communicator, no overlap -> Python driver, pairwise.  The line still arrives, says which
+    stage it came from and why.  A stall AFTER the timed point (in the extras beside it) keeps stage 1's number.
+    Dry run: the faults are simulated in bench.py at the stages a real one of that kind would hit."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DSEA_BENCH_INJECT_HANG=inject, DSEA_BENCH_STALL_S="6", DSEA_BENCH_STARTUP_S="120")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run-cpu"]
+    if inject != "extras":
+        cmd += ["--L", "10", "--k", "60"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1 and out.stdout.strip().splitlines()[-1] == lines[0]
+    d = json.loads(lines[0])
+    cfg = d["config"]
+    assert d["value"] > 0 and cfg["fallback_stage"] == stage, cfg["watchdog"]
+    wd = cfg["watchdog"]["stages"]
+    assert [r["stage"] for r in wd] == list(range(1, stage + 1))
+    if inject == "extras":
+        assert "extras_incomplete" in cfg and cfg["provisional"] is True and "no progress" in wd[0]["outcome"]
+        assert cfg["fallback_reason"] is None
+    else:
+        assert wd[-1]["outcome"] == "completed" and all(r["outcome"] != "completed" for r in wd[:-1])
+        assert ("exited with code" if inject == "crash" else "no progress") in cfg["fallback_reason"]
+        assert cfg["ladder_stage_env"]["DSEA_BENCH_STAGE"] == str(stage)
+    assert abs(cfg["E0_per_site"] - cfg["E0_per_site_closed_form"]) < 1e-9
