@@ -1347,6 +1347,25 @@ def main():
 
     # ---- beside the timed point: N > 1 default schedule / N = 1 anchors
     anchors_in, anchors_src = load_anchors(args) if world > 1 else ({}, None)
+    decomposition = None
+    if world > 1:
+        # what bounds this line: collectives on the run's own communicators, exposed exchange per step / iteration,
+        # SURVEY 8e's model beside the measurement (tools/bench_multi.py; outside the timed region, collective)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_multi
+        canonical = not pt.explicit and not pt.toy
+        tag = ("strong_L28_k%d" % STRONG_K if (pt.strong and k == STRONG_K and not prob_shadow) else
+               "strong_L28_k%d_shadow" % STRONG_K_SHADOW_MATCHED if (pt.strong and k == STRONG_K_SHADOW_MATCHED and prob_shadow) else
+               "weak_2p25_rows_k200" if (not pt.strong and k == 200 and pt.nloc == (1 << 25)) else None)
+        a1 = anchor_ms(anchors_in, tag, prob_shadow) if (canonical and tag) else None
+        if a1 and not pt.strong:
+            a1 = a1 * world          # weak point: T_1 of the N-fold problem (the model divides it by P again)
+        progress("scaling decomposition")
+        try:
+            decomposition = bench_multi.scaling_decomposition(ctx, prob, pt, ms_per_step, m, E0, a1)
+        except Exception as exc:  # noqa: BLE001  (every rank runs the same code: the exception is collective)
+            decomposition = "failed: %s: %s" % (type(exc).__name__, str(exc)[:200])
+        progress("scaling decomposition done")
     strong_fp64, strong_matched, weak_point = multi_gpu_extras(args, ctx, pt, prob, anchors_in)
     anchors = one_gpu_anchors(args, ctx, pt, prob)
 
@@ -1392,6 +1411,12 @@ def main():
                 cfg["weak_scaling_point"] = weak_point
             if overlap_fb is not None:
                 cfg["overlap_premise_fallbacks"] = int(overlap_fb)
+            if isinstance(decomposition, dict) and isinstance(strong_fp64, dict):
+                # the like-by-like pair the strong point has (all-fp64 correction pass on both sides), same k, same collectives
+                a_fp64 = anchor_ms(anchors_in, "strong_L28_k%d" % STRONG_K, False) if (not pt.explicit and not pt.toy) else None
+                decomposition["model"]["strong_point_fp64_basis"] = bench_multi.model_entry(
+                    a_fp64, strong_fp64["ms_per_step"], world, decomposition["communication_ms_per_step"])
+            cfg["scaling_decomposition"] = decomposition
         if world == 1 and not ctx.partitioned_path:
             cfg["multi_gpu_schedule"] = (
                 "bench.py --gpus N (N > 1) times the STRONG point TFIM L=28, k=%d over N GPUs as value/ms_per_step (shadow "

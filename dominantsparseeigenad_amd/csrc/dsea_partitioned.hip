@@ -217,7 +217,7 @@ int tfim_exchange_on(dsea_pop_s* P, const double* x, hipStream_t s) {
 // start the exchange of slab x: on the side stream (ordered after what `main` has enqueued so far) when there is one,
 // otherwise inline on main.  x must stay untouched until tfim_exchange_finish.
 int tfim_exchange_start(dsea_pop_s* P, const double* x, hipStream_t main) {
-  if (P->p == 0) return DSEA_OK;
+  if (P->p == 0 || (P->flags & DSEA_POP_NO_EXCHANGE)) return DSEA_OK;
   if (!P->side) return tfim_exchange_on(P, x, main);
   HIP_TRY(hipEventRecord(P->ev_ready, main));
   HIP_TRY(hipStreamWaitEvent(P->side, P->ev_ready, 0));
@@ -226,7 +226,7 @@ int tfim_exchange_start(dsea_pop_s* P, const double* x, hipStream_t main) {
   return DSEA_OK;
 }
 int tfim_exchange_finish(dsea_pop_s* P, hipStream_t main) {
-  if (P->p == 0 || !P->side) return DSEA_OK;
+  if (P->p == 0 || !P->side || (P->flags & DSEA_POP_NO_EXCHANGE)) return DSEA_OK;
   HIP_TRY(hipStreamWaitEvent(main, P->ev_done, 0));
   return DSEA_OK;
 }

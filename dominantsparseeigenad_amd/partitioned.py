@@ -1044,7 +1044,8 @@ class PartitionedTFIMOperator(PartitionedOperator):
     def _pop_flags(self):
         from . import _lib
         return (_lib.POP_OVERLAP if (self.overlap and self.p > 0) else 0) | \
-            (_lib.POP_PAIRWISE if self._pairwise_forced else 0)
+            (_lib.POP_PAIRWISE if self._pairwise_forced else 0) | \
+            (_lib.POP_NO_EXCHANGE if getattr(self, "measure_without_exchange", False) else 0)
 
     # With TWO ranks every mat-vec moves one whole slab over the single xGMI link between the two GPUs (268 MB at 2^25
     # rows: 3.5-5 ms) -- in the Lanczos step that hides behind the dots pass, in a CG iteration it does not: ~0.9 ms of
@@ -1098,6 +1099,8 @@ class PartitionedTFIMOperator(PartitionedOperator):
         """receive the slabs of the p hypercube partners (rank ^ (1<<b)); returns the list of buffers"""
         if self.p == 0:
             return []
+        if getattr(self, "measure_without_exchange", False):     # bench.py only: the step without its exchange (stale buffers)
+            return [self._z] if self.transposed else self._recv
         if self.transposed:   # returns ONE buffer holding the sum over all partner slabs
             self.comm.all_to_all(x, self._xT)
             self.be.flipsum(self._xT, self._zT, self.world)
@@ -1109,6 +1112,8 @@ class PartitionedTFIMOperator(PartitionedOperator):
     def _start_exchange(self, x):
         """the same exchange started on the communicator's side stream; ``_finish_exchange`` joins it and returns the
         buffers.  x must stay untouched until then."""
+        if getattr(self, "measure_without_exchange", False):
+            return None
         if self.transposed:
             return self.comm.start_flip_exchange(self.be, x, self._xT, self._zT, self._z)
         return self.comm.start_pair_exchange(x, self._recv, [self.rank ^ (1 << b) for b in range(self.p)])

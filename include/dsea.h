@@ -404,6 +404,9 @@ int dsea_comm_alltoall(dsea_comm_t comm, const double *send, double *recv, int64
 typedef struct dsea_pop_s *dsea_pop_t;
 #define DSEA_POP_OVERLAP 1
 #define DSEA_POP_PAIRWISE 2
+/* MEASUREMENT ONLY: the slab exchange is not issued and the receive buffers are used as they are -- the numbers are
+ * meaningless, the time is that of the same step without its exchange (bench.py: exposed exchange = step - this)  */
+#define DSEA_POP_NO_EXCHANGE 4
 size_t dsea_pop_tfim_scratch_doubles(int L, int world);
 int dsea_pop_create_tfim(int L, dsea_comm_t comm, const double *g_dev, double g_const, double diag_scale,
                          double *scratch, void *side_stream, int flags, double tau, dsea_pop_t *out);

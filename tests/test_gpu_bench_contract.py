@@ -136,6 +136,14 @@ def test_bench_multi_gpu_branch_rehearsal_on_hip_kernels(world):
         assert rec["ms_per_step"] > 0 and abs(rec["E0_per_site"] - rec["E0_per_site_closed_form"]) < 1e-6, (key, rec)
         assert rec["partitioned_driver"].startswith("library (callbacks") and "verified" in rec["distributed_self_check"]
     assert cfg["strong_point_fp64_basis"]["bf16_shadow_of_basis"] is False and cfg["bf16_shadow_of_basis"] is True
+    sd = cfg["scaling_decomposition"]          # what bounds the line: tools/bench_multi.py
+    assert sd["allreduce_us"]["8_bytes"] > 0 and sd["allreduce_us"]["1600_bytes"] > 0 and "library" in sd["allreduce_us"]["through"]
+    assert sd["exchange"]["ms_per_matvec"] > 0 and sd["exchange"]["GBs_sent_per_gpu"] > 0
+    assert sd["exposed_exchange_ms_per_lanczos_step"] >= 0 and sd["exposed_exchange_ms_per_cg_iteration"] >= 0
+    assert sd["lanczos_forward_ms"]["exchange_after_correction"] > 0 and sd["lanczos_forward_ms"]["without_exchange"] > 0
+    for key in ("timed_point", "strong_point_fp64_basis"):
+        assert "predicted_speedup" in sd["model"][key] and "measured_speedup" in sd["model"][key]
+    assert cfg["fallback_stage"] == 1 and cfg["watchdog"]["stages"][0]["outcome"] == "completed"
     anchor = cfg["one_gpu_anchor"]
     assert "speedup_vs_one_gpu" not in anchor and "speedup_vs_one_gpu_fp64_basis" in anchor
     assert "speedup_vs_one_gpu_k80_shadow" in anchor

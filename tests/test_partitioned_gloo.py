@@ -276,6 +276,14 @@ def test_bench_multi_rank_control_flow_dry_run(world, launcher, explicit):
     col = cfg["collectives"]
     assert col["world_size"] == world and col["backend"] == "gloo"
     assert sorted(r["rank"] for r in col["ranks"]) == list(range(world)) and len({r["pid"] for r in col["ranks"]}) == world
+    # what bounds the line (tools/bench_multi.py): collectives on the run's own communicators, exposed exchange, SURVEY 8e's model
+    sd = cfg["scaling_decomposition"]
+    assert sd["allreduce_us"]["8_bytes"] > 0 and sd["allreduce_us"]["1600_bytes"] > 0
+    assert sd["exchange"]["ms_per_matvec"] > 0 and sd["exchange"]["bytes_sent_per_gpu_per_matvec"] > 0
+    assert sd["exposed_exchange_ms_per_lanczos_step"] >= 0 and sd["exposed_exchange_ms_per_cg_iteration"] >= 0
+    assert sd["lanczos_forward_ms"]["without_exchange"] > 0 and sd["cg_ms_per_iteration"]["as_timed"] > 0
+    assert "predicted_speedup" in sd["model"]["timed_point"] and "measured_speedup" in sd["model"]["timed_point"]
+    assert cfg["fallback_stage"] == 1 and cfg["fallback_reason"] is None and cfg["watchdog"]["stages"][0]["outcome"] == "completed"
     if explicit:
         assert d["scaling"] == "weak" and "weak_scaling_point" not in cfg
     else:
