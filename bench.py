@@ -232,6 +232,84 @@ def c3_figures(dev):
                        "in exact arithmetic, 6e-14 relative deviation after 40 iterations), off by default"}
 
 
+def sweep_figures(dev, N=20, k=200, idxs=(25, 50, 75), warm=80):
+    """Row f-2 as a driver-timed figure: the reference's SECOND-ORDER workload per coupling (examples/TFIM/E0.py:53-67
+    ``E0_sparseAD`` = forward + d/dg + d2/dg2, chiF.py:40-53 ``chiF_sparseAD`` = forward + two derivatives of log F: two
+    forward passes and five adjoint solves per coupling) at N = 20, k = 200, on the three couplings the parity test uses,
+    against the reference's stored curves (tests/golden/ref_datas = its own outputs); cold, and with the previous
+    coupling's eigenvector as the start vector of a ``warm``-step Lanczos (an extension the reference lacks)."""
+    import importlib.util
+    import DominantSparseEigenAD.Lanczos as LZ
+
+    def load(fname, name):
+        d = os.path.join(ROOT, "examples", "TFIM")
+        if d not in sys.path:
+            sys.path.insert(0, d)
+        spec = importlib.util.spec_from_file_location(name, os.path.join(d, fname))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    E0m, chim = load("E0.py", "bench_ex_E0"), load("chiF.py", "bench_ex_chiF")
+    curE = np.load(os.path.join(ROOT, "tests", "golden", "ref_datas", "E0_N_%d.npz" % N))
+    curC = np.load(os.path.join(ROOT, "tests", "golden", "ref_datas", "chiF_N_%d.npz" % N))
+    model = E0m.TFIM(N, dev)
+    out = {"workload": "TFIM N=%d k=%d: E0, dE0/dg, d2E0/dg2 (E0.py:53-67) and chi_F (chiF.py:40-53) per coupling -- two forward "
+                       "passes + five adjoint solves; couplings g = %s" % (N, k, ", ".join("%.3f" % curE["gs"][i] for i in idxs))}
+    for label, kw in (("cold", 0), ("warm_%d" % warm, warm)):
+        torch.manual_seed(1)
+        dev_max = {"E0": 0.0, "dE0": 0.0, "d2E0": 0.0, "chiF": 0.0}
+        prev, times = None, []
+        try:
+            for idx in idxs:
+                g = float(curE["gs"][idx])
+                model.g = torch.tensor([g], dtype=torch.float64, device=dev, requires_grad=True)
+                kk = k
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                if kw and prev is not None:
+                    kk, LZ.WARM_START = kw, prev
+                e, de, d2e = E0m.E0_sparseAD(model, kk)
+                if kw and prev is not None:
+                    LZ.WARM_START = prev
+                _, psi, c = chim.chiF_sparseAD(model, kk)
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+                prev = psi.detach()
+                for key, got, want in (("E0", e, curE["E0s"][idx]), ("dE0", de, curE["dE0s"][idx]),
+                                       ("d2E0", d2e, curE["d2E0s"][idx]), ("chiF", c, curC["chiFs"][idx])):
+                    dev_max[key] = max(dev_max[key], abs(got - want) / abs(want))
+        finally:
+            LZ.WARM_START = None
+        # warm: the first coupling has no predecessor (it runs cold) -- the figure is the mean over the others
+        use = times[1:] if kw else times
+        out[label] = {"ms_per_coupling": round(sum(use) / len(use) * 1e3, 2), "couplings_timed": len(use),
+                      "max_rel_deviation_from_reference_curves": {kk2: float("%.2e" % v) for kk2, v in dev_max.items()}}
+    out["note"] = "the stored curves pin results at the 1e-6 ... 1e-5 level (SURVEY 8c: produced with a less converged setting)"
+    return out
+
+
+def sell_operand_figures(ctx, args, steps=3):
+    """SURVEY 8d C2 (ii) as a driver-observed figure: the headline workload with the operator given as an EXPLICIT matrix
+    (21 non-zeros per row, SELL-64 layout, fp64 values + int32 columns) instead of the matrix-free kernel"""
+    pa = Problem(ctx, 20, 200, False, operator="sell")
+    try:
+        dt, E0, _ = pa.measure(steps, 1)
+        ms = dt / steps * 1e3
+        m = pa.cg_iterations()
+        n, k = pa.n, pa.k
+        operand = 12.0 * 21 * n * (k + m + 1)
+        moved = traffic_model_bytes(n, k, m, (k - 1) if pa.use_shadow else 0) + operand
+        return {"workload": pa.describe(), "ms_per_step": round(ms, 3), "steps": steps, "cg_iterations": int(m),
+                "bytes_per_step": moved, "GBs": round(moved / (ms * 1e-3) / 1e9, 1),
+                "frac_of_hbm_peak": round(moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "E0_per_site_minus_closed_form": E0.item() / 20 - analytic_E0_per_site(20, 1.0),
+                "bytes_note": "the matrix-free step's traffic model + the matrix stream: 12 B per non-zero, 21 per row, in each "
+                              "of the %d mat-vecs" % (k + m + 1)}
+    finally:
+        pa.release()
+
+
 def c4_figures(dev):
     """BASELINE configs[3]: dominant eigen-triple of the MPS transfer matrix at bond dimension D = 512 (n = 262144),
     DominantSparseEig k = 200 (examples/TFIM_vumps/general.py:59-66, eig.py:115-149) -- the one MFMA-shaped operand of the path."""
@@ -1474,6 +1552,16 @@ def main():
                 cfg["config4"] = c4_figures(ctx.dev)
             except Exception as exc:  # noqa: BLE001
                 cfg["config4"] = "failed: %s" % exc
+            if L == 20 and k == 200 and args.operator == "matrix-free" and args.reorth == "full":
+                try:
+                    cfg["sweep_N20"] = sweep_figures(ctx.dev)
+                except Exception as exc:  # noqa: BLE001
+                    cfg["sweep_N20"] = "failed: %s: %s" % (type(exc).__name__, exc)
+                try:
+                    cfg["operand_sell"] = sell_operand_figures(ctx, args)
+                except Exception as exc:  # noqa: BLE001
+                    cfg["operand_sell"] = "failed: %s: %s" % (type(exc).__name__, exc)
+                prob.activate()
         if not args.no_cpu_baseline and world == 1 and not pt.big and not ctx.staged:
             out["cpu_baseline"] = _cpu_baseline_block(args, pt)
         # RCCL / HIP runtime banners go through C stdio: flush them first so the JSON is the last line

@@ -49,6 +49,7 @@ _SIGNATURES = {
     "dsea_ws_set_rows_per_lane": (c_int, [c_void_p, c_int]),
     "dsea_ws_set_split": (c_int, [c_void_p, c_int]),
     "dsea_ws_set_persist": (c_int, [c_void_p, c_int]),
+    "dsea_cg_last_form": (c_int, [c_void_p, POINTER(c_int)]),
     "dsea_ws_set_lanczos_persist": (c_int, [c_void_p, c_int]),
     "dsea_ws_set_reorth_passes": (c_int, [c_void_p, c_int]),
     "dsea_ws_set_fault_injection": (c_int, [c_void_p, c_int]),

@@ -188,6 +188,7 @@ int dsea_ws_create(void* device_buffer, size_t bytes, int64_t n, int kmax, dsea_
   ws->w.partial_reorth = 0;
   ws->w.pro_delta = DSEA_PRO_DELTA_DEFAULT;
   ws->w.lose_peer = 0;
+  ws->w.last_cg_form = DSEA_CG_FORM_STREAMING;
   ws->w.prof = nullptr;
   ws->w.shadow = nullptr;
   ws->w.shadow_ld = 0;
@@ -330,6 +331,12 @@ int dsea_ws_set_persist(dsea_ws_t ws, int mode) {
     return DSEA_ERR_ARG;
   if (mode >= 100 && geo == -1) return DSEA_ERR_ARG;
   ws->w.persist_override = mode;
+  return DSEA_OK;
+}
+
+int dsea_cg_last_form(dsea_ws_t ws, int* form) {
+  if (!ws || !form) return DSEA_ERR_ARG;
+  *form = ws->w.last_cg_form;
   return DSEA_OK;
 }
 
@@ -1283,6 +1290,9 @@ int dsea_cg_run(dsea_op_t op, dsea_ws_t ws, const double* shift, const double* b
       return DSEA_ERR_HIP;
     }
     if (pr == 0) {
+      const bool merged_form = tfim_big ? (w.persist_override != 200)
+                                        : (!tfim_persist && w.persist_override >= 100 && w.persist_override != 200);
+      w.last_cg_form = merged_form ? DSEA_CG_FORM_PERSISTENT_MERGED : DSEA_CG_FORM_PERSISTENT;
       double hs[DSEA_CG_STATE_LEN];
       if (hipMemcpyAsync(hs, state, sizeof(hs), hipMemcpyDeviceToHost, st) != hipSuccess ||
           hipStreamSynchronize(st) != hipSuccess) {
@@ -1298,6 +1308,7 @@ int dsea_cg_run(dsea_op_t op, dsea_ws_t ws, const double* shift, const double* b
     }
   }
 
+  w.last_cg_form = DSEA_CG_FORM_STREAMING;
   // r = b - A'x0 ; early out ; d = r                            (CG.py:26-30)
   int nb = launch_spmv(op->d, x, Ad, shift, nullptr, nullptr, st);
   if (nb < 0) return DSEA_ERR_UNSUPPORTED;

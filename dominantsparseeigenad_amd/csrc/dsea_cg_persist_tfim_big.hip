@@ -1,6 +1,9 @@
 // dsea_cg_persist_tfim_big.hip -- conjugate gradients (reference CG.py:24-41 with A' = A - shift, CG.py:120) for the
-// full-space matrix-free TFIM operator at 2^11 ... 2^20 rows (BASELINE configs[1] is L = 20) as ONE persistent launch
-// whose iterates are BIT-IDENTICAL to the streaming form (mat-vec + update + direction launches).
+// full-space matrix-free TFIM operator at 2^11 ... 2^20 rows (BASELINE configs[1] is L = 20) as ONE persistent launch.
+// Two forms, one kernel template: MERGED = false keeps the reference's recurrences -- iterates BIT-IDENTICAL to the streaming
+// form (mat-vec + update + direction launches); MERGED = true -- THE DEFAULT, see below -- makes one grid-wide exchange per
+// iteration with the Chronopoulos-Gear recurrences: the same iteration in exact arithmetic, NOT the same rounding sequence.
+// dsea_cg_last_form() / engine.last_cg.form say which one ran.
 //
 // Streaming form at L = 20: 25.6 us per iteration for 92 MB of algorithmic traffic -- three dependent launches, x / r /
 // d / A'd written and re-read through HBM between them.  Here every workgroup keeps x, r, d of its rows in registers
@@ -288,7 +291,13 @@ __global__ __launch_bounds__(256 * NVB) void k_cg_persist_tfim_big(CgbArgs a) {
     // ---- one exchange per iteration (Chronopoulos-Gear recurrences, see the header)
     // workgroup sums of two values, then all workgroups' pairs gathered and summed in a fixed order (thread t of the first
     // virtual block takes workgroup t): the totals are identical in every workgroup
+    // The pair granules are DOUBLE-BUFFERED by epoch parity (second buffer: the r.r region, unused in this form).  With
+    // ONE buffer a workgroup could overwrite its epoch-e pair with the epoch-(e+1) pair -- it only waits for its hypercube
+    // partners in between -- while a stalled non-partner workgroup had not read epoch e yet; that reader would then never
+    // see its tag and run into the time-out.  With two, the slot of epoch e is rewritten at epoch e + 2, which a workgroup
+    // reaches only after ALL workgroups have published epoch e + 1, i.e. after every one of them has left the gather of e.
     auto exchange2 = [&](double v0, double v1, unsigned epoch, bool& fail, double& out0, double& out1) {
+      cgb_gu64* PE = PA + (int64_t)(epoch & 1u) * 4 * (int64_t)gridDim.x;
       v0 = wave_sum(v0);
       v1 = wave_sum(v1);
       __syncthreads();
@@ -301,7 +310,7 @@ __global__ __launch_bounds__(256 * NVB) void k_cg_persist_tfim_big(CgbArgs a) {
         double tot = sm.red2[0][tid];
 #pragma unroll
         for (int w = 1; w < 4 * NVB; ++w) tot += sm.red2[w][tid];
-        granule_put(PA + 2 * ((int64_t)blockIdx.x * 2 + tid), epoch, tot);
+        granule_put(PE + 2 * ((int64_t)blockIdx.x * 2 + tid), epoch, tot);
       }
       double g0 = 0.0, g1 = 0.0;
       if (vb == 0) {
@@ -309,8 +318,8 @@ __global__ __launch_bounds__(256 * NVB) void k_cg_persist_tfim_big(CgbArgs a) {
         if (t < G) {
           const long long t0 = wall_clock64();
           for (;;) {
-            const bool ok0 = granule_try_get(PA + 2 * ((int64_t)t * 2), epoch, g0);
-            const bool ok1 = granule_try_get(PA + 2 * ((int64_t)t * 2 + 1), epoch, g1);
+            const bool ok0 = granule_try_get(PE + 2 * ((int64_t)t * 2), epoch, g0);
+            const bool ok1 = granule_try_get(PE + 2 * ((int64_t)t * 2 + 1), epoch, g1);
             if (ok0 && ok1) break;
             __builtin_amdgcn_s_sleep(1);
             if (wall_clock64() - t0 > CGB_TIMEOUT_TICKS) {

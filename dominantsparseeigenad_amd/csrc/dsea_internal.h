@@ -123,6 +123,7 @@ struct Workspace {
   int persist_override;  // persistent single-launch CG: -1 automatic, 0 off, 1/2/4 = row pairs per thread forced
   int lz_persist;        // single-launch Lanczos for small problems: -1 automatic (on where it applies), 0 off
   int arnoldi_optimistic;  // dsea_arnoldi_extend: 1 = the second Gram-Schmidt pass is not enqueued; a step failing the DGKS test records itself
+  int last_cg_form;      // which form the last dsea_cg_run took (DSEA_CG_FORM_*)
   int lose_peer;         // TEST HOOK (dsea_ws_set_fault_injection): the last workgroup of a persistent launch exits at once
   int reorth_passes;     // Gram-Schmidt passes per Lanczos step: 1 (the reference, Lanczos.py:66) or 2 (CGS2 option)
   int partial_reorth;    // 1 = re-orthogonalise only when the omega recurrence says so (option; dsea_ws_set_partial_reorth)

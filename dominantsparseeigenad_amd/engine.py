@@ -664,9 +664,15 @@ class CGInfo:
     iters = 0
     resnorm = float("nan")
     converged = True
+    # which form ran (dsea_cg_last_form): "streaming" | "persistent" (one launch, the reference's recurrences, bit-identical
+    # to streaming) | "persistent, one exchange" (Chronopoulos-Gear recurrences: same iteration in exact arithmetic, not
+    # CG.py:31-40's rounding sequence -- the default for the full-space TFIM operand at 2^11 ... 2^20 rows); a persistent
+    # launch that timed out is repeated in the streaming form and says so here
+    form = "streaming"
 
 
 last_cg = CGInfo()
+CG_FORMS = ("streaming", "persistent", "persistent, one exchange")
 
 
 # Latency-bound solves on small halo-1 operators (BASELINE config 3): run the persistent single-launch CG in its
@@ -734,6 +740,9 @@ def cg(b, x0, *, native=None, callable_A=None, shift=None, eps=1e-7, maxiter=Non
                     ws.set_persist(-1)
         check(rc, "dsea_cg_run", allow=(_lib.ERR_NOT_CONVERGED,))
         last_cg.iters, last_cg.resnorm, last_cg.converged = iters.value, res.value, rc == 0
+        form = ctypes.c_int(0)
+        check(lib.dsea_cg_last_form(ws.handle, byref(form)), "dsea_cg_last_form")
+        last_cg.form = CG_FORMS[form.value]
         return x
 
     r = torch.empty(n, dtype=F64, device=device)

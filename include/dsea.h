@@ -86,6 +86,12 @@ int dsea_ws_set_split(dsea_ws_t ws, int waves);
  * mode 200 selects the TWO-exchange form there, whose iterates are bit-identical to the streaming kernels, i.e. to
  * reference CG.py:31-40 evaluated in fp64 (other operands treat 200 as -1).                                       */
 int dsea_ws_set_persist(dsea_ws_t ws, int mode);
+/* which form the LAST dsea_cg_run on this workspace took (a persistent launch that times out is repeated by the caller in
+ * the streaming form, whose rounding sequence differs from the one-exchange form's: callers and tests can tell)       */
+#define DSEA_CG_FORM_STREAMING 0            /* mat-vec + update + direction launches: CG.py:31-40 in fp64            */
+#define DSEA_CG_FORM_PERSISTENT 1           /* one launch, the reference's recurrences (bit-identical to streaming)   */
+#define DSEA_CG_FORM_PERSISTENT_MERGED 2    /* one launch, Chronopoulos-Gear recurrences (one exchange per iteration) */
+int dsea_cg_last_form(dsea_ws_t ws, int *form);
 /* tuning knob: single-launch Lanczos of dsea_lanczos_run for README-sized problems (full-space matrix-free TFIM with
  * L <= 13, 3-point stencil without halo pointers with n <= 8192; k <= 512): the whole k-step loop is ONE launch of
  * ceil(n/128) <= 64 workgroups that own 128 rows each and meet three times per step (norm + neighbour rows, alpha,

@@ -132,7 +132,7 @@ def test_merged_reduction_form_converged_run_oracle_and_keyword():
     st = {}
     xo = oracle.cg_solve(lambda v: ref_op.H(v) - theta * v, b.cpu(), x0.cpu(), sparse=True, maxiter=50, stats=st)
     x = engine.cg(b, x0, native=op, shift=theta.to(cuda), eps=1e-7, maxiter=50, merged_reductions=True)   # keyword form
-    assert engine.last_cg.iters == st["iters"] == 50
+    assert engine.last_cg.iters == st["iters"] == 50 and engine.last_cg.form == "persistent, one exchange"
     assert float((x.cpu() - xo).abs().max()) <= 1e-10 * float(xo.abs().max())
     # the keyword leaves the workspace's own setting alone
     assert getattr(engine.Workspace.get(N, 8, cuda), "persist_mode", -1) == -1
@@ -544,6 +544,7 @@ def test_lost_peer_times_out_and_the_host_falls_back_to_the_multi_launch_kernels
             assert engine.last_cg.iters == ref[1] == 40
             assert torch.equal(x, ref[0])
             assert wsc.persist_mode == 0                                              # sticky
+            assert engine.last_cg.form == "streaming"                                 # (dsea_cg_last_form: the caller can tell)
         finally:
             lib.dsea_ws_set_fault_injection(wsc.handle, 0)
             wsc.set_persist(-1)
