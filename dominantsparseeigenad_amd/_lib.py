@@ -26,7 +26,7 @@ ERR_PREMISE = -10
 ERR_SECOND_PASS = -11
 ERR_UNSUPPORTED = -6
 COMM_ID_BYTES = 128
-POP_OVERLAP, POP_PAIRWISE, POP_NO_EXCHANGE = 1, 2, 4
+POP_OVERLAP, POP_PAIRWISE, POP_NO_EXCHANGE, POP_CG_REFERENCE, POP_CG_ONE_REDUCTION = 1, 2, 4, 8, 16
 # caller-supplied collectives of dsea_comm_create_callbacks (device pointers + the stream the data was produced on)
 ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_int64, c_void_p)
 ALLTOALL_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p)

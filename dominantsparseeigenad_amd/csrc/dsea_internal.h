@@ -194,6 +194,9 @@ void launch_cg_init_check(double* state, double eps, hipStream_t st);
 void launch_cg_update(double* x, double* r, const double* d, const double* Ad, double* state, int64_t n,
                       double* P, hipStream_t st);
 void launch_cg_check(double* state, double eps, hipStream_t st);
+int launch_pcg_update(double* x, double* r, double* p, double* s, const double* w, const double* state, int64_t n,
+                      double* P, hipStream_t st);
+void launch_pcg_scalars(double* state, const double* pair, double eps, int first, hipStream_t st);
 void launch_cg_direction(const double* r, double* d, const double* state, int64_t n, hipStream_t st);
 void launch_axpy_multi_dot(double a_host, const double* a_dev, const double* const* xs, int count,
                            const double* shift, const double* skip, const double* x, double* y, int64_t n,

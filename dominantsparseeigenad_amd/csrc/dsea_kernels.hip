@@ -1114,6 +1114,70 @@ __global__ __launch_bounds__(256) void k_cg_direction(const double* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
+// One-reduction CG of the row-partitioned driver (dsea_pop_cg_run, csrc/dsea_partitioned.hip): the Chronopoulos-Gear
+// recurrences of dsea_cg_persist_tfim_big.hip <., MERGED = true> as stream kernels -- w = A'r once per iteration,
+// gamma = r.r and delta = r.w reduced TOGETHER (one all-reduce per iteration instead of two), s = A'p carried by
+// s <- w + beta s.  Same rounded elementwise operations, in the same order, as that kernel.
+//   p <- r + beta p ; s <- w + beta s ; x <- x + alpha p ; r <- r - alpha s ; partial r.r
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pcg_update(double* __restrict__ x, double* __restrict__ r,
+                                                    double* __restrict__ p, double* __restrict__ s,
+                                                    const double* __restrict__ w,
+                                                    const double* __restrict__ state, int64_t n,
+                                                    double* __restrict__ P) {
+  __shared__ double sm4[4];
+  if (state[DSEA_CG_DONE] != 0.0) return;
+  const double alpha = state[DSEA_CG_ALPHA], beta = state[DSEA_CG_BETA];
+  double acc = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * 512;
+  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; row < n; row += stride) {
+    double2 xv = ld2<true>(x, row, n), rv = ld2<true>(r, row, n), pv = ld2<true>(p, row, n);
+    double2 sv = ld2<true>(s, row, n), wv = ld2<true>(w, row, n);
+    pv.x = __dadd_rn(rv.x, __dmul_rn(beta, pv.x));
+    pv.y = __dadd_rn(rv.y, __dmul_rn(beta, pv.y));
+    sv.x = __dadd_rn(wv.x, __dmul_rn(beta, sv.x));
+    sv.y = __dadd_rn(wv.y, __dmul_rn(beta, sv.y));
+    xv.x = __dadd_rn(xv.x, __dmul_rn(alpha, pv.x));
+    xv.y = __dadd_rn(xv.y, __dmul_rn(alpha, pv.y));
+    rv.x = __dsub_rn(rv.x, __dmul_rn(alpha, sv.x));
+    rv.y = __dsub_rn(rv.y, __dmul_rn(alpha, sv.y));
+    st2<true>(p, row, n, pv);
+    st2<true>(s, row, n, sv);
+    st2<true>(x, row, n, xv);
+    st2<true>(r, row, n, rv);
+    acc = fma(rv.x, rv.x, acc);
+    acc = fma(rv.y, rv.y, acc);
+  }
+  double t = block_sum(acc, sm4);
+  if (threadIdx.x == 0) P[blockIdx.x] = t;
+}
+
+// first = 1: gamma = state[RR] (all-reduced r.r of the start residual), delta = pair[1] -> alpha = gamma / delta, beta = 0
+// first = 0: (gamma', delta) = pair (all-reduced): stopping test, beta = gamma'/gamma, alpha = gamma' / (delta - beta gamma'/alpha)
+__global__ void k_pcg_scalars(double* __restrict__ state, const double* __restrict__ pair, double eps, int first) {
+  if (state[DSEA_CG_DONE] != 0.0) return;
+  if (first) {
+    state[DSEA_CG_ALPHA] = state[DSEA_CG_RR] / pair[1];
+    state[DSEA_CG_BETA] = 0.0;
+    return;
+  }
+  const double gam2 = pair[0], del2 = pair[1];
+  const double rn = sqrt(gam2);
+  state[DSEA_CG_ITERS] += 1.0;
+  state[DSEA_CG_RESNORM] = rn;
+  if (rn < eps) {
+    state[DSEA_CG_RR] = gam2;
+    state[DSEA_CG_DONE] = 1.0;
+  } else {
+    const double gam = state[DSEA_CG_RR], alpha = state[DSEA_CG_ALPHA];
+    const double beta = gam2 / gam;
+    state[DSEA_CG_BETA] = beta;
+    state[DSEA_CG_ALPHA] = gam2 / (del2 - beta * gam2 / alpha);
+    state[DSEA_CG_RR] = gam2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // operators
 // ------------------------------------------------------------------------------------------
 // TFIM, matrix-free.  A block stages a tile of 2^T consecutive rows of x in LDS: flips of the low
@@ -2626,6 +2690,18 @@ void launch_cg_update(double* x, double* r, const double* d, const double* Ad, d
   const int nb = ew_blocks(n);
   hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(256), 0, st, x, r, d, Ad, (const double*)state, n, P);
   hipLaunchKernelGGL(k_cg_finalize_rrnew, dim3(1), dim3(256), 0, st, (const double*)P, nb, state);
+}
+
+// returns the number of r.r partials left in P (NOT summed: the caller closes them together with the mat-vec's dot)
+int launch_pcg_update(double* x, double* r, double* p, double* s, const double* w, const double* state, int64_t n,
+                      double* P, hipStream_t st) {
+  const int nb = ew_blocks(n);
+  hipLaunchKernelGGL(k_pcg_update, dim3(nb), dim3(256), 0, st, x, r, p, s, w, state, n, P);
+  return nb;
+}
+
+void launch_pcg_scalars(double* state, const double* pair, double eps, int first, hipStream_t st) {
+  hipLaunchKernelGGL(k_pcg_scalars, dim3(1), dim3(1), 0, st, state, pair, eps, first);
 }
 
 void launch_cg_check(double* state, double eps, hipStream_t st) {

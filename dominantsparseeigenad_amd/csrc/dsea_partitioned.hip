@@ -270,6 +270,62 @@ int pop_apply(dsea_pop_s* P, dsea_ws_t ws, const double* x, double* y, const dou
   DSEA_TRY(stencil_halo_exchange(P, x, st));
   return dsea_spmv(&P->local, ws, x, y, shift, dot_local, skip, (void*)st);
 }
+// ---- CG with ONE all-reduce per iteration (Chronopoulos-Gear; kernels: k_pcg_update / k_pcg_scalars) ------------------
+// per iteration: [p, s, x, r update + local r.r partials] -> mat-vec w = A'r with its exchange (+ local r.w; the SAME
+// launch closes both local sums) -> all-reduce(gamma', delta) -> scalars (stopping test, beta, alpha).  Four launches
+// and one all-reduce where the reference's recurrences need seven and two.
+int pop_cg_run_one_reduction(dsea_pop_s* P, dsea_ws_t ws, const double* shift, const double* b, double* x, double* state,
+                             double eps, int64_t maxiter, int poll_every, int64_t* iters_out, double* resnorm_out,
+                             hipStream_t st) {
+  const int64_t n = P->nloc;
+  Workspace& w = ws->w;
+  double* s = w.vec[0];
+  double* r = w.vec[1];
+  double* p = w.vec[2];
+  double* wv = w.vec[3];
+  double* pair = w.scal + 32;                                   // (gamma', delta): local sums, then all-reduced in place
+  double* rrP = w.aux + 3 * DSEA_MAX_WAVE_TILES;                // partials of r.r left by k_pcg_update
+  const double* done = state + DSEA_CG_DONE;
+  // r = b - A'x0 ; early out                                           (CG.py:26-29)
+  DSEA_TRY(pop_apply(P, ws, x, wv, shift, nullptr, w.scal + 36, st));
+  DSEA_TRY(dsea_cg_init(ws, b, wv, r, p, state, n, (void*)st));       // (p = r: what beta = 0 makes of it anyway)
+  DSEA_TRY(comm_allreduce(P->comm, state + DSEA_CG_RR, 1, st));
+  DSEA_TRY(dsea_cg_init_check(ws, state, eps, (void*)st));
+  HIP_TRY(hipMemsetAsync(s, 0, (size_t)n * sizeof(double), st));
+  // w = A'r, delta = r.w ; alpha = gamma / delta, beta = 0
+  DSEA_TRY(pop_apply(P, ws, r, wv, shift, done, pair + 1, st));
+  DSEA_TRY(comm_allreduce(P->comm, pair + 1, 1, st));
+  launch_pcg_scalars(state, pair, eps, 1, st);
+  double host_state[DSEA_CG_STATE_LEN];
+  int64_t issued = 0;
+  HIP_TRY(hipMemcpyAsync(host_state, state, sizeof(host_state), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  bool finished = host_state[DSEA_CG_DONE] != 0.0 || maxiter == 0;
+  while (!finished) {
+    const int64_t chunk = (maxiter - issued) < poll_every ? (maxiter - issued) : poll_every;
+    for (int64_t it = 0; it < chunk; ++it) {
+      const int nb = launch_pcg_update(x, r, p, s, wv, state, n, rrP, st);
+      w.pend_P = rrP;                                             // closed by the mat-vec's own dot-closing launch
+      w.pend_count = nb;
+      w.pend_out = pair;
+      DSEA_TRY(pop_apply(P, ws, r, wv, shift, done, pair + 1, st));
+      if (w.pend_P) {
+        launch_finalize1(w.pend_P, w.pend_count, w.pend_out, st);
+        w.pend_P = nullptr;
+      }
+      DSEA_TRY(comm_allreduce(P->comm, pair, 2, st));
+      launch_pcg_scalars(state, pair, eps, 0, st);
+    }
+    issued += chunk;
+    HIP_TRY(hipMemcpyAsync(host_state, state, sizeof(host_state), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    finished = (host_state[DSEA_CG_DONE] != 0.0) || issued >= maxiter;
+  }
+  if (iters_out) *iters_out = (int64_t)host_state[DSEA_CG_ITERS];
+  if (resnorm_out) *resnorm_out = host_state[DSEA_CG_RESNORM];
+  if (hipGetLastError() != hipSuccess) return DSEA_ERR_HIP;
+  return host_state[DSEA_CG_DONE] != 0.0 ? DSEA_OK : DSEA_ERR_NOT_CONVERGED;
+}
 }  // namespace
 
 extern "C" {
@@ -613,6 +669,10 @@ int dsea_pop_cg_run(dsea_pop_t P, dsea_ws_t ws, const double* shift, const doubl
   double* Ad = w.vec[3];
   const double* done = state + DSEA_CG_DONE;
   if (poll_every <= 0) poll_every = 16;
+  const bool one_reduction = (P->flags & DSEA_POP_CG_ONE_REDUCTION) ||
+                             (P->kind == OP_TFIM && !(P->flags & DSEA_POP_CG_REFERENCE));
+  if (one_reduction)
+    return pop_cg_run_one_reduction(P, ws, shift, b, x, state, eps, maxiter, poll_every, iters_out, resnorm_out, st);
   // r = b - A'x0 ; early out ; d = r                                   (CG.py:26-30)
   DSEA_TRY(pop_apply(P, ws, x, Ad, shift, nullptr, w.scal + 36, st));
   DSEA_TRY(dsea_cg_init(ws, b, Ad, r, d, state, n, stream));

@@ -702,8 +702,21 @@ class PartitionedOperator:
     def driver(self):
         return "library (%s)" % self._ncomm.kind if self._pop else "python"
 
+    # library driver's CG: None = the library's default per operator (TFIM: one all-reduce per iteration, Chronopoulos-Gear
+    # recurrences; stencil: the reference's recurrences, two all-reduces), True / False force the reference's recurrences
+    # on / off.  DSEA_CG_REFERENCE_RECURRENCES=1 (read when the solve starts) = True everywhere, as for the one-GPU solver.
+    cg_reference_recurrences = None
+
+    def _cg_flags(self):
+        import os
+        from . import _lib
+        ref = self.cg_reference_recurrences
+        if os.environ.get("DSEA_CG_REFERENCE_RECURRENCES", "") == "1" or _engine_mod.CG_TFIM_REFERENCE_RECURRENCES:
+            ref = True
+        return 0 if ref is None else (_lib.POP_CG_REFERENCE if ref else _lib.POP_CG_ONE_REDUCTION)
+
     def _pop_flags(self):
-        return 0
+        return self._cg_flags()
 
     def _lanczos_library(self, k, q0_slab, arena):
         """the whole k-step loop inside libdsea (dsea_pop_lanczos_run): slab kernels and collectives issued back to
@@ -775,6 +788,11 @@ class PartitionedOperator:
         self.last_cg_iters, self.last_cg_resnorm = int(iters.value), float(res.value)
         info = _engine_mod.last_cg
         info.iters, info.resnorm, info.converged = self.last_cg_iters, self.last_cg_resnorm, rc == 0
+        flags = self._pop_flags()
+        one = bool(flags & _lib.POP_CG_ONE_REDUCTION) or (isinstance(self, PartitionedTFIMOperator) and
+                                                         not flags & _lib.POP_CG_REFERENCE)
+        info.form = "row-partitioned, one all-reduce per iteration" if one else \
+            "row-partitioned, reference recurrences (two all-reduces per iteration)"
         if x.data_ptr() != x0.data_ptr():
             x0.copy_(x)
         return x0
@@ -894,6 +912,7 @@ class PartitionedOperator:
         self.last_cg_resnorm = float(host[CG_RESNORM].item())
         info = _engine_mod.last_cg
         info.iters, info.resnorm, info.converged = self.last_cg_iters, self.last_cg_resnorm, host[CG_DONE].item() != 0.0
+        info.form = "row-partitioned, reference recurrences (two all-reduces per iteration; Python driver)"
         return x
 
     # ---- plain (non-differentiable) mat-vec on buffers
@@ -1045,7 +1064,7 @@ class PartitionedTFIMOperator(PartitionedOperator):
         from . import _lib
         return (_lib.POP_OVERLAP if (self.overlap and self.p > 0) else 0) | \
             (_lib.POP_PAIRWISE if self._pairwise_forced else 0) | \
-            (_lib.POP_NO_EXCHANGE if getattr(self, "measure_without_exchange", False) else 0)
+            (_lib.POP_NO_EXCHANGE if getattr(self, "measure_without_exchange", False) else 0) | self._cg_flags()
 
     # With TWO ranks every mat-vec moves one whole slab over the single xGMI link between the two GPUs (268 MB at 2^25
     # rows: 3.5-5 ms) -- in the Lanczos step that hides behind the dots pass, in a CG iteration it does not: ~0.9 ms of

@@ -413,6 +413,12 @@ typedef struct dsea_pop_s *dsea_pop_t;
 /* MEASUREMENT ONLY: the slab exchange is not issued and the receive buffers are used as they are -- the numbers are
  * meaningless, the time is that of the same step without its exchange (bench.py: exposed exchange = step - this)  */
 #define DSEA_POP_NO_EXCHANGE 4
+/* dsea_pop_cg_run: which recurrences.  Default: TFIM -- ONE all-reduce per iteration (Chronopoulos-Gear: r.r and r.A'r
+ * reduced together, A'p carried by a recurrence; the same iteration in exact arithmetic, not CG.py:31-40's rounding
+ * sequence; what the one-GPU single-launch solver does by default, dsea_ws_set_persist); stencil3 -- the reference's
+ * recurrences, two all-reduces per iteration.  The flags force one or the other.                                   */
+#define DSEA_POP_CG_REFERENCE 8
+#define DSEA_POP_CG_ONE_REDUCTION 16
 size_t dsea_pop_tfim_scratch_doubles(int L, int world);
 int dsea_pop_create_tfim(int L, dsea_comm_t comm, const double *g_dev, double g_const, double diag_scale,
                          double *scratch, void *side_stream, int flags, double tau, dsea_pop_t *out);
@@ -435,8 +441,8 @@ int dsea_pop_lanczos_run(dsea_pop_t pop, dsea_ws_t ws, int k, const double *q0, 
 /* SYNCHRONISES: DSEA_OK, or DSEA_ERR_PREMISE with *step = first step whose overlap premise failed                 */
 int dsea_pop_lanczos_status(dsea_pop_t pop, dsea_ws_t ws, int *step, void *stream);
 /* CG on (A - (*shift)) x = b on slabs (reference CG.py:24-41 distributed): per iteration one exchange and two scalar
- * all-reduces; the stopping test runs on the device on replicated scalars, the host polls every `poll_every`
- * iterations.  SYNCHRONISES before returning.  r, d, Ad: the workspace's vectors.                                 */
+ * all-reduces (reference recurrences) or ONE (DSEA_POP_CG_* above); the stopping test runs on the device on replicated
+ * scalars, the host polls every `poll_every` iterations.  SYNCHRONISES before returning.  Work vectors: the workspace's. */
 int dsea_pop_cg_run(dsea_pop_t pop, dsea_ws_t ws, const double *shift, const double *b, double *x, double *state,
                     double eps, int64_t maxiter, int poll_every, int64_t *iters_out, double *resnorm_out, void *stream);
 

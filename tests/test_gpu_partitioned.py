@@ -88,10 +88,11 @@ def _case_driver_env(rank, world, backend, dev, overlap, env, tau=None):
     q0 = torch.from_numpy(normal_vector(nloc, 5100, offset=off)).to(dev)
     x0 = torch.from_numpy(normal_vector(nloc, 5102, offset=off)).to(dev)
     t = torch.from_numpy(normal_vector(nloc, 5103, offset=off)).to(dev)
+    solver.op.replicate_cg = False      # (the row-partitioned solve is what these cases compare, also at two ranks)
     E0, psi, grad = solver.forward_backward(K, q0, x0, t)
     torch.cuda.synchronize()
     return (E0.item(), psi.cpu().numpy().copy(), grad.item(), solver.last_cg_iters, solver.op.driver,
-            solver.op.overlap_fallbacks)
+            solver.op.overlap_fallbacks, engine.last_cg.form)
 
 
 def _case_driver_partial(rank, world, backend, dev, partial):
@@ -348,7 +349,9 @@ def test_library_driver_equals_python_driver(world, backend, overlap):
     collectives from inside the library (RCCL at world size 1; caller-supplied callbacks -- host-staged gloo -- for
     ranks sharing the GPU).  Same kernels in the same order as the Python driver of partitioned.py, so the results are
     bit-identical: E0, psi, gradient, CG iteration count."""
-    lib_run = _run(world, backend, "_case_driver_env", overlap, {})
+    # (the Python driver keeps the reference's CG recurrences; the library's default for TFIM is the one-reduction form --
+    #  test_library_driver_one_reduction_cg -- so the bit-for-bit comparison asks the library for the reference's)
+    lib_run = _run(world, backend, "_case_driver_env", overlap, {"DSEA_CG_REFERENCE_RECURRENCES": "1"})
     py_run = _run(world, backend, "_case_driver_env", overlap, {"DSEA_DRIVER": "python"})
     for r in range(world):
         assert lib_run[r][4].startswith("library") and py_run[r][4] == "python", (lib_run[r][4], py_run[r][4])
@@ -359,6 +362,23 @@ def test_library_driver_equals_python_driver(world, backend, overlap):
         assert "rccl" in lib_run[0][4]
     else:
         assert "callbacks" in lib_run[0][4]
+
+
+@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (4, "gloo")])
+def test_library_driver_one_reduction_cg(world, backend):
+    """dsea_pop_cg_run's default for the TFIM operand: ONE all-reduce per iteration (Chronopoulos-Gear recurrences: r.r and
+    r.A'r reduced together, kernels k_pcg_update / k_pcg_scalars) against the reference's recurrences (CG.py:31-40, two
+    all-reduces) on the same slabs: same forward pass bit for bit, same iteration count, gradient to 1e-10 (CG eps 1e-12);
+    and against the CPU oracle through test_partitioned_hip_backend, which runs the default."""
+    one = _run(world, backend, "_case_driver_env", False, {})
+    ref = _run(world, backend, "_case_driver_env", False, {"DSEA_CG_REFERENCE_RECURRENCES": "1"})
+    for r in range(world):
+        assert one[r][4].startswith("library") and ref[r][4].startswith("library")
+        assert one[r][0] == ref[r][0] and np.array_equal(one[r][1], ref[r][1])                 # forward: untouched
+        assert one[r][2] == one[0][2] and one[r][3] == one[0][3]                               # replicated scalars
+        assert abs(one[r][3] - ref[r][3]) <= 1, (one[r][3], ref[r][3])
+        assert abs(one[r][2] - ref[r][2]) < 1e-10 * abs(ref[r][2]), (one[r][2], ref[r][2])
+        assert one[r][6] == "row-partitioned, one all-reduce per iteration" and "reference" in ref[r][6], (one[r][6], ref[r][6])
 
 
 @pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (4, "gloo")])

@@ -11,7 +11,7 @@
 #   stats               rocprofv3 --kernel-trace --stats of 3 headline steps -> kernel_stats.csv
 #   pmc                 FETCH_SIZE / WRITE_SIZE passes (separate) -> pmc_traffic.json via tools/pmc_traffic.py
 #   libdriver:LL        bench --force-partitioned --L-local LL (library driver, one rank over RCCL) + its kernel stats
-#   ldprof              native loop vs library driver at 2^20 rows, per-kernel averages per Lanczos step
+#   ldprof[:LL]         native loop vs library driver at 2^LL rows (default 20), per-kernel averages per Lanczos step
 #   c3                  config 3 (stencil N = 1e5, k = 300): timings + kernel stats (tools/bench_c3.py)
 #   small               single-launch regimes: tools/lanczos_small_timing.py, tools/cg_small_timing.py
 #   anchors             bench.py one-GPU anchors (L = 28 k = 100 / k = 80 shadow on+off; 2^25 rows k = 200)
@@ -70,15 +70,16 @@ for spec in "$@"; do
       python bench.py --force-partitioned --L-local $LL --no-cpu-baseline --no-extras > "$O/libdriver_2p$LL.json" 2> "$O/libdriver_2p$LL.err"; echo "rc=$?"; line "$O/libdriver_2p$LL.json" 500
       stats_of libdriver_2p${LL}_kernel_stats --force-partitioned --L-local $LL --steps 1 --warmup 1 --no-cpu-baseline --no-extras --no-kernel-events ;;
     ldprof)
+      LL=${a1:-20}; NS=3; [ "$LL" -ge 24 ] && NS=1
       for v in native libdriver; do
         extra=""; [ $v = libdriver ] && extra="--force-partitioned"
-        stats_of ld20_$v $extra --steps 3 --warmup 1 $Q --no-kernel-events > /dev/null
-        echo "== $v: $(tail -1 "$O/ld20_$v.statslog" | python3 -c 'import json,sys; print(json.loads(sys.stdin.read())["ms_per_step"])') ms per fwd+bwd under the profiler"
-        python3 - "$O/ld20_$v.csv" <<'PY'
+        stats_of ld${LL}_$v $extra --L-local $LL --k 200 --steps $NS --warmup 1 $Q --no-kernel-events > /dev/null
+        echo "== $v: $(tail -1 "$O/ld${LL}_$v.statslog" | python3 -c 'import json,sys; print(json.loads(sys.stdin.read())["ms_per_step"])') ms per fwd+bwd under the profiler"
+        python3 - "$O/ld${LL}_$v.csv" $NS <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-steps = 4 * 199.0
-for r in rows[:14]:
+steps = (int(sys.argv[2]) + 1) * 199.0
+for r in rows[:16]:
     per = float(r['TotalDurationNs']) / 1e3 / steps
     print("   %-46s calls %5s avg %8.2f us   per Lanczos step %7.2f us" % (r['Name'].split('(')[0][-46:], r['Calls'], float(r['AverageNs']) / 1e3, per))
 PY
