@@ -128,6 +128,12 @@ class Workspace:
         self.lanczos_persist_mode = -1
         if _NO_PERSIST:             # DSEA_NO_PERSIST=1: every solve on the multi-launch kernels (A/B measurements)
             self.set_persist(0)
+        # A/B measurements only: DSEA_WS_SPLIT=<waves> / DSEA_WS_RPL=<rows per lane> force the geometry of the basis-streaming
+        # kernels for every workspace of the process (dsea_ws_set_split / dsea_ws_set_rows_per_lane)
+        if _os.environ.get("DSEA_WS_SPLIT"):
+            self.set_split(int(_os.environ["DSEA_WS_SPLIT"]))
+        if _os.environ.get("DSEA_WS_RPL"):
+            self.set_rows_per_lane(int(_os.environ["DSEA_WS_RPL"]))
 
     def __del__(self):
         try:
