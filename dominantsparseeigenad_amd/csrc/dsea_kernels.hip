@@ -1,9 +1,4 @@
-  // a block walks tiles blockIdx.x, +gridDim.x, ... (the grid is capped so that the per-block partials fit)
-  // (round 5: mapping workgroup b to tile (b mod 8) * ntiles / 8 + b / 8 -- every XCD a CONTIGUOUS eighth of the vector instead
-  //  of every eighth tile -- was built and measured: 12.65 vs 12.69 us, PMC read 33.8 MB = 4.0 x the vector either way, as the
-  //  sub-cube argument of DESIGN.md section 3 says; profiles/r05_tfim_tail_xcd_map.txt.  Not kept.)
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t base = tile * TILE;// dsea_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the dominant-eigenpair hot path.
+// dsea_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the dominant-eigenpair hot path.
 //
 // Everything here is bandwidth-bound fp64 vector work (no MFMA): the Krylov basis is streamed
 // from HBM with 16-byte coalesced loads (one wave reads 1 KiB per instruction), partial sums are
@@ -1254,17 +1249,10 @@ __global__ __launch_bounds__(256) void k_spmv_tfim(TfimParams p, const double* _
   double beta = 1.0, g = 0.0, s = 0.0;
   bool first = true;
   // a block walks tiles blockIdx.x, +gridDim.x, ... (the grid is capped so that the per-block partials fit)
-#ifdef DSEA_TFIM_XCD_MAP
-  // A/B build only (round 5, verdict item 5; profiles/r05_tfim_tail_xcd_map.txt): workgroups go to the XCDs round robin, so
-  // with this map XCD x owns the CONTIGUOUS eighth x of the vector (top three tile bits) instead of every eighth tile
-  const bool xmap = gridDim.x == ntiles && (ntiles & 7) == 0;
-#endif
-  for (int64_t tile0 = blockIdx.x; tile0 < ntiles; tile0 += gridDim.x) {
-#ifdef DSEA_TFIM_XCD_MAP
-    const int64_t tile = xmap ? (tile0 & 7) * (ntiles >> 3) + (tile0 >> 3) : tile0;
-#else
-    const int64_t tile = tile0;
-#endif
+  // (round 5: mapping workgroup b to tile (b mod 8) * ntiles / 8 + b / 8 -- every XCD a CONTIGUOUS eighth of the vector instead
+  //  of every eighth tile -- was built and measured: 12.65 vs 12.69 us, PMC read 33.8 MB = 4.0 x the vector either way, as the
+  //  sub-cube argument of DESIGN.md section 3 says; profiles/r05_tfim_tail_xcd_map.txt.  Not kept.)
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t base = tile * TILE;
     // 1. everything that does not depend on a scalar is put in flight first: the block's own rows and the
     //    out-of-tile neighbours of the first FB far bits (they are scaled by 1/beta afterwards -- linearity).  The
