@@ -412,10 +412,8 @@ __global__ __launch_bounds__(256) void k_arnoldi_finish_opt(const double* __rest
   const double nrm1 = s_nrm1;
   const double ww = c1[j + 1];            // ||A v_j - shift v_j||^2
   if (!(nrm1 >= 0.5 * ww)) {              // DGKS: the first pass lost too much -- this step needs the second pass
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      brk[0] = -(double)(j + 1);
-      if (counter) counter[0] += 1.0;
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) brk[0] = -(double)(j + 1);
+    // (not counted here: the caller repeats the step in the default mode, whose k_dgks_decide counts the second pass once)
     return;
   }
   const double beta = sqrt(nrm1);

@@ -247,6 +247,12 @@ class BasisArena:
     SHRINK_RATIO = 4
     SHRINK_MIN_BYTES = 1 << 30
     last_placement = None           # [us per probe pass of each candidate], for the curious
+    # When the arena REPLACES a buffer (growth, shrink) or drops the probe's losing candidates it hands the freed blocks back
+    # to the driver with ``torch.cuda.empty_cache()`` -- at L = 28 the caching allocator otherwise keeps 200 GiB "reserved
+    # but unallocated" and the next basis does not fit.  That call also releases every OTHER cached block of the process
+    # (a training loop pays re-allocation for them): set False to keep the arena from touching the allocator's cache; the
+    # freed buffers then stay cached by torch like any other tensor's memory ("memory").
+    RELEASE_TO_DRIVER = True
 
     @classmethod
     def get(cls, device, tag, nbytes, probe=None):
@@ -260,7 +266,7 @@ class BasisArena:
             if buf is None or buf.numel() < nbytes or too_big:
                 if buf is not None:
                     del cls._bufs[key], buf
-                    if device.type == "cuda":
+                    if device.type == "cuda" and cls.RELEASE_TO_DRIVER:
                         torch.cuda.empty_cache()      # the old buffer goes back to the driver before the new one is taken
                 tries = 1
                 if probe is not None and device.type == "cuda" and nbytes >= cls.PLACEMENT_MIN_BYTES:
@@ -279,7 +285,8 @@ class BasisArena:
                     cls.last_placement = [t for t, _ in cands]
                     buf = min(cands, key=lambda tb: tb[0])[1]
                     del cands, nxt
-                    torch.cuda.empty_cache()          # the losing candidates go back to the driver
+                    if cls.RELEASE_TO_DRIVER:
+                        torch.cuda.empty_cache()      # the losing candidates go back to the driver
                 cls._bufs[key] = buf
         return buf
 

@@ -425,7 +425,10 @@ class TransferOperator:
     def __init__(self, A, transpose=False):
         if A.device.type != "cuda" or A.dim() != 3 or A.shape[1] != A.shape[2]:
             raise ValueError("TransferOperator takes a CUDA tensor of shape (d, D, D)")
-        self.A = A.detach().to(F64).contiguous()
+        # a private fp64 COPY: the operator is a snapshot of A at construction, whatever path applies it (the hand-written
+        # kernels read a fragment-packed copy made by dsea_op_create_transfer, the rocBLAS path reads this tensor) -- an
+        # in-place update of the caller's tensor is never seen; build a new operator for a new A (general.py:59 does)
+        self.A = A.detach().to(F64).clone(memory_format=torch.contiguous_format)
         self.d, self.D = int(A.shape[0]), int(A.shape[1])
         self.n = self.D * self.D
         self.shape = (self.n, self.n)

@@ -470,9 +470,16 @@ class NativeComm:
         mode = os.environ.get("DSEA_COMM", "")
         key = ("WORLD" if cls._is_world(group) else id(group), str(device), mode,
                id(exchange_group) if exchange_group is not None else None, os.environ.get("DSEA_COMM_SINGLE", ""))
+        live = group if group is not None else dist.group.WORLD
         hit = cls._cache.get(key)
-        if hit is not None and hit.handle:
+        if hit is not None and hit.handle and getattr(hit, "_group_ref", lambda: None)() is live:
             return hit
+        if hit is not None:
+            # the process group this pair was made for is gone (dist.destroy_process_group() and a new init in the same
+            # process give a NEW group object): an adopted handle points at a destroyed ncclComm_t -- drop it
+            hit.handle = None if "adopted" in hit.kind else hit.handle
+            hit.close()
+            del cls._cache[key]
         backend_cls = getattr(torch._C._distributed_c10d, "ProcessGroupNCCL", None)
         can_adopt = backend_cls is not None and hasattr(backend_cls, "_comm_ptr")
         adoptable = can_adopt and (exchange_group is not None or cls._is_world(group) or dist.get_world_size(group) == 1)
@@ -484,6 +491,8 @@ class NativeComm:
             nc = cls.own(group, device)
         else:
             nc = cls.adopt_torch(group, device, exchange_group)
+        import weakref
+        nc._group_ref = weakref.ref(live)
         cls._cache[key] = nc
         return nc
 
