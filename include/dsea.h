@@ -71,20 +71,14 @@ int dsea_ws_set_rows_per_lane(dsea_ws_t ws, int rpl);
  * 128-row tile and splits the basis vectors between its waves.  -1 = automatic (on below ~1.3e5 rows),
  * 0 = off, 4 / 8 / 16 = forced.                                                                          */
 int dsea_ws_set_split(dsea_ws_t ws, int waves);
-/* tuning knob: persistent single-launch CG of dsea_cg_run (3-point stencil without halo pointers, n <= 2^19): the
- * whole solve is ONE launch whose workgroups keep x, r, d in registers and exchange only per-tile partial sums and
- * edge elements; iterates are bit-identical to the streaming 3-launches-per-iteration form.
- * -1 = automatic (on where it applies), 0 = off (streaming form); forced geometries: 1 / 2 = that many row pairs per
- * thread in workgroups of 1024 threads, 21 / 22 = in workgroups of 512, 11 / 12 = in workgroups of 256.
- * 100 + g (g = 0 automatic geometry, or one of the codes above): the MERGED-REDUCTION form -- one grid-wide exchange
- * per iteration instead of two (r.r and r.Ar reduced together, A p carried by a recurrence: Chronopoulos-Gear).  The
- * same iteration in exact arithmetic, NOT the rounding sequence of reference CG.py:31-40: an option for
- * latency-bound solves on the STENCIL operand, never selected automatically there.
- * Full-space matrix-free TFIM operand at 2^11 ... 2^20 rows (the adjoint solve of BASELINE configs[1]): the single-launch
- * form makes ONE grid-wide exchange per iteration by default (the same Chronopoulos-Gear recurrences; measured within
- * 1e-15 of the two-exchange form on SPD systems, same iteration counts: profiles/r04_cg_one_exchange_check.txt);
- * mode 200 selects the TWO-exchange form there, whose iterates are bit-identical to the streaming kernels, i.e. to
- * reference CG.py:31-40 evaluated in fp64 (other operands treat 200 as -1).                                       */
+/* Persistent single-launch CG of dsea_cg_run (3-point stencil without halo pointers up to 2^19 rows; full-space matrix-free
+ * TFIM at 2^11 ... 2^20 rows): the whole solve is ONE launch.                    design: docs/design/04-kernels.md 3a, 3c, 3e
+ *   -1  automatic (on where it applies)          0  off (streaming form: three launches per iteration)
+ *   1, 2 / 21, 22 / 11, 12   forced geometry: row pairs per thread in workgroups of 1024 / 512 / 256 threads (stencil)
+ *   100 + g   MERGED-REDUCTION form, one grid-wide exchange per iteration (Chronopoulos-Gear recurrences: the same iteration
+ *             in exact arithmetic, NOT the rounding sequence of reference CG.py:31-40); never automatic on the stencil
+ *   200       TFIM: the TWO-exchange form, iterates bit-identical to the streaming kernels (other operands: as -1)
+ * Defaults: stencil -- the reference's recurrences (bit-identical to streaming); TFIM -- the one-exchange form.          */
 int dsea_ws_set_persist(dsea_ws_t ws, int mode);
 /* which form the LAST dsea_cg_run on this workspace took (a persistent launch that times out is repeated by the caller in
  * the streaming form, whose rounding sequence differs from the one-exchange form's: callers and tests can tell)       */
@@ -92,35 +86,22 @@ int dsea_ws_set_persist(dsea_ws_t ws, int mode);
 #define DSEA_CG_FORM_PERSISTENT 1           /* one launch, the reference's recurrences (bit-identical to streaming)   */
 #define DSEA_CG_FORM_PERSISTENT_MERGED 2    /* one launch, Chronopoulos-Gear recurrences (one exchange per iteration) */
 int dsea_cg_last_form(dsea_ws_t ws, int *form);
-/* tuning knob: single-launch Lanczos of dsea_lanczos_run for README-sized problems (full-space matrix-free TFIM with
- * L <= 13, 3-point stencil without halo pointers with n <= 8192; k <= 512): the whole k-step loop is ONE launch of
- * ceil(n/128) <= 64 workgroups that own 128 rows each and meet three times per step (norm + neighbour rows, alpha,
- * re-orthogonalisation coefficients).  Same algorithm and the same expressions as the multi-launch kernels; partial
- * sums are combined in a different order (per 128-row slab): T agrees with the multi-launch form to rounding, not bit
- * for bit.  -1 = automatic (on up to n = 4096, where it is measured to win), 0 = off, 1 = on wherever it applies.  A lost
- * peer workgroup (bounded spins) makes
- * dsea_lanczos_status return DSEA_ERR_TIMEOUT; the caller then repeats the run with the knob off.
- * The same knob governs the MID-SIZE single-launch form (3-point stencil without halo pointers, 8192 < n <= 131072 rows,
- * k <= 505: BASELINE configs[2]; csrc/dsea_lanczos_persist_mid.hip): one workgroup per CU owns a slab of rows and keeps
- * its rows of the first ~80 basis vectors in LDS and registers, the rest is streamed (fp64 dots, bf16 shadow correction
- * when a shadow is set).  Automatic from 49152 rows up to k = 400 (where it is measured to win), mode 1 forces it
- * wherever it applies, mode 2 = only the README-sized form (this one off).                                         */
+/* Single-launch Lanczos of dsea_lanczos_run: README-sized problems (TFIM L <= 13, stencil n <= 8192, k <= 512) and the
+ * MID-SIZE stencil form (8192 < n <= 131072 rows, k <= 505: BASELINE configs[2]).  Same algorithm and expressions as the
+ * multi-launch kernels; partial sums are combined per slab, so T agrees to rounding, not bit for bit.
+ *   -1  automatic (on where it is measured to win)    0  off    1  on wherever it applies    2  README-sized form only
+ * A lost peer workgroup (bounded spins) makes dsea_lanczos_status return DSEA_ERR_TIMEOUT; the caller repeats the run with
+ * the knob off.                                                                  design: docs/design/04-kernels.md 3c, 3d  */
 int dsea_ws_set_lanczos_persist(dsea_ws_t ws, int mode);
 /* Gram-Schmidt passes per step of dsea_lanczos_run: 1 = the reference (single-pass classical Gram-Schmidt against all
  * previous vectors, Lanczos.py:66), 2 = the pass is repeated on the corrected vector ("CGS2": orthogonality at rounding
  * level even where one pass leaves eps ||u|| / beta) -- an option the reference lacks, never selected automatically. */
 int dsea_ws_set_reorth_passes(dsea_ws_t ws, int passes);
-/* PARTIAL re-orthogonalisation for dsea_lanczos_run (Simon 1984) -- an option the reference lacks (it re-orthogonalises on
- * every step, Lanczos.py:66; SURVEY.md 8 f-4 lists "selective reorth"), never selected automatically: a one-block kernel per
- * step advances the estimates omega_{i,k} ~ q_i . q_k from alpha, beta alone; only when one of them exceeds `delta`
- * (0 = the default 1e-10, the path's stated tolerance: the Ritz VECTOR is good to about delta ||A|| / gap; Simon's classical
- * sqrt(eps) = 1.49e-8 is enough for the Ritz VALUES) are this step and the next one re-orthogonalised against the whole basis, every other
- * step costs the three-term update and the mat-vec.  The basis is then orthogonal to ~delta, T and the Ritz values keep
- * full accuracy (semi-orthogonality), the Ritz vector keeps its residual.  Operators with a fused tail only (TFIM, SELL,
- * stencil), multi-launch form, fp64 basis (no bf16 shadow: the coefficients are no longer at rounding level); otherwise
- * dsea_lanczos_run returns DSEA_ERR_UNSUPPORTED.  dsea_pop_lanczos_run honours it too (global norm by one more scalar
- * all-reduce per step, identical decisions on every rank, no overlapped exchange).  dsea_lanczos_reorth_stats (synchronises) reports how many steps of the
- * last run were re-orthogonalised and the ||A|| estimate the recurrence used.                                          */
+/* PARTIAL re-orthogonalisation for dsea_lanczos_run / dsea_pop_lanczos_run (Simon 1984) -- an option the reference lacks
+ * (it re-orthogonalises on every step, Lanczos.py:66), never selected automatically.  A step is re-orthogonalised only when
+ * the omega recurrence exceeds `delta` (0 = the default 1e-10).  Operators with a fused tail only, multi-launch form, fp64
+ * basis; otherwise DSEA_ERR_UNSUPPORTED.  dsea_lanczos_reorth_stats (synchronises): steps re-orthogonalised in the last run
+ * and the ||A|| estimate used.                                                  design: docs/design/09-next-rows-f1-f4.md 8.4 */
 int dsea_ws_set_partial_reorth(dsea_ws_t ws, int on, double delta);
 int dsea_lanczos_reorth_stats(dsea_ws_t ws, int64_t *reorth_steps, double *anorm, void *stream);
 /* TEST HOOK for the persistent single-launch forms (Lanczos, TFIM CG): with lose_peer != 0 the last workgroup of such a
@@ -185,27 +166,21 @@ int dsea_op_create_stencil3(int64_t n, double coef, const double *V_dev, const d
 #define DSEA_TUNE_CSR_GROUP 2
 int dsea_op_set_tuning(dsea_op_t op, int key, int value);
 
-/* GEMM-shaped operands of the NON-symmetric primitives (reference eig.py) -- the one place on this path where a matrix
- * core is the right unit.  The transfer operand runs on hand-written fp64 MFMA kernels up to D = 768 (below), the general
- * dense operand on a hand-written row-streaming GEMV (HBM-bound: 6.2 TB/s from n = 4096; transpose != 0 uses a column-strip
- * kernel that fills the chip only for large n -- callers that apply A^T repeatedly hand in the transposed matrix);
- * only transfer operands beyond D = 768 go to rocBLAS, bound at run time from the copy already in the process (it may
- * keep device memory of its own; without it the hand-written kernels run at every size).
- *   dense   : row-major n x n matrix (eig.py:28-30, DominantEig); transpose != 0 applies A^T.
- *   transfer: MPS transfer matrix of a rank-3 tensor A (d x D x D row-major), dimension D^2, vectors are D x D
- *             row-major (reference examples/TFIM_vumps/general.py:59-66):
+/* GEMM-shaped operands of the NON-symmetric primitives (reference eig.py) -- the one place on this path where a matrix core
+ * is the right unit.                                                            design: docs/design/09-next-rows-f1-f4.md 8.1
+ *   dense   : row-major n x n matrix (eig.py:28-30, DominantEig); transpose != 0 applies A^T.  Hand-written row-streaming
+ *             GEMV (HBM-bound); callers that apply A^T repeatedly hand in the transposed matrix.
+ *   transfer: MPS transfer matrix of a rank-3 tensor A (d x D x D row-major), dimension D^2, vectors are D x D row-major
+ *             (reference examples/TFIM_vumps/general.py:59-66):
  *                 transpose == 0:  y = sum_s A_s x A_s^T        ("Gong",  general.py:59-61)
  *                 transpose != 0:  y = sum_s A_s^T x A_s        ("GongT", general.py:62-64)
- *             as two strided-batched GEMMs in the "X Y^T" shape (the transposed form is the same contraction on
- *             the slice-wise transposed tensor, copied once) + a transpose and a slice-sum kernel (rocBLAS), or -- any D,
- *             zero-padded to a multiple of 64 inside -- as two hand-written fp64 MFMA kernels (csrc/dsea_transfer_mfma.hip: one stacked product
- *             and one product over the inner dimension d D; no transpose, no slice sum, no vendor library).  The hand-written
- *             pair is the default where it is measured faster (D <= 768: 9-89 us against 20-110, e.g. the reference examples'
- *             D = 80: 12.5 vs 20.8 us; beyond, the two paths are within 3 % of each other),
- *             the library GEMMs beyond; environment DSEA_TRANSFER_MFMA=1 / =0 forces one or the other;
- *             the hand-written pair is also the path taken when rocBLAS is not available.  `work`:
- *             caller-owned scratch of dsea_op_transfer_work_bytes(D, d) (~ (1 + 3 d) D^2 + 2 d Dp^2 doubles, Dp = D rounded up to 64); dsea_op_create_transfer
- *             fills part of it on `stream` (slice-wise transpose, MFMA-fragment-packed copy of the slices).   */
+ *             Two hand-written fp64 MFMA kernels (csrc/dsea_transfer_mfma.hip; any D, zero-padded to a multiple of 64 inside)
+ *             up to D = 768, two rocBLAS GEMMs beyond (bound at run time from the copy already in the process; absent: the
+ *             hand-written pair at every size).  DSEA_TRANSFER_MFMA=1 / =0 forces one or the other.
+ *             `work`: caller-owned scratch of dsea_op_transfer_work_bytes(D, d); dsea_op_create_transfer fills part of it on
+ *             `stream`.  THE TENSOR IS CAPTURED AT CREATION: the hand-written kernels read the fragment-packed copy made
+ *             then, the rocBLAS path reads A_dev itself -- A_dev must stay unchanged for the life of the operator, and an
+ *             updated tensor needs a new operator.                                                                       */
 int dsea_op_create_dense(int64_t n, const double *A_dev, int64_t lda, int transpose, dsea_op_t *out);
 /* dense SYMMETRIC operand (reference symeig.py:15-31 DominantSymeig; Lanczos.py:46-49 applies torch.matmul(A, v)):
  * hand-written mat-vec that reads only the UPPER triangle of the row-major matrix -- every 64 x 64 tile is loaded
@@ -369,7 +344,8 @@ int dsea_plz_finish(dsea_ws_t ws, const double *r, const double *y, const double
  * meant to hide behind).  Either adopt communicators that already exist (ncclComm_t values, e.g. the ones PyTorch's
  * ProcessGroupNCCL holds: torch exposes them) or let the library create its own from two unique ids that the caller
  * distributes (128 bytes each, produced on rank 0).  RCCL is bound at run time from the copy already in the process
- * (DSEA_ERR_UNSUPPORTED if there is none).  For transports other than RCCL (MPI, gloo in the tests) the caller
+ * (DSEA_ERR_UNSUPPORTED if there is none); environment DSEA_RCCL_LIB=<path> binds THAT library instead (RTLD_LOCAL) -- how
+ * the tests run this branch with several ranks on one GPU over a stand-in (tests/fake_rccl; docs/design/11-round5.md).  For transports other than RCCL (MPI, gloo in the tests) the caller
  * supplies three blocking callbacks instead; they receive DEVICE pointers and the stream the data was produced on.   */
 typedef struct dsea_comm_s *dsea_comm_t;
 #define DSEA_COMM_ID_BYTES 128
