@@ -158,7 +158,9 @@ void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, in
                   const double* alpha, const double* beta, double* r, double* P, double* c_out,
                   hipStream_t st, EventPair* ev = nullptr, const double* aP = nullptr, int aCount = 0,
                   double* a_store = nullptr, bool want_rr = false, double* brk = nullptr,
-                  const double* sel = nullptr, bool sel_exit = false);   // sel: device flag of the partial re-orthogonalisation,
+                  const double* sel = nullptr, bool sel_exit = false, const double* uscale = nullptr);
+// uscale (u divided by *uscale on the fly) exists for the wave-owned geometry without the partial-reorthogonalisation gate
+inline bool rdots_uscale_ok(const TileGeom& g) { return g.split_w == 0; }   // sel: device flag of the partial re-orthogonalisation,
                   // 0 = no basis vectors on this step (three-term update and ||r||^2 only; sel_exit: return at once)
 int launch_axpy_norm_lp(int64_t n, int rps, const double* Q, int64_t ldq, const uint16_t* Qs, int64_t lds, int i,
                         const double* c, double tau, double* r, double* P, double* lp_count, hipStream_t st,

@@ -84,12 +84,14 @@ struct RdotsPre {   // the first tile's rows of u, q_{i-1}, q_{i-2}, requested b
   double2 uu[NP], qa[NP], qb[NP];
 };
 
-template <int RPL, bool GUARD, bool PRE>
+// USCALE: u is given UN-SCALED and divided by `usc` on the fly (row-partitioned library step: u = y / beta of
+// k_plz_finish is formed here instead of being stored and re-read -- the same IEEE division, bit-identical)
+template <int RPL, bool GUARD, bool PRE, bool USCALE = false>
 __device__ __forceinline__ void rdots_tile(const double* __restrict__ Q, int64_t ldq, int i, int ii, int64_t n,
                                            int64_t base, int lane, const double* __restrict__ u,
                                            double a, double b, double* __restrict__ r,
                                            double* __restrict__ sP, bool accumulate, bool want_rr,
-                                           const RdotsPre<RPL / 2>& pre) {
+                                           const RdotsPre<RPL / 2>& pre, double usc = 1.0) {
   // sP: this wave's row of i + 1 partial sums in LDS.  They are NOT stored to global memory inside the loop: on
   // gfx9 loads and stores share the in-order vmcnt counter, so a store issued between two trips makes the next
   // trip's loads wait for the store's acknowledgement from L2 (measured: 12.6 us of a 273 us pass at i = 199 for the
@@ -112,6 +114,10 @@ __device__ __forceinline__ void rdots_tile(const double* __restrict__ Q, int64_t
       qa = ld2<GUARD>(q1, row, n);
       qb = make_double2(0.0, 0.0);
       if (q2) qb = ld2<GUARD>(q2, row, n);
+    }
+    if (USCALE) {
+      uu.x = uu.x / usc;
+      uu.y = uu.y / usc;
     }
     // (u - alpha*q) - beta*q' with each product rounded on its own, as the torch expression does
     rv[t].x = __dsub_rn(__dsub_rn(uu.x, __dmul_rn(a, qa.x)), __dmul_rn(b, qb.x));
@@ -183,7 +189,7 @@ __device__ __forceinline__ void rdots_tile(const double* __restrict__ Q, int64_t
 }
 
 // SEL: the partial re-orthogonalisation's gate compiled in (sel != null); the default instantiation carries none of it
-template <int RPL, bool SEL = false>
+template <int RPL, bool SEL = false, bool USCALE = false>
 __global__ __launch_bounds__(256) void k_rdots(const double* __restrict__ Q, int64_t ldq, int i,
                                                int64_t n, const double* __restrict__ u,
                                                const double* __restrict__ alpha,
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(256) void k_rdots(const double* __restrict__ Q, int
                                                int64_t ntiles, const double* __restrict__ aP, int aCount,
                                                double* __restrict__ a_store, int want_rr,
                                                double* __restrict__ brk, const double* __restrict__ sel,
-                                               int sel_exit) {
+                                               int sel_exit, const double* __restrict__ uscale) {
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;                                                     // 4, 2 or 1 waves per block
   if (SEL && sel_exit && sel[0] == 0.0) return;      // partial re-orthogonalisation: nothing to do on this step
@@ -228,6 +234,7 @@ __global__ __launch_bounds__(256) void k_rdots(const double* __restrict__ Q, int
       a = alpha[0];
     }
     const double b = beta ? beta[0] : 0.0;
+    const double usc = USCALE ? uscale[0] : 1.0;
     // (read by the tail kernel of this step -- a later launch -- only)
     if (brk && widx == 0 && lane == 0) brk[1] = fmax(brk[1], fmax(fabs(a), fabs(b)));
     // partial re-orthogonalisation (dsea_ws_set_partial_reorth): sel[0] == 0 = this step is not re-orthogonalised -- the
@@ -237,11 +244,11 @@ __global__ __launch_bounds__(256) void k_rdots(const double* __restrict__ Q, int
     for (int64_t tile = widx; tile < ntiles; tile += nw) {
       const int64_t base = tile * TILE;
       if (first && pre_ok)
-        rdots_tile<RPL, false, true>(Q, ldq, i, ii, n, base, lane, u, a, b, r, sP, false, want_rr != 0, pre);
+        rdots_tile<RPL, false, true, USCALE>(Q, ldq, i, ii, n, base, lane, u, a, b, r, sP, false, want_rr != 0, pre, usc);
       else if (base + TILE <= n)
-        rdots_tile<RPL, false, false>(Q, ldq, i, ii, n, base, lane, u, a, b, r, sP, !first, want_rr != 0, pre);
+        rdots_tile<RPL, false, false, USCALE>(Q, ldq, i, ii, n, base, lane, u, a, b, r, sP, !first, want_rr != 0, pre, usc);
       else
-        rdots_tile<RPL, true, false>(Q, ldq, i, ii, n, base, lane, u, a, b, r, sP, !first, want_rr != 0, pre);
+        rdots_tile<RPL, true, false, USCALE>(Q, ldq, i, ii, n, base, lane, u, a, b, r, sP, !first, want_rr != 0, pre, usc);
       first = false;
     }
   } else {
@@ -906,14 +913,17 @@ __global__ __launch_bounds__(256) void k_plz_finish(const double* __restrict__ r
   }
   const int64_t stride = (int64_t)gridDim.x * 512;
   for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; row < n; row += stride) {
-    double2 rv = ld2<true>(r, row, n), yv = ld2<true>(y, row, n);
+    double2 rv = ld2<true>(r, row, n);
     rv.x = rv.x / beta;
     rv.y = rv.y / beta;
-    yv.x = yv.x / beta;
-    yv.y = yv.y / beta;
     st2<true>(q, row, n, rv);
     if (qs) st_bf16x2(qs, row, n, rv);
-    st2<true>(u, row, n, yv);
+    if (u) {        // (u == null: the next dots pass divides y by beta itself -- k_rdots<., ., USCALE>)
+      double2 yv = ld2<true>(y, row, n);
+      yv.x = yv.x / beta;
+      yv.y = yv.y / beta;
+      st2<true>(u, row, n, yv);
+    }
   }
 }
 
@@ -2452,7 +2462,8 @@ void launch_finalize1(const double* P, int count, double* out, hipStream_t st) {
 void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* u,
                   const double* alpha, const double* beta, double* r, double* P, double* c_out,
                   hipStream_t st, EventPair* ev, const double* aP, int aCount, double* a_store, bool want_rr,
-                  double* brk, const double* sel, bool sel_exit) {
+                  double* brk, const double* sel, bool sel_exit, const double* uscale) {
+  // (uscale: wave-owned geometry without the partial re-orthogonalisation gate only -- callers check rdots_uscale_ok)
   if (g.split_w) {
     const int wr = want_rr ? 1 : 0;
     const size_t slds = (size_t)(i + 1) * sizeof(double);     // the tile's partial sums (see k_rdots_split)
@@ -2493,17 +2504,28 @@ void launch_rdots(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, in
   if (sel) {
     switch (g.rpl) {
       case 2: KLAUNCH_LDS(ev, (k_rdots<2, true>), grid, 64 * wpb, lds, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, g.nw,
-             g.ntiles, aP, aCount, a_store, want_rr ? 1 : 0, brk, sel, sel_exit ? 1 : 0); break;
+             g.ntiles, aP, aCount, a_store, want_rr ? 1 : 0, brk, sel, sel_exit ? 1 : 0, (const double*)nullptr); break;
       case 4: KLAUNCH_LDS(ev, (k_rdots<4, true>), grid, 64 * wpb, lds, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, g.nw,
-             g.ntiles, aP, aCount, a_store, want_rr ? 1 : 0, brk, sel, sel_exit ? 1 : 0); break;
+             g.ntiles, aP, aCount, a_store, want_rr ? 1 : 0, brk, sel, sel_exit ? 1 : 0, (const double*)nullptr); break;
       case 8: KLAUNCH_LDS(ev, (k_rdots<8, true>), grid, 64 * wpb, lds, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, g.nw,
-             g.ntiles, aP, aCount, a_store, want_rr ? 1 : 0, brk, sel, sel_exit ? 1 : 0); break;
+             g.ntiles, aP, aCount, a_store, want_rr ? 1 : 0, brk, sel, sel_exit ? 1 : 0, (const double*)nullptr); break;
       default: KLAUNCH_LDS(ev, (k_rdots<16, true>), grid, 64 * wpb, lds, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, g.nw,
-             g.ntiles, aP, aCount, a_store, want_rr ? 1 : 0, brk, sel, sel_exit ? 1 : 0); break;
+             g.ntiles, aP, aCount, a_store, want_rr ? 1 : 0, brk, sel, sel_exit ? 1 : 0, (const double*)nullptr); break;
+    }
+  } else if (uscale) {
+    switch (g.rpl) {
+      case 2: KLAUNCH_LDS(ev, (k_rdots<2, false, true>), grid, 64 * wpb, lds, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride,
+             g.nw, g.ntiles, aP, aCount, a_store, want_rr ? 1 : 0, brk, sel, 0, uscale); break;
+      case 4: KLAUNCH_LDS(ev, (k_rdots<4, false, true>), grid, 64 * wpb, lds, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride,
+             g.nw, g.ntiles, aP, aCount, a_store, want_rr ? 1 : 0, brk, sel, 0, uscale); break;
+      case 8: KLAUNCH_LDS(ev, (k_rdots<8, false, true>), grid, 64 * wpb, lds, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride,
+             g.nw, g.ntiles, aP, aCount, a_store, want_rr ? 1 : 0, brk, sel, 0, uscale); break;
+      default: KLAUNCH_LDS(ev, (k_rdots<16, false, true>), grid, 64 * wpb, lds, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride,
+             g.nw, g.ntiles, aP, aCount, a_store, want_rr ? 1 : 0, brk, sel, 0, uscale); break;
     }
   } else {
     LAUNCH_RPL(ev, k_rdots, g.rpl, grid, 64 * wpb, lds, st, Q, ldq, i, n, u, alpha, beta, r, P, (int64_t)g.pstride, g.nw,
-             g.ntiles, aP, aCount, a_store, want_rr ? 1 : 0, brk, sel, sel_exit ? 1 : 0);
+             g.ntiles, aP, aCount, a_store, want_rr ? 1 : 0, brk, sel, sel_exit ? 1 : 0, (const double*)nullptr);
   }
   // want_rr: one more row of partials (||r||^2) -> c_out[i]
   // (c_out null: the caller's next kernel sums the partial rows it needs itself -- rdots_partial_count of them)

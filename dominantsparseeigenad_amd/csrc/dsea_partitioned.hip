@@ -568,6 +568,12 @@ int dsea_pop_lanczos_run(dsea_pop_t P, dsea_ws_t ws, int k, const double* q0, do
   double* pro_om = w.aux + 4 * DSEA_MAX_WAVE_TILES;
   const double pro_eps1 = 64.0 * 2.220446049250313e-16;
   const TileGeom g = w.geom(n);
+  // "lite" finish (non-overlapped step, wave-owned geometry): k_plz_finish stores q = r / beta only; u = y / beta is formed by
+  // the NEXT step's dots pass while it reads y (k_rdots<., ., USCALE>: the same division, bit-identical) -- one vector
+  // written and one read fewer per step than storing u and reading it back
+  const char* lite_env = getenv("DSEA_POP_LITE");               // (A/B switch: 0 = store u and read it back)
+  const bool lite = !partial && rdots_uscale_ok(g) && !(lite_env && lite_env[0] == '0');
+  double* beta0 = w.scal + 37;                                   // beta of step 0 (= ||q0||; betas[] starts at step 1)
   // the step's two local sums (||r||^2 from the correction pass, r.Ar from the mat-vec) are closed by ONE launch
   struct DeferNorm {
     Workspace& w;
@@ -611,6 +617,10 @@ int dsea_pop_lanczos_run(dsea_pop_t P, dsea_ws_t ws, int k, const double* q0, do
       DSEA_TRY(comm_allreduce(P->comm, c, i, st));
       launch_axpy_norm(g, Q, ldq, n, i, c, r, w.partials, pair, st, w.prof ? w.prof->next(PROF_AXPY) : nullptr, nullptr,
                        pro_flag);
+    } else if (lite) {
+      launch_rdots(g, Q, ldq, n, i, y, a_prev, b_prev, r, w.partials, c, st, w.prof ? w.prof->next(PROF_RDOTS) : nullptr, nullptr,
+                   0, nullptr, true, nullptr, nullptr, false, i >= 2 ? betas + (i - 2) : beta0);
+      DSEA_TRY(comm_allreduce(P->comm, c, i + 1, st));
     } else {
       DSEA_TRY(dsea_plz_dots(ws, Q, ldq, n, i, u, a_prev, b_prev, r, c, stream));
       DSEA_TRY(comm_allreduce(P->comm, c, i + 1, st));
@@ -636,6 +646,9 @@ int dsea_pop_lanczos_run(dsea_pop_t P, dsea_ws_t ws, int k, const double* q0, do
       uint16_t* qs = (w.shadow && w.shadow_rows > i && w.shadow_ld >= n) ? w.shadow + (int64_t)i * w.shadow_ld : nullptr;
       launch_plz_finish_form(r, y, pair, Q + (int64_t)i * ldq, qs, i >= 1 ? Q + (int64_t)(i - 1) * ldq : nullptr, alphas + i,
                              i >= 1 ? betas + (i - 1) : nullptr, P->r_send, n, st);
+    } else if (lite && !overlap) {
+      uint16_t* qs = (w.shadow && w.shadow_rows > i && w.shadow_ld >= n) ? w.shadow + (int64_t)i * w.shadow_ld : nullptr;
+      launch_plz_finish(r, y, pair, Q + (int64_t)i * ldq, qs, nullptr, alphas + i, i >= 1 ? betas + (i - 1) : beta0, n, st);
     } else {
       DSEA_TRY(dsea_plz_finish(ws, r, y, pair, Q + (int64_t)i * ldq, i, u, alphas + i, i >= 1 ? betas + (i - 1) : nullptr, n,
                                stream));

@@ -18,6 +18,11 @@
 // Fragment layout of v_mfma_f64_16x16x4_f64 (cdna_hip_programming.md 3): A[i = lane & 15][k = lane >> 4], B[k = lane >> 4]
 // [j = lane & 15], one double each; C/D four doubles per lane: row = (lane >> 4) + 4 reg, col = lane & 15.
 // By default D > 512 keeps the rocBLAS path of dsea_krylov.hip.
+// Round 5: BOTH products in ONE launch (512 workgroups, T handed over inside the launch by an agent-scope release / acquire
+// pair) was built -- results bit-identical to the pair of launches -- and measured at D = 512: 37.6-38.5 us with one workgroup
+// per CU, 47.2-48.0 us with K2's workgroups co-resident, against 25.2-26.4 us for the two launches
+// (profiles/r05_transfer_single_launch.txt).  The kernel boundary is the cheaper hand-over of 4 MB across eight private L2s.
+// Removed.
 // -DTFM_DIAG=1/4: timing diagnostics only (no loads in the loop / two k blocks), wrong results.
 #include <hip/hip_runtime.h>
 #include <stdint.h>

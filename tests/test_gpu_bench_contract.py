@@ -182,7 +182,7 @@ def test_bench_watchdog_on_the_rccl_branch_rehearsal(inject, stage, driver):
     RCCL call would look like: no error, no return.  The supervisors notice the stall, kill both children and start fresh
     ones at the next stage; the line arrives from stage 2 (one communicator) resp. stage 3 (Python driver)."""
     assert os.path.exists(FAKE_RCCL), "build() compiles tests/fake_rccl/libfake_rccl.so"
-    env = {"DSEA_RCCL_LIB": FAKE_RCCL, "DSEA_BENCH_STALL_S": "30", "DSEA_BENCH_STARTUP_S": "300"}
+    env = {"DSEA_RCCL_LIB": FAKE_RCCL, "DSEA_BENCH_STALL_S": "15", "DSEA_BENCH_STARTUP_S": "300"}
     if inject:
         env["DSEA_BENCH_INJECT_HANG"] = inject
     d = _bench(["--gpus", "2", "--host-staged", "--steps", "2", "--warmup", "1"], env=env)

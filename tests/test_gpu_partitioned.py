@@ -71,7 +71,7 @@ def _case_driver(rank, world, backend, dev, overlap=False, replicate="auto"):
     return (E0.item(), psi.cpu().numpy().copy(), grad.item(), solver.last_cg_iters)
 
 
-def _case_driver_env(rank, world, backend, dev, overlap, env, tau=None):
+def _case_driver_env(rank, world, backend, dev, overlap, env, tau=None, Lc=None, Kc=None):
     """_case_driver with environment switches (DSEA_DRIVER=python: the Python driver; DSEA_COMM=own: library-created
     RCCL communicators) -- returns which driver ran and the premise-fallback count as well"""
     from dominantsparseeigenad_amd import engine
@@ -79,17 +79,18 @@ def _case_driver_env(rank, world, backend, dev, overlap, env, tau=None):
     os.environ.update(env)
     if tau is not None:
         engine.SHADOW_TAU = tau
+    Lx, Kx = (Lc or L), (Kc or K)
     p = world.bit_length() - 1
-    nloc = 1 << (L - p)
+    nloc = 1 << (Lx - p)
     off = rank * nloc
     g = torch.tensor([G], dtype=torch.float64, device=dev)
-    solver = PartitionedTFIM(L, g, dev, eps=1e-12, comm=_comm(backend))
+    solver = PartitionedTFIM(Lx, g, dev, eps=1e-12, comm=_comm(backend))
     solver.overlap = overlap
     q0 = torch.from_numpy(normal_vector(nloc, 5100, offset=off)).to(dev)
     x0 = torch.from_numpy(normal_vector(nloc, 5102, offset=off)).to(dev)
     t = torch.from_numpy(normal_vector(nloc, 5103, offset=off)).to(dev)
     solver.op.replicate_cg = False      # (the row-partitioned solve is what these cases compare, also at two ranks)
-    E0, psi, grad = solver.forward_backward(K, q0, x0, t)
+    E0, psi, grad = solver.forward_backward(Kx, q0, x0, t)
     torch.cuda.synchronize()
     return (E0.item(), psi.cpu().numpy().copy(), grad.item(), solver.last_cg_iters, solver.op.driver,
             solver.op.overlap_fallbacks, engine.last_cg.form)
@@ -364,6 +365,20 @@ def test_library_driver_equals_python_driver(world, backend, overlap):
         assert "callbacks" in lib_run[0][4]
 
 
+@pytest.mark.parametrize("world,backend,overlap", [(1, "nccl", False), (2, "gloo", False), (2, "gloo", True)])
+def test_library_driver_equals_python_driver_on_streaming_slabs(world, backend, overlap):
+    """the same bit-for-bit comparison on slabs of 2^18 rows -- the wave-owned geometry of the basis-streaming kernels, where
+    the library's non-overlapped step stores q = r / beta only and the NEXT dots pass divides y by beta while reading it
+    (k_rdots<., ., USCALE>; the Python driver stores u = y / beta and reads it back): the same division, the same bits."""
+    Lc = 18 + (world.bit_length() - 1)
+    lib_run = _run(world, backend, "_case_driver_env", overlap, {"DSEA_CG_REFERENCE_RECURRENCES": "1"}, None, Lc, 60)
+    py_run = _run(world, backend, "_case_driver_env", overlap, {"DSEA_DRIVER": "python"}, None, Lc, 60)
+    for r in range(world):
+        assert lib_run[r][4].startswith("library") and py_run[r][4] == "python"
+        assert lib_run[r][0] == py_run[r][0] and lib_run[r][2] == py_run[r][2] and lib_run[r][3] == py_run[r][3]
+        assert np.array_equal(lib_run[r][1], py_run[r][1])
+
+
 @pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (4, "gloo")])
 def test_library_driver_one_reduction_cg(world, backend):
     """dsea_pop_cg_run's default for the TFIM operand: ONE all-reduce per iteration (Chronopoulos-Gear recurrences: r.r and
@@ -480,7 +495,45 @@ def _rccl_branch_comm(dev, mode, env):
     if mode == "rccl":
         os.environ["DSEA_RCCL_LIB"] = FAKE_RCCL
         comm.native_comm = NativeComm.own(None, dev)
+    elif mode == "rccl-adopted":
+        comm.native_comm = _adopted_stand_in_comm(dev, comm.world, comm.rank)
     return comm
+
+
+def _adopted_stand_in_comm(dev, world, rank, single=False):
+    """dsea_comm_adopt on communicators that ALREADY EXIST -- the branch the real multi-GPU run takes by default (it adopts
+    the ncclComm_t pair torch's ProcessGroupNCCL holds).  Here the pair is created by calling the stand-in's own
+    ncclGetUniqueId / ncclCommInitRank through ctypes, as any host code owning RCCL communicators would, and handed over as
+    raw pointers; libdsea (DSEA_RCCL_LIB) binds the same library instance."""
+    import ctypes
+    from ctypes import byref, c_void_p
+    from dominantsparseeigenad_amd import _lib
+    from dominantsparseeigenad_amd.partitioned import NativeComm
+    os.environ["DSEA_RCCL_LIB"] = FAKE_RCCL
+    fake = ctypes.CDLL(FAKE_RCCL)
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    fake.ncclCommInitRank.argtypes = [ctypes.POINTER(c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    ids = [None, None]
+    if rank == 0:
+        for j in range(2):
+            u = UniqueId()
+            assert fake.ncclGetUniqueId(byref(u)) == 0
+            ids[j] = bytes(u)
+    dist.broadcast_object_list(ids, src=0)
+    comms = []
+    with torch.cuda.device(dev):
+        for j in range(1 if single else 2):
+            c = c_void_p()
+            assert fake.ncclCommInitRank(byref(c), world, UniqueId.from_buffer_copy(ids[j]), rank) == 0
+            comms.append(c)
+    h = c_void_p()
+    _lib.check(_lib.load().dsea_comm_adopt(comms[0], comms[-1], rank, world, byref(h)), "dsea_comm_adopt")
+    nc = NativeComm(h, rank, world, "rccl (adopted: %s)" % ("one communicator" if single else "two communicators"))
+    nc._stand_in = (fake, comms)          # the library never destroys adopted communicators: the test does
+    return nc
 
 
 def _case_rccl_branch(rank, world, backend, dev, overlap, mode, env):
@@ -500,10 +553,12 @@ def _case_rccl_branch(rank, world, backend, dev, overlap, mode, env):
     torch.cuda.synchronize()
     out = dict(E0=E0.item(), psi=psi.cpu().numpy().copy(), grad=grad.item(), iters=solver.last_cg_iters,
                driver=solver.op.driver, fallbacks=solver.op.overlap_fallbacks, transposed=bool(solver.op.transposed),
-               stats=_fake_rccl_stats() if mode == "rccl" else None)
+               stats=_fake_rccl_stats() if mode.startswith("rccl") else None)
     del solver
-    if mode == "rccl":
+    if mode.startswith("rccl"):
         comm.native_comm.close()
+        for c in getattr(comm.native_comm, "_stand_in", (None, []))[1]:
+            comm.native_comm._stand_in[0].ncclCommDestroy(c)
     return out
 
 
@@ -588,6 +643,20 @@ def test_rccl_branch_of_the_library_driver_equals_the_callback_path(world, overl
         # every Lanczos step and CG iteration went through the stand-in: all-reduces, sends, receives, groups
         assert st[0] > 2 * K and st[1] > K and st[2] == st[1] and st[3] > K and st[4] == 2, st
     assert rccl[0]["E0"] == rccl[world - 1]["E0"]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_rccl_branch_with_adopted_communicators(world):
+    """COMM_RCCL_ADOPTED at world > 1 -- dsea_comm_adopt's validation (ncclCommCount / ncclCommUserRank of the handed-over
+    handles) and the same collectives on communicators the library did not create: bit-identical to the library-owned pair"""
+    _need_fake_rccl()
+    adopted = _run(world, "gloo", "_case_rccl_branch", True, "rccl-adopted", {})
+    owned = _run(world, "gloo", "_case_rccl_branch", True, "rccl", {})
+    for r in range(world):
+        a, b = adopted[r], owned[r]
+        assert "rccl (adopted: two communicators)" in a["driver"], a["driver"]
+        assert a["E0"] == b["E0"] and a["grad"] == b["grad"] and a["iters"] == b["iters"] and np.array_equal(a["psi"], b["psi"])
+        assert a["stats"][4] == 2 and a["stats"][1] > K
 
 
 def test_rccl_branch_with_one_communicator():
