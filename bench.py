@@ -1245,8 +1245,11 @@ def _metric_name(args, ctx):
         return "DRY RUN on CPU processes (gloo, torch test double of the slab kernels): control flow of the multi-rank " \
                "bench only, not a measurement"
     if ctx.staged:
+        how = ("the library's RCCL calls over the stand-in RCCL of tests/fake_rccl (DSEA_RCCL_LIB), host-side control over gloo"
+               if os.environ.get("DSEA_RCCL_LIB") and os.environ.get("DSEA_DRIVER", "") != "python" else
+               "collectives over gloo staged through the host")
         return "REHEARSAL, not a measurement: the N > 1 branch on the HIP slab kernels with %d ranks SHARING ONE GPU, " \
-               "collectives over gloo staged through the host, toy sizes" % ctx.world
+               "%s, toy sizes" % (ctx.world, how)
     if args.reorth == "full":
         return "DominantSparseSymeig fwd+bwd ms & HBM GB/s (TFIM, fp64)"
     if args.reorth == "partial":

@@ -16,6 +16,8 @@
 #   small               single-launch regimes: tools/lanczos_small_timing.py, tools/cg_small_timing.py
 #   anchors             bench.py one-GPU anchors (L = 28 k = 100 / k = 80 shadow on+off; 2^25 rows k = 200)
 #   rehearsal           bench.py --host-staged at N = 2, 4, 8 (the real N > 1 branch, ranks sharing the GPU, toy sizes)
+#   rehearsal_rccl      the same with the library's RCCL branch executing over the stand-in RCCL (DSEA_RCCL_LIB)
+#   watchdog:KIND[:S]   N = 2 rehearsal with a hang injected inside the stand-in (exchange | allreduce), stall deadline S s
 #   fuzzpart:SEEDS:N    tools/fuzz_partitioned.py for each seed (comma separated), N cases each
 #   fuzz:SEEDS:N        tools/fuzz_parity.py likewise
 #   ab:VARIANTS:REPS    alternate library builds csrc/libdsea_<name>.so ("-" = in-tree) on the headline bench
@@ -97,6 +99,13 @@ PY
       for n in 2 4 8; do
         timeout 900 python bench.py --gpus $n --host-staged --steps 2 --warmup 1 > "$O/rehearsal_n$n.json" 2> "$O/rehearsal_n$n.err"; echo "rehearsal N=$n rc=$?"; line "$O/rehearsal_n$n.json" 700
       done ;;
+    rehearsal_rccl)   # the same rehearsal with the LIBRARY'S OWN RCCL calls executing over the stand-in of tests/fake_rccl
+      for n in 2 4 8; do
+        DSEA_RCCL_LIB=$PWD/tests/fake_rccl/libfake_rccl.so timeout 900 python bench.py --gpus $n --host-staged --steps 2 --warmup 1 > "$O/rehearsal_rccl_n$n.json" 2> "$O/rehearsal_rccl_n$n.err"; echo "rehearsal (stand-in RCCL) N=$n rc=$?"; line "$O/rehearsal_rccl_n$n.json" 300
+      done ;;
+    watchdog)         # watchdog:exchange / watchdog:allreduce -- a hang injected INSIDE the stand-in RCCL, N = 2
+      DSEA_BENCH_INJECT_HANG=$a1 DSEA_BENCH_STALL_S=${a2:-20} DSEA_RCCL_LIB=$PWD/tests/fake_rccl/libfake_rccl.so timeout 900 python bench.py --gpus 2 --host-staged --steps 2 --warmup 1 > "$O/watchdog_$a1.json" 2> "$O/watchdog_$a1.err"; echo "watchdog $a1 rc=$?"
+      tail -1 "$O/watchdog_$a1.json" | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); c=d["config"]; print("stage", c["fallback_stage"], "|", c["fallback_stage_is"], "|", c["fallback_reason"], "|", c.get("partitioned_driver"))' ;;
     fuzzpart)
       for s in ${a1//,/ }; do python tools/fuzz_partitioned.py --cases ${a2:-30} --seed $s 2>&1 | grep -v "amdgpu\|Gloo" > "$O/fuzz_partitioned_seed$s.txt"; tail -1 "$O/fuzz_partitioned_seed$s.txt"; done ;;
     fuzz)
