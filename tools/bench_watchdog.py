@@ -216,6 +216,8 @@ def supervise(script, argv, anchors, describe):
                            "total_wall_s": round(time.time() - t_start, 1)}
         sys.stdout.flush()
         print(json.dumps(final), flush=True)
+    import shutil
+    shutil.rmtree(tmpdir, ignore_errors=True)
     code = torch.tensor([float(rc_exit)])
     dist.broadcast(code, src=0)
     try:
