@@ -1106,6 +1106,16 @@ int dsea_arnoldi_status(dsea_ws_t ws, int* break_step, int* redo_step, void* str
   return h != 0.0 ? DSEA_ERR_BREAKDOWN : DSEA_OK;
 }
 
+int dsea_arnoldi_status_enqueue(dsea_ws_t ws, double* host_record, void* stream) {
+  if (!ws || !host_record) return DSEA_ERR_ARG;
+  if (hipMemcpyAsync(host_record, ws->w.scal + DSEA_SCAL_BREAK, sizeof(double), hipMemcpyDeviceToHost,
+                     static_cast<hipStream_t>(stream)) != hipSuccess) {
+    g_last_hip = (int)hipGetLastError();
+    return DSEA_ERR_HIP;
+  }
+  return DSEA_OK;
+}
+
 int dsea_arnoldi_orth(dsea_ws_t ws, const double* u, const double* shift, double* V, int64_t ldv, int64_t n, int j,
                       double* H, int ldh, void* stream) {
   REQUIRE(ws && u && V && H && j >= 0 && ldh >= j + 2 && n >= 1 && ldv >= n && ws->w.n >= n, DSEA_ERR_ARG);

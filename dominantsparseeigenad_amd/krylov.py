@@ -69,6 +69,7 @@ class _one_thread:
     _lock = None
     _depth = 0
     _ctx = None
+    _controller = None
 
     def __enter__(self):
         import threading
@@ -78,8 +79,13 @@ class _one_thread:
         with cls._lock:
             if cls._depth == 0:
                 try:
-                    from threadpoolctl import threadpool_limits
-                    cls._ctx = threadpool_limits(limits=1)
+                    # ONE controller for the life of the process: constructing it scans the loaded libraries (0.6 ms per
+                    # ``threadpool_limits(...)`` -- as long as the 32 x 32 eigen-solve it was protecting); ``limit`` on a
+                    # cached controller costs 15 us
+                    if cls._controller is None:
+                        from threadpoolctl import ThreadpoolController
+                        cls._controller = ThreadpoolController()
+                    cls._ctx = cls._controller.limit(limits=1)
                     cls._ctx.__enter__()
                 except Exception:           # threadpoolctl not installed: run as is
                     cls._ctx = None
@@ -145,6 +151,87 @@ OPTIMISTIC_SECOND_PASS = True
 # every solve: measured no gain (config 4 backward 10.4-11.0 ms against 9.1-10.5), so it is off unless asked for.
 OPTIMISTIC_SECOND_PASS_GMRES = False
 STAGE_LOG = None        # set to a list to record [columns, ms until the stage's H is on the host, host ms, residual]
+# The stage test of stage s runs on the host WHILE THE DEVICE ALREADY EXECUTES STAGE s + 1 (native operands, optimistic second
+# pass): the H block and the break record of a stage are copied to pinned memory behind its last kernel, the next stage is
+# enqueued at once, and only then does the host wait for the copy and solve the small eigen-problem.  The device no longer
+# idles for the host's 1 - 4 ms per test (40 % of a config-4 forward); the price is at most one speculative stage of columns
+# that a converged test makes unnecessary (they are computed and ignored).  False = test, then enqueue (round-4 behaviour).
+PIPELINED_STAGES = __import__("os").environ.get("DSEA_ARNOLDI_PIPELINED", "1") != "0"
+
+
+def _speculative_stage_end(j1, p, m, hist, tol):
+    """end of the stage enqueued BEHIND the stage ending at j1 whose test is still pending: the convergence history knows
+    the stages up to the one before, so the extrapolated target is taken from its last point"""
+    if j1 >= m:
+        return None
+    j2 = j1 + STAGE_FIRST // 2
+    if len(hist) >= 2:
+        (ja, ra), (jb, rb) = hist[-2], hist[-1]
+        if rb < ra and rb > 0.0 and jb > ja:
+            rate = np.log(rb / ra) / (jb - ja)
+            jstar = jb + int(np.ceil(np.log(0.3 * tol / rb) / rate)) + 2
+            j2 = max(j1 + STAGE_MIN, min(jstar, j1 + STAGE_MAX))
+    return m if j2 + STAGE_MIN > m else j2
+
+
+class _StagePipe:
+    """two pinned snapshots (H block + break record) and their events, for the pipelined stage tests of arnoldi_dominant"""
+
+    # pinned buffers are POOLED per (m, ldh) for the life of the process: allocating and freeing pinned memory costs ~1 ms and
+    # the free synchronises the device (the left solve of eig._two_sides runs on a fresh thread every call, so a thread-local
+    # cache would allocate and free on every forward pass)
+    _pool, _pool_lock = {}, _threading.Lock()
+
+    def __init__(self, lp, V, ldv, Hd, ldh, m):
+        self.lp, self.V, self.ldv, self.Hd, self.ldh, self.m = lp, V, ldv, Hd, ldh, m
+        self.key = (m, ldh)
+        with _StagePipe._pool_lock:
+            free = _StagePipe._pool.setdefault(self.key, [])
+            entry = free.pop() if free else None
+        if entry is None:
+            entry = ([torch.empty((m, ldh), dtype=F64).pin_memory() for _ in range(2)],
+                     [torch.zeros(1, dtype=F64).pin_memory() for _ in range(2)], [None, None])
+        for ev in entry[2]:                 # the previous user's last (speculative) copy into these buffers, long finished
+            if ev is not None:
+                ev.synchronize()
+        self.entry = entry
+        self.Hpin, self.rec = entry[0], entry[1]
+        self.ev = [None, None]
+        self.t_issue = [0.0, 0.0]
+
+    def release(self):
+        """give the pinned buffers back WITHOUT waiting for the speculative stage's copy: its event travels with them and the
+        next user waits for it before writing"""
+        if self.entry is not None:
+            entry = (self.entry[0], self.entry[1], list(self.ev))
+            with _StagePipe._pool_lock:
+                _StagePipe._pool[self.key].append(entry)
+            self.entry = None
+
+    def extend(self, j0, j1):
+        lp = self.lp
+        lib, ws = lp.lib, lp.ws
+        check(lib.dsea_ws_set_arnoldi_optimistic(ws.handle, 1), "dsea_ws_set_arnoldi_optimistic")
+        try:
+            check(lib.dsea_arnoldi_extend(lp.native.handle, ws.handle, None, _ptr(self.V), self.ldv, j0, j1, _ptr(self.Hd),
+                                          self.ldh, lp.st()), "dsea_arnoldi_extend")
+        finally:
+            check(lib.dsea_ws_set_arnoldi_optimistic(ws.handle, 0), "dsea_ws_set_arnoldi_optimistic")
+
+    def snapshot(self, j1, slot):
+        """behind everything enqueued so far: H[:j1] and the break record to pinned memory, and an event"""
+        lp = self.lp
+        self.Hpin[slot][:j1].copy_(self.Hd[:j1], non_blocking=True)
+        check(lp.lib.dsea_arnoldi_status_enqueue(lp.ws.handle, c_void_p(self.rec[slot].data_ptr()), lp.st()),
+              "dsea_arnoldi_status_enqueue")
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(lp.device))
+        self.ev[slot] = ev
+        self.t_issue[slot] = time.perf_counter()
+
+    def wait(self, j1, slot):
+        self.ev[slot].synchronize()
+        return float(self.rec[slot][0]), self.Hpin[slot][:j1, :j1 + 1].numpy()
 
 
 def _next_stage_end(j, p, m, hist, tol):
@@ -227,7 +314,66 @@ def arnoldi_dominant(A, n, ncv, device, which="LM", v0=None, tol=1e-13, max_rest
         # exist, eig.py:29; a converged pair is the same pair, found with fewer mat-vecs) and chooses the end of the
         # next stage from the observed convergence rate.
         j, hist = p, []
-        while True:
+        pipelined = PIPELINED_STAGES and lp.native is not None and OPTIMISTIC_SECOND_PASS and STAGE_FIRST > 0
+        if pipelined:
+            pipe = _StagePipe(lp, V, ldv, Hd, ldh, m)
+            slot, j1 = 0, _next_stage_end(j, p, m, hist, tol)
+            pipe.extend(j, j1)
+            pipe.snapshot(j1, slot)
+        while pipelined:
+            # the NEXT stage goes to the device before the host looks at this one
+            j2 = _speculative_stage_end(j1, p, m, hist, tol)
+            if j2 is not None:
+                pipe.extend(j1, j2)
+                pipe.snapshot(j2, 1 - slot)
+            rec, Hh = pipe.wait(j1, slot)
+            t_issue = pipe.t_issue[slot]
+            stages_run += 1
+            if rec < 0.0:
+                # step `redo` of this stage needs its second Gram-Schmidt pass: every launch behind it (the rest of the stage
+                # and the speculative one) was a no-op.  Clear the record, repeat the step in the default mode, re-enqueue.
+                brk_c, redo_c = ctypes.c_int(0), ctypes.c_int(-1)
+                check(lib.dsea_arnoldi_status(ws.handle, byref(brk_c), byref(redo_c), st()), "dsea_arnoldi_status",
+                      allow=(_lib.ERR_BREAKDOWN, _lib.ERR_SECOND_PASS))
+                redo = int(-rec) - 1
+                DIAG.arnoldi_second_pass_redos = getattr(DIAG, "arnoldi_second_pass_redos", 0) + 1
+                check(lib.dsea_arnoldi_extend(lp.native.handle, ws.handle, None, _ptr(V), ldv, redo, redo + 1, _ptr(Hd), ldh,
+                                              st()), "dsea_arnoldi_extend")
+                if redo + 1 < j1:
+                    pipe.extend(redo + 1, j1)
+                pipe.snapshot(j1, slot)
+                stages_run -= 1
+                continue                        # (the speculative stage is enqueued again at the top of the loop)
+            brk_value = int(rec) if rec > 0.0 else 0
+            me = j1 if brk_value == 0 else brk_value              # invariant subspace reached at step me
+            B = Hh[:me, :me].T.copy()
+            coupling = 0.0 if me < j1 or brk_value else float(Hh[j1 - 1, j1])
+            j = j1
+            t_dev = time.perf_counter()
+            if STAGE_LOG is not None:
+                STAGE_LOG.append([j1, (t_dev - t_issue) * 1e3, None])
+            try:
+                theta, y, evals = _wanted_pair(B, which)
+            except ValueError:
+                if j1 >= m or me < j1:
+                    raise                      # the full factorisation says the wanted eigenvalue is complex: eig.py:31-32
+                theta = None
+            if theta is not None:
+                res = abs(coupling * y[-1])
+                if STAGE_LOG is not None:
+                    STAGE_LOG[-1][2] = (time.perf_counter() - t_dev) * 1e3
+                    STAGE_LOG[-1].append(res / max(abs(theta), 1e-300))
+                if res <= tol * abs(theta) or me < j1 or j1 >= m:
+                    break
+                hist.append((j1, res / max(abs(theta), 1e-300)))
+            if j2 is None:                      # (cannot happen: j1 < m here) -- keep the loop well-formed
+                j2 = _next_stage_end(j1, p, m, hist, tol)
+                pipe.extend(j1, j2)
+                pipe.snapshot(j2, 1 - slot)
+            j1, slot = j2, 1 - slot
+        if pipelined:
+            pipe.release()
+        while not pipelined:
             j1 = _next_stage_end(j, p, m, hist, tol)
             brk = ctypes.c_int(0)
             if lp.native is not None and OPTIMISTIC_SECOND_PASS:

@@ -476,6 +476,11 @@ int dsea_arnoldi_second_passes(dsea_ws_t ws, int64_t *count, void *stream);
 #define DSEA_ERR_SECOND_PASS (-11)
 int dsea_ws_set_arnoldi_optimistic(dsea_ws_t ws, int on);
 int dsea_arnoldi_status(dsea_ws_t ws, int *break_step, int *redo_step, void *stream);
+/* the same record WITHOUT synchronising: enqueues a copy of it into host_record[0] (caller-owned, preferably pinned) on
+ * `stream`; the caller waits for its own event and reads: 0 = fine so far, > 0 = invariant subspace at that step, < 0 = step
+ * -value - 1 needs its second pass (then dsea_arnoldi_status clears the record as above).  Lets a caller test the stage it
+ * has just enqueued while the NEXT stage is already running (krylov.arnoldi_dominant).                                  */
+int dsea_arnoldi_status_enqueue(dsea_ws_t ws, double *host_record, void *stream);
 
 /* the orthogonalisation of ONE Arnoldi step when the mat-vec is the caller's code: u = A v_j given, writes column j
  * of H (entries 0..j+1) and V[j+1]; (*shift) v_j is subtracted from u inside the first pass.                    */
