@@ -13,6 +13,27 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: GPU test that allocates most of the 288 GB of HBM and runs for ~30 s")
+    # Host threads.  The GPU box has 256 cores and torch's CPU ops (the oracle side of the parity tests) are pathologically slow
+    # with all of them (measured in round 2: the CPU port of the headline 31.5 s with 8 threads, 554 s with 256).  Eight threads
+    # for this process and -- through the environment -- for every worker process the tests spawn.
+    os.environ.setdefault("OMP_NUM_THREADS", "8")
+    os.environ.setdefault("MKL_NUM_THREADS", "8")
+    try:
+        import torch
+        torch.set_num_threads(min(8, os.cpu_count() or 1))
+    except Exception:       # noqa: BLE001
+        pass
+
+
+def pytest_collection_modifyitems(config, items):
+    """A GPU test that stops making progress must END the run with every thread's stack on stderr, not hold the box until
+    some outer limit: pytest-timeout, thread method (it fires even when the main thread sits in a C call), 900 s -- the
+    slowest test takes ~80 s."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") is not None and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(900, method="thread"))
 
 
 @pytest.fixture(scope="session")

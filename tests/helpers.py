@@ -66,3 +66,38 @@ def rel(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+class _ResultChannel:
+    """what a spawned worker writes its result into (``ret[rank] = value``): a pipe of the SPAWN context.  No manager
+    process: ``multiprocessing.Manager()`` FORKS the calling process -- here a pytest process that holds an initialised HIP
+    runtime -- and the forked copies linger until garbage collection."""
+
+    def __init__(self, queue):
+        self.queue = queue
+
+    def __setitem__(self, rank, value):
+        self.queue.put((rank, value))
+
+
+def spawn_collect(fn, args, nprocs):
+    """``torch.multiprocessing.spawn(fn, args + (ret,), nprocs)`` where every worker does ``ret[rank] = value``; returns
+    {rank: value}.  The parent reads while the workers run (a result larger than the pipe buffer would otherwise block its
+    writer) and a crashed worker raises here instead of leaving the parent waiting."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    queue = ctx.SimpleQueue()
+    pc = mp.spawn(fn, args=tuple(args) + (_ResultChannel(queue),), nprocs=nprocs, join=False)
+    out, done = {}, False
+    while len(out) < nprocs and not done:
+        while not queue.empty():
+            rank, value = queue.get()
+            out[rank] = value
+        if len(out) < nprocs:
+            done = pc.join(timeout=0.05)          # raises if a worker failed
+    while not queue.empty():
+        rank, value = queue.get()
+        out[rank] = value
+    while not done:
+        done = pc.join(timeout=1.0)
+    return out

@@ -112,10 +112,8 @@ def _spawn_config5(Lg, k):
     """run the case in a fresh process (its 67 GB must not meet whatever the pytest process still caches)"""
     import torch.multiprocessing as mp
     from test_gpu_partitioned import _free_port
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    mp.spawn(_worker_config5, args=(_free_port(), Lg, k, ret), nprocs=1, join=True)
-    return ret[0]
+    from helpers import spawn_collect
+    return spawn_collect(_worker_config5, (_free_port(), Lg, k), 1)[0]
 
 
 @pytest.mark.slow

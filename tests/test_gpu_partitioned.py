@@ -250,9 +250,8 @@ def _run(world, backend, case, *args):
     if world >= 8 and torch.cuda.is_initialized():
         pytest.skip("eight workers beside a parent that holds a GPU context exceed the eight compute processes the GPU "
                     "serves at a time (time-sliced: minutes per test); the 8-rank cases run first, in test_gpu_0_world8.py")
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), backend, case, args, ret), nprocs=world, join=True)
+    from helpers import spawn_collect
+    ret = spawn_collect(_worker, (world, _free_port(), backend, case, args), world)
     assert len(ret) == world
     return [ret[r] for r in range(world)]
 

@@ -164,9 +164,8 @@ def _worker(rank, world, port, case, args, ret):
 
 
 def _run(world, case, *args):
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), case, args, ret), nprocs=world, join=True)
+    from helpers import spawn_collect
+    ret = spawn_collect(_worker, (world, _free_port(), case, args), world)
     assert len(ret) == world
     return [ret[r] for r in range(world)]
 

@@ -146,9 +146,9 @@ def main():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
         s.close()
-        mgr = mp.Manager()
-        ret = mgr.dict()
-        mp.spawn(worker, args=(world, port, [c[1:] for _, c in sub], ret), nprocs=world, join=True)
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+        from helpers import spawn_collect          # (no Manager: it would fork this process)
+        ret = spawn_collect(worker, (world, port, [c[1:] for _, c in sub]), world)
         for j, (i, _) in enumerate(sub):
             results[i] = [ret[r][0][j] for r in range(world)]
         drivers[world] = ret[0][1]
