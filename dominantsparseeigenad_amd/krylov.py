@@ -85,7 +85,10 @@ class _one_thread:
                     if cls._controller is None:
                         from threadpoolctl import ThreadpoolController
                         cls._controller = ThreadpoolController()
-                    cls._ctx = cls._controller.limit(limits=1)
+                    # BLAS pools only (numpy's and scipy's OpenBLAS: process-wide settings, hence the reference count).
+                    # The OpenMP runtime torch uses keeps its thread count PER THREAD: limiting it here and restoring it on
+                    # whichever thread leaves last used to leave the caller's thread at one OpenMP thread for good.
+                    cls._ctx = cls._controller.limit(limits=1, user_api="blas")
                     cls._ctx.__enter__()
                 except Exception:           # threadpoolctl not installed: run as is
                     cls._ctx = None
