@@ -231,6 +231,22 @@ def _case_api_stencil_partial(rank, world, backend, dev, partial):
     return out
 
 
+def _case_stencil_lanczos(rank, world, backend, dev, env, N, k):
+    """k-step Lanczos of the row-partitioned 3-point stencil on slabs large enough for the wave-owned geometry"""
+    from dominantsparseeigenad_amd.partitioned import PartitionedStencil3Operator, stencil_partition
+    os.environ.update(env)
+    rows, off = stencil_partition(N, world, rank)
+    xmesh = torch.from_numpy(np.linspace(-1.0, 1.0, num=N, endpoint=False))
+    potential = (0.5 * xmesh ** 2)[off:off + rows].clone().to(dev)
+    op = PartitionedStencil3Operator(N, 2.0 / N, potential, dev, comm=_comm(backend))
+    op.force_driver = True
+    q0 = torch.from_numpy(normal_vector(rows, 6100, offset=off)).to(dev)
+    Q, ldq, alphas, betas = op.lanczos(k, q0)
+    torch.cuda.synchronize()
+    return dict(alphas=alphas.cpu().numpy().copy(), betas=betas.cpu().numpy().copy(), q_last=Q[k - 1, :rows].cpu().numpy().copy(),
+                driver=op.driver)
+
+
 def _worker(rank, world, port, backend, case, args, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dev = torch.device("cuda:0")
@@ -376,6 +392,19 @@ def test_library_driver_equals_python_driver_on_streaming_slabs(world, backend, 
         assert lib_run[r][4].startswith("library") and py_run[r][4] == "python"
         assert lib_run[r][0] == py_run[r][0] and lib_run[r][2] == py_run[r][2] and lib_run[r][3] == py_run[r][3]
         assert np.array_equal(lib_run[r][1], py_run[r][1])
+
+
+@pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo")])
+def test_library_driver_equals_python_driver_on_streaming_stencil_slabs(world, backend):
+    """the "lite" finish of the library's Lanczos step on the HALO-type operand (3-point stencil, 2^18 rows per rank: halo
+    exchange, then the slab mat-vec with its dot) -- T and the last basis vector bit-identical to the Python driver's"""
+    N, k = (1 << 18) * world, 40
+    lib_run = _run(world, backend, "_case_stencil_lanczos", {}, N, k)
+    py_run = _run(world, backend, "_case_stencil_lanczos", {"DSEA_DRIVER": "python"}, N, k)
+    for r in range(world):
+        assert lib_run[r]["driver"].startswith("library") and py_run[r]["driver"] == "python"
+        for key in ("alphas", "betas", "q_last"):
+            assert np.array_equal(lib_run[r][key], py_run[r][key]), key
 
 
 @pytest.mark.parametrize("world,backend", [(1, "nccl"), (2, "gloo"), (4, "gloo")])
