@@ -181,6 +181,8 @@ def test_bench_watchdog_on_the_rccl_branch_rehearsal(inject, stage, driver):
     stand-in -- in the point-to-point traffic of the second communicator, or in the all-reduce -- is what a dead-locked
     RCCL call would look like: no error, no return.  The supervisors notice the stall, kill both children and start fresh
     ones at the next stage; the line arrives from stage 2 (one communicator) resp. stage 3 (Python driver)."""
+    if not os.path.exists(FAKE_RCCL):       # normally shipped in-tree by build(); else build it on the box
+        subprocess.run(["make", "-C", os.path.dirname(FAKE_RCCL), "libfake_rccl.so"], capture_output=True, timeout=300)
     assert os.path.exists(FAKE_RCCL), "build() compiles tests/fake_rccl/libfake_rccl.so"
     env = {"DSEA_RCCL_LIB": FAKE_RCCL, "DSEA_BENCH_STALL_S": "15", "DSEA_BENCH_STARTUP_S": "300"}
     if inject:
