@@ -145,13 +145,14 @@ int comm_alltoall(dsea_comm_s* c, const double* send, double* recv, int64_t chun
   HIP_TRY(hipMemcpyAsync(recv + (int64_t)c->rank * chunk, send + (int64_t)c->rank * chunk, (size_t)chunk * sizeof(double),
                          hipMemcpyDeviceToDevice, st));
   NCCL_OK(g_rccl.group_start());
-  for (int j = 0; j < c->world; ++j) {
+  bool ok = true;                                            // (a failed call must not leave the group open)
+  for (int j = 0; j < c->world && ok; ++j) {
     if (j == c->rank) continue;
-    NCCL_OK(g_rccl.send(send + (int64_t)j * chunk, (size_t)chunk, ncclDouble, j, c->xchg, st));
-    NCCL_OK(g_rccl.recv(recv + (int64_t)j * chunk, (size_t)chunk, ncclDouble, j, c->xchg, st));
+    ok = g_rccl.send(send + (int64_t)j * chunk, (size_t)chunk, ncclDouble, j, c->xchg, st) == ncclSuccess &&
+         g_rccl.recv(recv + (int64_t)j * chunk, (size_t)chunk, ncclDouble, j, c->xchg, st) == ncclSuccess;
   }
-  NCCL_OK(g_rccl.group_end());
-  return DSEA_OK;
+  const bool closed = g_rccl.group_end() == ncclSuccess;
+  return ok && closed ? DSEA_OK : DSEA_ERR_COMM;
 }
 
 struct P2P {
@@ -169,12 +170,12 @@ int comm_sendrecv(dsea_comm_s* c, const P2P* items, int n_items, hipStream_t st)
     return DSEA_OK;
   }
   NCCL_OK(g_rccl.group_start());
-  for (int k = 0; k < n_items; ++k) {
-    NCCL_OK(g_rccl.send(items[k].send, (size_t)items[k].count, ncclDouble, items[k].peer, c->xchg, st));
-    NCCL_OK(g_rccl.recv(items[k].recv, (size_t)items[k].count, ncclDouble, items[k].peer, c->xchg, st));
-  }
-  NCCL_OK(g_rccl.group_end());
-  return DSEA_OK;
+  bool ok = true;
+  for (int k = 0; k < n_items && ok; ++k)
+    ok = g_rccl.send(items[k].send, (size_t)items[k].count, ncclDouble, items[k].peer, c->xchg, st) == ncclSuccess &&
+         g_rccl.recv(items[k].recv, (size_t)items[k].count, ncclDouble, items[k].peer, c->xchg, st) == ncclSuccess;
+  const bool closed = g_rccl.group_end() == ncclSuccess;
+  return ok && closed ? DSEA_OK : DSEA_ERR_COMM;
 }
 
 // ---- the overlap premise, on the device -----------------------------------------------------------------------------

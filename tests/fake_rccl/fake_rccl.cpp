@@ -23,6 +23,8 @@
 // Fault injection for the bench watchdog tests: FAKE_RCCL_HANG=<kind>[@comm<i>][:<after>] with kind = allreduce | p2p
 // makes the (after+1)-th operation of that kind (on the i-th communicator this process created, default: any) sleep
 // forever on the host, on the ranks FAKE_RCCL_HANG_RANK selects (default: all).
+// FAKE_RCCL_FAIL=<allreduce|send>[:<after>] makes the (after+1)-th call of that kind return ncclInternalError, once, on
+// every rank alike (no operation is recorded): what the caller does with a failed call inside an open group.
 #include <fcntl.h>
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
@@ -177,6 +179,27 @@ void maybe_hang(ncclComm* c, int kind) {
           c->index);
   fflush(stderr);
   for (;;) pause();
+}
+
+bool injected_failure(int kind) {      // kind 0 all-reduce, 1 send
+  static int want = -2;
+  static long after = 0;
+  static std::atomic<long> seen{0};
+  static std::once_flag once;
+  std::call_once(once, [] {
+    want = -1;
+    const char* e = getenv("FAKE_RCCL_FAIL");
+    if (!e || !*e) return;
+    std::string s(e);
+    size_t colon = s.find(':');
+    if (colon != std::string::npos) {
+      after = atol(s.c_str() + colon + 1);
+      s.resize(colon);
+    }
+    if (s == "allreduce") want = 0;
+    if (s == "send") want = 1;
+  });
+  return want == kind && seen.fetch_add(1) == after;
 }
 
 // ---- shared-memory protocol --------------------------------------------------------------------------------------------
@@ -519,6 +542,7 @@ ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, n
   if (!c || !sendbuff || !recvbuff) return ncclInvalidArgument;
   if (op != ncclSum || dtype_size(datatype) < 4) return ncclInvalidArgument;
   g_stats[0].fetch_add(1);
+  if (injected_failure(0)) return ncclInternalError;
   if (count == 0) return ncclSuccess;
   Op o{};
   o.kind = 2;
@@ -533,6 +557,7 @@ ncclResult_t ncclSend(const void* sendbuff, size_t count, ncclDataType_t datatyp
   if (!c || (!sendbuff && count) || peer < 0 || peer >= c->world || peer == c->rank || dtype_size(datatype) == 0)
     return ncclInvalidArgument;
   g_stats[1].fetch_add(1);
+  if (injected_failure(1)) return ncclInternalError;
   g_stats[6].fetch_add(count * dtype_size(datatype));
   Op o{};
   o.kind = 0;
