@@ -617,6 +617,33 @@ def _case_rccl_collectives(rank, world, backend, dev, env):
     return out
 
 
+def _case_rccl_failed_call(rank, world, backend, dev, env):
+    """a point-to-point call that FAILS inside the group of an exchange: the library reports DSEA_ERR_COMM and leaves no group
+    open behind it -- the next exchange and the next all-reduce on the same communicator pair are complete and correct"""
+    from ctypes import c_void_p
+    from dominantsparseeigenad_amd import _lib
+    comm = _rccl_branch_comm(dev, "rccl", env)
+    nc, lib = comm.native_comm, _lib.load()
+    chunk = 4099
+    src = torch.arange(world * chunk, dtype=torch.float64, device=dev) + 1e6 * rank
+    dst = torch.zeros_like(src)
+    st = c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    first = lib.dsea_comm_alltoall(nc.handle, c_void_p(src.data_ptr()), c_void_p(dst.data_ptr()), chunk, st)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dst.zero_()
+    second = lib.dsea_comm_alltoall(nc.handle, c_void_p(src.data_ptr()), c_void_p(dst.data_ptr()), chunk, st)
+    red = torch.full((5,), float(rank + 1), dtype=torch.float64, device=dev)
+    third = lib.dsea_comm_allreduce(nc.handle, c_void_p(red.data_ptr()), 5, st)
+    torch.cuda.synchronize()
+    ok = all(bool(torch.equal(dst[j * chunk:(j + 1) * chunk],
+                              torch.arange(rank * chunk, (rank + 1) * chunk, dtype=torch.float64, device=dev) + 1e6 * j))
+             for j in range(world))
+    out = dict(first=first, second=second, third=third, a2a=ok, red=red.cpu().tolist(), stats=_fake_rccl_stats())
+    nc.close()
+    return out
+
+
 def _case_rccl_stencil(rank, world, backend, dev, mode, env):
     """_case_api_stencil with the halo exchange through the library driver's communicator: stand-in RCCL or callbacks"""
     comm = _rccl_branch_comm(dev, mode, env)
@@ -713,3 +740,16 @@ def test_rccl_branch_halo_exchange_of_the_stencil(world):
         assert np.array_equal(rccl[r]["psi"], cb[r]["psi"]) and np.array_equal(rccl[r]["grad"], cb[r]["grad"])
         assert rccl[r]["stats"][1] > 100 and rccl[r]["stats"][0] > 100
     assert abs(rccl[0]["E"] - float(gd["E"])) < 1e-10 * abs(float(gd["E"]))
+
+
+def test_rccl_call_that_fails_inside_a_group_leaves_the_communicator_usable():
+    """FAKE_RCCL_FAIL=send:0 -- the first ncclSend of the first exchange returns an error on both ranks: dsea_comm_alltoall
+    answers DSEA_ERR_COMM with the group closed, and the same exchange repeated is complete"""
+    _need_fake_rccl()
+    from dominantsparseeigenad_amd import _lib
+    ret = _run(2, "gloo", "_case_rccl_failed_call", {"FAKE_RCCL_FAIL": "send:0"})
+    for r in range(2):
+        assert ret[r]["first"] == _lib.ERR_COMM and ret[r]["second"] == 0 and ret[r]["third"] == 0, ret[r]
+        assert ret[r]["a2a"] and ret[r]["red"] == [3.0] * 5, ret[r]
+        st = ret[r]["stats"]
+        assert st[1] == 2 and st[2] == 1 and st[3] == 2 and st[0] == 1, st      # sends tried, receives, groups closed, all-reduces
