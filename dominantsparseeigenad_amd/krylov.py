@@ -160,6 +160,11 @@ STAGE_LOG = None        # set to a list to record [columns, ms until the stage's
 # idles for the host's 1 - 4 ms per test (40 % of a config-4 forward); the price is at most one speculative stage of columns
 # that a converged test makes unnecessary (they are computed and ignored).  False = test, then enqueue (round-4 behaviour).
 PIPELINED_STAGES = __import__("os").environ.get("DSEA_ARNOLDI_PIPELINED", "1") != "0"
+# A stage whose end WAS the extrapolated convergence point (margin: 0.3 tol and two columns) is expected to pass its test, so
+# nothing is enqueued behind it: the columns of a speculative stage there are computed in vain in the common case, and the Ritz
+# combination and the other side's kernels wait behind them.  If the test fails after all, the next stage is enqueued then (one
+# host test exposed).  True = always keep a speculative stage in flight.
+SPECULATE_PAST_PREDICTION = __import__("os").environ.get("DSEA_ARNOLDI_SPECULATE_PAST_PREDICTION", "0") == "1"
 
 
 def _speculative_stage_end(j1, p, m, hist, tol):
@@ -173,6 +178,8 @@ def _speculative_stage_end(j1, p, m, hist, tol):
         if rb < ra and rb > 0.0 and jb > ja:
             rate = np.log(rb / ra) / (jb - ja)
             jstar = jb + int(np.ceil(np.log(0.3 * tol / rb) / rate)) + 2
+            if jstar <= j1 and not SPECULATE_PAST_PREDICTION:
+                return None                 # the pending stage ends at the predicted convergence point: nothing behind it
             j2 = max(j1 + STAGE_MIN, min(jstar, j1 + STAGE_MAX))
     return m if j2 + STAGE_MIN > m else j2
 
@@ -369,7 +376,7 @@ def arnoldi_dominant(A, n, ncv, device, which="LM", v0=None, tol=1e-13, max_rest
                 if res <= tol * abs(theta) or me < j1 or j1 >= m:
                     break
                 hist.append((j1, res / max(abs(theta), 1e-300)))
-            if j2 is None:                      # (cannot happen: j1 < m here) -- keep the loop well-formed
+            if j2 is None:                      # the stage was expected to converge and did not: enqueue the next one now
                 j2 = _next_stage_end(j1, p, m, hist, tol)
                 pipe.extend(j1, j2)
                 pipe.snapshot(j2, 1 - slot)

@@ -15,7 +15,7 @@ if os.environ.get("DSEA_C4_SERIAL") == "1":          # left / right solves one a
     import dominantsparseeigenad_amd.eig as _eig
     _eig.CONCURRENT_SIDES = False
 dev = torch.device("cuda:0")
-tag = " ".join("%s=%s" % (k, os.environ[k]) for k in ("DSEA_WS_SPLIT", "DSEA_WS_RPL", "DSEA_LIB", "DSEA_TRANSFER_MFMA", "DSEA_C4_SERIAL", "DSEA_ARNOLDI_PIPELINED") if k in os.environ)
+tag = " ".join("%s=%s" % (k, os.environ[k]) for k in ("DSEA_WS_SPLIT", "DSEA_WS_RPL", "DSEA_LIB", "DSEA_TRANSFER_MFMA", "DSEA_C4_SERIAL", "DSEA_ARNOLDI_PIPELINED", "DSEA_ARNOLDI_SPECULATE_PAST_PREDICTION") if k in os.environ)
 for _ in range(reps):
     r = bench.c4_figures(dev)
     print("[%s] forward %.2f ms  backward %.2f ms  mat-vec %.2f us  residual %.1e" % (tag or "default", r["forward_ms"], r["backward_ms"],
