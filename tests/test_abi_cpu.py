@@ -59,3 +59,17 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libdsea.so")
     with pytest.raises(_lib.DseaError):
         _lib.load()
+
+
+def test_integration_md_indexes_every_entry_point():
+    """INTEGRATION.md section 4 = tools/abi_index.py on the header as it stands: one row per declared function, and the
+    declared functions are the library's exports (test_library_exports_every_declared_symbol)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("abi_index", os.path.join(ROOT, "tools", "abi_index.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    block, count = mod.block()
+    assert count == len(header_symbols())
+    assert sorted(r[0] for r in mod.rows()) == sorted(header_symbols())
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert block in doc, "INTEGRATION.md section 4 is stale: python tools/abi_index.py --write"
