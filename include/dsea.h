@@ -198,6 +198,7 @@ int dsea_op_destroy(dsea_op_t op);
 int dsea_op_dim(dsea_op_t op, int64_t *n);
 
 /* y = A x - (*shift) x  (shift may be null);  if dot_out != null: *dot_out = x.y (local sum).
+ * The Amap(v) of Lanczos.py:54,71 and CG.py:27,31,34,40 (with q.u of Lanczos.py:55,72 / d.Ad of CG.py:31 through dot_out).
  * If skip_flag != null and *skip_flag != 0 the call is a no-op on the device (converged CG). */
 int dsea_spmv(dsea_op_t op, dsea_ws_t ws, const double *x, double *y, const double *shift,
               double *dot_out, const double *skip_flag, void *stream);
@@ -206,18 +207,18 @@ int dsea_spmv(dsea_op_t op, dsea_ws_t ws, const double *x, double *y, const doub
  * Used one by one in the generic-callable and the multi-GPU modes, and composed by
  * dsea_lanczos_run.                                                                       */
 
-/* out = x.y */
+/* out = x.y   (torch.matmul(q, u) of Lanczos.py:55,72 ; the inner products of CG.py:31,37) */
 int dsea_dot(dsea_ws_t ws, const double *x, const double *y, int64_t n, double *out, void *stream);
 
 /* y -= (*shift) * x ; *dot_out = x.y      (generic A: turns A(d) into (A - E0) d, CG.py:120)   */
 int dsea_shift_dot(dsea_ws_t ws, const double *x, double *y, const double *shift, double *dot_out,
                    const double *skip_flag, int64_t n, void *stream);
 
-/* y += (a_host * (*a_dev)) * x   (a_dev may be null = 1)                                      */
+/* y += (a_host * (*a_dev)) * x   (a_dev may be null = 1)       (x + alpha d of CG.py:33 for a caller-composed loop) */
 int dsea_axpy(dsea_ws_t ws, double a_host, const double *a_dev, const double *x, double *y,
               int64_t n, void *stream);
 
-/* nrm2_out = ||x||^2 (local) */
+/* nrm2_out = ||x||^2 (local)   (torch.norm of Lanczos.py:53,69 and CG.py:28,35, before its square root) */
 int dsea_nrm2sq(dsea_ws_t ws, const double *x, int64_t n, double *nrm2_out, void *stream);
 
 /* Measurement probe, not part of the path (bench.py "measured_ceilings"; SURVEY.md 8d asks for the box's own streaming
@@ -308,27 +309,30 @@ int dsea_lanczos_form_r(dsea_ws_t ws, const double *Q, int64_t ldq, int64_t n, i
 /* Top-bit flips of the row-partitioned TFIM mat-vec in TRANSPOSED form (P = 2^p ranks, P >= 4): the caller
  * all-to-alls its slab (chunk c of every rank's slab goes to rank c), calls this on the received buffer
  * xT[P][chunk]:  zT[s][m] = sum_{b<p} xT[s ^ (1<<b)][m],  and all-to-alls zT back (zT[s] to rank s).  Every
- * link then carries 1/P of a slab per phase instead of a whole slab per partner.                          */
+ * link then carries 1/P of a slab per phase instead of a whole slab per partner.  (The flips of the top p bits in the
+ * gather-table mat-vec of examples/TFIM/TFIM.py:39-51.)                                                   */
 int dsea_hypercube_flipsum(const double *xT, double *zT, int P, int64_t chunk, void *stream);
 
-/* r = u - (*alpha) Q[i-1] - (*beta) Q[i-2] ; c_out[j] = Q[j].r (j < i) ; c_out[i] = r.r   (local sums)   */
+/* r = u - (*alpha) Q[i-1] - (*beta) Q[i-2] ; c_out[j] = Q[j].r (j < i) ; c_out[i] = r.r   (local sums)
+ * (Lanczos.py:61 and the inner product of :66, on a slab)                                                 */
 int dsea_plz_dots(dsea_ws_t ws, const double *Q, int64_t ldq, int64_t n, int i, const double *u,
                   const double *alpha, const double *beta, double *r, double *c_out, void *stream);
 /* row >= 1: r -= sum_{j<row} c[j] Q[j] (bf16 shadow if registered and the premise holds) ; pair_out[0] = ||r||^2
- * (local).  row == 0: only pair_out[0] = r.r.                                                              */
+ * (local).  row == 0: only pair_out[0] = r.r.          (the outer product of Lanczos.py:66 and the norm of :69, on a slab) */
 int dsea_plz_correct(dsea_ws_t ws, const double *Q, int64_t ldq, int64_t n, int row, const double *c,
                      double *r, double *pair_out, void *stream);
-/* the same followed by y = A_local r (operators whose remote part is ADDED after the local one, e.g. TFIM;
+/* the same followed by y = A_local r (Lanczos.py:71 applied to the un-normalised r; operators whose remote part is ADDED after the local one, e.g. TFIM;
  * halo-type operators call dsea_plz_correct, exchange the halo, then dsea_spmv)                            */
 int dsea_plz_correct_matvec(dsea_op_t op, dsea_ws_t ws, const double *Q, int64_t ldq, int row,
                             const double *c, double *r, double *y, double *pair_out, void *stream);
 /* y += a_host*(*a_dev) * (xs[0] + ... + xs[count-1]) - (*shift) x ; *dot_out = x.y (local).  count <= 6,
- * a_dev / shift / skip_flag nullable.  (remote part of the TFIM mat-vec: a = -g, xs = partner slabs)       */
+ * a_dev / shift / skip_flag nullable.  (remote part of the TFIM mat-vec: a = -g, xs = partner slabs -- the flips of
+ * examples/TFIM/TFIM.py:39-51 whose partner row lives on another rank; the dot is Lanczos.py:72 / CG.py:31)   */
 int dsea_axpy_multi_dot(dsea_ws_t ws, double a_host, const double *a_dev, const double *const *xs, int count,
                         const double *shift, const double *skip_flag, const double *x, double *y, int64_t n,
                         double *dot_out, void *stream);
 /* pair = global (||r||^2, r.Ar): q_out = r/beta (row `row` of the basis; also its bf16 shadow row if registered),
- * u_out = y/beta, *alpha_out = pair[1]/pair[0], *beta_out = beta (nullable)                               */
+ * u_out = y/beta, *alpha_out = pair[1]/pair[0], *beta_out = beta (nullable)            (Lanczos.py:69-70,72-75) */
 int dsea_plz_finish(dsea_ws_t ws, const double *r, const double *y, const double *pair, double *q_out, int row,
                     double *u_out, double *alpha_out, double *beta_out, int64_t n, void *stream);
 
@@ -402,11 +406,11 @@ int dsea_pop_create_stencil3(int64_t n_local, double coef, const double *V_dev, 
                              dsea_pop_t *out);
 int dsea_pop_destroy(dsea_pop_t pop);
 int dsea_pop_set_flags(dsea_pop_t pop, int flags);
-/* y = (A - (*shift)) x over all ranks; if dot_out != null: *dot_out = GLOBAL x.y (all-reduced, identical on every
+/* y = (A - (*shift)) x over all ranks (Amap of Lanczos.py:54,71 / CG.py:27,31 and A(v) - E0 v of CG.py:120); if dot_out != null: *dot_out = GLOBAL x.y (all-reduced, identical on every
  * rank); skip_flag as in dsea_spmv.                                                                              */
 int dsea_pop_matvec(dsea_pop_t pop, dsea_ws_t ws, const double *x, double *y, const double *shift, double *dot_out,
                     const double *skip_flag, void *stream);
-/* out = GLOBAL x.y */
+/* out = GLOBAL x.y   (the inner products of Lanczos.py:55,72 and CG.py:31,37 across ranks) */
 int dsea_pop_dot(dsea_pop_t pop, dsea_ws_t ws, const double *x, const double *y, int64_t n, double *out, void *stream);
 /* k-step Lanczos with full re-orthogonalisation on slabs (reference Lanczos.py:49-77 distributed): per step the
  * macro phases above with TWO all-reduces (coefficients + ||r||^2 ; ||r||^2, r.Ar) and ONE exchange, all issued by
@@ -482,7 +486,8 @@ int dsea_arnoldi_status(dsea_ws_t ws, int *break_step, int *redo_step, void *str
  * has just enqueued while the NEXT stage is already running (krylov.arnoldi_dominant).                                  */
 int dsea_arnoldi_status_enqueue(dsea_ws_t ws, double *host_record, void *stream);
 
-/* the orthogonalisation of ONE Arnoldi step when the mat-vec is the caller's code: u = A v_j given, writes column j
+/* the orthogonalisation of ONE Arnoldi step (one step of what eig.py:29-30,116-117 runs inside ARPACK and :54,57,140,144
+ * inside scipy's gmres) when the mat-vec is the caller's code: u = A v_j given, writes column j
  * of H (entries 0..j+1) and V[j+1]; (*shift) v_j is subtracted from u inside the first pass.                    */
 int dsea_arnoldi_orth(dsea_ws_t ws, const double *u, const double *shift, double *V, int64_t ldv, int64_t n, int j,
                       double *H, int ldh, void *stream);
@@ -494,8 +499,9 @@ int dsea_arnoldi_orth(dsea_ws_t ws, const double *u, const double *shift, double
  * state (8 device doubles): [0] residual estimate  [1] converged  [2] columns used  [3] ||r0||  [4] finished early.
  * The caller reads `state` after the cycle (its one sync) and issues the next cycle if [1] == 0.                 */
 size_t dsea_gmres_work_doubles(int m);
-/* the three stages of a cycle, for operands whose mat-vec is the caller's code (op == NULL, u = A v_j supplied per
- * step; Ax = (A - shift) x supplied to begin, NULL for x = 0); dsea_gmres_cycle composes them for native operators */
+/* the three stages of a cycle (the gmres calls of eig.py:54,57,140,144), for operands whose mat-vec is the caller's code
+ * (op == NULL, u = A v_j supplied per step; Ax = (A - shift) x supplied to begin, NULL for x = 0); dsea_gmres_cycle
+ * composes them for native operators                                                                              */
 int dsea_gmres_begin(dsea_ws_t ws, const double *b, const double *Ax, double *V, int64_t ldv, int64_t n, int m,
                      double *work, double target, double *state, void *stream);
 int dsea_gmres_step(dsea_op_t op, dsea_ws_t ws, const double *shift, const double *u, double *V, int64_t ldv,
