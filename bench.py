@@ -235,7 +235,7 @@ def c3_figures(dev):
 def sweep_figures(dev, N=20, k=200, idxs=(25, 50, 75), warm=80):
     """Row f-2 as a driver-timed figure: the reference's SECOND-ORDER workload per coupling (examples/TFIM/E0.py:53-67
     ``E0_sparseAD`` = forward + d/dg + d2/dg2, chiF.py:40-53 ``chiF_sparseAD`` = forward + two derivatives of log F: two
-    forward passes and five adjoint solves per coupling) at N = 20, k = 200, on the three couplings the parity test uses,
+    forward passes and six CG solves per coupling, counted in the kernel trace) at N = 20, k = 200, on the three couplings the parity test uses,
     against the reference's stored curves (tests/golden/ref_datas = its own outputs); cold, and with the previous
     coupling's eigenvector as the start vector of a ``warm``-step Lanczos (an extension the reference lacks)."""
     import importlib.util
@@ -255,7 +255,7 @@ def sweep_figures(dev, N=20, k=200, idxs=(25, 50, 75), warm=80):
     curC = np.load(os.path.join(ROOT, "tests", "golden", "ref_datas", "chiF_N_%d.npz" % N))
     model = E0m.TFIM(N, dev)
     out = {"workload": "TFIM N=%d k=%d: E0, dE0/dg, d2E0/dg2 (E0.py:53-67) and chi_F (chiF.py:40-53) per coupling -- two forward "
-                       "passes + five adjoint solves; couplings g = %s" % (N, k, ", ".join("%.3f" % curE["gs"][i] for i in idxs))}
+                       "passes + six CG solves; couplings g = %s" % (N, k, ", ".join("%.3f" % curE["gs"][i] for i in idxs))}
     for label, kw in (("cold", 0), ("warm_%d" % warm, warm)):
         torch.manual_seed(1)
         dev_max = {"E0": 0.0, "dE0": 0.0, "d2E0": 0.0, "chiF": 0.0}
