@@ -26,6 +26,8 @@ ERR_PREMISE = -10
 ERR_SECOND_PASS = -11
 ERR_UNSUPPORTED = -6
 COMM_ID_BYTES = 128
+TUNE_TFIM_TILE_LOG2, TUNE_CSR_GROUP, TUNE_SELL_UNROLL, TUNE_SELL_XCD_MAP = 1, 2, 3, 4
+SDDMM_ACCUMULATE, SDDMM_SYMMETRIC = 1, 2
 POP_OVERLAP, POP_PAIRWISE, POP_NO_EXCHANGE, POP_CG_REFERENCE, POP_CG_ONE_REDUCTION = 1, 2, 4, 8, 16
 # caller-supplied collectives of dsea_comm_create_callbacks (device pointers + the stream the data was produced on)
 ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_int64, c_void_p)
@@ -64,12 +66,16 @@ _SIGNATURES = {
     "dsea_op_create_tfim": (c_int, [c_int, c_int, c_int64, c_void_p, c_double, c_double, POINTER(c_void_p)]),
     "dsea_op_create_csr": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
     "dsea_op_create_sell": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
+    "dsea_op_create_sell16": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
     "dsea_op_create_stencil3": (c_int, [c_int64, c_double, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
     "dsea_op_create_dense": (c_int, [c_int64, c_void_p, c_int64, c_int, POINTER(c_void_p)]),
     "dsea_op_symdense_work_bytes": (c_size_t, [c_int64]),
     "dsea_op_create_symdense": (c_int, [c_int64, c_void_p, c_int, c_int64, c_void_p, POINTER(c_void_p)]),
     "dsea_op_transfer_work_bytes": (c_size_t, [c_int, c_int]),
     "dsea_op_create_transfer": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, POINTER(c_void_p)]),
+    "dsea_op_update_vals": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dsea_op_sddmm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p]),
+    "dsea_op_set_slab": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "dsea_op_destroy": (c_int, [c_void_p]),
     "dsea_op_dim": (c_int, [c_void_p, POINTER(c_int64)]),
     "dsea_spmv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -111,10 +117,13 @@ _SIGNATURES = {
     "dsea_comm_destroy": (c_int, [c_void_p]),
     "dsea_comm_allreduce": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "dsea_comm_alltoall": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "dsea_comm_allgather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "dsea_pop_tfim_scratch_doubles": (c_size_t, [c_int, c_int]),
     "dsea_pop_create_tfim": (c_int, [c_int, c_void_p, c_void_p, c_double, c_double, c_void_p, c_void_p, c_int, c_double,
                                      POINTER(c_void_p)]),
     "dsea_pop_create_stencil3": (c_int, [c_int64, c_double, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
+    "dsea_pop_create_csr": (c_int, [c_void_p, c_void_p, POINTER(c_void_p)]),
+    "dsea_pop_sddmm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p]),
     "dsea_pop_destroy": (c_int, [c_void_p]),
     "dsea_pop_set_flags": (c_int, [c_void_p, c_int]),
     "dsea_pop_matvec": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -157,6 +157,14 @@ int dsea_op_set_tuning(dsea_op_t op, int key, int value) {
       if (value != 0 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64) return DSEA_ERR_ARG;
       op->d.tune_csr_group = value;
       return DSEA_OK;
+    case DSEA_TUNE_SELL_UNROLL:
+      if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return DSEA_ERR_ARG;
+      op->d.tune_sell_unroll = value;
+      return DSEA_OK;
+    case DSEA_TUNE_SELL_XCD_MAP:
+      if (op->d.kind != OP_SELL || (value != 0 && value != 1)) return DSEA_ERR_ARG;
+      op->d.sell.xcd = value;
+      return DSEA_OK;
     default: return DSEA_ERR_ARG;
   }
 }
@@ -426,6 +434,24 @@ int dsea_op_create_sell(int64_t n, int64_t nslices, const int64_t* slice_ptr, co
   op->d.kind = OP_SELL;
   op->d.n = n;
   op->d.sell = SellParams{n, nslices, slice_ptr, colidx, vals};
+  op->d.sell.xcd = 1;
+  *out = op;
+  return DSEA_OK;
+}
+
+int dsea_op_create_sell16(int64_t n, int64_t nslices, const int64_t* slice_ptr, const int32_t* colbase,
+                          const uint16_t* coldelta, const double* vals, dsea_op_t* out) {
+  if (!out || n < 1 || nslices != (n + 63) / 64 || !slice_ptr || !colbase || !coldelta || !vals) return DSEA_ERR_ARG;
+  dsea_op_s* op = new (std::nothrow) dsea_op_s;
+  if (!op) return DSEA_ERR_ARG;
+  memset(&op->d, 0, sizeof(op->d));
+  op->d.tune_tile_log2 = DSEA_TFIM_TILE_LOG2;
+  op->d.kind = OP_SELL;
+  op->d.n = n;
+  op->d.sell = SellParams{n, nslices, slice_ptr, nullptr, vals};
+  op->d.sell.colbase = colbase;
+  op->d.sell.col16 = coldelta;
+  op->d.sell.xcd = 1;
   *out = op;
   return DSEA_OK;
 }
@@ -511,6 +537,59 @@ int dsea_op_create_transfer(int D, int d, const double* A_dev, int transpose, do
   if (Bp) launch_pack_fragments(op->d.transfer.B, Bp, D, d, static_cast<hipStream_t>(stream));   // (MFMA fragment order, once)
   *out = op;
   return check_launch();
+}
+
+int dsea_op_update_vals(dsea_op_t op, const int64_t* rowptr, const double* vals_csr, void* stream) {
+  if (!op || !vals_csr) return DSEA_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (op->d.kind == OP_SELL) {
+    if (!rowptr) return DSEA_ERR_ARG;
+    launch_sell_update_vals(op->d, rowptr, vals_csr, st);
+    return check_launch();
+  }
+  if (op->d.kind == OP_CSR) {
+    const CsrParams& p = op->d.csr;
+    if (vals_csr != p.vals && p.nnz > 0 &&
+        hipMemcpyAsync(const_cast<double*>(p.vals), vals_csr, (size_t)p.nnz * sizeof(double), hipMemcpyDeviceToDevice, st) !=
+            hipSuccess)
+      return DSEA_ERR_HIP;
+    return DSEA_OK;
+  }
+  return DSEA_ERR_UNSUPPORTED;
+}
+
+int dsea_op_sddmm(dsea_op_t op, const int64_t* rowptr, const double* v1, const double* v2, double alpha, int flags,
+                  double* out, void* stream) {
+  if (!op || !v1 || !v2 || !out || (flags & ~(DSEA_SDDMM_ACCUMULATE | DSEA_SDDMM_SYMMETRIC))) return DSEA_ERR_ARG;
+  if (op->d.kind != OP_SELL && op->d.kind != OP_CSR) return DSEA_ERR_UNSUPPORTED;
+  if (op->d.kind == OP_SELL && !rowptr) return DSEA_ERR_ARG;
+  // a slab (dsea_op_set_slab): the caller has exchanged v2's halo / gathered copy; the symmetric form needs both operands
+  // exchanged -- dsea_pop_sddmm issues it as two one-sided launches
+  if (op->d.kind == OP_SELL && op->d.sell.mode != 0 && (flags & DSEA_SDDMM_SYMMETRIC)) return DSEA_ERR_UNSUPPORTED;
+  if (launch_sddmm(op->d, rowptr, v1, v2, alpha, (flags & DSEA_SDDMM_ACCUMULATE) ? 1 : 0, (flags & DSEA_SDDMM_SYMMETRIC) != 0,
+                   out, static_cast<hipStream_t>(stream)) != 0)
+    return DSEA_ERR_UNSUPPORTED;
+  return check_launch();
+}
+
+int dsea_op_set_slab(dsea_op_t op, int64_t halo_width, double* halo_lo, double* halo_hi, double* x_gathered) {
+  if (!op || op->d.kind != OP_SELL) return op ? DSEA_ERR_UNSUPPORTED : DSEA_ERR_ARG;
+  SellParams& p = op->d.sell;
+  if (halo_width == -1) {
+    if (!x_gathered) return DSEA_ERR_ARG;
+    p.mode = 2;
+    p.hb = 0;
+    p.halo_lo = p.halo_hi = nullptr;
+    p.xg = x_gathered;
+    return DSEA_OK;
+  }
+  if (halo_width < 0 || halo_width > p.n) return DSEA_ERR_ARG;
+  p.mode = 1;
+  p.hb = halo_width;
+  p.halo_lo = halo_lo;
+  p.halo_hi = halo_hi;
+  p.xg = nullptr;
+  return DSEA_OK;
 }
 
 int dsea_op_destroy(dsea_op_t op) {

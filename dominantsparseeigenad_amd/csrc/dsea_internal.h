@@ -43,6 +43,18 @@ struct SellParams {
   const int64_t* slice_ptr;
   const int32_t* colidx;
   const double* vals;
+  // row-partitioned slab (dsea_pop_create_csr; all zero for a one-GPU operator): where x[col] is read from
+  //   mode 0: x itself;  1: LOCAL columns in [-hb, n + hb): c < 0 -> halo_lo[c + hb], c >= n -> halo_hi[c - n];
+  //   2: GLOBAL columns, read from the all-gathered copy xg
+  int mode;
+  int64_t hb;
+  const double* halo_lo;
+  const double* halo_hi;
+  const double* xg;
+  // 16-bit column deltas (dsea_op_create_sell16): column of element e = colbase[e / 64] + col16[e]; colidx unused (null)
+  const int32_t* colbase;
+  const uint16_t* col16;
+  int xcd;   // 1: XCD-contiguous slice map (dsea_op_set_tuning DSEA_TUNE_SELL_XCD_MAP)
 };
 struct Stencil3Params {
   int64_t n;
@@ -79,6 +91,7 @@ struct OpDesc {
   int64_t n;
   int tune_tile_log2;  // TFIM: log2 rows of x staged in LDS per block (6..12)
   int tune_csr_group;  // CSR: lanes per row, 0 = automatic
+  int tune_sell_unroll;  // SELL: slice-column pairs in flight per lane {0 = automatic, 2, 4, 6, 8}; 1 = the round-5 kernel (A/B)
   TfimParams tfim;
   CsrParams csr;
   Stencil3Params st3;
@@ -236,6 +249,9 @@ int launch_cg_persist(const OpDesc& op, const double* shift, const double* b, do
                       int64_t maxiter, void* comm, int ppt_override, hipStream_t st, int lose_peer = 0);
 int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shift, const double* skip,
                 double* P, hipStream_t st, EventPair* ev = nullptr);
+int launch_sell_update_vals(const OpDesc& op, const int64_t* rowptr, const double* vals_csr, hipStream_t st);
+int launch_sddmm(const OpDesc& op, const int64_t* rowptr, const double* v1, const double* v2, double alpha, int accumulate,
+                 bool sym, double* out, hipStream_t st);
 // dsea_cg_persist_tfim_big.hip
 bool cg_persist_tfim_big_applicable(const OpDesc& op);
 size_t cg_persist_tfim_big_comm_bytes(int64_t n);

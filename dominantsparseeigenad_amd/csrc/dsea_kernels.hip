@@ -1567,8 +1567,11 @@ __global__ __launch_bounds__(256) void k_spmv_csr_stream(CsrParams p, const doub
 // (element k of lane l at slice_ptr[s] + 64 k + l) and padded to the slice's longest row with (col = own row,
 // val = 0).  Matrix loads are perfectly coalesced, and for the banded / structured operators of this domain the
 // gather x[col] of a wave hits consecutive addresses as well (lane = row).
+//
+// k_spmv_sell_r5: the round-5 kernel (lane = row, scalar 8-byte matrix loads, two columns in flight), kept behind
+// DSEA_TUNE_SELL_UNROLL = 1 as the "before" arm of tools/kbench_csr.py.  It ran at 0.65 of the HBM peak.
 template <bool FUSED>
-__global__ __launch_bounds__(256) void k_spmv_sell(SellParams p, const double* __restrict__ x,
+__global__ __launch_bounds__(256) void k_spmv_sell_r5(SellParams p, const double* __restrict__ x,
                                                    double* __restrict__ y, const double* __restrict__ shift,
                                                    const double* __restrict__ skip, double* __restrict__ P,
                                                    TfimFusedArgs fa) {
@@ -1618,6 +1621,236 @@ __global__ __launch_bounds__(256) void k_spmv_sell(SellParams p, const double* _
     __syncthreads();
     double tot = block_sum(acc, sm5);
     if (threadIdx.x == 0) P[blockIdx.x] = tot;
+  }
+}
+
+
+// k_spmv_sell (round 6).  What was measured on MI355X with the 21-nnz/row TFIM matrix at n = 2^20 (tools/kbench_csr.py,
+// profiles/r06_kbench_csr.txt; kernel alone, 281 MB algorithmic):
+//   * the round-5 kernel: 48.8 us = 5.76 TB/s.  Requesting 4 / 8 columns instead of 2 before the first gather: 48.7 / 47.8 us --
+//     the kernel is NOT short of loads in flight (8 waves per SIMD already cover the latency);
+//   * non-temporal matrix loads: 52-53 us (worse: the stream then bypasses the path that keeps x's lines next to it);
+//   * 16-byte matrix loads (a lane takes two rows of one slice column, half-waves take alternate columns, v_permlane32_swap
+//     at the end): bit-identical, 53.6 us -- every gather instruction then touches twice the cache lines at half density;
+//   * what it sits on is the FABRIC: besides the 264 MB matrix stream every XCD's L2 re-fetches the parts of x its rows
+//     gather from (the matrix-free kernel alone moves 4 x the vector, docs/design/04-kernels.md), ~310 MB at the box's
+//     6.8 TB/s read ceiling = 46 us.  The lever that is left is BYTES: k_spmv_sell16 below (16-bit column deltas).
+// The fused Lanczos tail divided every gathered element by beta (21 fp64 divisions per row: 65 us against 52 for the plain
+// launch); it now uses linearity like the matrix-free tail: u = (A r) / beta, one division per row beside q = r / beta.
+template <int MODE>
+__device__ __forceinline__ double sell_gather(const SellParams& p, const double* __restrict__ x, int c) {
+  if (MODE == 1) {
+    const double* base = x;
+    int64_t idx = c;
+    if (c < 0) {
+      base = p.halo_lo;
+      idx = (int64_t)c + p.hb;
+    } else if ((int64_t)c >= p.n) {
+      base = p.halo_hi;
+      idx = (int64_t)c - p.n;
+    }
+    return base[idx];
+  }
+  if (MODE == 2) return p.xg[c];
+  return x[c];
+}
+
+// slice handled by wave w of block b in trip t: plain round-robin, or (xcd != 0) XCD-contiguous -- workgroups are dealt
+// to the 8 XCDs in turn, so block b works on eighth b % 8 of the slices and that XCD's L2 keeps one eighth of x hot
+__device__ __forceinline__ int64_t sell_slice_of(const SellParams& p, int64_t linear) {
+  if (!p.xcd) return linear;
+  const int64_t nchunk = (p.nslices + 3) / 4;               // chunks of 4 slices (one block)
+  const int64_t per = (nchunk + 7) / 8;
+  const int64_t chunk = linear >> 2;
+  const int64_t mapped = (chunk & 7) * per + (chunk >> 3);
+  return mapped < nchunk ? mapped * 4 + (linear & 3) : p.nslices;
+}
+
+// sum_k vals[k] x[col k] of this lane's row of slice [b0, b1): even / odd slice columns accumulated separately, in order
+template <int MODE, int UN, bool C16>
+__device__ __forceinline__ double sell_row_sum(const SellParams& p, const double* __restrict__ x, int64_t b0, int64_t b1,
+                                               int lane) {
+  double s0 = 0.0, s1 = 0.0;
+  // 16-bit columns: lane j keeps the base of slice column kb + j (one coalesced load per 64 columns); a column's base is
+  // then a v_readlane with a wave-uniform index instead of a broadcast load per column (44.8 vs 47.2 us)
+  int cbl = 0;
+  int kb = -64;
+  for (int64_t e0 = b0 + lane; C16 ? (e0 - lane < b1) : (e0 < b1); e0 += 64 * UN) {
+    double v[UN], g[UN];
+    int c[UN];
+    const int k0 = __builtin_amdgcn_readfirstlane((int)((e0 - lane - b0) >> 6));
+    if (C16 && (k0 & ~63) != kb) {
+      kb = k0 & ~63;
+      const int64_t cbi = (b0 >> 6) + kb + lane;
+      cbl = cbi < (b1 >> 6) ? p.colbase[cbi] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int64_t e = e0 + 64 * u;
+      v[u] = 0.0;
+      c[u] = 0;
+      if (e < b1) {
+        v[u] = p.vals[e];
+        c[u] = C16 ? __builtin_amdgcn_readlane(cbl, (k0 + u) & 63) + (int)p.col16[e] : p.colidx[e];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) g[u] = (e0 + 64 * u < b1) ? sell_gather<MODE>(p, x, c[u]) : 0.0;
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (e0 + 64 * u < b1) {
+        if (u & 1) s1 = fma(v[u], g[u], s1);
+        else s0 = fma(v[u], g[u], s0);
+      }
+    }
+  }
+  return s0 + s1;
+}
+
+template <bool FUSED, int MODE, int UN, bool C16>
+__global__ __launch_bounds__(256) void k_spmv_sell(SellParams p, const double* __restrict__ x,
+                                                   double* __restrict__ y, const double* __restrict__ shift,
+                                                   const double* __restrict__ skip, double* __restrict__ P,
+                                                   TfimFusedArgs fa) {
+  __shared__ double sm5[5];
+  if (!FUSED && skip && skip[0] != 0.0) return;
+  const double s = shift ? shift[0] : 0.0;
+  const int lane = threadIdx.x & 63;
+  double acc = 0.0, beta = 1.0;
+  auto finish = [&](int64_t sl, double v) {
+    const int64_t row = sl * 64 + lane;
+    if (row < p.n) {
+      double xi = x[row];
+      if (FUSED) {
+        xi = xi / beta;
+        v = v / beta;
+        fa.q_out[row] = xi;
+        if (fa.qs_out) fa.qs_out[row] = f64_to_bf16(xi);
+      }
+      if (!FUSED && shift) v = __dsub_rn(v, __dmul_rn(s, xi));
+      y[row] = v;
+      acc = fma(xi, v, acc);
+    }
+  };
+  const int64_t ntrip = p.xcd ? ((p.nslices + 3) / 4 + 7) / 8 * 8 * 4 : p.nslices;
+  const int64_t lin0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  // First trip.  Lanczos tail (x is the un-normalised r; q = r/beta is stored, u = (A r)/beta): by linearity the row sums
+  // need no beta, so the wait for the ||r||^2 partials (a block-wide reduction with two barriers) sits BEHIND the matrix
+  // stream of the wave's first slice instead of in front of it; nothing has been written when a breakdown returns.
+  int64_t sl = lin0 < ntrip ? sell_slice_of(p, lin0) : p.nslices;
+  double v0 = 0.0;
+  if (sl < p.nslices) v0 = sell_row_sum<MODE, UN, C16>(p, x, p.slice_ptr[sl], p.slice_ptr[sl + 1], lane);
+  if (FUSED && !fused_beta(fa, sm5, beta)) return;
+  if (sl < p.nslices) finish(sl, v0);
+  for (int64_t lin = lin0 + (int64_t)gridDim.x * 4; lin < ntrip; lin += (int64_t)gridDim.x * 4) {
+    sl = sell_slice_of(p, lin);
+    if (sl >= p.nslices) continue;
+    finish(sl, sell_row_sum<MODE, UN, C16>(p, x, p.slice_ptr[sl], p.slice_ptr[sl + 1], lane));
+  }
+  if (P) {
+    __syncthreads();
+    double tot = block_sum(acc, sm5);
+    if (threadIdx.x == 0) P[blockIdx.x] = tot;
+  }
+}
+
+// The explicit-matrix operand as a PARAMETER (reference symeig.py:29,56-64,82-84: A-bar = v1 v2^T pushed to the parameters
+// of A; for a sparse A whose parameters are its non-zeros that is vals-bar[e] = v1[row(e)] v2[col(e)]).  Both kernels walk
+// the SELL copy (coalesced column indices) and address the caller's CSR arrays through rowptr: entry k of row i is CSR
+// element rowptr[i] + k.
+//   k_sell_update_vals : vals_sell[slice, k, lane] = vals_csr[rowptr[row] + k]        (in-place refresh, padding stays 0)
+//   k_sell_sddmm       : out[rowptr[row] + k] (+)= alpha * v1[row] * v2[col]   (SYM: alpha/2 (v1[row] v2[col] + v1[col] v2[row]))
+#define SELL_SEG_CAP 2048   /* doubles of LDS per wave: CSR segments of 64 rows up to 32 non-zeros per row on average */
+// Both kernels move a slice's values between the SELL order (lane = row, coalesced) and the caller's CSR order, where
+// the 64 rows of a slice are ONE contiguous segment [rowptr[r0], rowptr[r0 + 64)): the segment is staged in LDS so that
+// both sides are coalesced (measured at L = 20 without the staging: 514 us sddmm / 216 us update -- the per-lane CSR
+// accesses are 168 bytes apart).  Segments beyond SELL_SEG_CAP use the direct form.
+__global__ __launch_bounds__(256) void k_sell_update_vals(SellParams p, const int64_t* __restrict__ rowptr,
+                                                          const double* __restrict__ vals_csr, double* __restrict__ vals_sell) {
+  __shared__ double seg[4][SELL_SEG_CAP];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int64_t sl = (int64_t)blockIdx.x * 4 + w; sl < p.nslices; sl += (int64_t)gridDim.x * 4) {
+    const int64_t b0 = p.slice_ptr[sl], b1 = p.slice_ptr[sl + 1];
+    const int64_t r0 = sl * 64, r1 = r0 + 64 < p.n ? r0 + 64 : p.n;
+    const int64_t row = r0 + lane;
+    const int64_t lo0 = rowptr[r0], hi0 = rowptr[r1];
+    int64_t lo = 0, len = 0;
+    if (row < p.n) {
+      lo = rowptr[row];
+      len = rowptr[row + 1] - lo;
+    }
+    const bool staged = hi0 - lo0 <= SELL_SEG_CAP;
+    if (staged)
+      for (int64_t i = lane; i < hi0 - lo0; i += 64) seg[w][i] = vals_csr[lo0 + i];
+    // one wave owns seg[w]: the LDS operations of a wave are executed in order; the fence keeps the compiler from moving them
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int64_t k = 0;
+    for (int64_t e = b0 + lane; e < b1; e += 64, ++k)
+      vals_sell[e] = k < len ? (staged ? seg[w][lo - lo0 + k] : vals_csr[lo + k]) : 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int MODE, bool SYM>
+__global__ __launch_bounds__(256) void k_sell_sddmm(SellParams p, const int64_t* __restrict__ rowptr,
+                                                    const double* __restrict__ v1, const double* __restrict__ v2,
+                                                    double alpha, int accumulate, double* __restrict__ out) {
+  __shared__ double seg[4][SELL_SEG_CAP];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int64_t sl = (int64_t)blockIdx.x * 4 + w; sl < p.nslices; sl += (int64_t)gridDim.x * 4) {
+    const int64_t b0 = p.slice_ptr[sl], b1 = p.slice_ptr[sl + 1];
+    const int64_t r0 = sl * 64, r1 = r0 + 64 < p.n ? r0 + 64 : p.n;
+    const int64_t row = r0 + lane;
+    const int64_t lo0 = rowptr[r0], hi0 = rowptr[r1];
+    int64_t lo = 0, len = 0;
+    double a1 = 0.0, a2 = 0.0;
+    if (row < p.n) {
+      lo = rowptr[row];
+      len = rowptr[row + 1] - lo;
+      a1 = v1[row];
+      if (SYM) a2 = v2[row];
+    }
+    const bool staged = hi0 - lo0 <= SELL_SEG_CAP;
+    int64_t k = 0;
+    for (int64_t e = b0 + lane; e < b1; e += 64, ++k) {
+      if (k < len) {
+        const int c = p.col16 ? p.colbase[e >> 6] + (int)p.col16[e] : p.colidx[e];
+        double g = __dmul_rn(a1, sell_gather<MODE>(p, v2, c));
+        if (SYM) g = __dmul_rn(0.5, __dadd_rn(g, __dmul_rn(sell_gather<MODE>(p, v1, c), a2)));
+        g = __dmul_rn(alpha, g);
+        if (staged) seg[w][lo - lo0 + k] = g;
+        else out[lo + k] = accumulate ? __dadd_rn(out[lo + k], g) : g;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (staged)
+      for (int64_t i = lane; i < hi0 - lo0; i += 64) out[lo0 + i] = accumulate ? __dadd_rn(out[lo0 + i], seg[w][i]) : seg[w][i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// the same on a plain CSR operand: G lanes per row
+template <bool SYM>
+__global__ __launch_bounds__(256) void k_csr_sddmm(CsrParams p, const double* __restrict__ v1, const double* __restrict__ v2,
+                                                   double alpha, int accumulate, double* __restrict__ out) {
+  constexpr int G = 8;
+  const int sub = threadIdx.x % G;
+  const int64_t rows_per_block = 256 / G;
+  for (int64_t row = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / G; row < p.n;
+       row += (int64_t)gridDim.x * rows_per_block) {
+    const int64_t lo = p.rowptr[row], hi = p.rowptr[row + 1];
+    const double a1 = v1[row], a2 = SYM ? v2[row] : 0.0;
+    for (int64_t e = lo + sub; e < hi; e += G) {
+      const int c = p.colidx[e];
+      double g = __dmul_rn(a1, v2[c]);
+      if (SYM) g = __dmul_rn(0.5, __dadd_rn(g, __dmul_rn(v1[c], a2)));
+      g = __dmul_rn(alpha, g);
+      out[e] = accumulate ? __dadd_rn(out[e], g) : g;
+    }
   }
 }
 
@@ -2793,7 +3026,23 @@ int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shif
       if (nb > DSEA_MAX_TFIM_BLOCKS) nb = DSEA_MAX_TFIM_BLOCKS;
       if (nb < 1) nb = 1;
       TfimFusedArgs fa0 = {nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
-      KLAUNCH(ev, (k_spmv_sell<false>), (unsigned)nb, 256, st, p, x, y, shift, skip, P, fa0);
+#define SELL_GO(F, M, U, C) KLAUNCH(ev, (k_spmv_sell<F, M, U, C>), (unsigned)nb, 256, st, p, x, y, shift, skip, P, fa0)
+      const bool c16 = p.col16 != nullptr;
+      if (p.mode == 1) {
+        if (c16) SELL_GO(false, 1, 8, true); else SELL_GO(false, 1, 4, false);
+      } else if (p.mode == 2) {
+        if (c16) SELL_GO(false, 2, 8, true); else SELL_GO(false, 2, 4, false);
+      } else if (c16) {
+        SELL_GO(false, 0, 8, true);
+      } else {
+        switch (op.tune_sell_unroll) {
+          case 1: KLAUNCH(ev, (k_spmv_sell_r5<false>), (unsigned)nb, 256, st, p, x, y, shift, skip, P, fa0); break;
+          case 2: SELL_GO(false, 0, 2, false); break;
+          case 8: SELL_GO(false, 0, 8, false); break;
+          default: SELL_GO(false, 0, 4, false);
+        }
+      }
+#undef SELL_GO
       return (int)nb;
     }
     case OP_SYMDENSE: {
@@ -2839,7 +3088,19 @@ int launch_tfim_fused(const OpDesc& op, const double* r, const double* nP, int n
     const SellParams& p = op.sell;
     int64_t nb = (p.nslices + 3) / 4;
     if (nb > DSEA_MAX_TFIM_BLOCKS) nb = DSEA_MAX_TFIM_BLOCKS;
-    KLAUNCH(ev, (k_spmv_sell<true>), (unsigned)nb, 256, st, p, r, y, nullc, nullc, P, fa);
+    if (p.mode != 0) return -1;                         // slab of a row-partitioned matrix: the unfused sequence
+#define SELL_GO(U, C) KLAUNCH(ev, (k_spmv_sell<true, 0, U, C>), (unsigned)nb, 256, st, p, r, y, nullc, nullc, P, fa)
+    if (p.col16) {
+      SELL_GO(8, true);
+    } else {
+      switch (op.tune_sell_unroll) {
+        case 1: KLAUNCH(ev, (k_spmv_sell_r5<true>), (unsigned)nb, 256, st, p, r, y, nullc, nullc, P, fa); break;
+        case 2: SELL_GO(2, false); break;
+        case 8: SELL_GO(8, false); break;
+        default: SELL_GO(4, false);
+      }
+    }
+#undef SELL_GO
     return (int)nb;
   }
   if (op.kind == OP_STENCIL3) {
@@ -2863,6 +3124,46 @@ int launch_tfim_fused(const OpDesc& op, const double* r, const double* nP, int n
   }
 #undef TFIM_FCASE
   return (int)nb;
+}
+
+// explicit-matrix operand as a parameter: refresh of the SELL copy / sampled outer product, CSR order through rowptr
+int launch_sell_update_vals(const OpDesc& op, const int64_t* rowptr, const double* vals_csr, hipStream_t st) {
+  const SellParams& p = op.sell;
+  int64_t nb = (p.nslices + 3) / 4;
+  if (nb > DSEA_MAX_TFIM_BLOCKS) nb = DSEA_MAX_TFIM_BLOCKS;
+  hipLaunchKernelGGL(k_sell_update_vals, dim3((unsigned)nb), dim3(256), 0, st, p, rowptr, vals_csr, const_cast<double*>(p.vals));
+  return 0;
+}
+
+int launch_sddmm(const OpDesc& op, const int64_t* rowptr, const double* v1, const double* v2, double alpha, int accumulate,
+                 bool sym, double* out, hipStream_t st) {
+  if (op.kind == OP_SELL) {
+    const SellParams& p = op.sell;
+    int64_t nb = (p.nslices + 3) / 4;
+    if (nb > DSEA_MAX_TFIM_BLOCKS) nb = DSEA_MAX_TFIM_BLOCKS;
+#define SDDMM_CASE(M, S) hipLaunchKernelGGL((k_sell_sddmm<M, S>), dim3((unsigned)nb), dim3(256), 0, st, p, rowptr, v1, v2, alpha, accumulate, out)
+    if (p.mode == 0) {
+      if (sym) SDDMM_CASE(0, true); else SDDMM_CASE(0, false);
+    } else if (sym) {
+      return -1;                                        // (the slab driver issues two one-sided launches instead)
+    } else if (p.mode == 1) {
+      SDDMM_CASE(1, false);
+    } else {
+      SDDMM_CASE(2, false);
+    }
+#undef SDDMM_CASE
+    return 0;
+  }
+  if (op.kind == OP_CSR) {
+    const CsrParams& p = op.csr;
+    int64_t nb = (p.n + 31) / 32;
+    if (nb > DSEA_MAX_EW_BLOCKS) nb = DSEA_MAX_EW_BLOCKS;
+    if (nb < 1) nb = 1;
+    if (sym) hipLaunchKernelGGL(k_csr_sddmm<true>, dim3((unsigned)nb), dim3(256), 0, st, p, v1, v2, alpha, accumulate, out);
+    else hipLaunchKernelGGL(k_csr_sddmm<false>, dim3((unsigned)nb), dim3(256), 0, st, p, v1, v2, alpha, accumulate, out);
+    return 0;
+  }
+  return -1;
 }
 
 int launch_cg_update_fused(double* x, double* r, const double* d, const double* Ad, const double* state,

@@ -178,6 +178,21 @@ int comm_sendrecv(dsea_comm_s* c, const P2P* items, int n_items, hipStream_t st)
   return ok && closed ? DSEA_OK : DSEA_ERR_COMM;
 }
 
+int comm_allgather(dsea_comm_s* c, const double* send, double* recv, int64_t count, hipStream_t st) {
+  HIP_TRY(hipMemcpyAsync(recv + (int64_t)c->rank * count, send, (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, st));
+  if (c->world == 1) return DSEA_OK;
+  P2P items[256];
+  if (c->world > 256) return DSEA_ERR_ARG;
+  int n = 0;
+  // round s pairs rank r with (s - r) mod world: a perfect matching per round, every pair exactly once over the rounds --
+  // with blocking pairwise callbacks every rank walks the rounds in the same order; over RCCL it is one group
+  for (int s = 0; s < c->world; ++s) {
+    const int peer = ((s - c->rank) % c->world + c->world) % c->world;
+    if (peer != c->rank) items[n++] = P2P{send, recv + (int64_t)peer * count, count, peer};
+  }
+  return comm_sendrecv(c, items, n, st);
+}
+
 // ---- the overlap premise, on the device -----------------------------------------------------------------------------
 // rec[0] = first step i at which max_j c_j^2 > tau^2 * c[i] (c[i] = ||r||^2), 0 = never.  c is replicated (it has
 // been all-reduced), so every rank records the same step.
@@ -257,6 +272,21 @@ int stencil_halo_exchange(dsea_pop_s* P, const double* x, hipStream_t st) {
   return comm_sendrecv(P->comm, items, n, st);
 }
 
+// explicit-matrix slab (dsea_pop_create_csr): hb elements with each neighbour, or the all-gather fallback
+int sell_halo_exchange(dsea_pop_s* P, const double* x, hipStream_t st) {
+  const SellParams& p = P->local.d.sell;
+  if (p.mode == 2) return comm_allgather(P->comm, x, const_cast<double*>(p.xg), P->nloc, st);
+  if (p.hb == 0) return DSEA_OK;
+  P2P items[2];
+  int n = 0;
+  if (P->has_lo) items[n++] = P2P{x, const_cast<double*>(p.halo_lo), p.hb, P->comm->rank - 1};
+  if (P->has_hi) items[n++] = P2P{x + (P->nloc - p.hb), const_cast<double*>(p.halo_hi), p.hb, P->comm->rank + 1};
+  return comm_sendrecv(P->comm, items, n, st);
+}
+inline int halo_exchange(dsea_pop_s* P, const double* x, hipStream_t st) {
+  return P->kind == OP_SELL ? sell_halo_exchange(P, x, st) : stencil_halo_exchange(P, x, st);
+}
+
 // y = (A - shift) x over all ranks, LOCAL x.y into dot_local (ws scalar)
 int pop_apply(dsea_pop_s* P, dsea_ws_t ws, const double* x, double* y, const double* shift, const double* skip,
               double* dot_local, hipStream_t st) {
@@ -268,7 +298,7 @@ int pop_apply(dsea_pop_s* P, dsea_ws_t ws, const double* x, double* y, const dou
     DSEA_TRY(tfim_exchange_finish(P, st));
     return tfim_remote_part(P, ws, shift, skip, x, y, dot_local, st);
   }
-  DSEA_TRY(stencil_halo_exchange(P, x, st));
+  DSEA_TRY(halo_exchange(P, x, st));
   return dsea_spmv(&P->local, ws, x, y, shift, dot_local, skip, (void*)st);
 }
 // ---- CG with ONE all-reduce per iteration (Chronopoulos-Gear; kernels: k_pcg_update / k_pcg_scalars) ------------------
@@ -428,6 +458,11 @@ int dsea_comm_alltoall(dsea_comm_t comm, const double* send, double* recv, int64
   return comm_alltoall(comm, send, recv, chunk, static_cast<hipStream_t>(stream));
 }
 
+int dsea_comm_allgather(dsea_comm_t comm, const double* send, double* recv, int64_t count, void* stream) {
+  if (!comm || !send || !recv || count < 1) return DSEA_ERR_ARG;
+  return comm_allgather(comm, send, recv, count, static_cast<hipStream_t>(stream));
+}
+
 // ---------------------------------------------------------------------------------------------- operators
 size_t dsea_pop_tfim_scratch_doubles(int L, int world) {
   if (L < 1 || L > 62 || world < 1) return 0;
@@ -506,6 +541,45 @@ int dsea_pop_create_stencil3(int64_t n_local, double coef, const double* V_dev, 
   P->local.d.st3 = Stencil3Params{n_local, coef, V_dev, P->has_lo ? halo2 : nullptr, P->has_hi ? halo2 + 1 : nullptr};
   *out = P;
   return DSEA_OK;
+}
+
+int dsea_pop_create_csr(dsea_op_t local_op, dsea_comm_t comm, dsea_pop_t* out) {
+  if (!out || !comm || !local_op) return DSEA_ERR_ARG;
+  if (local_op->d.kind != OP_SELL) return DSEA_ERR_UNSUPPORTED;
+  const SellParams& sp = local_op->d.sell;
+  if (sp.mode != 1 && sp.mode != 2) return DSEA_ERR_ARG;       // dsea_op_set_slab first
+  dsea_pop_s* P = new (std::nothrow) dsea_pop_s;
+  if (!P) return DSEA_ERR_ARG;
+  memset(static_cast<void*>(P), 0, sizeof(*P));
+  P->kind = OP_SELL;
+  P->comm = comm;
+  P->nloc = local_op->d.n;
+  P->has_lo = comm->rank > 0;
+  P->has_hi = comm->rank < comm->world - 1;
+  if (sp.mode == 1 && sp.hb > 0 && ((P->has_lo && !sp.halo_lo) || (P->has_hi && !sp.halo_hi))) {
+    delete P;
+    return DSEA_ERR_ARG;
+  }
+  P->local = *local_op;                                          // (arrays and exchange buffers stay the caller's)
+  *out = P;
+  return DSEA_OK;
+}
+
+int dsea_pop_sddmm(dsea_pop_t P, const int64_t* rowptr, const double* v1, const double* v2, double alpha, int flags,
+                   double* out, void* stream) {
+  if (!P || !rowptr || !v1 || !v2 || !out || (flags & ~(DSEA_SDDMM_ACCUMULATE | DSEA_SDDMM_SYMMETRIC))) return DSEA_ERR_ARG;
+  if (P->kind != OP_SELL) return DSEA_ERR_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int acc = (flags & DSEA_SDDMM_ACCUMULATE) ? 1 : 0;
+  const bool sym = (flags & DSEA_SDDMM_SYMMETRIC) != 0;
+  // the column operand travels like the x of a mat-vec; the symmetric form is two one-sided launches (one exchange each)
+  DSEA_TRY(sell_halo_exchange(P, v2, st));
+  if (launch_sddmm(P->local.d, rowptr, v1, v2, sym ? 0.5 * alpha : alpha, acc, false, out, st) != 0) return DSEA_ERR_UNSUPPORTED;
+  if (sym) {
+    DSEA_TRY(sell_halo_exchange(P, v1, st));
+    if (launch_sddmm(P->local.d, rowptr, v2, v1, 0.5 * alpha, 1, false, out, st) != 0) return DSEA_ERR_UNSUPPORTED;
+  }
+  return hipGetLastError() == hipSuccess ? DSEA_OK : DSEA_ERR_HIP;
 }
 
 int dsea_pop_destroy(dsea_pop_t P) {
@@ -635,7 +709,7 @@ int dsea_pop_lanczos_run(dsea_pop_t P, dsea_ws_t ws, int k, const double* q0, do
       DSEA_TRY(tfim_exchange_finish(P, st));
       DSEA_TRY(tfim_remote_part(P, ws, nullptr, nullptr, r, y, pair + 1, st));
     } else {
-      DSEA_TRY(stencil_halo_exchange(P, r, st));
+      DSEA_TRY(halo_exchange(P, r, st));
       DSEA_TRY(dsea_spmv(&P->local, ws, r, y, nullptr, pair + 1, nullptr, stream));
     }
     if (w.pend_P) {     // (no dot-closing call consumed the deferred ||r||^2 on this path: close it now)

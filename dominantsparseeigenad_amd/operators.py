@@ -116,7 +116,7 @@ class TFIMOperator:
             raise RuntimeError("set the parameter g before using the operator")
         return self._H.handle
 
-    def to_csr(self, layout="sell"):
+    def to_csr(self, layout="sell", col16="auto"):
         """The same operator as an explicit device CSR matrix (L + 1 entries per row, int32 columns): the
         "generic sparse operand" form of BASELINE config 2.  Built on the device with index arithmetic."""
         n, L = self.n, self.L_local
@@ -138,7 +138,7 @@ class TFIMOperator:
         cols = torch.gather(cols, 1, order)
         vals = torch.gather(vals, 1, order)
         rowptr = torch.arange(n + 1, dtype=torch.int64, device=self.device) * (L + 1)
-        return CSROperator(rowptr, cols.reshape(-1), vals.reshape(-1), n, layout=layout)
+        return CSROperator(rowptr, cols.reshape(-1), vals.reshape(-1), n, layout=layout, col16=col16)
 
     def pHpg(self, v):
         """dH/dg v = -sum_j v[i xor (1<<j)]   (TFIM.py:58-65)"""
@@ -234,65 +234,165 @@ class _Stencil3Apply(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------ CSR
+def sell_layout(rowptr, colidx, n, col16="auto"):
+    """SELL-64 structure of a CSR pattern (device tensors, torch index ops -- built once per operator):
+    returns (slice_ptr int64 [nslices+1], columns, total) with ``columns`` = (int32 [total],) or, when every
+    64-element slice column spans fewer than 65536 columns (``col16`` "auto" / True), (colbase int32 [total/64],
+    coldelta uint16-as-int16 [total]) -- include/dsea.h dsea_op_create_sell / dsea_op_create_sell16.  Entry k of
+    row i sits at slice_ptr[i // 64] + 64 k + i % 64; padding entries carry the smallest real column of their
+    slice column (value 0), so gathers stay in range and the 16-bit deltas are not widened by them."""
+    dev = rowptr.device
+    nsl = (n + 63) // 64
+    lens = rowptr[1:] - rowptr[:-1]
+    padded = torch.zeros(nsl * 64, dtype=torch.int64, device=dev)
+    padded[:n] = lens
+    width = padded.view(nsl, 64).max(dim=1).values
+    slice_ptr = torch.zeros(nsl + 1, dtype=torch.int64, device=dev)
+    slice_ptr[1:] = torch.cumsum(width * 64, 0)
+    total = int(slice_ptr[-1].item())
+    rows = torch.repeat_interleave(torch.arange(n, dtype=torch.int64, device=dev), lens)
+    k_in_row = torch.arange(rows.numel(), dtype=torch.int64, device=dev) - rowptr[rows]
+    dest = slice_ptr[rows // 64] + k_in_row * 64 + (rows % 64)
+    big = torch.iinfo(torch.int32).max
+    s_cols = torch.full((max(total, 64),), big, dtype=torch.int32, device=dev)[:total]
+    s_cols[dest] = colidx.to(torch.int32)
+    blocks = s_cols.view(-1, 64)
+    cmin = blocks.min(dim=1, keepdim=True).values
+    blocks.copy_(torch.where(blocks == big, cmin.expand_as(blocks), blocks))
+    span_ok = total > 0 and int((blocks.max(dim=1).values - cmin[:, 0]).max().item()) < 65536
+    if col16 is True and not span_ok and total > 0:
+        raise ValueError("col16=True: a slice column of this pattern spans 65536 columns or more")
+    if col16 in ("auto", True) and span_ok:
+        delta = blocks - cmin                                        # 0 .. 65535
+        delta = torch.where(delta >= 32768, delta - 65536, delta).to(torch.int16)   # the same 16 bits, as torch can hold them
+        return slice_ptr, (cmin[:, 0].contiguous(), delta.reshape(-1).contiguous()), total
+    return slice_ptr, (s_cols.contiguous(),), total
+
+
 class CSROperator:
     """General sparse symmetric matrix given in CSR (rowptr int64, colidx int32, vals fp64) on the device.
 
     The mat-vec kernel reads a SELL-64 copy (sliced ELLPACK, slices of one wave = 64 rows, column-major inside a
     slice) built once here on the device with torch index ops: matrix loads become perfectly coalesced and, for
-    banded / structured operators, so does the gather of x.  ``layout="csr"`` keeps the plain CSR kernel.
-    ``from_scipy`` / ``from_dense`` build the CSR arrays on the host once."""
+    banded / structured operators, so does the gather of x; where the pattern allows it the columns are stored as
+    16-bit deltas (10 instead of 12 bytes per non-zero: the kernel is bound by the bytes it moves).
+    ``layout="csr"`` keeps the plain CSR kernel.  ``from_scipy`` / ``from_dense`` build the CSR arrays on the host once.
+
+    THE MATRIX AS A PARAMETER (reference README.md:88-126, symeig.py:56-64,82-84: the adjoint A-bar = v1 v2^T is pushed to
+    the parameters that produced A).  ``vals`` may be a leaf tensor with ``requires_grad``:
+
+        op = CSROperator(rowptr, colidx, vals, n)                       # vals: nn.Parameter-like, fp64, on the device
+        symeig.setDominantSparseSymeig(op, op.Aadjoint_to_valsadjoint)  # hook: vals-bar[e] = v1[row e] v2[col e]
+        E0, psi = symeig.DominantSparseSymeig.apply(op.vals, k, n)
+        loss.backward(); optimiser.step()                               # in-place update of vals ...
+        E0, psi = symeig.DominantSparseSymeig.apply(op.vals, k, n)      # ... is picked up: the SELL copy is refreshed in
+                                                                        #     place (dsea_op_update_vals), no rebuild
+
+    The hooks are differentiable (second order: examples/TFIM/E0.py:63-64 pattern) -- their backward is a mat-vec with
+    the incoming gradient as the values of the same pattern.  ``Aadjoint_to_valsadjoint_symmetric`` is the adjoint for a
+    matrix whose entry pairs (i,j), (j,i) are tied, i.e. of  vals -> eigh((M + M^T)/2)."""
 
     _native_methods = ("__call__",)
 
-    def __init__(self, rowptr, colidx, vals, n, layout="sell"):
+    def __init__(self, rowptr, colidx, vals, n, layout="sell", col16="auto"):
         self.n = int(n)
         self.rowptr = rowptr.to(torch.int64).contiguous()
         self.colidx = colidx.to(torch.int32).contiguous()
-        self.vals = vals.to(F64).contiguous()
-        self.device = self.vals.device
+        data = vals.detach()
+        if data.dtype != F64 or not data.is_contiguous():
+            data = data.to(F64).contiguous()
+            self.vals = data          # a converted copy: not the caller's storage (no parameter semantics)
+        else:
+            self.vals = vals          # the caller's tensor: its in-place updates are seen by refresh()
+        self._vals_data = data
+        self.nnz = int(data.numel())
+        self.device = data.device
+        self.layout = layout
         if self.device.type != "cuda":
             raise ValueError("CSROperator is a device operator")
+        self._T = None
         raw = c_void_p()
         lib = _lib.load()
         if layout == "sell":
-            n, dev = self.n, self.device
-            nsl = (n + 63) // 64
-            lens = self.rowptr[1:] - self.rowptr[:-1]
-            padded = torch.zeros(nsl * 64, dtype=torch.int64, device=dev)
-            padded[:n] = lens
-            width = padded.view(nsl, 64).max(dim=1).values
-            slice_ptr = torch.zeros(nsl + 1, dtype=torch.int64, device=dev)
-            slice_ptr[1:] = torch.cumsum(width * 64, 0)
-            total = int(slice_ptr[-1].item())
-            rows = torch.repeat_interleave(torch.arange(n, dtype=torch.int64, device=dev), lens)
-            k_in_row = torch.arange(rows.numel(), dtype=torch.int64, device=dev) - self.rowptr[rows]
-            dest = slice_ptr[rows // 64] + k_in_row * 64 + (rows % 64)
-            # padding entries: value 0, column = the lane's own row (clamped) so the gather stays in range
-            lane_row = torch.arange(max(total, 1), dtype=torch.int64, device=dev)
-            sl_of = torch.repeat_interleave(torch.arange(nsl, dtype=torch.int64, device=dev), width * 64)
-            pad_cols = torch.clamp(sl_of * 64 + (lane_row[:total] - slice_ptr[sl_of]) % 64, max=n - 1)
-            s_cols = pad_cols.to(torch.int32)
-            s_vals = torch.zeros(total, dtype=F64, device=dev)
-            s_cols[dest] = self.colidx
-            s_vals[dest] = self.vals
-            self._sell = (slice_ptr, s_cols.contiguous(), s_vals.contiguous())
-            check(lib.dsea_op_create_sell(n, nsl, c_void_p(slice_ptr.data_ptr()), c_void_p(self._sell[1].data_ptr()),
-                                          c_void_p(self._sell[2].data_ptr()), byref(raw)), "dsea_op_create_sell")
+            slice_ptr, cols, total = sell_layout(self.rowptr, self.colidx, self.n, col16)
+            s_vals = torch.zeros(max(total, 1), dtype=F64, device=self.device)
+            nsl = (self.n + 63) // 64
+            if len(cols) == 2:
+                check(lib.dsea_op_create_sell16(self.n, nsl, c_void_p(slice_ptr.data_ptr()), c_void_p(cols[0].data_ptr()),
+                                                c_void_p(cols[1].data_ptr()), c_void_p(s_vals.data_ptr()), byref(raw)),
+                      "dsea_op_create_sell16")
+            else:
+                check(lib.dsea_op_create_sell(self.n, nsl, c_void_p(slice_ptr.data_ptr()), c_void_p(cols[0].data_ptr()),
+                                              c_void_p(s_vals.data_ptr()), byref(raw)), "dsea_op_create_sell")
+            self._sell = (slice_ptr,) + tuple(cols) + (s_vals,)
+            self.col16 = len(cols) == 2
             keep = self._sell
-        else:
-            check(lib.dsea_op_create_csr(self.n, int(self.vals.numel()), c_void_p(self.rowptr.data_ptr()),
-                                         c_void_p(self.colidx.data_ptr()), c_void_p(self.vals.data_ptr()),
+        elif layout == "csr":
+            check(lib.dsea_op_create_csr(self.n, self.nnz, c_void_p(self.rowptr.data_ptr()),
+                                         c_void_p(self.colidx.data_ptr()), c_void_p(data.data_ptr()),
                                          byref(raw)), "dsea_op_create_csr")
-            keep = (self.rowptr, self.colidx, self.vals)
+            self.col16 = False
+            keep = (self.rowptr, self.colidx, data)
+        else:
+            raise ValueError("layout must be 'sell' or 'csr'")
         self._H = _NativeView(_Handle(raw, self.n, keep))
+        self._seen_version = None
+        self.refresh()
+
+    # -- structure shared, values replaced (the mat-vec M(G) x of the hooks' backward)
+    def with_vals(self, vals):
+        """an operator on the SAME pattern with other values (shares the SELL structure; one value array is allocated)"""
+        twin = object.__new__(CSROperator)
+        twin.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("_H", "_sell", "vals", "_vals_data", "_T")})
+        data = vals.detach().to(F64).contiguous()
+        twin.vals, twin._vals_data, twin._T = data, data, None
+        raw = c_void_p()
+        lib = _lib.load()
+        if self.layout == "sell":
+            s_vals = torch.zeros_like(self._sell[-1])
+            st = self._sell
+            if self.col16:
+                check(lib.dsea_op_create_sell16(self.n, (self.n + 63) // 64, c_void_p(st[0].data_ptr()), c_void_p(st[1].data_ptr()),
+                                                c_void_p(st[2].data_ptr()), c_void_p(s_vals.data_ptr()), byref(raw)),
+                      "dsea_op_create_sell16")
+            else:
+                check(lib.dsea_op_create_sell(self.n, (self.n + 63) // 64, c_void_p(st[0].data_ptr()), c_void_p(st[1].data_ptr()),
+                                              c_void_p(s_vals.data_ptr()), byref(raw)), "dsea_op_create_sell")
+            twin._sell = st[:-1] + (s_vals,)
+            keep = twin._sell
+        else:
+            check(lib.dsea_op_create_csr(self.n, self.nnz, c_void_p(self.rowptr.data_ptr()), c_void_p(self.colidx.data_ptr()),
+                                         c_void_p(data.data_ptr()), byref(raw)), "dsea_op_create_csr")
+            keep = (self.rowptr, self.colidx, data)
+        twin._H = _NativeView(_Handle(raw, self.n, keep))
+        twin._seen_version = None
+        twin.refresh()
+        return twin
+
+    def refresh(self):
+        """make the device operator's values equal ``vals`` as it is now (dsea_op_update_vals: the SELL copy is rewritten
+        in place through rowptr, the layout is not rebuilt).  Called automatically when ``vals`` has been modified in
+        place since the last look (optimiser step); call it yourself after writing through a view torch cannot see."""
+        data = self.vals.detach()
+        if data.data_ptr() != self._vals_data.data_ptr():
+            self._vals_data = data          # (vals re-bound to another tensor of the same shape)
+        check(_lib.load().dsea_op_update_vals(self._H.handle, c_void_p(self.rowptr.data_ptr()),
+                                              c_void_p(self._vals_data.data_ptr()), engine._stream(self.device)),
+              "dsea_op_update_vals")
+        self._seen_version = self.vals._version
+
+    def _current(self):
+        if self.vals._version != self._seen_version and self.layout == "sell":
+            self.refresh()
+        return self._H
 
     @classmethod
-    def from_scipy(cls, M, device="cuda", layout="sell"):
+    def from_scipy(cls, M, device="cuda", layout="sell", col16="auto"):
         M = M.tocsr()
         M.sort_indices()
         return cls(torch.from_numpy(M.indptr.astype("int64")).to(device),
                    torch.from_numpy(M.indices.astype("int32")).to(device),
-                   torch.from_numpy(M.data.astype("float64")).to(device), M.shape[0], layout=layout)
+                   torch.from_numpy(M.data.astype("float64")).to(device), M.shape[0], layout=layout, col16=col16)
 
     @classmethod
     def from_npz(cls, path, device="cuda", layout="sell"):
@@ -307,10 +407,102 @@ class CSROperator:
 
     @property
     def handle(self):
-        return self._H.handle
+        return self._current().handle
 
     def __call__(self, v):
-        return _SymmetricApply.apply(v, self._H)
+        return _SymmetricApply.apply(v, self._current())
+
+    # -- the adjoint hooks (reference symeig.py:84 calls Aadjoint_to_padjoint(v1, v2) with A-bar = v1 v2^T)
+    def Aadjoint_to_valsadjoint(self, v1, v2):
+        """vals-bar[e] = v1[row(e)] * v2[col(e)], in the caller's CSR order (dsea_op_sddmm)"""
+        return _SampledOuter.apply(v1, v2, self, False)
+
+    def Aadjoint_to_valsadjoint_symmetric(self, v1, v2):
+        """vals-bar[e] = (v1[row] v2[col] + v1[col] v2[row]) / 2"""
+        return _SampledOuter.apply(v1, v2, self, True)
+
+    def apply_with_vals(self, vals, v, transpose=False):
+        """M(vals) v (or M(vals)^T v) on this operator's pattern, differentiable in ``vals`` and ``v``"""
+        return _ValsApply.apply(vals, v, self, bool(transpose))
+
+    def sddmm(self, v1, v2, symmetric=False, out=None, alpha=1.0, accumulate=False):
+        """raw kernel call (no autograd): out[e] (+)= alpha * v1[row e] * v2[col e]"""
+        v1, v2 = engine.as_vector(v1.detach(), self.n), engine.as_vector(v2.detach(), self.n)
+        if out is None:
+            out = torch.empty(self.nnz, dtype=F64, device=self.device)
+        flags = (_lib.SDDMM_ACCUMULATE if accumulate else 0) | (_lib.SDDMM_SYMMETRIC if symmetric else 0)
+        check(_lib.load().dsea_op_sddmm(self._H.handle, c_void_p(self.rowptr.data_ptr()), c_void_p(v1.data_ptr()),
+                                        c_void_p(v2.data_ptr()), float(alpha), flags, c_void_p(out.data_ptr()),
+                                        engine._stream(self.device)), "dsea_op_sddmm")
+        return out
+
+    def transposed(self):
+        """(operator of the transposed PATTERN with this operator's values, perm) with vals_T = vals[perm]; built lazily
+        (torch sort, once) -- the backward of the hooks needs M(G)^T x for non-symmetric G"""
+        if self._T is None:
+            n = self.n
+            lens = self.rowptr[1:] - self.rowptr[:-1]
+            rows = torch.repeat_interleave(torch.arange(n, dtype=torch.int64, device=self.device), lens)
+            cols = self.colidx.to(torch.int64)
+            perm = torch.argsort(cols * n + rows)
+            rowptr_t = torch.zeros(n + 1, dtype=torch.int64, device=self.device)
+            rowptr_t[1:] = torch.cumsum(torch.bincount(cols, minlength=n), 0)
+            opT = CSROperator(rowptr_t, rows[perm].to(torch.int32), self._vals_data[perm], n, layout=self.layout)
+            self._T = (opT, perm)
+        return self._T
+
+
+class _SampledOuter(torch.autograd.Function):
+    """out[e] = v1[row e] v2[col e]  (sym: the average with v1 <-> v2) on a CSROperator's pattern.
+    backward (G = gradient w.r.t. out, itself on the pattern):  v1-bar = M(G) v2,  v2-bar = M(G)^T v1  (sym: both averaged
+    with their transposes) -- mat-vecs of the same SELL kernel, differentiable again through _ValsApply."""
+
+    @staticmethod
+    def forward(ctx, v1, v2, op, sym):
+        ctx.op, ctx.sym = op, sym
+        ctx.save_for_backward(v1, v2)
+        return op.sddmm(v1, v2, symmetric=sym)
+
+    @staticmethod
+    def backward(ctx, G):
+        v1, v2 = ctx.saved_tensors
+        op, sym = ctx.op, ctx.sym
+        g1 = g2 = None
+        if ctx.needs_input_grad[0]:
+            g1 = _ValsApply.apply(G, v2, op, False)
+            if sym:
+                g1 = 0.5 * (g1 + _ValsApply.apply(G, v2, op, True))
+        if ctx.needs_input_grad[1]:
+            g2 = _ValsApply.apply(G, v1, op, True)
+            if sym:
+                g2 = 0.5 * (g2 + _ValsApply.apply(G, v1, op, False))
+        return g1, g2, None, None
+
+
+class _ValsApply(torch.autograd.Function):
+    """y = M(vals) x  /  M(vals)^T x  on a CSROperator's pattern, differentiable in vals and x."""
+
+    @staticmethod
+    def forward(ctx, vals, x, op, transpose):
+        ctx.op, ctx.transpose = op, transpose
+        ctx.save_for_backward(vals, x)
+        if transpose:
+            opT, perm = op.transposed()
+            twin = opT.with_vals(vals.detach()[perm])
+        else:
+            twin = op.with_vals(vals)
+        return engine.spmv(twin._H, engine.as_vector(x.detach(), op.n))
+
+    @staticmethod
+    def backward(ctx, gy):
+        vals, x = ctx.saved_tensors
+        op, tr = ctx.op, ctx.transpose
+        gvals = gx = None
+        if ctx.needs_input_grad[0]:       # y_r = sum_e vals_e x[col e]  ->  vals-bar_e = gy[row e] x[col e]   (transpose: swapped)
+            gvals = _SampledOuter.apply(x, gy, op, False) if tr else _SampledOuter.apply(gy, x, op, False)
+        if ctx.needs_input_grad[1]:
+            gx = _ValsApply.apply(vals, gy, op, not tr)
+        return gvals, gx, None, None
 
 
 # ------------------------------------------------------------------------------------------ GEMM-shaped operands

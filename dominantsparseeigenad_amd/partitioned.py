@@ -101,6 +101,31 @@ class HipBackend(_engine_mod.Phases):
         self._ck(self.lib.dsea_spmv(self.op.handle, self.ws.handle, self._p(x), self._p(y), self._p(shift),
                                     self._p(out), self._p(skip), self._st()), "dsea_spmv")
 
+    def attach_csr(self, rowptr, cols, vals, n_local, hb, halo, xg):
+        """explicit-matrix slab: SELL-64 operator on n_local rows whose columns are LOCAL in [-hb, n_local + hb) with the
+        two neighbour halos in ``halo`` (2 hb doubles: [from rank-1 | from rank+1]), or GLOBAL with the all-gathered
+        vector ``xg`` (hb = -1)                                                   include/dsea.h: dsea_op_set_slab"""
+        from .operators import CSROperator
+        self.op = CSROperator(rowptr, cols, vals, int(n_local))
+        lo = c_void_p(halo.data_ptr()) if hb > 0 else c_void_p(None)
+        hi = c_void_p(halo.data_ptr() + 8 * hb) if hb > 0 else c_void_p(None)
+        self._ck(self.lib.dsea_op_set_slab(self.op._H.handle, int(hb), lo, hi, self._p(xg) if hb < 0 else c_void_p(None)),
+                 "dsea_op_set_slab")
+        self._csr_keep = (halo, xg)
+        return self.op
+
+    def csr_local(self, x, y, shift, out, skip):
+        """y = A_slab x - shift x (halo / gathered vector already exchanged) ; out = local x.y"""
+        self._ck(self.lib.dsea_spmv(self.op.handle, self.ws.handle, self._p(x), self._p(y), self._p(shift),
+                                    self._p(out), self._p(skip), self._st()), "dsea_spmv")
+
+    def csr_sddmm_local(self, v1, v2, alpha, accumulate, out):
+        """out[e] (+)= alpha v1[row e] v2[col e] on the slab (v2's halo / gathered copy already exchanged)"""
+        from . import _lib
+        self._ck(self.lib.dsea_op_sddmm(self.op._H.handle, self._p(self.op.rowptr), self._p(v1), self._p(v2),
+                                        float(alpha), _lib.SDDMM_ACCUMULATE if accumulate else 0, self._p(out),
+                                        self._st()), "dsea_op_sddmm")
+
     # -- macro phases of the partitioned Lanczos step (include/dsea.h "row-partitioned macro phases")
     def basis(self, k, ldq, arena):
         if arena:
@@ -1347,6 +1372,176 @@ class PartitionedStencil3Operator(PartitionedOperator):
     def Hadjoint_to_padjoint(v1, v2):
         """adjoint hook of schrodinger1D.py:29-34: potential-bar = v1 o v2 (this rank's slab)"""
         return v1 * v2
+
+
+# ------------------------------------------------------------------------------------------ explicit sparse matrix
+def csr_partition(n, world, rank):
+    """(slab rows incl. padding, first row, real rows) of rank's slab: EQUAL slabs of ceil(n / world) rows -- the last
+    one padded with empty rows (include/dsea.h: dsea_pop_create_csr wants the same n_local everywhere)"""
+    nloc = -(-int(n) // int(world))
+    off = rank * nloc
+    return nloc, off, max(0, min(nloc, int(n) - off))
+
+
+class _PartSampledOuter(torch.autograd.Function):
+    """vals-bar of this rank's rows: out[e] = v1[row e] v2[col e] (sym: averaged with v1 <-> v2); the column operand is
+    exchanged like the x of a mat-vec.  First order (the hook of reference symeig.py:84 on slabs)."""
+
+    @staticmethod
+    def forward(ctx, v1, v2, op, sym):
+        out = op._sddmm(_as_slab(v1.detach(), op), _as_slab(v2.detach(), op), sym)
+        ctx.mark_non_differentiable(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        raise NotImplementedError("second order through the non-zeros of a ROW-PARTITIONED matrix is not implemented "
+                                  "(one GPU: operators.CSROperator)")
+
+
+class PartitionedCSROperator(PartitionedOperator):
+    """General sparse symmetric matrix in contiguous row slabs: this rank passes ITS rows in CSR with GLOBAL column
+    indices (``rowptr`` of its real rows, local element offsets).  Slabs are equal -- ceil(n / world) rows, the last one
+    padded with empty rows; vectors are slabs of that length and the padding stays zero (start vectors are masked).
+
+    SpMV locality: if every column a slab touches lies within ``hb <= n_local`` rows of the slab (a banded
+    matrix), a mat-vec exchanges hb elements with each neighbour; otherwise it all-gathers x first.  The decision is made
+    once here from the global pattern (one all-reduce).  The slab operator is the SELL-64 kernel of operators.CSROperator
+    with its gathers redirected to the halo / gathered copy (include/dsea.h: dsea_op_set_slab, dsea_pop_create_csr).
+
+    ``vals`` may be a leaf with requires_grad: ``Aadjoint_to_valsadjoint`` is the hook (this rank's non-zeros)."""
+
+    def __init__(self, rowptr, colidx, vals, n, device=None, backend=None, group=None, comm=None, exchange_group=None,
+                 mode="auto"):
+        comm = comm if comm is not None else TorchDistComm(group)
+        self._exchange_group = exchange_group
+        nloc, off, real = csr_partition(n, comm.world, comm.rank)
+        if rowptr.numel() != real + 1:
+            raise ValueError("rank %d holds rows %d..%d: expected rowptr of %d entries, got %d"
+                             % (comm.rank, off, off + real, real + 1, rowptr.numel()))
+        device = torch.device(device) if device is not None else vals.device
+        rp = rowptr.to(torch.int64)
+        rowptr_pad = torch.cat([rp, rp[-1:].expand(nloc - real)]) if real < nloc else rp
+        gcols = colidx.to(torch.int64)
+        # how far outside the slab do the columns reach?  (global maximum: every rank takes the same decision)
+        if gcols.numel():
+            reach = max(0, off - int(gcols.min().item()), int(gcols.max().item()) - (off + nloc - 1))
+        else:
+            reach = 0
+        r = torch.tensor([float(reach)], dtype=F64)
+        if comm.world > 1:
+            rr = r.to(device) if (isinstance(comm, TorchDistComm) and type(comm) is TorchDistComm and
+                                  dist.get_backend(comm.group) == "nccl") else r
+            rr = rr.clone()
+            dist.all_reduce(rr, op=dist.ReduceOp.MAX, group=getattr(comm, "group", None))
+            reach = int(rr.item())
+        if mode not in ("auto", "halo", "gather"):
+            raise ValueError("mode must be 'auto', 'halo' or 'gather'")
+        if mode == "halo" and reach > nloc:
+            raise ValueError("mode='halo': columns reach %d rows beyond the slab of %d rows" % (reach, nloc))
+        self.mode = "halo" if (mode == "halo" or (mode == "auto" and reach <= nloc)) else "gather"
+        self.hb = reach if self.mode == "halo" else -1
+        self.real_rows = real
+        self.vals = vals
+        if backend is None:
+            backend = HipBackend(nloc, device)
+        self._halo = backend.zeros(max(2 * max(self.hb, 0), 2))
+        self._xg = backend.zeros(nloc * comm.world) if self.mode == "gather" else None
+        cols = (gcols - off) if self.mode == "halo" else gcols
+        self._local = backend.attach_csr(rowptr_pad, cols.to(torch.int32), vals, nloc, self.hb, self._halo, self._xg)
+        self.has_lo, self.has_hi = comm.rank > 0, comm.rank < comm.world - 1
+        super().__init__(nloc * comm.world, nloc, off, device, comm, backend)
+        self.n_unpadded = int(n)
+        self._mask = None
+        if real < nloc:
+            self._mask = backend.zeros(nloc)
+            self._mask[:real] = 1.0
+        self._ncomm = self._make_native_comm()
+        if self._ncomm is not None:
+            from . import _lib
+            h = c_void_p()
+            _lib.check(self.be.lib.dsea_pop_create_csr(self._local._H.handle, self._ncomm.handle, byref(h)),
+                       "dsea_pop_create_csr")
+            self._pop = h
+
+    def _local_native(self):
+        return getattr(self.be, "op", None)
+
+    # the padding rows of the last slab are empty: a vector that is zero there stays zero there under A
+    def _masked(self, v):
+        return v if self._mask is None else v * self._mask
+
+    def lanczos(self, k, q0_slab, arena=False):
+        return super().lanczos(k, self._masked(q0_slab.detach().to(F64)), arena=arena)
+
+    def solve_shifted(self, E0, b, x0, eps=1e-7, maxiter=None):
+        if self._mask is not None:
+            x0.mul_(self._mask)
+            b = b * self._mask
+        return super().solve_shifted(E0, b, x0, eps=eps, maxiter=maxiter)
+
+    def _exchange(self, x):
+        if self.mode == "gather":
+            self.comm.all_gather(x, self._xg)
+            return
+        hb = self.hb
+        if hb == 0:
+            return
+        items = []
+        if self.has_lo:
+            items.append((x[0:hb], self._halo[0:hb], self.rank - 1))
+        if self.has_hi:
+            items.append((x[self.nloc - hb:self.nloc], self._halo[hb:2 * hb], self.rank + 1))
+        if items:
+            self.comm.sendrecv(items)
+
+    def apply_shift_dot(self, x, y, shift, out, skip):
+        self._exchange(x)
+        self.be.csr_local(x, y, shift, out, skip)
+
+    def matvec(self, x, y, which="H"):
+        if which != "H":
+            raise ValueError("this operator has no '%s' map" % which)
+        if self._pop:
+            from . import _lib
+            be = self.be
+            _lib.check(be.lib.dsea_pop_matvec(self._pop, be.ws.handle, be._p(x), be._p(y), None, None, None, be._st()),
+                       "dsea_pop_matvec")
+            return
+        self.apply_shift_dot(x, y, None, None, None)
+
+    def H(self, v):
+        return _PartApply.apply(v, self, "H")
+
+    __call__ = H
+    Hsparse = H
+
+    def refresh(self):
+        """after an in-place update of this rank's ``vals`` (optimiser step): rewrite the slab operator's SELL copy"""
+        if hasattr(self._local, "refresh"):
+            self._local.refresh()
+
+    def _sddmm(self, v1, v2, sym):
+        be = self.be
+        out = be.zeros(int(self.vals.numel()))
+        if self._pop:
+            from . import _lib
+            _lib.check(be.lib.dsea_pop_sddmm(self._pop, be._p(self._local.rowptr), be._p(v1), be._p(v2), 1.0,
+                                             _lib.SDDMM_SYMMETRIC if sym else 0, be._p(out), be._st()), "dsea_pop_sddmm")
+            return out
+        self._exchange(v2)
+        be.csr_sddmm_local(v1, v2, 0.5 if sym else 1.0, False, out)
+        if sym:
+            self._exchange(v1)
+            be.csr_sddmm_local(v2, v1, 0.5, True, out)
+        return out
+
+    def Aadjoint_to_valsadjoint(self, v1, v2):
+        """vals-bar[e] = v1[row e] v2[col e] for this rank's non-zeros (CSR order)"""
+        return _PartSampledOuter.apply(v1, v2, self, False)
+
+    def Aadjoint_to_valsadjoint_symmetric(self, v1, v2):
+        return _PartSampledOuter.apply(v1, v2, self, True)
 
 
 # =========================================================================== convenience driver

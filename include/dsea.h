@@ -153,6 +153,14 @@ int dsea_op_create_csr(int64_t n, int64_t nnz, const int64_t *rowptr, const int3
 int dsea_op_create_sell(int64_t n, int64_t nslices, const int64_t *slice_ptr, const int32_t *colidx,
                         const double *vals, dsea_op_t *out);
 
+/* The same layout with 16-BIT COLUMN DELTAS: the column of element e is colbase[e / 64] + coldelta[e] -- one int32 base per
+ * 64-element slice column (the smallest column index in it) and a uint16 per element, 10.06 instead of 12 bytes per
+ * non-zero.  Valid when every slice column spans fewer than 65536 columns (banded / structured patterns: the 21-nnz/row
+ * TFIM matrix does; the host layer checks and falls back to dsea_op_create_sell).  The SELL mat-vec sits on the bytes it
+ * moves (docs/design/12-round6.md): fewer bytes is the one lever it has.  colbase: int32 [slice_ptr[nslices] / 64].       */
+int dsea_op_create_sell16(int64_t n, int64_t nslices, const int64_t *slice_ptr, const int32_t *colbase,
+                          const uint16_t *coldelta, const double *vals, dsea_op_t *out);
+
 /* 3-point stencil + diagonal (reference examples/schrodinger1D.py:18-27):
  *     y[i] = coef * ((-2 x[i] + x[i+1]) + x[i-1]) + V[i] * x[i],  x[-1] = *halo_lo, x[n] = *halo_hi
  * (null halo pointer = 0, the Dirichlet padding of the reference).                            */
@@ -164,7 +172,36 @@ int dsea_op_create_stencil3(int64_t n, double coef, const double *V_dev, const d
  * (0 = automatic, or 4..64)                                                                                */
 #define DSEA_TUNE_TFIM_TILE_LOG2 1
 #define DSEA_TUNE_CSR_GROUP 2
+/* SELL mat-vec (32-bit columns): slice columns requested per lane before the first gather {0 = automatic (4), 2, 4, 8};
+ * 1 = the round-5 kernel kept as the "before" arm of tools/kbench_csr.py                                       */
+#define DSEA_TUNE_SELL_UNROLL 3
+/* SELL mat-vec: 1 = XCD-contiguous slice map (workgroup b works on eighth b % 8 of the slices), 0 = round-robin (default) */
+#define DSEA_TUNE_SELL_XCD_MAP 4
 int dsea_op_set_tuning(dsea_op_t op, int key, int value);
+
+/* The explicit-matrix operand as a PARAMETER of the primitives.  The reference's contract is that the adjoint of the
+ * operator, A-bar = v1 v2^T, is pushed to whatever parameters produced A (reference README.md:88-126, symeig.py:56-64,
+ * 82-84; its dense primitive returns exactly that outer product, symeig.py:29).  For a sparse A whose parameters ARE
+ * its stored non-zeros the push-forward is the sampled outer product  vals-bar[e] = v1[row(e)] * v2[col(e)].
+ * Both calls address the caller's CSR arrays: `rowptr` (int64 [n+1], the array the operator was built from; ignored
+ * for a dsea_op_create_csr operand, which has its own) maps entry k of row i of the SELL copy to CSR element
+ * rowptr[i] + k -- the order the host layer's conversion keeps.
+ *
+ * dsea_op_update_vals: the operator's values become vals_csr[0..nnz).  SELL: its value array (caller-owned, handed to
+ *     dsea_op_create_sell) is REWRITTEN IN PLACE through that map, padding stays 0; no rebuild of the layout.  CSR: a
+ *     device copy into the operator's array unless vals_csr already is that array.
+ * dsea_op_sddmm: out[e] = alpha * v1[row(e)] * v2[col(e)]            (flags = 0)
+ *     DSEA_SDDMM_ACCUMULATE : out[e] += ...
+ *     DSEA_SDDMM_SYMMETRIC  : alpha * (v1[row] v2[col] + v1[col] v2[row]) / 2 -- the adjoint w.r.t. the entries of a matrix
+ *                             that is applied as (M + M^T)/2, i.e. of a symmetric operand whose pairs (i,j), (j,i) move together
+ *     out: CSR order, nnz doubles.  Deterministic (one writer per element).
+ *     On a slab operator (dsea_op_set_slab) v2[col] is read where the mat-vec reads x[col]: the caller has exchanged v2's
+ *     halo / gathered copy; DSEA_SDDMM_SYMMETRIC is DSEA_ERR_UNSUPPORTED there (dsea_pop_sddmm does both exchanges).     */
+#define DSEA_SDDMM_ACCUMULATE 1
+#define DSEA_SDDMM_SYMMETRIC 2
+int dsea_op_update_vals(dsea_op_t op, const int64_t *rowptr, const double *vals_csr, void *stream);
+int dsea_op_sddmm(dsea_op_t op, const int64_t *rowptr, const double *v1, const double *v2, double alpha, int flags,
+                  double *out, void *stream);
 
 /* GEMM-shaped operands of the NON-symmetric primitives (reference eig.py) -- the one place on this path where a matrix core
  * is the right unit.                                                            design: docs/design/09-next-rows-f1-f4.md 8.1
@@ -193,6 +230,18 @@ int dsea_op_create_symdense(int64_t n, const void *A_dev, int elem_bytes, int64_
 size_t dsea_op_transfer_work_bytes(int D, int d);
 int dsea_op_create_transfer(int D, int d, const double *A_dev, int transpose, double *work, void *stream,
                             dsea_op_t *out);
+
+/* A SELL operator as the SLAB of a row-partitioned matrix (SURVEY.md 8e "CSR-banded: halo"; no reference counterpart -- the
+ * reference is single-device): the operator holds n consecutive rows of a larger matrix and says where x[col] lives when
+ * col is not one of its own rows.
+ *   halo_width = hb >= 0 : column indices are LOCAL, in [-hb, n + hb): c < 0 reads halo_lo[c + hb] (the last hb elements of the
+ *                          previous slab), c >= n reads halo_hi[c - n] (the first hb of the next slab).  A banded matrix
+ *                          with half-bandwidth <= hb <= n: one pairwise exchange of hb elements with each neighbour per mat-vec.
+ *                          A missing neighbour's pointer may be null (no column points there).
+ *   halo_width = -1      : column indices are GLOBAL and x[col] is read from x_gathered (all slabs, rank-major): the
+ *                          mat-vec is preceded by an all-gather of x -- the fallback for patterns without a band.
+ * The row operand of dsea_spmv (x, y) stays the slab.  dsea_pop_create_csr wraps such an operator with the exchange. */
+int dsea_op_set_slab(dsea_op_t op, int64_t halo_width, double *halo_lo, double *halo_hi, double *x_gathered);
 
 int dsea_op_destroy(dsea_op_t op);
 int dsea_op_dim(dsea_op_t op, int64_t *n);
@@ -371,6 +420,9 @@ int dsea_comm_destroy(dsea_comm_t comm);
 /* the collectives themselves, as the solvers issue them (tests, user-side inner products) */
 int dsea_comm_allreduce(dsea_comm_t comm, double *buf, int64_t count, void *stream);
 int dsea_comm_alltoall(dsea_comm_t comm, const double *send, double *recv, int64_t chunk, void *stream);
+/* recv[r * count .. (r+1) * count) = rank r's send[0..count): RCCL -- one group of point-to-point operations on the exchange
+ * communicator; callbacks -- world rounds of the pairwise sendrecv callback (round s pairs rank r with (s - r) mod world) */
+int dsea_comm_allgather(dsea_comm_t comm, const double *send, double *recv, int64_t count, void *stream);
 
 /* Row-partitioned operator = slab-local operator + communicator + exchange scratch.
  *   tfim     : chain of L sites over world = 2^p ranks, this rank holds rows [rank 2^(L-p), (rank+1) 2^(L-p)).  Low-bit
@@ -404,6 +456,17 @@ int dsea_pop_create_tfim(int L, dsea_comm_t comm, const double *g_dev, double g_
                          double *scratch, void *side_stream, int flags, double tau, dsea_pop_t *out);
 int dsea_pop_create_stencil3(int64_t n_local, double coef, const double *V_dev, double *halo2, dsea_comm_t comm,
                              dsea_pop_t *out);
+/*   csr      : explicit sparse matrix in contiguous row slabs of the SAME n_local rows on every rank (the host layer pads
+ *              the last slab with empty rows): `local_op` is this rank's SELL operator with its slab description
+ *              (dsea_op_set_slab) -- neighbour halo of hb elements per side, or the all-gather fallback.  The pop borrows
+ *              local_op's arrays and exchange buffers; the caller keeps them alive.  Halo-type operator: the exchange
+ *              precedes the slab mat-vec (as for stencil3).                                                          */
+int dsea_pop_create_csr(dsea_op_t local_op, dsea_comm_t comm, dsea_pop_t *out);
+/* the adjoint hook of a row-partitioned explicit matrix (dsea_op_sddmm on slabs): out[e] (+)= alpha v1[row e] v2[col e] for this
+ * rank's rows; v2 (and v1 for DSEA_SDDMM_SYMMETRIC) is exchanged like the x of a mat-vec.  rowptr: this slab's CSR row
+ * pointers (local element offsets), out: this slab's non-zeros in CSR order.                                          */
+int dsea_pop_sddmm(dsea_pop_t pop, const int64_t *rowptr, const double *v1, const double *v2, double alpha, int flags,
+                   double *out, void *stream);
 int dsea_pop_destroy(dsea_pop_t pop);
 int dsea_pop_set_flags(dsea_pop_t pop, int flags);
 /* y = (A - (*shift)) x over all ranks (Amap of Lanczos.py:54,71 / CG.py:27,31 and A(v) - E0 v of CG.py:120); if dot_out != null: *dot_out = GLOBAL x.y (all-reduced, identical on every

@@ -61,6 +61,50 @@ class CpuBackend:
         if out is not None:
             out[0] = torch.dot(x, y)
 
+    def attach_csr(self, rowptr, cols, vals, n_local, hb, halo, xg):
+        """explicit-matrix slab (same semantics as include/dsea.h dsea_op_set_slab): columns LOCAL in [-hb, n + hb) with the
+        neighbour halos in ``halo`` = [from rank-1 | from rank+1], or GLOBAL with the gathered vector ``xg`` (hb = -1)"""
+        assert n_local == self.n and rowptr.numel() == n_local + 1
+        rp = rowptr.to(torch.int64)
+        self.csr_rowptr = rp
+        self.csr_rows = torch.repeat_interleave(torch.arange(n_local, dtype=torch.int64), rp[1:] - rp[:-1])
+        self.csr_cols, self.csr_vals = cols.to(torch.int64), vals
+        self.csr_hb, self.csr_halo, self.csr_xg = int(hb), halo, xg
+
+        class _Local:            # what PartitionedCSROperator keeps as the slab operator
+            pass
+        loc = _Local()
+        loc.rowptr = rp
+        return loc
+
+    def _csr_source(self, x):
+        """(vector the columns index into, offset to add to the stored column)"""
+        hb = self.csr_hb
+        if hb < 0:
+            return self.csr_xg, 0
+        if hb == 0:
+            return x, 0
+        return torch.cat([self.csr_halo[:hb], x, self.csr_halo[hb:2 * hb]]), hb
+
+    def csr_local(self, x, y, shift, out, skip):
+        if skip is not None and skip[0] != 0:
+            return
+        src, o = self._csr_source(x)
+        res = torch.zeros(self.n, dtype=F64).index_add_(0, self.csr_rows, self.csr_vals.detach() * src[self.csr_cols + o])
+        if shift is not None:
+            res = res - shift[0] * x
+        y.copy_(res)
+        if out is not None:
+            out[0] = torch.dot(x, y)
+
+    def csr_sddmm_local(self, v1, v2, alpha, accumulate, out):
+        src, o = self._csr_source(v2)
+        g = alpha * (v1[self.csr_rows] * src[self.csr_cols + o])
+        if accumulate:
+            out.add_(g)
+        else:
+            out.copy_(g)
+
     def form_r(self, Q, ldq, n, i, u, alpha, beta, r, r_copy):
         r.copy_(u - alpha[0] * Q[i - 1, :n] - (beta[0] * Q[i - 2, :n] if (beta is not None and i >= 2) else 0.0))
         if r_copy is not None:

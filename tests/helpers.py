@@ -68,6 +68,47 @@ def rel(a, b):
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
 
 
+# ---- explicit sparse matrices as parameters (tests/test_gpu_csr_param.py, tests/test_partitioned_gloo.py)
+def banded_spd(n, hb, seed):
+    import scipy.sparse as sp
+    rng = np.random.RandomState(seed)
+    diags, offs = [], []
+    for d in range(1, hb + 1):
+        if rng.rand() < 0.7 or d == 1:
+            band = rng.randn(n - d) * 0.3
+            diags += [band, band]
+            offs += [d, -d]
+    M = sp.diags(diags, offs, shape=(n, n), format="csr")
+    rowsum = np.asarray(abs(M).sum(axis=1)).ravel()
+    M = (M + sp.diags(rowsum + 1.0 + np.linspace(0.0, 3.0, n), 0)).tocsr()      # diagonally dominant: SPD, gapped bottom
+    M.sort_indices()
+    return M
+
+
+def eigh_reference(M_rowptr, M_cols, vals, n, t, w_E=1.0, w_psi=1.0, psi_like=None, autograd=True):
+    """loss = w_E E0 + w_psi psi.t from torch.linalg.eigh of the SYMMETRISED dense matrix built from vals (CPU, fp64);
+    returns (E0, psi, d loss / d vals) -- the tied-pair adjoint (chain rule through (A + A^T)/2).
+    autograd=True : torch's own eigh backward (needs a spectrum without degeneracies ANYWHERE: it forms 1/(lam_i - lam_j)
+                    for all pairs, and the TFIM spectrum is degenerate above the ground state -> NaN);
+    autograd=False: first-order perturbation theory written out from the eigh factors,
+                    A-bar = w_E psi psi^T + w_psi v psi^T,  v = sum_{j>0} u_j (u_j . t) / (lam_0 - lam_j), then symmetrised."""
+    rows = torch.repeat_interleave(torch.arange(n), M_rowptr.cpu()[1:] - M_rowptr.cpu()[:-1])
+    cols = M_cols.cpu().long()
+    vals = vals.detach().cpu().clone().requires_grad_(autograd)
+    A = torch.zeros((n, n), dtype=torch.float64).index_put((rows, cols), vals, accumulate=True)
+    lam, U = torch.linalg.eigh(0.5 * (A + A.T))
+    psi = U[:, 0]
+    sgn = 1.0 if psi_like is None or float(psi.detach() @ psi_like.cpu()) > 0 else -1.0
+    if autograd:
+        loss = w_E * lam[0] + (w_psi * sgn * (psi @ t.cpu()) if w_psi else 0.0)
+        (g,) = torch.autograd.grad(loss, vals)
+        return lam[0].detach(), sgn * psi.detach(), g
+    p0 = sgn * psi
+    v = U[:, 1:] @ ((U[:, 1:].T @ t.cpu()) / (lam[0] - lam[1:]))
+    g = w_E * p0[rows] * p0[cols] + w_psi * 0.5 * (v[rows] * p0[cols] + v[cols] * p0[rows])
+    return lam[0], p0, g
+
+
 class _ResultChannel:
     """what a spawned worker writes its result into (``ret[rank] = value``): a pipe of the SPAWN context.  No manager
     process: ``multiprocessing.Manager()`` FORKS the calling process -- here a pytest process that holds an initialised HIP

@@ -1,0 +1,207 @@
+"""The explicit-matrix operand as a PARAMETER of the primitives (reference README.md:88-126, symeig.py:29,56-64,82-84:
+the adjoint A-bar = v1 v2^T is pushed to the parameters that produced A; for a sparse A whose parameters are its
+stored non-zeros that is the sampled outer product vals-bar[e] = v1[row e] v2[col e]).
+
+  * dsea_op_sddmm / dsea_op_update_vals against torch index arithmetic, bit for bit (ragged rows, both layouts,
+    32-bit and 16-bit columns);
+  * d E0 / d vals and d (E0 + psi.t) / d vals through DominantSparseSymeig + CSROperator.Aadjoint_to_valsadjoint against
+    (i) the dense primitive's A-bar (symeig.py:29) sampled on the pattern and (ii) torch.linalg.eigh autograd on the
+    symmetrised dense matrix, at 1e-10 with the CG tolerance at 1e-12 (tests/test_gpu_parity.py explains why);
+  * second order once; update-then-solve == rebuild-then-solve bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import PatchRandn, unit, rel, banded_spd as _banded_spd, eigh_reference as _eigh_reference  # noqa: E402
+from dominantsparseeigenad_amd import engine  # noqa: E402
+from dominantsparseeigenad_amd.operators import TFIMOperator, CSROperator  # noqa: E402
+from dominantsparseeigenad_amd.synthetic import normal_vector  # noqa: E402
+import dominantsparseeigenad_amd.symeig as symeig  # noqa: E402
+import dominantsparseeigenad_amd.CG as CG  # noqa: E402
+
+F64 = torch.float64
+TOL = 1e-10
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X (no fallback)"
+    return torch.device("cuda:0")
+
+
+def _ragged(n=1037, seed=3, density=0.02):
+    import scipy.sparse as sp
+    rng = np.random.RandomState(seed)
+    M = sp.random(n, n, density=density, random_state=rng, format="lil")
+    M[5, :] = 0
+    M[:, 5] = 0                                      # an empty row / column
+    M = sp.csr_matrix(M)
+    M = (M + M.T).tocsr()
+    M.sort_indices()
+    return M
+
+
+def _rows_of(M):
+    return np.repeat(np.arange(M.shape[0]), np.diff(M.indptr))
+
+
+@pytest.mark.parametrize("layout,col16", [("sell", "auto"), ("sell", False), ("csr", False)])
+def test_sddmm_and_update_kernels_bitwise(layout, col16):
+    M = _ragged()
+    n = M.shape[0]
+    op = CSROperator.from_scipy(M, dev(), layout=layout, col16=col16)
+    assert op.col16 == (layout == "sell" and col16 == "auto")
+    rows, cols = torch.from_numpy(_rows_of(M)), torch.from_numpy(M.indices.astype("int64"))
+    v1, v2 = torch.from_numpy(normal_vector(n, 7001)), torch.from_numpy(normal_vector(n, 7002))
+    plain = v1[rows] * v2[cols]
+    assert torch.equal(op.sddmm(v1.to(dev()), v2.to(dev())).cpu(), plain)
+    sym = 0.5 * (v1[rows] * v2[cols] + v1[cols] * v2[rows])
+    assert torch.equal(op.sddmm(v1.to(dev()), v2.to(dev()), symmetric=True).cpu(), sym)
+    out = torch.from_numpy(normal_vector(M.nnz, 7003)).to(dev())
+    base = out.cpu().clone()
+    op.sddmm(v1.to(dev()), v2.to(dev()), out=out, alpha=-0.75, accumulate=True)
+    assert torch.equal(out.cpu(), base + (-0.75) * plain)
+    # in-place refresh == rebuild, bit for bit; the SELL padding stays zero
+    x = torch.from_numpy(normal_vector(n, 7004)).to(dev())
+    newv = torch.from_numpy(normal_vector(M.nnz, 7005)).to(dev())
+    op.vals.copy_(newv)                               # in place: picked up through the tensor's version counter
+    rebuilt = CSROperator(op.rowptr, op.colidx, newv.clone(), n, layout=layout, col16=col16)
+    assert torch.equal(op(x), rebuilt(x))
+    M2 = M.copy()
+    M2.data = newv.cpu().numpy()
+    assert rel(op(x).cpu(), torch.from_numpy(M2 @ x.cpu().numpy())) < 1e-13
+
+
+def test_sell16_falls_back_when_a_slice_column_is_too_wide():
+    """a slice column spanning >= 65536 columns cannot use 16-bit deltas: 'auto' keeps 32-bit columns, True refuses"""
+    import scipy.sparse as sp
+    n = 70000
+    rows = np.array([0, 1, 69999, 69998], dtype=np.int64)
+    cols = np.array([69999, 1, 0, 69998], dtype=np.int64)
+    M = sp.csr_matrix((np.ones(4), (rows, cols)), shape=(n, n))
+    op = CSROperator.from_scipy(M, dev())
+    assert not op.col16
+    x = torch.from_numpy(normal_vector(n, 7010)).to(dev())
+    assert rel(op(x).cpu(), torch.from_numpy(M @ x.cpu().numpy())) < 1e-14
+    with pytest.raises(ValueError):
+        CSROperator.from_scipy(M, dev(), col16=True)
+
+
+@pytest.mark.parametrize("case", ["tfim-L12", "banded-spd"])
+def test_gradient_wrt_nonzeros_vs_dense_primitive_and_eigh(monkeypatch, case):
+    monkeypatch.setattr(CG, "EPS_DEFAULT", 1e-12)
+    if case == "tfim-L12":
+        L = 12
+        n, k = 1 << L, 120
+        src = TFIMOperator(L, dev(), g=torch.tensor([1.0], dtype=F64, device=dev())).to_csr()
+        rowptr, colidx, vals0 = src.rowptr, src.colidx, src.vals.clone()
+    else:
+        n, k = 3000, 200
+        M = _banded_spd(n, 9, 11)
+        rowptr = torch.from_numpy(M.indptr.astype("int64")).to(dev())
+        colidx = torch.from_numpy(M.indices.astype("int32")).to(dev())
+        vals0 = torch.from_numpy(M.data.copy()).to(dev())
+    vals = vals0.clone().requires_grad_(True)
+    op = CSROperator(rowptr, colidx, vals, n)
+    assert op.vals is vals
+    t = unit(n, 7100).to(dev())
+    rows = torch.repeat_interleave(torch.arange(n, device=dev()), rowptr[1:] - rowptr[:-1])
+    cols = colidx.long()
+
+    # (i) the dense primitive on the same matrix: its A-bar = v1 v2^T (symeig.py:29) sampled on the pattern
+    Ad = torch.zeros((n, n), dtype=F64, device=dev()).index_put((rows, cols), vals0, accumulate=True).requires_grad_(True)
+    with PatchRandn(7200):
+        E0d, psid = symeig.DominantSymeig.apply(Ad, k)
+        (gAd,) = torch.autograd.grad(E0d + psid @ t, Ad)
+    dense_sampled = gAd[rows, cols]
+
+    symeig.setDominantSparseSymeig(op, op.Aadjoint_to_valsadjoint)
+    with PatchRandn(7200):
+        E0, psi = symeig.DominantSparseSymeig.apply(op.vals, k, n)
+        (g_plain,) = torch.autograd.grad(E0 + psi @ t, op.vals)
+    assert engine.last_cg.converged and engine.last_cg.resnorm < 1e-12
+    assert abs(E0.item() - E0d.item()) < 1e-12 * abs(E0d.item())
+    sgn = 1.0 if float(psi.detach() @ psid.detach()) > 0 else -1.0
+    assert sgn == 1.0                                   # same start vector, same algorithm: same sign
+    scale = float(dense_sampled.abs().max())
+    assert float((g_plain - dense_sampled).abs().max()) < TOL * scale, float((g_plain - dense_sampled).abs().max()) / scale
+
+    # (ii) torch.linalg.eigh autograd on the symmetrised dense matrix: the tied-pair adjoint
+    symeig.setDominantSparseSymeig(op, op.Aadjoint_to_valsadjoint_symmetric)
+    for w_psi in (0.0, 1.0):
+        with PatchRandn(7300):
+            E0, psi = symeig.DominantSparseSymeig.apply(op.vals, k, n)
+            loss = E0 + w_psi * (psi @ t) if w_psi else E0
+            (g_sym,) = torch.autograd.grad(loss, op.vals)
+        E_ref, psi_ref, g_ref = _eigh_reference(rowptr, colidx, vals0, n, t, 1.0, w_psi, psi_like=psi.detach(),
+                                                autograd=(case == "banded-spd"))
+        if case == "banded-spd":                        # the closed form used for the TFIM case, checked where autograd works
+            _, _, g_pt = _eigh_reference(rowptr, colidx, vals0, n, t, 1.0, w_psi, psi_like=psi.detach(), autograd=False)
+            assert float((g_pt - g_ref).abs().max()) < 1e-11 * float(g_ref.abs().max())
+        assert abs(E0.item() - E_ref.item()) < 1e-12 * abs(E_ref.item())
+        assert rel(psi.detach().cpu(), psi_ref) < 1e-9
+        scale = float(g_ref.abs().max())
+        err = float((g_sym.cpu() - g_ref).abs().max()) / scale
+        assert err < TOL, (case, w_psi, err)
+        print("%s: d(E0 + %g psi.t)/d vals vs eigh autograd: max abs err / max |g| = %.2e over %d non-zeros"
+              % (case, w_psi, err, g_ref.numel()))
+
+
+def test_second_order_through_the_nonzeros(monkeypatch):
+    """d/d vals of (dE0/d vals . w): the hooks are differentiable (their backward is a mat-vec with the incoming gradient as
+    the values of the same pattern), as the reference's torch-code hooks are (examples/TFIM/E0.py:63-64)"""
+    monkeypatch.setattr(CG, "EPS_DEFAULT", 1e-12)
+    n, k = 400, 400
+    M = _banded_spd(n, 4, 5)
+    rowptr = torch.from_numpy(M.indptr.astype("int64")).to(dev())
+    colidx = torch.from_numpy(M.indices.astype("int32")).to(dev())
+    vals = torch.from_numpy(M.data.copy()).to(dev()).requires_grad_(True)
+    op = CSROperator(rowptr, colidx, vals, n)
+    symeig.setDominantSparseSymeig(op, op.Aadjoint_to_valsadjoint_symmetric)
+    w = torch.from_numpy(normal_vector(M.nnz, 7400)).to(dev())
+    with PatchRandn(7500):
+        E0, _ = symeig.DominantSparseSymeig.apply(op.vals, k, n)
+        (g1,) = torch.autograd.grad(E0, op.vals, create_graph=True)
+        (g2,) = torch.autograd.grad(g1 @ w, op.vals)
+    # reference: eigh double backward on the symmetrised dense matrix
+    v = vals.detach().cpu().clone().requires_grad_(True)
+    rows = torch.repeat_interleave(torch.arange(n), rowptr.cpu()[1:] - rowptr.cpu()[:-1])
+    A = torch.zeros((n, n), dtype=F64).index_put((rows, colidx.cpu().long()), v, accumulate=True)
+    lam, _ = torch.linalg.eigh(0.5 * (A + A.T))
+    (r1,) = torch.autograd.grad(lam[0], v, create_graph=True)
+    (r2,) = torch.autograd.grad(r1 @ w.cpu(), v)
+    assert float((g1.detach().cpu() - r1.detach()).abs().max()) < TOL * float(r1.detach().abs().max())
+    err = float((g2.cpu() - r2).abs().max()) / float(r2.abs().max())
+    assert err < 1e-8, err
+    print("second order through the non-zeros: max abs err / max = %.2e" % err)
+
+
+def test_optimiser_loop_update_then_solve_equals_rebuild_then_solve():
+    """an optimiser steps the non-zeros in place; the next solve sees them (dsea_op_update_vals through the stored map,
+    no rebuild) and equals a solve on an operator rebuilt from the new values, bit for bit"""
+    n, k = 3000, 64
+    M = _banded_spd(n, 6, 21)
+    rowptr = torch.from_numpy(M.indptr.astype("int64")).to(dev())
+    colidx = torch.from_numpy(M.indices.astype("int32")).to(dev())
+    vals = torch.from_numpy(M.data.copy()).to(dev()).requires_grad_(True)
+    op = CSROperator(rowptr, colidx, vals, n)
+    symeig.setDominantSparseSymeig(op, op.Aadjoint_to_valsadjoint_symmetric)
+    opt = torch.optim.SGD([vals], lr=0.05)
+    E_hist = []
+    for it in range(3):
+        opt.zero_grad()
+        with PatchRandn(7600 + it):
+            E0, psi = symeig.DominantSparseSymeig.apply(op.vals, k, n)
+        E0.backward()
+        E_hist.append(E0.item())
+        opt.step()                                      # in place on vals
+    assert E_hist[2] < E_hist[1] < E_hist[0]            # descending the smallest eigenvalue
+    with PatchRandn(7700):
+        E_upd, psi_upd = symeig.DominantSparseSymeig.apply(op.vals, k, n)
+    fresh = CSROperator(rowptr, colidx, vals.detach().clone(), n)
+    symeig.setDominantSparseSymeig(fresh, fresh.Aadjoint_to_valsadjoint_symmetric)
+    with PatchRandn(7700):
+        E_new, psi_new = symeig.DominantSparseSymeig.apply(fresh.vals, k, n)
+    assert E_upd.item() == E_new.item()
+    assert torch.equal(psi_upd, psi_new)

@@ -152,6 +152,50 @@ def _case_api_stencil(rank, world):
     return dict(E=E.item(), psi=psi.detach().numpy().copy(), loss=loss.item(), grad=gp.numpy().copy(), off=off)
 
 
+def _csr_case_matrix(kind):
+    """the two patterns of the row-partitioned explicit-matrix tests: a banded SPD matrix (halo exchange) and a symmetric
+    matrix with far couplings (all-gather fallback); n is not a multiple of 3 or 4 (padded last slab)"""
+    import scipy.sparse as sp
+    from helpers import banded_spd
+    n = 601
+    M = banded_spd(n, 7, 31)
+    if kind == "scattered":
+        rng = np.random.RandomState(32)
+        extra = sp.random(n, n, density=0.004, random_state=rng, format="csr") * 0.05
+        M = (M + extra + extra.T).tocsr()
+        M.sort_indices()
+    return M
+
+
+def _case_api_csr(rank, world, kind):
+    """E0, psi and d(E0 + psi.t)/d vals (this rank's non-zeros) through the reference API on PartitionedCSROperator"""
+    from cpu_backend import CpuBackend
+    from helpers import PatchRandn
+    import dominantsparseeigenad_amd.symeig as symeig
+    import dominantsparseeigenad_amd.CG as CG
+    from dominantsparseeigenad_amd.partitioned import PartitionedCSROperator, csr_partition
+    CG.EPS_DEFAULT = 1e-12
+    M = _csr_case_matrix(kind)
+    n, k = M.shape[0], 150
+    nloc, off, real = csr_partition(n, world, rank)
+    sub = M[off:off + real]
+    vals = torch.from_numpy(sub.data.copy()).requires_grad_(True)
+    op = PartitionedCSROperator(torch.from_numpy(sub.indptr.astype("int64")), torch.from_numpy(sub.indices.astype("int64")),
+                                vals, n, "cpu", backend=CpuBackend(nloc))
+    t_full = torch.zeros(nloc * world, dtype=torch.float64)
+    t_full[:n] = unit(n, 8100)
+    t = op.slab(t_full)
+    symeig.setDominantSparseSymeig(op, op.Aadjoint_to_valsadjoint_symmetric)
+    with PatchRandn(8200, offset=off):
+        E0, psi = symeig.DominantSparseSymeig.apply(vals, k, op.dim, "cpu")
+        loss = E0 + op.dot(psi, t)
+        (gv,) = torch.autograd.grad(loss, vals)
+    x = op.slab(torch.cat([torch.from_numpy(normal_vector(n, 8300)), torch.zeros(nloc * world - n, dtype=torch.float64)]))
+    y = op.H(x.clone())
+    return dict(mode=op.mode, hb=op.hb, E=E0.item(), psi=psi.detach().numpy()[:real].copy(), pad=float(psi.detach()[real:].abs().sum()),
+                grad=gv.numpy().copy(), y=y.numpy()[:real].copy(), loss=loss.item())
+
+
 def _worker(rank, world, port, case, args, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(1)
@@ -237,6 +281,37 @@ def test_reference_api_on_partitioned_stencil_matches_reference_fixture(world):
     assert signed_close(psi, gd["psi"], 1e-9)[0]
     assert abs(ret[0]["loss"] - float(gd["loss"])) < 1e-9
     assert np.max(np.abs(grad - gd["grad"])) < 1e-5 * np.max(np.abs(gd["grad"]))   # CG hits the n-iteration cap
+
+
+@pytest.mark.parametrize("world,kind", [(2, "banded"), (3, "banded"), (4, "banded"), (2, "scattered"), (3, "scattered"),
+                                        (4, "scattered")])
+def test_reference_api_on_partitioned_csr_matches_dense_eigh(world, kind):
+    """row-partitioned explicit matrix (SURVEY 8e "CSR-banded: halo", all-gather fallback otherwise): mat-vec equal to
+    scipy's, E0 / psi / d(E0 + psi.t)/d vals (tied-pair adjoint) at 1e-10 against first-order perturbation theory on
+    the dense eigh factors; the padding of the last slab stays zero"""
+    from helpers import eigh_reference
+    M = _csr_case_matrix(kind)
+    n = M.shape[0]
+    ret = _run(world, "_case_api_csr", kind)
+    # (two ranks: the one neighbour IS everybody else, a wide halo; from three on the far couplings need the all-gather)
+    assert all(r["mode"] == ("halo" if kind == "banded" or world == 2 else "gather") for r in ret), [r["mode"] for r in ret]
+    if kind == "banded":
+        assert all(1 <= r["hb"] <= 7 and r["hb"] == ret[0]["hb"] for r in ret)
+    y = np.concatenate([r["y"] for r in ret])
+    x = normal_vector(n, 8300)
+    assert np.max(np.abs(y - M @ x)) < 1e-13 * np.max(np.abs(M @ x))
+    psi = torch.from_numpy(np.concatenate([r["psi"] for r in ret]))
+    assert all(r["pad"] == 0.0 for r in ret)
+    grad = torch.from_numpy(np.concatenate([r["grad"] for r in ret]))
+    t = unit(n, 8100)
+    E_ref, psi_ref, g_ref = eigh_reference(torch.from_numpy(M.indptr.astype("int64")), torch.from_numpy(M.indices.astype("int64")),
+                                           torch.from_numpy(M.data.copy()), n, t, 1.0, 1.0, psi_like=psi, autograd=False)
+    for r in ret:
+        assert r["E"] == ret[0]["E"] and r["loss"] == ret[0]["loss"]          # replicated scalars: bit-identical
+    assert abs(ret[0]["E"] - E_ref.item()) < 1e-12 * abs(E_ref.item())
+    assert float((psi - psi_ref).abs().max()) < 1e-9
+    err = float((grad - g_ref).abs().max()) / float(g_ref.abs().max())
+    assert err < 1e-10, err
 
 
 @pytest.mark.parametrize("world,launcher,explicit", [(2, "self", True), (4, "torchrun", False), (8, "self", False)])
