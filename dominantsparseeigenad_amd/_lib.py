@@ -143,6 +143,7 @@ _SIGNATURES = {
     "dsea_ws_set_arnoldi_optimistic": (c_int, [c_void_p, c_int]),
     "dsea_arnoldi_status": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), c_void_p]),
     "dsea_arnoldi_status_enqueue": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "dsea_arnoldi_clear_record": (c_int, [c_void_p, c_void_p]),
     "dsea_arnoldi_orth": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int,
                                   c_void_p]),
     "dsea_gmres_work_doubles": (c_size_t, [c_int]),

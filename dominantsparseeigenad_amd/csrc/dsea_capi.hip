@@ -1185,6 +1185,14 @@ int dsea_arnoldi_status(dsea_ws_t ws, int* break_step, int* redo_step, void* str
   return h != 0.0 ? DSEA_ERR_BREAKDOWN : DSEA_OK;
 }
 
+int dsea_arnoldi_clear_record(dsea_ws_t ws, void* stream) {
+  if (!ws) return DSEA_ERR_ARG;
+  if (hipMemsetAsync(ws->w.scal + DSEA_SCAL_BREAK, 0, sizeof(double), static_cast<hipStream_t>(stream)) != hipSuccess) {
+    g_last_hip = (int)hipGetLastError();
+    return DSEA_ERR_HIP;
+  }
+  return DSEA_OK;
+}
 int dsea_arnoldi_status_enqueue(dsea_ws_t ws, double* host_record, void* stream) {
   if (!ws || !host_record) return DSEA_ERR_ARG;
   if (hipMemcpyAsync(host_record, ws->w.scal + DSEA_SCAL_BREAK, sizeof(double), hipMemcpyDeviceToHost,

@@ -301,10 +301,61 @@ int pop_apply(dsea_pop_s* P, dsea_ws_t ws, const double* x, double* y, const dou
   DSEA_TRY(halo_exchange(P, x, st));
   return dsea_spmv(&P->local, ws, x, y, shift, dot_local, skip, (void*)st);
 }
+// ---- CG on the reference's recurrences (CG.py:24-41 distributed): one exchange and two scalar all-reduces per iteration ----
+int pop_cg_run_reference(dsea_pop_s* P, dsea_ws_t ws, const double* shift, const double* b, double* x, double* state,
+                         double eps, int64_t maxiter, int poll_every, int64_t* iters_out, double* resnorm_out, hipStream_t st) {
+  const int64_t n = P->nloc;
+  Workspace& w = ws->w;
+  void* stream = (void*)st;
+  double* r = w.vec[1];
+  double* d = w.vec[2];
+  double* Ad = w.vec[3];
+  const double* done = state + DSEA_CG_DONE;
+  // r = b - A'x0 ; early out ; d = r                                   (CG.py:26-30)
+  DSEA_TRY(pop_apply(P, ws, x, Ad, shift, nullptr, w.scal + 36, st));
+  DSEA_TRY(dsea_cg_init(ws, b, Ad, r, d, state, n, stream));
+  DSEA_TRY(comm_allreduce(P->comm, state + DSEA_CG_RR, 1, st));
+  DSEA_TRY(dsea_cg_init_check(ws, state, eps, stream));
+  double host_state[DSEA_CG_STATE_LEN];
+  int64_t issued = 0;
+  bool finished = false;
+  HIP_TRY(hipMemcpyAsync(host_state, state, sizeof(host_state), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  finished = host_state[DSEA_CG_DONE] != 0.0 || maxiter == 0;
+  while (!finished) {
+    const int64_t chunk = (maxiter - issued) < poll_every ? (maxiter - issued) : poll_every;
+    for (int64_t it = 0; it < chunk; ++it) {
+      DSEA_TRY(pop_apply(P, ws, d, Ad, shift, done, state + DSEA_CG_DAD, st));          // A'd, local d.A'd  (CG.py:31/40)
+      DSEA_TRY(comm_allreduce(P->comm, state + DSEA_CG_DAD, 1, st));
+      DSEA_TRY(dsea_cg_update(ws, x, r, d, Ad, state, n, stream));                       // CG.py:31,33-34
+      DSEA_TRY(comm_allreduce(P->comm, state + DSEA_CG_RRNEW, 1, st));
+      DSEA_TRY(dsea_cg_check(ws, state, eps, stream));                                   // CG.py:35-38
+      DSEA_TRY(dsea_cg_direction(ws, r, d, state, n, stream));                           // CG.py:39
+    }
+    issued += chunk;
+    HIP_TRY(hipMemcpyAsync(host_state, state, sizeof(host_state), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    finished = (host_state[DSEA_CG_DONE] != 0.0) || issued >= maxiter;
+  }
+  if (iters_out) *iters_out = (int64_t)host_state[DSEA_CG_ITERS];
+  if (resnorm_out) *resnorm_out = host_state[DSEA_CG_RESNORM];
+  if (hipGetLastError() != hipSuccess) return DSEA_ERR_HIP;
+  return host_state[DSEA_CG_DONE] != 0.0 ? DSEA_OK : DSEA_ERR_NOT_CONVERGED;
+}
+
 // ---- CG with ONE all-reduce per iteration (Chronopoulos-Gear; kernels: k_pcg_update / k_pcg_scalars) ------------------
 // per iteration: [p, s, x, r update + local r.r partials] -> mat-vec w = A'r with its exchange (+ local r.w; the SAME
 // launch closes both local sums) -> all-reduce(gamma', delta) -> scalars (stopping test, beta, alpha).  Four launches
 // and one all-reduce where the reference's recurrences need seven and two.
+//
+// TRUE-RESIDUAL CHECK (round-5 advisor, medium).  Both r and s = A'p are carried by recurrences here, and Chronopoulos-Gear
+// is known to lose attainable accuracy against standard CG: the recursive ||r|| can pass the stopping test while b - A'x is
+// still above it.  A stop is therefore only accepted after r = b - A'x has been recomputed from x (one extra mat-vec and
+// all-reduce per solve) and found below eps -- which is simply the first thing a RESTART from x does.  If it is not, the
+// restart continues (residual replacement: the recurrences start again from the true residual); after
+// DSEA_PCG_MAX_RESTARTS of those the solve is finished on the reference's recurrences from the current x.  resnorm_out is
+// the TRUE residual whenever the solve converged on this path.
+#define DSEA_PCG_MAX_RESTARTS 3
 int pop_cg_run_one_reduction(dsea_pop_s* P, dsea_ws_t ws, const double* shift, const double* b, double* x, double* state,
                              double eps, int64_t maxiter, int poll_every, int64_t* iters_out, double* resnorm_out,
                              hipStream_t st) {
@@ -317,42 +368,64 @@ int pop_cg_run_one_reduction(dsea_pop_s* P, dsea_ws_t ws, const double* shift, c
   double* pair = w.scal + 32;                                   // (gamma', delta): local sums, then all-reduced in place
   double* rrP = w.aux + 3 * DSEA_MAX_WAVE_TILES;                // partials of r.r left by k_pcg_update
   const double* done = state + DSEA_CG_DONE;
-  // r = b - A'x0 ; early out                                           (CG.py:26-29)
-  DSEA_TRY(pop_apply(P, ws, x, wv, shift, nullptr, w.scal + 36, st));
-  DSEA_TRY(dsea_cg_init(ws, b, wv, r, p, state, n, (void*)st));       // (p = r: what beta = 0 makes of it anyway)
-  DSEA_TRY(comm_allreduce(P->comm, state + DSEA_CG_RR, 1, st));
-  DSEA_TRY(dsea_cg_init_check(ws, state, eps, (void*)st));
-  HIP_TRY(hipMemsetAsync(s, 0, (size_t)n * sizeof(double), st));
-  // w = A'r, delta = r.w ; alpha = gamma / delta, beta = 0
-  DSEA_TRY(pop_apply(P, ws, r, wv, shift, done, pair + 1, st));
-  DSEA_TRY(comm_allreduce(P->comm, pair + 1, 1, st));
-  launch_pcg_scalars(state, pair, eps, 1, st);
+  // the pending-partials hand-off to the mat-vec's dot-closing launch must not survive an early error return: the next
+  // dsea_spmv / dsea_axpy_multi_dot on this workspace would fold stale partials into a stale slot (round-5 advisor, low)
+  struct PendGuard {
+    Workspace& w;
+    explicit PendGuard(Workspace& ww) : w(ww) { w.pend_P = nullptr; }
+    ~PendGuard() { w.pend_P = nullptr; }
+  } pend_guard(w);
   double host_state[DSEA_CG_STATE_LEN];
-  int64_t issued = 0;
-  HIP_TRY(hipMemcpyAsync(host_state, state, sizeof(host_state), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  bool finished = host_state[DSEA_CG_DONE] != 0.0 || maxiter == 0;
-  while (!finished) {
-    const int64_t chunk = (maxiter - issued) < poll_every ? (maxiter - issued) : poll_every;
-    for (int64_t it = 0; it < chunk; ++it) {
-      const int nb = launch_pcg_update(x, r, p, s, wv, state, n, rrP, st);
-      w.pend_P = rrP;                                             // closed by the mat-vec's own dot-closing launch
-      w.pend_count = nb;
-      w.pend_out = pair;
-      DSEA_TRY(pop_apply(P, ws, r, wv, shift, done, pair + 1, st));
-      if (w.pend_P) {
-        launch_finalize1(w.pend_P, w.pend_count, w.pend_out, st);
-        w.pend_P = nullptr;
-      }
-      DSEA_TRY(comm_allreduce(P->comm, pair, 2, st));
-      launch_pcg_scalars(state, pair, eps, 0, st);
-    }
-    issued += chunk;
+  int64_t total_iters = 0;
+  for (int attempt = 0;; ++attempt) {
+    // r = b - A'x (the TRUE residual of the current x) ; early out / acceptance of the previous attempt's stop   (CG.py:26-29)
+    DSEA_TRY(pop_apply(P, ws, x, wv, shift, nullptr, w.scal + 36, st));
+    DSEA_TRY(dsea_cg_init(ws, b, wv, r, p, state, n, (void*)st));       // (p = r: what beta = 0 makes of it anyway)
+    DSEA_TRY(comm_allreduce(P->comm, state + DSEA_CG_RR, 1, st));
+    DSEA_TRY(dsea_cg_init_check(ws, state, eps, (void*)st));
     HIP_TRY(hipMemcpyAsync(host_state, state, sizeof(host_state), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    finished = (host_state[DSEA_CG_DONE] != 0.0) || issued >= maxiter;
+    if (host_state[DSEA_CG_DONE] != 0.0 || total_iters >= maxiter) break;
+    if (attempt > DSEA_PCG_MAX_RESTARTS) {
+      // the one-reduction recurrences keep stopping above the true tolerance: finish on the reference's
+      int64_t it2 = 0;
+      const int rc = pop_cg_run_reference(P, ws, shift, b, x, state, eps, maxiter - total_iters, poll_every, &it2, resnorm_out, st);
+      if (iters_out) *iters_out = total_iters + it2;
+      return rc;
+    }
+    HIP_TRY(hipMemsetAsync(s, 0, (size_t)n * sizeof(double), st));
+    // w = A'r, delta = r.w ; alpha = gamma / delta, beta = 0
+    DSEA_TRY(pop_apply(P, ws, r, wv, shift, done, pair + 1, st));
+    DSEA_TRY(comm_allreduce(P->comm, pair + 1, 1, st));
+    launch_pcg_scalars(state, pair, eps, 1, st);
+    int64_t issued = 0;
+    const int64_t budget = maxiter - total_iters;
+    bool finished = false;
+    while (!finished) {
+      const int64_t chunk = (budget - issued) < poll_every ? (budget - issued) : poll_every;
+      for (int64_t it = 0; it < chunk; ++it) {
+        const int nb = launch_pcg_update(x, r, p, s, wv, state, n, rrP, st);
+        w.pend_P = rrP;                                             // closed by the mat-vec's own dot-closing launch
+        w.pend_count = nb;
+        w.pend_out = pair;
+        DSEA_TRY(pop_apply(P, ws, r, wv, shift, done, pair + 1, st));
+        if (w.pend_P) {
+          launch_finalize1(w.pend_P, w.pend_count, w.pend_out, st);
+          w.pend_P = nullptr;
+        }
+        DSEA_TRY(comm_allreduce(P->comm, pair, 2, st));
+        launch_pcg_scalars(state, pair, eps, 0, st);
+      }
+      issued += chunk;
+      HIP_TRY(hipMemcpyAsync(host_state, state, sizeof(host_state), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      finished = (host_state[DSEA_CG_DONE] != 0.0) || issued >= budget;
+    }
+    total_iters += (int64_t)host_state[DSEA_CG_ITERS];
+    if (host_state[DSEA_CG_DONE] == 0.0) break;                     // iteration budget spent
+    // the recursive residual passed the test: the next round's first step recomputes the true one and decides
   }
-  if (iters_out) *iters_out = (int64_t)host_state[DSEA_CG_ITERS];
+  if (iters_out) *iters_out = total_iters;
   if (resnorm_out) *resnorm_out = host_state[DSEA_CG_RESNORM];
   if (hipGetLastError() != hipSuccess) return DSEA_ERR_HIP;
   return host_state[DSEA_CG_DONE] != 0.0 ? DSEA_OK : DSEA_ERR_NOT_CONVERGED;
@@ -751,46 +824,12 @@ int dsea_pop_cg_run(dsea_pop_t P, dsea_ws_t ws, const double* shift, const doubl
   if (ws->w.n < n) return DSEA_ERR_ARG;
   if (!aligned16(b) || !aligned16(x)) return DSEA_ERR_ALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  Workspace& w = ws->w;
-  double* r = w.vec[1];
-  double* d = w.vec[2];
-  double* Ad = w.vec[3];
-  const double* done = state + DSEA_CG_DONE;
   if (poll_every <= 0) poll_every = 16;
   const bool one_reduction = (P->flags & DSEA_POP_CG_ONE_REDUCTION) ||
                              (P->kind == OP_TFIM && !(P->flags & DSEA_POP_CG_REFERENCE));
   if (one_reduction)
     return pop_cg_run_one_reduction(P, ws, shift, b, x, state, eps, maxiter, poll_every, iters_out, resnorm_out, st);
-  // r = b - A'x0 ; early out ; d = r                                   (CG.py:26-30)
-  DSEA_TRY(pop_apply(P, ws, x, Ad, shift, nullptr, w.scal + 36, st));
-  DSEA_TRY(dsea_cg_init(ws, b, Ad, r, d, state, n, stream));
-  DSEA_TRY(comm_allreduce(P->comm, state + DSEA_CG_RR, 1, st));
-  DSEA_TRY(dsea_cg_init_check(ws, state, eps, stream));
-  double host_state[DSEA_CG_STATE_LEN];
-  int64_t issued = 0;
-  bool finished = false;
-  HIP_TRY(hipMemcpyAsync(host_state, state, sizeof(host_state), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  finished = host_state[DSEA_CG_DONE] != 0.0 || maxiter == 0;
-  while (!finished) {
-    const int64_t chunk = (maxiter - issued) < poll_every ? (maxiter - issued) : poll_every;
-    for (int64_t it = 0; it < chunk; ++it) {
-      DSEA_TRY(pop_apply(P, ws, d, Ad, shift, done, state + DSEA_CG_DAD, st));          // A'd, local d.A'd  (CG.py:31/40)
-      DSEA_TRY(comm_allreduce(P->comm, state + DSEA_CG_DAD, 1, st));
-      DSEA_TRY(dsea_cg_update(ws, x, r, d, Ad, state, n, stream));                       // CG.py:31,33-34
-      DSEA_TRY(comm_allreduce(P->comm, state + DSEA_CG_RRNEW, 1, st));
-      DSEA_TRY(dsea_cg_check(ws, state, eps, stream));                                   // CG.py:35-38
-      DSEA_TRY(dsea_cg_direction(ws, r, d, state, n, stream));                           // CG.py:39
-    }
-    issued += chunk;
-    HIP_TRY(hipMemcpyAsync(host_state, state, sizeof(host_state), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    finished = (host_state[DSEA_CG_DONE] != 0.0) || issued >= maxiter;
-  }
-  if (iters_out) *iters_out = (int64_t)host_state[DSEA_CG_ITERS];
-  if (resnorm_out) *resnorm_out = host_state[DSEA_CG_RESNORM];
-  if (hipGetLastError() != hipSuccess) return DSEA_ERR_HIP;
-  return host_state[DSEA_CG_DONE] != 0.0 ? DSEA_OK : DSEA_ERR_NOT_CONVERGED;
+  return pop_cg_run_reference(P, ws, shift, b, x, state, eps, maxiter, poll_every, iters_out, resnorm_out, st);
 }
 
 }  // extern "C"

@@ -82,7 +82,10 @@ class _one_thread:
                     # ONE controller for the life of the process: constructing it scans the loaded libraries (0.6 ms per
                     # ``threadpool_limits(...)`` -- as long as the 32 x 32 eigen-solve it was protecting); ``limit`` on a
                     # cached controller costs 15 us
+                    # (the controller only knows the BLAS libraries loaded when it was built: scipy.linalg's bundled OpenBLAS
+                    # must be in the process first, or its pool is never limited -- import it before the scan)
                     if cls._controller is None:
+                        import scipy.linalg  # noqa: F401
                         from threadpoolctl import ThreadpoolController
                         cls._controller = ThreadpoolController()
                     # BLAS pools only (numpy's and scipy's OpenBLAS: process-wide settings, hence the reference count).
@@ -330,59 +333,66 @@ def arnoldi_dominant(A, n, ncv, device, which="LM", v0=None, tol=1e-13, max_rest
             slot, j1 = 0, _next_stage_end(j, p, m, hist, tol)
             pipe.extend(j, j1)
             pipe.snapshot(j1, slot)
-        while pipelined:
-            # the NEXT stage goes to the device before the host looks at this one
-            j2 = _speculative_stage_end(j1, p, m, hist, tol)
-            if j2 is not None:
-                pipe.extend(j1, j2)
-                pipe.snapshot(j2, 1 - slot)
-            rec, Hh = pipe.wait(j1, slot)
-            t_issue = pipe.t_issue[slot]
-            stages_run += 1
-            if rec < 0.0:
-                # step `redo` of this stage needs its second Gram-Schmidt pass: every launch behind it (the rest of the stage
-                # and the speculative one) was a no-op.  Clear the record, repeat the step in the default mode, re-enqueue.
-                brk_c, redo_c = ctypes.c_int(0), ctypes.c_int(-1)
-                check(lib.dsea_arnoldi_status(ws.handle, byref(brk_c), byref(redo_c), st()), "dsea_arnoldi_status",
-                      allow=(_lib.ERR_BREAKDOWN, _lib.ERR_SECOND_PASS))
-                redo = int(-rec) - 1
-                DIAG.arnoldi_second_pass_redos = getattr(DIAG, "arnoldi_second_pass_redos", 0) + 1
-                check(lib.dsea_arnoldi_extend(lp.native.handle, ws.handle, None, _ptr(V), ldv, redo, redo + 1, _ptr(Hd), ldh,
-                                              st()), "dsea_arnoldi_extend")
-                if redo + 1 < j1:
-                    pipe.extend(redo + 1, j1)
-                pipe.snapshot(j1, slot)
-                stages_run -= 1
-                continue                        # (the speculative stage is enqueued again at the top of the loop)
-            brk_value = int(rec) if rec > 0.0 else 0
-            me = j1 if brk_value == 0 else brk_value              # invariant subspace reached at step me
-            B = Hh[:me, :me].T.copy()
-            coupling = 0.0 if me < j1 or brk_value else float(Hh[j1 - 1, j1])
-            j = j1
-            t_dev = time.perf_counter()
-            if STAGE_LOG is not None:
-                STAGE_LOG.append([j1, (t_dev - t_issue) * 1e3, None])
-            try:
-                theta, y, evals = _wanted_pair(B, which)
-            except ValueError:
-                if j1 >= m or me < j1:
-                    raise                      # the full factorisation says the wanted eigenvalue is complex: eig.py:31-32
-                theta = None
-            if theta is not None:
-                res = abs(coupling * y[-1])
+        # V and Hd must outlive the speculative stage that may still be in flight when the loop leaves (they do: both are
+        # locals of this function and the stream is drained by the Ritz-vector combination below before they go)
+        try:
+            while pipelined:
+                # the NEXT stage goes to the device before the host looks at this one
+                j2 = _speculative_stage_end(j1, p, m, hist, tol)
+                if j2 is not None:
+                    pipe.extend(j1, j2)
+                    pipe.snapshot(j2, 1 - slot)
+                rec, Hh = pipe.wait(j1, slot)
+                t_issue = pipe.t_issue[slot]
+                stages_run += 1
+                if rec < 0.0:
+                    # step `redo` of this stage needs its second Gram-Schmidt pass: every launch behind it (the rest of the stage
+                    # and the speculative one) was a no-op.  Clear the record, repeat the step in the default mode, re-enqueue.
+                    brk_c, redo_c = ctypes.c_int(0), ctypes.c_int(-1)
+                    check(lib.dsea_arnoldi_status(ws.handle, byref(brk_c), byref(redo_c), st()), "dsea_arnoldi_status",
+                          allow=(_lib.ERR_BREAKDOWN, _lib.ERR_SECOND_PASS))
+                    redo = int(-rec) - 1
+                    DIAG.arnoldi_second_pass_redos = getattr(DIAG, "arnoldi_second_pass_redos", 0) + 1
+                    check(lib.dsea_arnoldi_extend(lp.native.handle, ws.handle, None, _ptr(V), ldv, redo, redo + 1, _ptr(Hd), ldh,
+                                                  st()), "dsea_arnoldi_extend")
+                    if redo + 1 < j1:
+                        pipe.extend(redo + 1, j1)
+                    pipe.snapshot(j1, slot)
+                    stages_run -= 1
+                    continue                        # (the speculative stage is enqueued again at the top of the loop)
+                brk_value = int(rec) if rec > 0.0 else 0
+                me = j1 if brk_value == 0 else brk_value              # invariant subspace reached at step me
+                B = Hh[:me, :me].T.copy()
+                coupling = 0.0 if me < j1 or brk_value else float(Hh[j1 - 1, j1])
+                j = j1
+                t_dev = time.perf_counter()
                 if STAGE_LOG is not None:
-                    STAGE_LOG[-1][2] = (time.perf_counter() - t_dev) * 1e3
-                    STAGE_LOG[-1].append(res / max(abs(theta), 1e-300))
-                if res <= tol * abs(theta) or me < j1 or j1 >= m:
-                    break
-                hist.append((j1, res / max(abs(theta), 1e-300)))
-            if j2 is None:                      # the stage was expected to converge and did not: enqueue the next one now
-                j2 = _next_stage_end(j1, p, m, hist, tol)
-                pipe.extend(j1, j2)
-                pipe.snapshot(j2, 1 - slot)
-            j1, slot = j2, 1 - slot
-        if pipelined:
-            pipe.release()
+                    STAGE_LOG.append([j1, (t_dev - t_issue) * 1e3, None])
+                try:
+                    theta, y, evals = _wanted_pair(B, which)
+                except ValueError:
+                    if j1 >= m or me < j1:
+                        raise                      # the full factorisation says the wanted eigenvalue is complex: eig.py:31-32
+                    theta = None
+                if theta is not None:
+                    res = abs(coupling * y[-1])
+                    if STAGE_LOG is not None:
+                        STAGE_LOG[-1][2] = (time.perf_counter() - t_dev) * 1e3
+                        STAGE_LOG[-1].append(res / max(abs(theta), 1e-300))
+                    if res <= tol * abs(theta) or me < j1 or j1 >= m:
+                        break
+                    hist.append((j1, res / max(abs(theta), 1e-300)))
+                if j2 is None:                      # the stage was expected to converge and did not: enqueue the next one now
+                    j2 = _next_stage_end(j1, p, m, hist, tol)
+                    pipe.extend(j1, j2)
+                    pipe.snapshot(j2, 1 - slot)
+                j1, slot = j2, 1 - slot
+        finally:
+            if pipelined:
+                # a speculative stage may still be running behind the converged one: whatever it records must not reach a
+                # later continuation on this cached workspace; and the pinned buffers go back to the pool on every path
+                lib.dsea_arnoldi_clear_record(ws.handle, st())
+                pipe.release()
         while not pipelined:
             j1 = _next_stage_end(j, p, m, hist, tol)
             brk = ctypes.c_int(0)

@@ -485,7 +485,11 @@ int dsea_pop_lanczos_run(dsea_pop_t pop, dsea_ws_t ws, int k, const double *q0, 
 int dsea_pop_lanczos_status(dsea_pop_t pop, dsea_ws_t ws, int *step, void *stream);
 /* CG on (A - (*shift)) x = b on slabs (reference CG.py:24-41 distributed): per iteration one exchange and two scalar
  * all-reduces (reference recurrences) or ONE (DSEA_POP_CG_* above); the stopping test runs on the device on replicated
- * scalars, the host polls every `poll_every` iterations.  SYNCHRONISES before returning.  Work vectors: the workspace's. */
+ * scalars, the host polls every `poll_every` iterations.  SYNCHRONISES before returning.  Work vectors: the workspace's.
+ * The one-reduction form carries r AND A'p by recurrences, so its stop is only ACCEPTED after r = b - A'x has been recomputed
+ * from x and found below eps (one extra mat-vec + all-reduce per solve); otherwise the recurrences restart from the true
+ * residual, and after three such restarts the solve is finished on the reference's recurrences.  resnorm_out then is the
+ * TRUE residual norm ||b - A'x||; iters_out counts the iterations of all rounds.                                          */
 int dsea_pop_cg_run(dsea_pop_t pop, dsea_ws_t ws, const double *shift, const double *b, double *x, double *state,
                     double eps, int64_t maxiter, int poll_every, int64_t *iters_out, double *resnorm_out, void *stream);
 
@@ -548,6 +552,10 @@ int dsea_arnoldi_status(dsea_ws_t ws, int *break_step, int *redo_step, void *str
  * -value - 1 needs its second pass (then dsea_arnoldi_status clears the record as above).  Lets a caller test the stage it
  * has just enqueued while the NEXT stage is already running (krylov.arnoldi_dominant).                                  */
 int dsea_arnoldi_status_enqueue(dsea_ws_t ws, double *host_record, void *stream);
+/* enqueue (no synchronisation) a clear of the record behind everything issued so far: a caller that stops at a converged
+ * stage while a SPECULATIVE stage is still in flight leaves this behind it, so that whatever that stage records (a breakdown,
+ * a second-pass request) cannot turn a later continuation (j0 > 0) on the same workspace into no-ops                     */
+int dsea_arnoldi_clear_record(dsea_ws_t ws, void *stream);
 
 /* the orthogonalisation of ONE Arnoldi step (one step of what eig.py:29-30,116-117 runs inside ARPACK and :54,57,140,144
  * inside scipy's gmres) when the mat-vec is the caller's code: u = A v_j given, writes column j

@@ -75,6 +75,18 @@ def _case_config5_slab(rank, world, backend, dev, Lg, k):
     out.update(E0=E0.item(), dE0=dE0.item(), resid=float(op.dot(res, res).sqrt()), norm=float(op.dot(p, p).sqrt()),
                cg_iters=int(op.last_cg_iters), cg_resnorm=float(op.last_cg_resnorm),
                cg_converged=bool(engine.last_cg.converged), overlap_fallbacks=int(op.overlap_fallbacks))
+    # (3) the library driver's default CG for this operand carries r and A'p by recurrences (one all-reduce per iteration,
+    # Chronopoulos-Gear); its stop is accepted only on the TRUE residual.  Checked here from outside: solve, then form
+    # b - (H - E0) x with the operator (round-5 advisor: "a test at the config-5 slab size with eps = 1e-12")
+    b = torch.randn(n, dtype=F64, device=dev, generator=gen)
+    b = b - op.dot(p, b) * p
+    b = b / op.dot(b, b).sqrt()
+    x0 = torch.randn(n, dtype=F64, device=dev, generator=gen)
+    x0 = x0 - op.dot(p, x0) * p
+    x = op.solve_shifted(E0.detach(), b, x0, eps=1e-12)
+    true_r = b - (op.H(x) - E0.detach() * x)
+    out.update(cg2_true=float(op.dot(true_r, true_r).sqrt()), cg2_reported=float(op.last_cg_resnorm), cg2_iters=int(op.last_cg_iters),
+               cg2_form=str(engine.last_cg.form))
     torch.cuda.synchronize()
     return out
 
@@ -94,6 +106,11 @@ def test_config5_per_gpu_load_on_the_distributed_driver_over_rccl():
     assert o["orth"] < 1e-12, o["orth"]
     assert o["cg_converged"] and o["cg_resnorm"] < 1e-12 and 0 < o["cg_iters"] < 2000
     assert abs(o["dE0"] - dE_an) < 1e-10 * abs(dE_an), (o["dE0"], dE_an)
+    print("config-5 slab, one-reduction CG at eps 1e-12: %d iterations, reported %.3e, true ||b - (H - E0) x|| %.3e (%s)"
+          % (o["cg2_iters"], o["cg2_reported"], o["cg2_true"], o["cg2_form"]))
+    assert "one all-reduce" in o["cg2_form"]
+    assert o["cg2_reported"] < 1e-12 and o["cg2_true"] < 1.01e-12, (o["cg2_reported"], o["cg2_true"])
+    assert abs(o["cg2_true"] - o["cg2_reported"]) < 1e-14          # what is reported IS the true residual
 
 
 def _worker_config5(rank, port, Lg, k, ret):

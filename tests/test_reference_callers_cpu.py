@@ -126,3 +126,144 @@ def test_reference_vumps_caller_on_the_drop_in():
     (gm,) = torch.autograd.grad(Em, model.A)
     (gs,) = torch.autograd.grad(Es, model.A)
     assert float((gm - gs).abs().max()) < 1e-9 * max(1.0, float(gm.abs().max()))
+
+
+# ------------------------------------------------------------------ the reference's OWN UNIT TESTS on the drop-in
+# (round-5 verdict, Next 6).  /root/reference/DominantSparseEigenAD/tests/test_{Lanczos,CG,symeig,gradient}.py are loaded
+# by path -- nothing of them is copied or travels -- with this repository first on sys.path, so their
+# ``from DominantSparseEigenAD.Lanczos import symeigLanczos`` etc. bind to the drop-in package, and every test function
+# in them is called.  Shims: ``torch.symeig`` (removed from torch; the tests use it as their dense reference) and the
+# ``.T`` of a 1-D tensor the CG test takes (a deprecation warning turned error by nothing here -- left as is).
+# CUDA-gated functions skip here (no GPU in the build container) exactly as they do in the reference's CI.
+REF_TESTS = os.path.join(REF, "DominantSparseEigenAD", "tests")
+_REF_TEST_FILES = ("test_Lanczos.py", "test_CG.py", "test_symeig.py", "test_gradient.py")
+
+
+def _ref_test_functions():
+    out = []
+    for fname in _REF_TEST_FILES:
+        path = os.path.join(REF_TESTS, fname)
+        if not os.path.exists(path):
+            continue
+        import ast
+        tree = ast.parse(open(path).read())
+        out += [(fname, node.name) for node in tree.body if isinstance(node, ast.FunctionDef) and node.name.startswith("test_")]
+    return out
+
+
+@pytest.mark.parametrize("fname,func", _ref_test_functions() or [("-", "-")])
+def test_reference_unit_tests_on_the_drop_in(symeig_shim, fname, func):
+    if fname == "-":
+        pytest.skip("the reference's tests are only present in the build container")
+    mod = _load(os.path.join(REF_TESTS, fname), "ref_unit_" + fname[:-3])
+    bound = [getattr(mod, name) for name in ("symeigLanczos", "CG_torch", "DominantSymeig", "DominantEig") if hasattr(mod, name)]
+    assert bound, "the reference test imports none of the primitives?"
+    for obj in bound:                                   # what the reference's test calls IS this repository's code
+        src = sys.modules[obj.__module__].__file__
+        assert os.path.realpath(src).startswith(os.path.realpath(ROOT)), (obj, src)
+    fn = getattr(mod, func)
+    for mark in getattr(fn, "pytestmark", []):
+        if mark.name == "skipif" and mark.args and mark.args[0]:
+            pytest.skip("reference skipif: " + str(mark.kwargs.get("reason", "")))
+    torch.manual_seed(2026)
+    np.random.seed(2026)
+    fn()
+
+
+# ------------------------------------------------------------------ examples/schrodinger1D.py and TFIM_vumps/symmetric.py
+@pytest.fixture()
+def pyplot_stub(monkeypatch):
+    """schrodinger1D.py imports matplotlib.pyplot at the top for its plotting loop (not run here); give it a stand-in when
+    matplotlib is not installed"""
+    try:
+        import matplotlib.pyplot  # noqa: F401
+    except Exception:       # noqa: BLE001
+        import types
+        from unittest import mock
+        mpl = types.ModuleType("matplotlib")
+        mpl.pyplot = mock.MagicMock()
+        monkeypatch.setitem(sys.modules, "matplotlib", mpl)
+        monkeypatch.setitem(sys.modules, "matplotlib.pyplot", mpl.pyplot)
+
+
+def test_reference_schrodinger1d_compute_functions_on_the_drop_in(symeig_shim, pyplot_stub):
+    """examples/schrodinger1D.py:36-71: the model's three forward computations at the script's own setting (N = 300, k = 300,
+    triangle target) -- full diagonalisation with torch, DominantSymeig on the dense matrix, DominantSparseSymeig on
+    ``Hsparse`` with ``Hadjoint_to_padjoint`` -- agree in the loss and in the gradient w.r.t. the potential; then two LBFGS
+    steps of the script's optimisation loop through the sparse primitive lower the loss."""
+    mod = _load(os.path.join(REF, "examples", "schrodinger1D.py"), "ref_example_schrodinger1D")
+    _drop_in_is_ours()
+    xmin, xmax, N, k = -1.0, 1.0, 300, 300
+    xm = np.linspace(xmin, xmax, num=N, endpoint=False)
+    target = np.zeros(N)
+    idx = np.abs(xm) < 0.5
+    target[idx] = 1.0 - np.abs(xm[idx])
+    target /= np.linalg.norm(target)
+    xmesh, target = torch.from_numpy(xm).to(torch.float64), torch.from_numpy(target).to(torch.float64)
+    torch.manual_seed(5)
+    model = mod.Schrodinger1D(xmin, xmax, N, xmesh)
+    res = {}
+    for name, fwd in (("torch", lambda: model.forward_torch(target)), ("matrix", lambda: model.forward_matrixAD(target, k)),
+                      ("sparse", lambda: model.forward_sparseAD(target, k))):
+        model.potential.grad = None
+        loss = fwd()
+        loss.backward()
+        res[name] = (loss.item(), model.potential.grad.clone())
+    for name in ("matrix", "sparse"):
+        assert abs(res[name][0] - res["torch"][0]) < 1e-9, (name, res[name][0], res["torch"][0])
+        # the adjoint solve of this operator runs into CG's n-iteration cap (SURVEY.md 8d C3): gradients agree to ~1e-5
+        gerr = float((res[name][1] - res["torch"][1]).abs().max()) / float(res["torch"][1].abs().max())
+        assert gerr < 1e-4, (name, gerr)
+    opt = torch.optim.LBFGS(model.parameters(), max_iter=10, tolerance_change=1e-7, tolerance_grad=1e-7, line_search_fn="strong_wolfe")
+
+    def closure():
+        opt.zero_grad()
+        loss = model.forward_sparseAD(target, k)
+        loss.backward()
+        return loss
+
+    first = opt.step(closure).item()
+    second = opt.step(closure).item()
+    last = model.forward_sparseAD(target, k).item()
+    assert last < second <= first and last < 0.5 * first, (first, second, last)
+
+
+def test_reference_vumps_symmetric_caller_on_the_drop_in():
+    """examples/TFIM_vumps/symmetric.py:11-49: the symmetric-MPS model's forward (DominantSymeig on -Gong) against the same
+    energy from a full diagonalisation of its transfer matrix, gradient included; then its optimisation loop (LBFGS) at
+    D = 8 for g = 1.0 against the stored exact energy per site (datas/E0_sum.npz) at the accuracy a D = 8 MPS reaches."""
+    mod = _load(os.path.join(REF, "examples", "TFIM_vumps", "symmetric.py"), "ref_example_vumps_symmetric")
+    _drop_in_is_ours()
+    stored = np.load(os.path.join(REF, "examples", "TFIM_vumps", "datas", "E0_sum.npz"))
+    i = int(np.argmin(np.abs(stored["gs"] - 1.0)))
+    torch.manual_seed(4)
+    D, k = 8, 64
+    model = mod.TFIM(D, k)
+    model.seth(float(stored["gs"][i]))
+    model.setparameters()
+
+    def dense_energy():
+        A = 0.5 * (model.A + model.A.permute(0, 2, 1))
+        Gong = torch.einsum("kij,kmn->imjn", A, A).reshape(D ** 2, D ** 2)
+        lam, U = torch.linalg.eigh(-Gong)
+        v = U[:, 0].reshape(D, D)
+        return torch.einsum("aik,bkj,abcd,cml,dln,im,jn", A, A, model.h, A, A, v, v) / lam[0] ** 2
+
+    E_prim = model()
+    (g_prim,) = torch.autograd.grad(E_prim, model.A)
+    E_full = dense_energy()
+    (g_full,) = torch.autograd.grad(E_full, model.A)
+    assert abs(E_prim.item() - E_full.item()) < 1e-10 * abs(E_full.item())
+    assert float((g_prim - g_full).abs().max()) < 1e-7 * float(g_full.abs().max())
+    opt = torch.optim.LBFGS(model.parameters(), max_iter=10, tolerance_grad=1e-7)
+
+    def closure():
+        E0 = model()
+        opt.zero_grad()
+        E0.backward()
+        return E0
+
+    E0 = None
+    for _ in range(25):
+        E0 = opt.step(closure)
+    assert abs(E0.item() - float(stored["E0s"][i])) < 2e-4 * abs(float(stored["E0s"][i])), (E0.item(), float(stored["E0s"][i]))

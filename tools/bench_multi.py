@@ -175,10 +175,20 @@ def scaling_decomposition(ctx, prob, pt, ms_per_step, m, E0, one_gpu_ms):
     # SURVEY 8e's model: local work divides by P; each Lanczos step adds two latency-bound all-reduces (coefficients; the
     # pair of scalars) and whatever of its exchange is not hidden; each CG iteration two scalar all-reduces and its exchange
     ar8, ar1600 = out["allreduce_us"]["8_bytes"] * 1e-3, out["allreduce_us"]["1600_bytes"] * 1e-3
-    comm_ms = k * (ar1600 + ar8 + exp_lz) + (0.0 if replicated else m * (2.0 * ar8 + exp_cg))
+    # all-reduces per CG iteration of the form ACTUALLY run (round-5 advisor): the library driver's default for the TFIM operand
+    # is the one-reduction form (one 16-byte all-reduce), the Python step driver and the reference recurrences issue two scalars
+    from dominantsparseeigenad_amd import engine as _engine
+    form = str(getattr(_engine.last_cg, "form", ""))
+    one_red = "one all-reduce" in form
+    out["allreduce_us"]["16_bytes"] = round(_allreduce_us(ctx, op, 2, reps), 2)
+    ar16 = out["allreduce_us"]["16_bytes"] * 1e-3
+    cg_ar = ar16 if one_red else 2.0 * ar8
+    out["cg_allreduces_per_iteration"] = {"count": 1 if one_red else 2, "form": form}
+    comm_ms = k * (ar1600 + ar8 + exp_lz) + (0.0 if replicated else m * (cg_ar + exp_cg))
     out["communication_ms_per_step"] = round(comm_ms, 3)
-    out["model"] = {"formula": "T_P = T_1 / P + k (allreduce_1600B + allreduce_8B + exposed_exchange_lanczos) + m (2 allreduce_8B + "
-                               "exposed_exchange_cg)   [m-term dropped when the solve is replicated]; SURVEY 8e",
+    out["model"] = {"formula": "T_P = T_1 / P + k (allreduce_1600B + allreduce_8B + exposed_exchange_lanczos) + m (%s + "
+                               "exposed_exchange_cg)   [m-term dropped when the solve is replicated]; SURVEY 8e"
+                               % ("allreduce_16B" if one_red else "2 allreduce_8B"),
                     "timed_point": model_entry(one_gpu_ms, ms_per_step, P, comm_ms)}
     return out
 
