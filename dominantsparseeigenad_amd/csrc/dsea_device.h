@@ -113,6 +113,9 @@ __device__ __forceinline__ double2 ld2(const double* __restrict__ p, int64_t row
 template <bool GUARD>
 __device__ __forceinline__ double2 ld2_stream(const double* __restrict__ p, int64_t row, int64_t n) {
   // measured on MI355X (tools/kbench.py, n = 2^20, i = 199): dots pass 290 us -> 255 us with the nt hint
+#ifdef DSEA_NO_NT   /* A/B build (make libdsea_nont.so EXTRA=-DDSEA_NO_NT): default cache policy on the basis stream */
+  return ld2<GUARD>(p, row, n);
+#endif
   if (!GUARD || row + 1 < n) {
     typedef double v2d __attribute__((ext_vector_type(2)));
     v2d t = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p + row));

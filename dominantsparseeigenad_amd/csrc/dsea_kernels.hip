@@ -523,7 +523,10 @@ __device__ __forceinline__ double axpy_lp_tile(const double* __restrict__ Q, int
 #pragma unroll
     for (int e = 0; e < 8; ++e) w[s][e] = 0.0;
   if (use_lp) {
-#pragma unroll 4
+#ifndef DSEA_LP_UNROLL
+#define DSEA_LP_UNROLL 4
+#endif
+#pragma unroll DSEA_LP_UNROLL
     for (int jj = 0; jj < i; ++jj) {
       const int j = i - 1 - jj;
       const uint16_t* __restrict__ qj = Qs + (int64_t)j * lds;

@@ -682,6 +682,7 @@ class CGInfo:
     # CG.py:31-40's rounding sequence -- the default for the full-space TFIM operand at 2^11 ... 2^20 rows); a persistent
     # launch that timed out is repeated in the streaming form and says so here
     form = "streaming"
+    polls = 0          # host looks at the device-side stop flag (callable operand: one synchronising copy each)
 
 
 last_cg = CGInfo()
@@ -773,6 +774,7 @@ def cg(b, x0, *, native=None, callable_A=None, shift=None, eps=1e-7, maxiter=Non
         check(lib.dsea_cg_init_check(ws.handle, _ptr(state), float(eps), st), "dsea_cg_init_check")
         issued = 0
         host = state.cpu()
+        polls = 1
         while host[_lib.CG_DONE].item() == 0.0 and issued < cap:
             chunk = min(int(poll_every), cap - issued)
             for _ in range(chunk):
@@ -787,6 +789,8 @@ def cg(b, x0, *, native=None, callable_A=None, shift=None, eps=1e-7, maxiter=Non
                 check(lib.dsea_cg_direction(ws.handle, _ptr(r), _ptr(d), _ptr(state), n, st), "dsea_cg_direction")
             issued += chunk
             host = state.cpu()
+            polls += 1
+    last_cg.polls, last_cg.form = polls, "streaming (callable operand: phase calls from Python)"
     last_cg.iters = int(host[_lib.CG_ITERS].item())
     last_cg.resnorm = float(host[_lib.CG_RESNORM].item())
     last_cg.converged = host[_lib.CG_DONE].item() != 0.0

@@ -1,4 +1,6 @@
 """Shared test helpers: pinned draws (the same injection the golden script used on the reference)."""
+import os
+
 import numpy as np
 import torch
 
@@ -125,10 +127,18 @@ def spawn_collect(fn, args, nprocs):
     """``torch.multiprocessing.spawn(fn, args + (ret,), nprocs)`` where every worker does ``ret[rank] = value``; returns
     {rank: value}.  The parent reads while the workers run (a result larger than the pipe buffer would otherwise block its
     writer) and a crashed worker raises here instead of leaving the parent waiting."""
+    import multiprocessing
     import torch.multiprocessing as mp
-    ctx = mp.get_context("spawn")
+    # Workers come from a FORK SERVER that has imported torch / numpy / scipy and nothing else: a fresh process per worker as
+    # with "spawn" (no state shared between cases, HIP is initialised by the worker itself -- the server never touches the
+    # GPU), minus the ~1 s of imports per worker (measured on the GPU box, tools/probes/spawn_cost.py: 4 ranks 1.7-2.4 s ->
+    # 0.3-0.5 s; ~100 spawns in `pytest -m gpu`).  The package itself is NOT preloaded: it reads environment switches at import.
+    method = os.environ.get("DSEA_TEST_START_METHOD", "forkserver")
+    if method == "forkserver":
+        multiprocessing.set_forkserver_preload(["torch", "torch.distributed", "numpy", "scipy.sparse", "scipy.linalg"])
+    ctx = mp.get_context(method)
     queue = ctx.SimpleQueue()
-    pc = mp.spawn(fn, args=tuple(args) + (_ResultChannel(queue),), nprocs=nprocs, join=False)
+    pc = mp.start_processes(fn, args=tuple(args) + (_ResultChannel(queue),), nprocs=nprocs, join=False, start_method=method)
     out, done = {}, False
     while len(out) < nprocs and not done:
         while not queue.empty():

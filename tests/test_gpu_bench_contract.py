@@ -118,7 +118,11 @@ def test_bench_multi_gpu_branch_rehearsal_on_hip_kernels(world):
     decisions, overlapped-exchange self-check, strong point + fp64 / shadow-matched extras + weak point, rank evidence,
     one final JSON line) with the N ranks sharing the one GPU of this box at toy sizes.  N = 8 is the p = 3 geometry of
     BASELINE configs[4]: transposed exchange with three far bits.  A rehearsal, labelled as such -- no measurement."""
-    d = _bench(["--gpus", str(world), "--host-staged", "--steps", "2", "--warmup", "1"])
+    # N = 8 (eight processes time-slicing one GPU: 82 s with the full schedule) runs the timed strong point only -- the extras
+    # beside it (fp64 / shadow-matched / weak points, scaling decomposition) are the same code at N = 2 and N = 4
+    reduced = world >= 8
+    d = _bench(["--gpus", str(world), "--host-staged", "--steps", "2", "--warmup", "1"],
+               env={"DSEA_BENCH_REDUCED": "1"} if reduced else None)
     assert d["metric"].startswith("REHEARSAL") and d["n_gpus"] == world and d["scaling"] == "strong"
     assert "roofline" not in d or d["roofline"]["frac"] <= 1.0
     cfg = d["config"]
@@ -129,6 +133,9 @@ def test_bench_multi_gpu_branch_rehearsal_on_hip_kernels(world):
     col = cfg["collectives"]
     assert col["world_size"] == world and sorted(r["rank"] for r in col["ranks"]) == list(range(world))
     assert len({r["pid"] for r in col["ranks"]}) == world and col["distinct_devices"] == 1
+    assert cfg["fallback_stage"] == 1 and cfg["watchdog"]["stages"][0]["outcome"] == "completed"
+    if reduced:
+        return
     for key in ("strong_point_fp64_basis", "strong_point_shadow_matched_k", "weak_scaling_point"):
         rec = cfg[key]
         assert isinstance(rec, dict), (key, rec)
@@ -184,7 +191,7 @@ def test_bench_watchdog_on_the_rccl_branch_rehearsal(inject, stage, driver):
     if not os.path.exists(FAKE_RCCL):       # normally shipped in-tree by build(); else build it on the box
         subprocess.run(["make", "-C", os.path.dirname(FAKE_RCCL), "libfake_rccl.so"], capture_output=True, timeout=300)
     assert os.path.exists(FAKE_RCCL), "build() compiles tests/fake_rccl/libfake_rccl.so"
-    env = {"DSEA_RCCL_LIB": FAKE_RCCL, "DSEA_BENCH_STALL_S": "15", "DSEA_BENCH_STARTUP_S": "300"}
+    env = {"DSEA_RCCL_LIB": FAKE_RCCL, "DSEA_BENCH_STALL_S": "8", "DSEA_BENCH_STARTUP_S": "300"}
     if inject:
         env["DSEA_BENCH_INJECT_HANG"] = inject
     d = _bench(["--gpus", "2", "--host-staged", "--steps", "2", "--warmup", "1"], env=env)

@@ -160,7 +160,7 @@ def test_partitioned_csr_library_driver(world, kind, mode):
     print("world %d %s (%s, hb = %d): d(E0 + psi.t)/d vals max abs err / max = %.2e" % (world, kind, ret[0]["mode"], ret[0]["hb"], err))
 
 
-@pytest.mark.parametrize("world,kind", [(2, "banded"), (4, "banded"), (4, "scattered")])
+@pytest.mark.parametrize("world,kind", [(2, "banded"), (4, "scattered")])
 def test_partitioned_csr_rccl_branch_equals_callback_path(world, kind):
     """the library's RCCL branch (ncclGroupStart / Send / Recv / End for the halo and the all-gather, ncclAllReduce for the
     inner products) executing over the stand-in, against the callback communicator and the Python step driver"""

@@ -1,3 +1,4 @@
+"""us per CG iteration of the native TFIM solve at L = 20 (fixed iteration count): the figure docs/design/04-kernels.md quotes for the streaming form."""
 import os, sys, time
 sys.path.insert(0, "/root/repo")
 import torch

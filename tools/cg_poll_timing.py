@@ -1,3 +1,4 @@
+"""Host polling of the streaming CG: pipelined state copies against a drain per poll (profiles/r03_cg_pipelined_polling.txt)."""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch

@@ -1,5 +1,6 @@
+"""Functional probe of the explicit-matrix-as-parameter kernels (dsea_op_sddmm, dsea_op_update_vals) on a ragged matrix, both layouts."""
 import torch, numpy as np, scipy.sparse as sp, sys
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dominantsparseeigenad_amd.operators import CSROperator, TFIMOperator
 dev=torch.device('cuda:0')
 rng=np.random.RandomState(3)
