@@ -523,6 +523,10 @@ __device__ __forceinline__ double axpy_lp_tile(const double* __restrict__ Q, int
 #pragma unroll
     for (int e = 0; e < 8; ++e) w[s][e] = 0.0;
   if (use_lp) {
+    // Round 6, one bounded attempt at the 0.78 -> 0.83 the round-5 verdict asked for (profiles/r06_axpy_norm_lp_attempts.txt, same
+    // box, alternated): unroll 4 / 8 / 16 = 37.2 / 38.3 / 40.1 us -- the pass is not short of loads in flight; requesting the
+    // wave's rows of r (and its first four shadow rows) before the premise is waited for, as k_rdots does with its prologue:
+    // 37 -> 104 us in both variants (the compiler no longer pipelines the eight loads of a trip).  Left as it was.
 #ifndef DSEA_LP_UNROLL
 #define DSEA_LP_UNROLL 4
 #endif
