@@ -165,6 +165,10 @@ int dsea_op_set_tuning(dsea_op_t op, int key, int value) {
       if (op->d.kind != OP_SELL || (value != 0 && value != 1)) return DSEA_ERR_ARG;
       op->d.sell.xcd = value;
       return DSEA_OK;
+    case DSEA_TUNE_SELL_NT:
+      if (op->d.kind != OP_SELL || (value != 0 && value != 1)) return DSEA_ERR_ARG;
+      op->d.sell.nt = value;
+      return DSEA_OK;
     default: return DSEA_ERR_ARG;
   }
 }

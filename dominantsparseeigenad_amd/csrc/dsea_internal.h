@@ -55,6 +55,7 @@ struct SellParams {
   const int32_t* colbase;
   const uint16_t* col16;
   int xcd;   // 1: XCD-contiguous slice map (dsea_op_set_tuning DSEA_TUNE_SELL_XCD_MAP)
+  int nt;    // 1: non-temporal matrix loads (DSEA_TUNE_SELL_NT; 16-bit-column operands)
 };
 struct Stencil3Params {
   int64_t n;

@@ -1674,7 +1674,7 @@ __device__ __forceinline__ int64_t sell_slice_of(const SellParams& p, int64_t li
 }
 
 // sum_k vals[k] x[col k] of this lane's row of slice [b0, b1): even / odd slice columns accumulated separately, in order
-template <int MODE, int UN, bool C16>
+template <int MODE, int UN, bool C16, bool NT = false>
 __device__ __forceinline__ double sell_row_sum(const SellParams& p, const double* __restrict__ x, int64_t b0, int64_t b1,
                                                int lane) {
   double s0 = 0.0, s1 = 0.0;
@@ -1697,8 +1697,9 @@ __device__ __forceinline__ double sell_row_sum(const SellParams& p, const double
       v[u] = 0.0;
       c[u] = 0;
       if (e < b1) {
-        v[u] = p.vals[e];
-        c[u] = C16 ? __builtin_amdgcn_readlane(cbl, (k0 + u) & 63) + (int)p.col16[e] : p.colidx[e];
+        v[u] = NT ? __builtin_nontemporal_load(p.vals + e) : p.vals[e];
+        const int d16 = C16 ? (int)(NT ? __builtin_nontemporal_load(p.col16 + e) : p.col16[e]) : 0;
+        c[u] = C16 ? __builtin_amdgcn_readlane(cbl, (k0 + u) & 63) + d16 : p.colidx[e];
       }
     }
 #pragma unroll
@@ -1714,7 +1715,7 @@ __device__ __forceinline__ double sell_row_sum(const SellParams& p, const double
   return s0 + s1;
 }
 
-template <bool FUSED, int MODE, int UN, bool C16>
+template <bool FUSED, int MODE, int UN, bool C16, bool NT = false>
 __global__ __launch_bounds__(256) void k_spmv_sell(SellParams p, const double* __restrict__ x,
                                                    double* __restrict__ y, const double* __restrict__ shift,
                                                    const double* __restrict__ skip, double* __restrict__ P,
@@ -1746,13 +1747,13 @@ __global__ __launch_bounds__(256) void k_spmv_sell(SellParams p, const double* _
   // stream of the wave's first slice instead of in front of it; nothing has been written when a breakdown returns.
   int64_t sl = lin0 < ntrip ? sell_slice_of(p, lin0) : p.nslices;
   double v0 = 0.0;
-  if (sl < p.nslices) v0 = sell_row_sum<MODE, UN, C16>(p, x, p.slice_ptr[sl], p.slice_ptr[sl + 1], lane);
+  if (sl < p.nslices) v0 = sell_row_sum<MODE, UN, C16, NT>(p, x, p.slice_ptr[sl], p.slice_ptr[sl + 1], lane);
   if (FUSED && !fused_beta(fa, sm5, beta)) return;
   if (sl < p.nslices) finish(sl, v0);
   for (int64_t lin = lin0 + (int64_t)gridDim.x * 4; lin < ntrip; lin += (int64_t)gridDim.x * 4) {
     sl = sell_slice_of(p, lin);
     if (sl >= p.nslices) continue;
-    finish(sl, sell_row_sum<MODE, UN, C16>(p, x, p.slice_ptr[sl], p.slice_ptr[sl + 1], lane));
+    finish(sl, sell_row_sum<MODE, UN, C16, NT>(p, x, p.slice_ptr[sl], p.slice_ptr[sl + 1], lane));
   }
   if (P) {
     __syncthreads();
@@ -3040,7 +3041,8 @@ int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shif
       } else if (p.mode == 2) {
         if (c16) SELL_GO(false, 2, 8, true); else SELL_GO(false, 2, 4, false);
       } else if (c16) {
-        SELL_GO(false, 0, 8, true);
+        if (p.nt) KLAUNCH(ev, (k_spmv_sell<false, 0, 8, true, true>), (unsigned)nb, 256, st, p, x, y, shift, skip, P, fa0);
+        else SELL_GO(false, 0, 8, true);
       } else {
         switch (op.tune_sell_unroll) {
           case 1: KLAUNCH(ev, (k_spmv_sell_r5<false>), (unsigned)nb, 256, st, p, x, y, shift, skip, P, fa0); break;
@@ -3098,7 +3100,8 @@ int launch_tfim_fused(const OpDesc& op, const double* r, const double* nP, int n
     if (p.mode != 0) return -1;                         // slab of a row-partitioned matrix: the unfused sequence
 #define SELL_GO(U, C) KLAUNCH(ev, (k_spmv_sell<true, 0, U, C>), (unsigned)nb, 256, st, p, r, y, nullc, nullc, P, fa)
     if (p.col16) {
-      SELL_GO(8, true);
+      if (p.nt) KLAUNCH(ev, (k_spmv_sell<true, 0, 8, true, true>), (unsigned)nb, 256, st, p, r, y, nullc, nullc, P, fa);
+      else SELL_GO(8, true);
     } else {
       switch (op.tune_sell_unroll) {
         case 1: KLAUNCH(ev, (k_spmv_sell_r5<true>), (unsigned)nb, 256, st, p, r, y, nullc, nullc, P, fa); break;

@@ -10,6 +10,7 @@
 #   bench               default bench.py line                            benchq         bench without baseline / anchors / pmc
 #   stats               rocprofv3 --kernel-trace --stats of 3 headline steps -> kernel_stats.csv
 #   pmc                 FETCH_SIZE / WRITE_SIZE passes (separate) -> pmc_traffic.json via tools/pmc_traffic.py
+#   pmcsell             the same with --operator sell -> pmc_traffic_sell.json          statsop:OP   kernel stats with --operator OP
 #   libdriver:LL        bench --force-partitioned --L-local LL (library driver, one rank over RCCL) + its kernel stats
 #   ldprof[:LL]         native loop vs library driver at 2^LL rows (default 20), per-kernel averages per Lanczos step
 #   c3                  config 3 (stencil N = 1e5, k = 300): timings + kernel stats (tools/bench_c3.py)
@@ -67,6 +68,16 @@ for spec in "$@"; do
       F=$(find "$O/_pmc_FETCH_SIZE" -name "*counter_collection.csv" | head -1); W=$(find "$O/_pmc_WRITE_SIZE" -name "*counter_collection.csv" | head -1)
       DSEA_COMMIT=$(cat .commit 2>/dev/null) python tools/pmc_traffic.py "$F" "$W" 2 "$O/pmc_traffic.json" > "$O/pmc_traffic.log" 2>&1; tail -24 "$O/pmc_traffic.log"
       rm -rf "$O"/_pmc_* ;;
+    pmcsell)   # the same two passes with the operator as an explicit SELL matrix (raw FETCH_SIZE of k_spmv_sell: its 8 / 2-byte
+               # per-lane loads are not the 16-byte streaming reads the x2 correction was calibrated on -- read it both ways)
+      for c in FETCH_SIZE WRITE_SIZE; do
+        rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$O/_pmcs_$c" -o p -- python3 bench.py --operator sell --steps 1 --warmup 1 $Q --no-kernel-events > "$O/pmcsell_$c.log" 2>&1; echo "pmc $c rc=$?"
+      done
+      F=$(find "$O/_pmcs_FETCH_SIZE" -name "*counter_collection.csv" | head -1); W=$(find "$O/_pmcs_WRITE_SIZE" -name "*counter_collection.csv" | head -1)
+      DSEA_COMMIT=$(cat .commit 2>/dev/null) python tools/pmc_traffic.py "$F" "$W" 2 "$O/pmc_traffic_sell.json" > "$O/pmc_traffic_sell.log" 2>&1; tail -24 "$O/pmc_traffic_sell.log"
+      rm -rf "$O"/_pmcs_* ;;
+    statsop)   # statsop:<operator>: rocprofv3 kernel stats of 3 headline steps with --operator <operator>
+      stats_of kernel_stats_$a1 --operator $a1 --steps 3 --warmup 1 $Q ;;
     libdriver)
       LL=${a1:-20}
       python bench.py --force-partitioned --L-local $LL --no-cpu-baseline --no-extras > "$O/libdriver_2p$LL.json" 2> "$O/libdriver_2p$LL.err"; echo "rc=$?"; line "$O/libdriver_2p$LL.json" 500
