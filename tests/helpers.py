@@ -129,6 +129,13 @@ def spawn_collect(fn, args, nprocs):
     writer) and a crashed worker raises here instead of leaving the parent waiting."""
     import multiprocessing
     import torch.multiprocessing as mp
+    if os.environ.get("DSEA_TEST_RESULT_CHANNEL", "") == "manager":
+        # EXPERIMENT ONLY (docs/design/12-round6.md: is this what stalled two round-5 runs?): the round-4 way -- a
+        # multiprocessing.Manager() per multi-rank case, which FORKS the pytest process (it holds an initialised HIP runtime)
+        mgr = mp.Manager()
+        ret = mgr.dict()
+        mp.spawn(fn, args=tuple(args) + (ret,), nprocs=nprocs, join=True)
+        return dict(ret)
     # Workers come from a FORK SERVER that has imported torch / numpy / scipy and nothing else: a fresh process per worker as
     # with "spawn" (no state shared between cases, HIP is initialised by the worker itself -- the server never touches the
     # GPU), minus the ~1 s of imports per worker (measured on the GPU box, tools/probes/spawn_cost.py: 4 ranks 1.7-2.4 s ->
