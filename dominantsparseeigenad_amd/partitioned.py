@@ -1471,10 +1471,19 @@ class PartitionedCSROperator(PartitionedOperator):
     def _masked(self, v):
         return v if self._mask is None else v * self._mask
 
+    def _sync_vals(self):
+        """an optimiser may have stepped this rank's ``vals`` in place since the last solve: the slab operator's SELL copy
+        follows (CSROperator tracks the tensor's version counter; the CPU test double reads the tensor itself)"""
+        cur = getattr(self._local, "_current", None)
+        if cur is not None:
+            cur()
+
     def lanczos(self, k, q0_slab, arena=False):
+        self._sync_vals()
         return super().lanczos(k, self._masked(q0_slab.detach().to(F64)), arena=arena)
 
     def solve_shifted(self, E0, b, x0, eps=1e-7, maxiter=None):
+        self._sync_vals()
         if self._mask is not None:
             x0.mul_(self._mask)
             b = b * self._mask
@@ -1511,6 +1520,7 @@ class PartitionedCSROperator(PartitionedOperator):
         self.apply_shift_dot(x, y, None, None, None)
 
     def H(self, v):
+        self._sync_vals()
         return _PartApply.apply(v, self, "H")
 
     __call__ = H

@@ -205,3 +205,41 @@ def test_optimiser_loop_update_then_solve_equals_rebuild_then_solve():
         E_new, psi_new = symeig.DominantSparseSymeig.apply(fresh.vals, k, n)
     assert E_upd.item() == E_new.item()
     assert torch.equal(psi_upd, psi_new)
+
+
+def test_sell_kernel_beyond_one_trip_and_beyond_64_slice_columns():
+    """two geometry edges of k_spmv_sell that the headline size (exactly 4096 blocks, 21 slice columns) does not reach:
+    (a) more than 4096 blocks' worth of slices -- blocks walk several chunks, with the XCD-contiguous map on and off;
+    (b) a slice wider than 64 columns -- the lane-held column bases of the 16-bit layout are reloaded per 64 columns."""
+    import scipy.sparse as sp
+    from dominantsparseeigenad_amd import _lib
+    rng = np.random.RandomState(17)
+    n = (1 << 20) + (1 << 18) + 37                       # 20481 slices -> 5121 chunks of four > 4096 blocks
+    offs = [-700, -3, -1, 0, 1, 3, 700]
+    M = sp.diags([rng.randn(n - abs(o)) for o in offs], offs, shape=(n, n), format="csr")
+    M.sort_indices()
+    x = torch.from_numpy(normal_vector(n, 7800)).to(dev())
+    ref = torch.from_numpy(M @ x.cpu().numpy())
+    for col16 in ("auto", False):
+        op = CSROperator.from_scipy(M, dev(), col16=col16)
+        for xcd in (1, 0):
+            _lib.check(_lib.load().dsea_op_set_tuning(op._H.handle, _lib.TUNE_SELL_XCD_MAP, xcd), "dsea_op_set_tuning")
+            assert rel(op(x).cpu(), ref) < 1e-13, (col16, xcd)
+    # (b) 300 rows, rows 70 and 130 hold 150 / 200 non-zeros: their slices are 150 / 200 columns wide
+    n2 = 300
+    D = sp.lil_matrix((n2, n2))
+    D.setdiag(1.0 + rng.rand(n2))
+    for r, cnt in ((70, 150), (130, 200)):
+        cols = rng.choice(n2, size=cnt, replace=False)
+        D[r, cols] = rng.randn(cnt)
+    D = sp.csr_matrix(D)
+    D.sort_indices()
+    x2 = torch.from_numpy(normal_vector(n2, 7801)).to(dev())
+    ref2 = torch.from_numpy(D @ x2.cpu().numpy())
+    for col16 in ("auto", False):
+        op2 = CSROperator.from_scipy(D, dev(), col16=col16)
+        assert op2.col16 == (col16 == "auto")
+        assert rel(op2(x2).cpu(), ref2) < 1e-13, col16
+        rows = torch.from_numpy(_rows_of(D))
+        v1 = torch.from_numpy(normal_vector(n2, 7802))
+        assert torch.equal(op2.sddmm(v1.to(dev()), x2).cpu(), v1[rows] * x2.cpu()[torch.from_numpy(D.indices.astype("int64"))])

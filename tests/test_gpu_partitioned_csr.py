@@ -86,8 +86,12 @@ def _case(rank, world, dev, kind, mode, python_driver):
         E0, psi = symeig.DominantSparseSymeig.apply(vals, k, op.dim, dev)
         loss = E0 + op.dot(psi, t)
         (gv,) = torch.autograd.grad(loss, vals)
+    with torch.no_grad():
+        vals.mul_(1.5)                                   # what an optimiser step does: in place, seen through the version counter
+    y_upd = op.H(x.clone())
     torch.cuda.synchronize()
     return dict(mode=op.mode, hb=op.hb, driver=op.driver, E=E0.item(), loss=loss.item(), y=y.cpu().numpy()[:real].copy(),
+                y_upd=y_upd.cpu().numpy()[:real].copy(),
                 psi=psi.detach().cpu().numpy()[:real].copy(), pad=float(psi.detach()[real:].abs().sum()),
                 grad=gv.cpu().numpy().copy(), g_plain=g_plain.cpu().numpy().copy(), g_sym=g_sym.cpu().numpy().copy())
 
@@ -123,17 +127,19 @@ def _one_gpu(kind):
     op = CSROperator.from_scipy(M, dev)
     x = torch.from_numpy(normal_vector(n, 8300)).to(dev)
     v1 = torch.from_numpy(normal_vector(n, 8301)).to(dev)
-    return M, op(x).cpu().numpy(), op.sddmm(v1, x).cpu().numpy(), op.sddmm(v1, x, symmetric=True).cpu().numpy()
+    upd = CSROperator.from_scipy(M * 1.5, dev)
+    return M, op(x).cpu().numpy(), op.sddmm(v1, x).cpu().numpy(), op.sddmm(v1, x, symmetric=True).cpu().numpy(), upd(x).cpu().numpy()
 
 
 def _check(ret, kind, world):
     from helpers import eigh_reference
-    M, y1, gp1, gs1 = _one_gpu(kind)
+    M, y1, gp1, gs1, y_upd1 = _one_gpu(kind)
     n = M.shape[0]
     expect = "halo" if (kind == "banded" or world <= 2) else "gather"
     assert all(r["mode"] == expect for r in ret), [r["mode"] for r in ret]
     y = np.concatenate([r["y"] for r in ret])
     assert np.array_equal(y, y1)                                     # slab mat-vec == one-GPU operator, bit for bit
+    assert np.array_equal(np.concatenate([r["y_upd"] for r in ret]), y_upd1)   # ... also after an in-place step of the non-zeros
     assert np.array_equal(np.concatenate([r["g_plain"] for r in ret]), gp1)
     gs = np.concatenate([r["g_sym"] for r in ret])
     assert np.max(np.abs(gs - gs1)) <= 4e-16 * np.max(np.abs(gs1))   # (two one-sided launches vs one: last-bit rounding)
@@ -175,7 +181,7 @@ def test_partitioned_csr_rccl_branch_equals_callback_path(world, kind):
     for r in range(world):
         for key in ("E", "loss"):
             assert rccl[r][key] == cb[r][key], key
-        for key in ("y", "psi", "grad", "g_plain", "g_sym"):
+        for key in ("y", "y_upd", "psi", "grad", "g_plain", "g_sym"):
             assert np.array_equal(rccl[r][key], cb[r][key]), key
     py = _run(world, kind, "callbacks", True)
     assert all(r["driver"] == "python" for r in py)

@@ -123,5 +123,27 @@ for case in range(args.cases):
                    "CG iterate dev %.3e" % float((xd.cpu() - xo).abs().max()))
         except Exception as exc:  # noqa: BLE001
             report(tag, False, "CG raised %s: %s" % (type(exc).__name__, str(exc)[:200]))
+    # round 6: the explicit matrix as a parameter -- the SDDMM hook (plain, symmetric, accumulating) and the in-place refresh
+    # against torch index arithmetic, bit for bit, on the same ragged patterns (16-bit and 32-bit columns, both layouts)
+    if kind in ("csr", "csr-plain") and op.nnz > 0:
+        try:
+            rows = torch.repeat_interleave(torch.arange(n), (op.rowptr[1:] - op.rowptr[:-1]).cpu())
+            cols = op.colidx.cpu().long()
+            v1, v2 = torch.from_numpy(rng.randn(n)), torch.from_numpy(rng.randn(n))
+            plain = v1[rows] * v2[cols]
+            report(tag + " sddmm", torch.equal(op.sddmm(v1.to(dev), v2.to(dev)).cpu(), plain), "plain")
+            symm = 0.5 * (v1[rows] * v2[cols] + v1[cols] * v2[rows])
+            report(tag + " sddmm", torch.equal(op.sddmm(v1.to(dev), v2.to(dev), symmetric=True).cpu(), symm), "symmetric")
+            acc0 = torch.from_numpy(rng.randn(op.nnz))
+            out = acc0.clone().to(dev)
+            op.sddmm(v1.to(dev), v2.to(dev), out=out, alpha=0.375, accumulate=True)
+            report(tag + " sddmm", torch.equal(out.cpu(), acc0 + 0.375 * plain), "accumulate")
+            newv = torch.from_numpy(rng.randn(op.nnz)).to(dev)
+            op.vals.copy_(newv)
+            fresh = CSROperator(op.rowptr, op.colidx, newv.clone(), n, layout=op.layout, col16=("auto" if op.col16 else False))
+            x = torch.from_numpy(rng.randn(n)).to(dev)
+            report(tag + " update_vals", torch.equal(op(x), fresh(x)), "in-place refresh differs from a rebuild")
+        except Exception as exc:  # noqa: BLE001
+            report(tag, False, "parameter kernels raised %s: %s" % (type(exc).__name__, str(exc)[:200]))
 engine.USE_SHADOW = True
 print("cases %d  mismatches %d  %.1f s" % (args.cases, bad, time.time() - t0))
