@@ -332,7 +332,11 @@ class _ReferenceStyleTFIM:
 
 def _kernel_time_of(fn):
     """(wall ms, sum of kernel durations ms) of fn() from torch's profiler (kineto over roctracer), or (wall, None)"""
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or \
+        "rocprof" in os.environ.get("LD_PRELOAD", "")
     try:
+        if under_profiler:       # the whole bench is being traced by rocprofv3: no second tracer inside it
+            raise RuntimeError("external profiler attached")
         from torch.profiler import profile, ProfilerActivity
         torch.cuda.synchronize()
         with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:

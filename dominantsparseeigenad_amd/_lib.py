@@ -98,6 +98,8 @@ _SIGNATURES = {
     "dsea_cg_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "dsea_cg_check": (c_int, [c_void_p, c_void_p, c_double, c_void_p]),
     "dsea_cg_direction": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "dsea_cg_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int64, c_int64,
+                             c_void_p]),
     "dsea_lanczos_form_r": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p]),
     "dsea_hypercube_flipsum": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p]),

@@ -806,6 +806,23 @@ int dsea_cg_direction(dsea_ws_t ws, const double* r, double* d, const double* st
   return check_launch();
 }
 
+int dsea_cg_step(dsea_ws_t ws, double* x, double* r, double* d, double* Ad, const double* shift, double* state, double eps,
+                 int64_t iteration, int64_t n, void* stream) {
+  REQUIRE(ws && x && r && d && Ad && state && n >= 1 && iteration >= 0, DSEA_ERR_ARG);
+  REQUIRE(aligned16(x) && aligned16(r) && aligned16(d) && aligned16(Ad), DSEA_ERR_ALIGN);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Workspace& w = ws->w;
+  double* dP = w.aux;
+  double* rP = w.aux + DSEA_MAX_WAVE_TILES;
+  const int parity = (int)(iteration & 1);
+  // the three launches dsea_cg_run issues per iteration of its streaming form, with the mat-vec replaced by the caller's A d
+  const int nd = launch_shift_dot_partials(d, Ad, shift, state + DSEA_CG_DONE, n, dP, st);            // (A - shift) d, d.A'd partials
+  const int nr = launch_cg_update_fused(x, r, d, Ad, state, parity, dP, nd, n, rP, st);               // CG.py:31,33-34
+  launch_cg_direction_fused(r, d, state, parity, rP, nr, eps, n, st);                                 // CG.py:35-39
+  return check_launch();
+}
+
+
 // ---------------------------------------------------------------------------- row-partitioned macro phases
 int dsea_axpy_multi_dot(dsea_ws_t ws, double a_host, const double* a_dev, const double* const* xs, int count,
                         const double* shift, const double* skip_flag, const double* x, double* y, int64_t n,
@@ -981,7 +998,7 @@ int dsea_lanczos_run(dsea_op_t op, dsea_ws_t ws, int k, const double* q0, double
     if (pr == 0) return check_launch();
   }
   const int rps = lp_rows_per_step(n, g.split_w != 0);   // 0 = split form
-  const bool has_fused_tail = (op->d.kind == OP_TFIM && op->d.tfim.L_local >= 1) || op->d.kind == OP_SELL ||
+  const bool has_fused_tail = (op->d.kind == OP_TFIM && op->d.tfim.L_local >= 1) || (op->d.kind == OP_SELL && op->d.sell.mode == 0) ||
                               op->d.kind == OP_STENCIL3;
   // (operators without a fused tail: full re-orthogonalisation only -- refused BEFORE anything is enqueued; the partial
   //  option reaches them through dsea_lanczos_partial_step)
@@ -1095,7 +1112,7 @@ int dsea_lanczos_run_basisfree(dsea_op_t op, dsea_ws_t ws, int k, const double* 
   const int64_t n = op->d.n;
   REQUIRE(ldq >= n && ws->w.n >= n, DSEA_ERR_ARG);
   REQUIRE(aligned16(q0) && aligned16(Qrot) && (!psi || aligned16(psi)) && (ldq % 2 == 0), DSEA_ERR_ALIGN);
-  const bool has_fused_tail = (op->d.kind == OP_TFIM && op->d.tfim.L_local >= 1) || op->d.kind == OP_SELL ||
+  const bool has_fused_tail = (op->d.kind == OP_TFIM && op->d.tfim.L_local >= 1) || (op->d.kind == OP_SELL && op->d.sell.mode == 0) ||
                               op->d.kind == OP_STENCIL3;
   REQUIRE(has_fused_tail, DSEA_ERR_UNSUPPORTED);
   hipStream_t st = static_cast<hipStream_t>(stream);

@@ -199,6 +199,8 @@ int rdots_partial_count(const TileGeom& g, int i);
 void launch_probe(const double* x, double* y, int64_t n, double* P, int nP, hipStream_t st);   // y != null: copy
 void launch_shift_dot(const double* x, double* y, const double* shift, const double* skip, int64_t n,
                       double* P, double* out, hipStream_t st);
+int launch_shift_dot_partials(const double* x, double* y, const double* shift, const double* skip, int64_t n, double* P,
+                              hipStream_t st);
 void launch_axpy(double a_host, const double* a_dev, const double* x, double* y, int64_t n, hipStream_t st);
 void launch_scale_store(const double* r, const double* nrm2, double* q, double* beta_out, int64_t n,
                         hipStream_t st, uint16_t* qs = nullptr, double* brk = nullptr, int step = 0);

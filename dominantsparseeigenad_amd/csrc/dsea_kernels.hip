@@ -1748,6 +1748,7 @@ __global__ __launch_bounds__(256) void k_spmv_sell(SellParams p, const double* _
   int64_t sl = lin0 < ntrip ? sell_slice_of(p, lin0) : p.nslices;
   double v0 = 0.0;
   if (sl < p.nslices) v0 = sell_row_sum<MODE, UN, C16, NT>(p, x, p.slice_ptr[sl], p.slice_ptr[sl + 1], lane);
+  // (measured and dropped, round 6: every WAVE summing the partials itself -- no block barrier in the middle -- 52 -> 59 us)
   if (FUSED && !fused_beta(fa, sm5, beta)) return;
   if (sl < p.nslices) finish(sl, v0);
   for (int64_t lin = lin0 + (int64_t)gridDim.x * 4; lin < ntrip; lin += (int64_t)gridDim.x * 4) {
@@ -2922,6 +2923,14 @@ void launch_shift_dot(const double* x, double* y, const double* shift, const dou
   const int nb = ew_blocks(n);
   hipLaunchKernelGGL(k_shift_dot, dim3(nb), dim3(256), 0, st, x, y, shift, skip, n, P);
   hipLaunchKernelGGL(k_cg_finalize_slot, dim3(1), dim3(256), 0, st, (const double*)P, nb, out, skip);
+}
+
+// y -= shift x with the x.y partials LEFT UNSUMMED (the consumer folds the second stage into its prologue); returns their count
+int launch_shift_dot_partials(const double* x, double* y, const double* shift, const double* skip, int64_t n, double* P,
+                              hipStream_t st) {
+  const int nb = ew_blocks(n);
+  hipLaunchKernelGGL(k_shift_dot, dim3(nb), dim3(256), 0, st, x, y, shift, skip, n, P);
+  return nb;
 }
 
 void launch_axpy(double a_host, const double* a_dev, const double* x, double* y, int64_t n,

@@ -702,6 +702,11 @@ CG_MERGED_REDUCTIONS = False
 CG_TFIM_REFERENCE_RECURRENCES = _os.environ.get("DSEA_CG_REFERENCE_RECURRENCES", "") == "1"
 
 
+# CG around an opaque callable (the reference's own calling convention): one library call per iteration (dsea_cg_step: the three
+# fused launches of the native streaming form) instead of the four phase calls.  False = the phase calls (A/B, tests).
+CALLABLE_CG_FUSED_STEP = _os.environ.get("DSEA_CALLABLE_CG_FUSED", "1") != "0"
+
+
 def cg(b, x0, *, native=None, callable_A=None, shift=None, eps=1e-7, maxiter=None, poll_every=8,
        merged_reductions=None):
     """Conjugate gradients on the GPU (reference CG.py:24-41) for (A - shift I) x = b.
@@ -777,10 +782,16 @@ def cg(b, x0, *, native=None, callable_A=None, shift=None, eps=1e-7, maxiter=Non
         polls = 1
         while host[_lib.CG_DONE].item() == 0.0 and issued < cap:
             chunk = min(int(poll_every), cap - issued)
-            for _ in range(chunk):
+            for it in range(chunk):
                 Ad = as_vector(callable_A(d), n)
-                if Ad.data_ptr() == d.data_ptr():
+                if Ad.data_ptr() == d.data_ptr() or not Ad.is_contiguous():
                     Ad = Ad.clone()
+                if CALLABLE_CG_FUSED_STEP:
+                    # one call = the three fused launches of dsea_cg_run's streaming iteration (bit-identical to the native
+                    # operand's streaming form) instead of four phase calls and six launches
+                    check(lib.dsea_cg_step(ws.handle, _ptr(x), _ptr(r), _ptr(d), _ptr(Ad), _ptr(shift_t), _ptr(state),
+                                           float(eps), issued + it, n, st), "dsea_cg_step")
+                    continue
                 check(lib.dsea_shift_dot(ws.handle, _ptr(d), _ptr(Ad), _ptr(shift_t), dad_ptr, done_ptr, n, st),
                       "dsea_shift_dot")
                 check(lib.dsea_cg_update(ws.handle, _ptr(x), _ptr(r), _ptr(d), _ptr(Ad), _ptr(state), n, st),

@@ -301,10 +301,11 @@ class CSROperator:
         data = vals.detach()
         if data.dtype != F64 or not data.is_contiguous():
             data = data.to(F64).contiguous()
-            self.vals = data          # a converted copy: not the caller's storage (no parameter semantics)
+            self._vals = data         # a converted copy: not the caller's storage (no parameter semantics)
         else:
-            self.vals = vals          # the caller's tensor: its in-place updates are seen by refresh()
+            self._vals = vals         # the caller's tensor: its in-place updates are seen by refresh()
         self._vals_data = data
+        self._seen_version = None
         self.nnz = int(data.numel())
         self.device = data.device
         self.layout = layout
@@ -342,13 +343,26 @@ class CSROperator:
         self._seen_version = None
         self.refresh()
 
+    # -- the parameter tensor (reference: ``model.g`` / ``model.potential``): in-place updates are followed through its version
+    #    counter; binding ANOTHER tensor of the same shape (``op.vals = new``) marks the device copy stale as well
+    @property
+    def vals(self):
+        return self._vals
+
+    @vals.setter
+    def vals(self, value):
+        if value.numel() != self.nnz or value.device != self.device or value.dtype != F64 or not value.is_contiguous():
+            raise ValueError("vals must be a contiguous float64 tensor of %d elements on %s" % (self.nnz, self.device))
+        self._vals = value
+        self._seen_version = None
+
     # -- structure shared, values replaced (the mat-vec M(G) x of the hooks' backward)
     def with_vals(self, vals):
         """an operator on the SAME pattern with other values (shares the SELL structure; one value array is allocated)"""
         twin = object.__new__(CSROperator)
-        twin.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("_H", "_sell", "vals", "_vals_data", "_T")})
+        twin.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("_H", "_sell", "_vals", "_vals_data", "_T")})
         data = vals.detach().to(F64).contiguous()
-        twin.vals, twin._vals_data, twin._T = data, data, None
+        twin._vals, twin._vals_data, twin._T = data, data, None
         raw = c_void_p()
         lib = _lib.load()
         if self.layout == "sell":
@@ -385,7 +399,8 @@ class CSROperator:
         self._seen_version = self.vals._version
 
     def _current(self):
-        if self.vals._version != self._seen_version and self.layout == "sell":
+        # (plain CSR layout: the kernel reads the registered tensor itself, so only a re-bound ``vals`` needs the copy)
+        if self._seen_version is None or (self.layout == "sell" and self._vals._version != self._seen_version):
             self.refresh()
         return self._H
 

@@ -343,6 +343,15 @@ int dsea_cg_check(dsea_ws_t ws, double *state, double eps, void *stream);
 int dsea_cg_direction(dsea_ws_t ws, const double *r, double *d, const double *state, int64_t n,
                       void *stream);
 
+/* ONE iteration of CG around a CALLER-SUPPLIED mat-vec (reference CG.py:31-40 with Amap = the user's Python function, the
+ * reference's own calling convention): on entry Ad = A d.  Ad -= (*shift) d (shift nullable); alpha = rr / d.Ad;
+ * x += alpha d; r -= alpha Ad; the stopping test on ||r||; beta; d = r + beta d -- the three fused launches dsea_cg_run issues
+ * per iteration of its streaming form (same kernels, same partial-sum order: bit-identical iterates), in one call instead of
+ * dsea_shift_dot + dsea_cg_update + dsea_cg_check + dsea_cg_direction.  `iteration` = 0, 1, 2, ... since dsea_cg_init /
+ * dsea_cg_init_check (it selects which of the two rr slots of `state` is current).  No-op on the device once DONE is set. */
+int dsea_cg_step(dsea_ws_t ws, double *x, double *r, double *d, double *Ad, const double *shift, double *state, double eps,
+                 int64_t iteration, int64_t n, void *stream);
+
 /* ------------------------------------------------------------------ row-partitioned macro phases
  * One Lanczos step of the row-partitioned mode (no reference counterpart) is
  *     dsea_plz_dots            -> caller all-reduces c[0..i]   (i coefficients + ||r||^2)

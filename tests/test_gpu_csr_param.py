@@ -71,6 +71,12 @@ def test_sddmm_and_update_kernels_bitwise(layout, col16):
     M2 = M.copy()
     M2.data = newv.cpu().numpy()
     assert rel(op(x).cpu(), torch.from_numpy(M2 @ x.cpu().numpy())) < 1e-13
+    # binding ANOTHER tensor (``op.vals = new``: what a model that recomputes its matrix entries every step does)
+    third = torch.from_numpy(normal_vector(M.nnz, 7006)).to(dev())
+    op.vals = third
+    assert torch.equal(op(x), CSROperator(op.rowptr, op.colidx, third.clone(), n, layout=layout, col16=col16)(x))
+    with pytest.raises(ValueError):
+        op.vals = third[:-1]
 
 
 def test_sell16_falls_back_when_a_slice_column_is_too_wide():

@@ -184,3 +184,33 @@ def test_reorth_pair_split_form(n, i, waves):
         assert float((out - Qn.T @ cc).abs().max()) <= 1e-12 * float((Qn.T @ cc).abs().max() + 1e-300)
     finally:
         ws.set_split(-1)
+
+
+@pytest.mark.parametrize("n", [1, 65, 1000, 4097, 100000])
+def test_cg_step_around_a_callable_equals_the_phase_calls_and_the_native_streaming_form(monkeypatch, n):
+    """dsea_cg_step (one call per iteration around the CALLER'S mat-vec: reference CG.py:31-40 with Amap a Python function)
+    against the four phase calls it replaces and against dsea_cg_run's streaming form on the same operator given natively (the
+    same update / direction kernels; the d.Ad partials come from different kernels): same iteration count, iterates to 1e-13."""
+    import scipy.sparse as sp
+    from dominantsparseeigenad_amd.operators import CSROperator
+    rng = np.random.RandomState(n)
+    M = sp.diags([rng.rand(n) + 3.0] + ([rng.randn(n - 1) * 0.3] * 2 if n > 1 else []), [0, 1, -1][:(3 if n > 1 else 1)], format="csr")
+    op = CSROperator.from_scipy(M, dev(), layout="csr")
+    b, x0 = vec(n, 9100), vec(n, 9101)
+    shift = torch.tensor([-0.25], dtype=F64, device=dev())
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(engine, "CALLABLE_CG_FUSED_STEP", fused)
+        outs[fused] = (engine.cg(b, x0, callable_A=lambda v: op(v), shift=shift, eps=1e-11, maxiter=60).clone(), engine.last_cg.iters,
+                       engine.last_cg.resnorm)
+    assert outs[True][1] == outs[False][1]
+    scale = float(outs[False][0].abs().max())
+    assert float((outs[True][0] - outs[False][0]).abs().max()) <= 1e-13 * scale
+    ws = Workspace.get(n, 8, dev())
+    ws.set_persist(0)                                   # the native operand's STREAMING form
+    try:
+        xn = engine.cg(b, x0, native=op, shift=shift, eps=1e-11, maxiter=60)
+    finally:
+        ws.set_persist(-1)
+    assert engine.last_cg.iters == outs[True][1]
+    assert float((xn - outs[True][0]).abs().max()) <= 1e-13 * scale

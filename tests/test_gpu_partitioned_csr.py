@@ -58,7 +58,7 @@ def _comm_for(dev, mode):
     return comm
 
 
-def _case(rank, world, dev, kind, mode, python_driver):
+def _case(rank, world, dev, kind, mode, python_driver, force=True):
     from helpers import PatchRandn
     import dominantsparseeigenad_amd.symeig as symeig
     import dominantsparseeigenad_amd.CG as CG
@@ -73,7 +73,7 @@ def _case(rank, world, dev, kind, mode, python_driver):
     vals = torch.from_numpy(sub.data.copy()).to(dev).requires_grad_(True)
     op = PartitionedCSROperator(torch.from_numpy(sub.indptr.astype("int64")).to(dev), torch.from_numpy(sub.indices.astype("int64")).to(dev),
                                 vals, n, dev, comm=_comm_for(dev, mode))
-    op.force_driver = True
+    op.force_driver = bool(force)
     pad = nloc * world - n
     x = op.slab(torch.cat([torch.from_numpy(normal_vector(n, 8300)), torch.zeros(pad, dtype=torch.float64)])).to(dev)
     v1 = op.slab(torch.cat([torch.from_numpy(normal_vector(n, 8301)), torch.zeros(pad, dtype=torch.float64)])).to(dev)
@@ -111,10 +111,10 @@ def _worker(rank, world, port, backend, args, ret):
         dist.destroy_process_group()
 
 
-def _run(world, kind, mode, python_driver=False):
+def _run(world, kind, mode, python_driver=False, force=True):
     from helpers import spawn_collect
     backend = "nccl" if mode == "nccl" else "gloo"
-    ret = spawn_collect(_worker, (world, _free_port(), backend, (kind, mode, python_driver)), world)
+    ret = spawn_collect(_worker, (world, _free_port(), backend, (kind, mode, python_driver, force)), world)
     assert len(ret) == world
     return [ret[r] for r in range(world)]
 
@@ -164,6 +164,13 @@ def test_partitioned_csr_library_driver(world, kind, mode):
     assert all("library" in r["driver"] for r in ret), ret[0]["driver"]
     err = _check(ret, kind, world)
     print("world %d %s (%s, hb = %d): d(E0 + psi.t)/d vals max abs err / max = %.2e" % (world, kind, ret[0]["mode"], ret[0]["hb"], err))
+
+
+def test_partitioned_csr_world1_takes_the_one_gpu_loops():
+    """world size 1 without ``force_driver``: the slab IS the matrix, so the in-library single-GPU loops run on the slab
+    operator (a SELL operand in slab mode has no fused Lanczos tail: dsea_lanczos_run takes its unfused sequence)"""
+    ret = _run(1, "banded", "nccl", False, False)
+    _check(ret, "banded", 1)
 
 
 @pytest.mark.parametrize("world,kind", [(2, "banded"), (4, "scattered")])

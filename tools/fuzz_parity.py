@@ -17,6 +17,7 @@ args = ap.parse_args()
 dev = torch.device("cuda:0"); F64 = torch.float64
 rng = np.random.RandomState(args.seed)
 bad = 0
+ill_posed = 0
 
 
 def report(tag, ok, msg):
@@ -86,8 +87,40 @@ for case in range(args.cases):
         # step and takes the pair from the leading block.  Such cases are held to the TRUE extreme eigenvalues below.
         broke = engine.last_break > 0 or getattr(engine, "last_truncated", 0) > 0
         if k <= n and torch.isfinite(rvlo).all() and not broke:
-            report(tag, abs(float(lo) - float(rlo)) <= 1e-9 * scale and abs(float(hi) - float(rhi)) <= 1e-9 * scale,
-                   "ritz values %.15g %.15g vs %.15g %.15g" % (float(lo), float(hi), float(rlo), float(rhi)))
+            okr = abs(float(lo) - float(rlo)) <= 1e-9 * scale and abs(float(hi) - float(rhi)) <= 1e-9 * scale
+            if not okr and kind != "dense":
+                # is the CASE ill-posed at this tolerance?  The oracle against itself with q0 perturbed in the last bit: an
+                # unconverged extreme Ritz value of a matrix with empty rows (exact zero eigenvalues) can move by 1e-8 on that
+                # (round 6, seed 1: oracle 2.99920648929 / perturbed 2.99920647965 / three device kernels within the same spread)
+                q0b = q0 * (1.0 + 1e-15 * torch.from_numpy(np.random.RandomState(case).randn(n)))
+                drp = iter([q0b.clone(), torch.zeros(n, dtype=F64)])
+                pl, _, ph, _ = oracle.symeig_lanczos(refmap, kk, "both", sparse=True, dim=n, draw=lambda m, dt: next(drp))
+                spread = max(abs(float(pl) - float(rlo)), abs(float(ph) - float(rhi)))
+                if spread > 0.3e-9 * scale:
+                    ill_posed += 1
+                    print("   ill-posed at 1e-9 (%s): the oracle moves by %.1e relative when q0 is perturbed by 1e-15; device %.15g %.15g, "
+                          "oracle %.15g %.15g" % (tag, spread / scale, float(lo), float(hi), float(rlo), float(rhi)), flush=True)
+                    okr = max(abs(float(lo) - float(rlo)), abs(float(hi) - float(rhi))) <= 30.0 * spread
+            report(tag, okr, "ritz values %.15g %.15g vs %.15g %.15g" % (float(lo), float(hi), float(rlo), float(rhi)))
+            if not okr and kind in ("csr", "csr-plain") and os.environ.get("DSEA_FUZZ_DIAG"):
+                # which ingredient moves the value: the operand's layout / kernel variant, the shadow, or the oracle's own sensitivity
+                from dominantsparseeigenad_amd import _lib as _l
+                Mfull = torch.stack([apply_ref(e) for e in torch.eye(n, dtype=F64)], 1)
+                w = torch.linalg.eigvalsh(0.5 * (Mfull + Mfull.T))
+                print("   true extremes %.15g %.15g" % (float(w[0]), float(w[-1])))
+                for lay, c16, unroll, xcd, sh in (("sell", "auto", 0, 1, True), ("sell", "auto", 0, 1, False), ("sell", False, 0, 1, False),
+                                                  ("sell", False, 1, 0, False), ("csr", False, 0, 0, False)):
+                    o2 = CSROperator(op.rowptr, op.colidx, op.vals.clone(), n, layout=lay, col16=c16)
+                    if lay == "sell":
+                        _l.load().dsea_op_set_tuning(o2._H.handle, 3, unroll)
+                        _l.load().dsea_op_set_tuning(o2._H.handle, 4, xcd)
+                    engine.USE_SHADOW = sh
+                    l2, _, h2, _ = symeigLanczos(o2, k, dev, extreme="both", sparse=True, dim=n, q0=q0.to(dev))
+                    print("   %s col16=%s unroll=%d xcd=%d shadow=%s: %.15g %.15g" % (lay, c16, unroll, xcd, sh, float(l2), float(h2)))
+                q0b = q0 * (1.0 + 1e-15 * torch.from_numpy(rng.randn(n)))
+                dr = iter([q0b.clone(), torch.zeros(n, dtype=F64)])
+                pl, _, ph, _ = oracle.symeig_lanczos(refmap, kk, "both", sparse=True, dim=n, draw=lambda m, dt: next(dr))
+                print("   oracle with q0 perturbed by 1e-15 relative: %.15g %.15g" % (float(pl), float(ph)))
         elif k <= n and broke and n <= 400:
             Mfull = torch.stack([apply_ref(e) for e in torch.eye(n, dtype=F64)], 1)
             w = torch.linalg.eigvalsh(0.5 * (Mfull + Mfull.T))
@@ -146,4 +179,5 @@ for case in range(args.cases):
         except Exception as exc:  # noqa: BLE001
             report(tag, False, "parameter kernels raised %s: %s" % (type(exc).__name__, str(exc)[:200]))
 engine.USE_SHADOW = True
-print("cases %d  mismatches %d  %.1f s" % (args.cases, bad, time.time() - t0))
+print("cases %d  mismatches %d  ill-posed at the tolerance (oracle moves under a last-bit change of q0) %d  %.1f s"
+      % (args.cases, bad, ill_posed, time.time() - t0))
