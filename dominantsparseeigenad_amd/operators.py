@@ -262,6 +262,8 @@ def sell_layout(rowptr, colidx, n, col16="auto"):
     span_ok = total > 0 and int((blocks.max(dim=1).values - cmin[:, 0]).max().item()) < 65536
     if col16 is True and not span_ok and total > 0:
         raise ValueError("col16=True: a slice column of this pattern spans 65536 columns or more")
+    if total == 0:        # no stored entry at all: keep the arrays addressable (the C ABI refuses null pointers)
+        return slice_ptr, (torch.zeros(64, dtype=torch.int32, device=dev)[:0],), 0
     if col16 in ("auto", True) and span_ok:
         delta = blocks - cmin                                        # 0 .. 65535
         delta = torch.where(delta >= 32768, delta - 65536, delta).to(torch.int16)   # the same 16 bits, as torch can hold them
