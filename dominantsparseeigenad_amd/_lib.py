@@ -91,6 +91,9 @@ _SIGNATURES = {
                                        c_void_p, c_void_p]),
     "dsea_lanczos_store": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64,
                                    c_void_p]),
+    "dsea_lanczos_callable_alpha": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "dsea_lanczos_callable_step": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p]),
     "dsea_ritz_combine": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "dsea_project_out": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "dsea_cg_init": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),

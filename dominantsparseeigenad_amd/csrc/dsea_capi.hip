@@ -206,6 +206,7 @@ int dsea_ws_create(void* device_buffer, size_t bytes, int64_t n, int kmax, dsea_
   ws->w.shadow_ld = 0;
   ws->w.shadow_rows = 0;
   ws->w.lp_tau = 1e-12;
+  ws->w.callable_na = 0;
   ws->w.defer_norm = 0;
   ws->w.pend_P = nullptr;
   ws->w.pend_count = 0;
@@ -743,6 +744,47 @@ int dsea_lanczos_store(dsea_ws_t ws, const double* r, const double* nrm2, double
   uint16_t* qs = nullptr;
   if (w.shadow && w.shadow_rows > row && w.shadow_ld >= n) qs = w.shadow + (int64_t)row * w.shadow_ld;
   launch_scale_store(r, nrm2, Q + (int64_t)row * ldq, beta_out, n, static_cast<hipStream_t>(stream), qs);
+  return check_launch();
+}
+
+int dsea_lanczos_callable_alpha(dsea_ws_t ws, const double* q, const double* u, int64_t n, double* alpha_out, void* stream) {
+  REQUIRE(ws && q && u && n >= 1, DSEA_ERR_ARG);
+  REQUIRE(aligned16(q) && aligned16(u), DSEA_ERR_ALIGN);
+  Workspace& w = ws->w;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  w.callable_na = launch_dot_partials(q, u, n, w.aux, st);                   // consumed by the next dsea_lanczos_callable_step
+  if (alpha_out) launch_finalize1(w.aux, w.callable_na, alpha_out, st);      // (the last step: nobody else will sum them)
+  return check_launch();
+}
+
+int dsea_lanczos_callable_step(dsea_ws_t ws, double* Q, int64_t ldq, int64_t n, int i, const double* u, double* alphas,
+                               double* betas, double* r, void* stream) {
+  REQUIRE(ws && Q && u && alphas && betas && r && n >= 1 && i >= 1 && ldq >= n, DSEA_ERR_ARG);
+  REQUIRE(i <= ws->w.kmax, DSEA_ERR_WORKSPACE);
+  REQUIRE(aligned16(Q) && aligned16(u) && aligned16(r) && (ldq % 2 == 0), DSEA_ERR_ALIGN);
+  Workspace& w = ws->w;
+  REQUIRE(w.callable_na > 0, DSEA_ERR_ARG);                                  // dsea_lanczos_callable_alpha first
+  if (w.partial_reorth || w.reorth_passes != 1) return DSEA_ERR_UNSUPPORTED; // (those options keep the phase calls)
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const TileGeom g = w.geom(n);
+  double* aP = w.aux;
+  double* nP = w.aux + DSEA_MAX_WAVE_TILES;
+  // (the bf16 shadow of the basis, if registered, under dsea_lanczos_axpy_norm's own condition)
+  uint16_t* Qs = (w.shadow && w.shadow_rows >= i && w.shadow_ld >= n && !g.split_w) ? w.shadow : nullptr;
+  const int rps = lp_rows_per_step(n, false);
+  // the four launches of dsea_lanczos_run's step with the operator's fused tail replaced by a fused normalise-and-store:
+  // alpha_{i-1} from the partials the caller's q.u left, ||r||^2 from the correction pass's partials -- no stand-alone
+  // second-stage launches (Lanczos.py:61,66,69-70,73-75)
+  launch_rdots(g, Q, ldq, n, i, u, nullptr, i >= 2 ? betas + (i - 2) : nullptr, r, w.partials, w.coef, st, nullptr, aP,
+               w.callable_na, alphas + (i - 1), Qs != nullptr, nullptr);
+  int nn = g.nw;
+  if (Qs)
+    nn = launch_axpy_norm_lp(n, rps, Q, ldq, Qs, w.shadow_ld, i, w.coef, w.lp_tau, r, nP, w.scal + 16, st);
+  else
+    launch_axpy_norm(g, Q, ldq, n, i, w.coef, r, nP, nullptr, st);
+  uint16_t* qs_row = (w.shadow && w.shadow_rows > i && w.shadow_ld >= n) ? w.shadow + (int64_t)i * w.shadow_ld : nullptr;
+  launch_scale_store_fused(r, nP, nn, Q + (int64_t)i * ldq, qs_row, betas + (i - 1), n, st);
+  w.callable_na = 0;
   return check_launch();
 }
 

@@ -156,6 +156,7 @@ struct Workspace {
   double lp_tau;     // low-precision pass allowed while max|c_j| <= lp_tau * ||r||
   // row-partitioned library driver: dsea_plz_correct leaves its ||r||^2 partials un-summed (defer_norm) and the NEXT
   // dot-closing call of the step sums both in one launch (k_finalize_pair) -- bit-identical, one launch fewer per step
+  int callable_na;       // dsea_lanczos_callable_alpha: number of alpha partials left in aux[0..] for the next callable step
   int defer_norm;
   const double* pend_P;
   int pend_count;
@@ -204,6 +205,9 @@ int launch_shift_dot_partials(const double* x, double* y, const double* shift, c
 void launch_axpy(double a_host, const double* a_dev, const double* x, double* y, int64_t n, hipStream_t st);
 void launch_scale_store(const double* r, const double* nrm2, double* q, double* beta_out, int64_t n,
                         hipStream_t st, uint16_t* qs = nullptr, double* brk = nullptr, int step = 0);
+void launch_scale_store_fused(const double* r, const double* nP, int nCount, double* q, uint16_t* qs, double* beta_store,
+                              int64_t n, hipStream_t st);
+int launch_dot_partials(const double* x, const double* y, int64_t n, double* P, hipStream_t st);
 void launch_project_apply(const double* v, const double* a, const double* dot, double* out, int64_t n,
                           hipStream_t st);
 void launch_cg_init(const double* b, const double* Ax0, double* r, double* d, double* state, int64_t n,

@@ -1229,6 +1229,25 @@ __device__ __forceinline__ bool fused_beta(const TfimFusedArgs& fa, double* sm5,
   return true;
 }
 
+// q = r / beta with beta from the ||r||^2 PARTIALS (every block sums them in its prologue, as the fused operator tails do):
+// the normalise-and-store of a Lanczos step whose mat-vec is the caller's code (dsea_lanczos_callable_step) without the
+// stand-alone second-stage launch in front of it
+__global__ __launch_bounds__(256) void k_scale_store_fused(const double* __restrict__ r, TfimFusedArgs fa, int64_t n) {
+  __shared__ double sm5[5];
+  const int64_t stride = (int64_t)gridDim.x * 512;
+  const int64_t row0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+  double2 v = ld2<true>(r, row0, n);                       // (requested before the partials are waited for)
+  double beta = 1.0;
+  if (!fused_beta(fa, sm5, beta)) return;
+  for (int64_t row = row0; row < n; row += stride) {
+    if (row != row0) v = ld2<true>(r, row, n);
+    v.x = v.x / beta;
+    v.y = v.y / beta;
+    st2<true>(fa.q_out, row, n, v);
+    if (fa.qs_out) st_bf16x2(fa.qs_out, row, n, v);
+  }
+}
+
 __device__ __forceinline__ double tfim_diag(const TfimParams& p, int64_t i, uint64_t maskL) {
   const uint64_t gi = (uint64_t)(p.row_offset + i);
   const uint64_t rot = ((gi << 1) | (gi >> (p.L - 1))) & maskL;
@@ -2936,6 +2955,18 @@ int launch_shift_dot_partials(const double* x, double* y, const double* shift, c
 void launch_axpy(double a_host, const double* a_dev, const double* x, double* y, int64_t n,
                  hipStream_t st) {
   hipLaunchKernelGGL(k_axpy, dim3(ew_blocks(n)), dim3(256), 0, st, a_host, a_dev, x, y, n);
+}
+
+void launch_scale_store_fused(const double* r, const double* nP, int nCount, double* q, uint16_t* qs, double* beta_store,
+                              int64_t n, hipStream_t st) {
+  TfimFusedArgs fa = {nP, nCount, q, qs, beta_store, nullptr, 0};
+  hipLaunchKernelGGL(k_scale_store_fused, dim3(ew_blocks(n)), dim3(256), 0, st, r, fa, n);
+}
+
+int launch_dot_partials(const double* x, const double* y, int64_t n, double* P, hipStream_t st) {
+  const int nb = ew_blocks(n);
+  hipLaunchKernelGGL(k_dot, dim3(nb), dim3(256), 0, st, x, y, n, P);
+  return nb;
 }
 
 void launch_scale_store(const double* r, const double* nrm2, double* q, double* beta_out, int64_t n,

@@ -523,8 +523,23 @@ def lanczos(A, k, n, device, q0, native=None, callable_A=None, arena=False):
             check(lib.dsea_nrm2sq(ws.handle, _ptr(q0), n, _ptr(nrm2), st), "dsea_nrm2sq")
             check(lib.dsea_lanczos_store(ws.handle, _ptr(q0), _ptr(nrm2), _ptr(Q), ldq, 0, None, n, st), "dsea_lanczos_store")
             u = as_vector(callable_A(Q[0, :n]), n)
-            check(lib.dsea_dot(ws.handle, _ptr(Q), _ptr(u), n, _ptr(alphas), st), "dsea_dot")
-            for i in range(1, k):
+            fused_step = CALLABLE_LANCZOS_FUSED_STEP and not partial and int(REORTH_PASSES) == 1
+            if fused_step:
+                # two library calls per step (dsea_lanczos_callable_step: the four launches of the native step with a fused
+                # normalise-and-store; dsea_lanczos_callable_alpha: q.u as partials its consumer sums) instead of five phase calls
+                # and eight launches; the mat-vec stays the caller's code
+                check(lib.dsea_lanczos_callable_alpha(ws.handle, _ptr(Q), _ptr(u), n, _ptr(alphas) if k == 1 else None, st),
+                      "dsea_lanczos_callable_alpha")
+                for i in range(1, k):
+                    check(lib.dsea_lanczos_callable_step(ws.handle, _ptr(Q), ldq, n, i, _ptr(u), _ptr(alphas), _ptr(betas),
+                                                         _ptr(r), st), "dsea_lanczos_callable_step")
+                    qi = Q[i]
+                    u = as_vector(callable_A(qi[:n]), n)
+                    last = c_void_p(alphas.data_ptr() + i * esz) if i == k - 1 else None
+                    check(lib.dsea_lanczos_callable_alpha(ws.handle, _ptr(qi), _ptr(u), n, last, st), "dsea_lanczos_callable_alpha")
+            else:
+                check(lib.dsea_dot(ws.handle, _ptr(Q), _ptr(u), n, _ptr(alphas), st), "dsea_dot")
+            for i in range(1, k if not fused_step else 1):
                 a_ptr = c_void_p(alphas.data_ptr() + (i - 1) * esz)
                 b_ptr = c_void_p(betas.data_ptr() + (i - 2) * esz) if i >= 2 else c_void_p(None)
                 if partial:
@@ -702,6 +717,9 @@ CG_MERGED_REDUCTIONS = False
 CG_TFIM_REFERENCE_RECURRENCES = _os.environ.get("DSEA_CG_REFERENCE_RECURRENCES", "") == "1"
 
 
+# Lanczos around an opaque callable: two library calls per step (dsea_lanczos_callable_step / _alpha) instead of five phase calls.
+# False = the phase calls (A/B, tests); the partial / CGS2 options always take the phase calls.
+CALLABLE_LANCZOS_FUSED_STEP = _os.environ.get("DSEA_CALLABLE_LANCZOS_FUSED", "1") != "0"
 # CG around an opaque callable (the reference's own calling convention): one library call per iteration (dsea_cg_step: the three
 # fused launches of the native streaming form) instead of the four phase calls.  False = the phase calls (A/B, tests).
 CALLABLE_CG_FUSED_STEP = _os.environ.get("DSEA_CALLABLE_CG_FUSED", "1") != "0"

@@ -307,6 +307,20 @@ int dsea_lanczos_partial_step(dsea_ws_t ws, const double *Q, int64_t ldq, int64_
 int dsea_lanczos_store(dsea_ws_t ws, const double *r, const double *nrm2, double *Q, int64_t ldq, int row,
                        double *beta_out, int64_t n, void *stream);
 
+/* One Lanczos step around a CALLER-SUPPLIED mat-vec (reference Lanczos.py:60-75 with Amap a Python function -- the reference's
+ * own calling convention, examples/TFIM/E0.py:59-62), as TWO calls per step instead of five phase calls:
+ *     dsea_lanczos_callable_alpha(ws, Q[i-1], u, n, NULL)      u = A Q[i-1] is the caller's: leaves the partial sums of
+ *                                                              alpha_{i-1} = Q[i-1].u in the workspace (one launch)
+ *     dsea_lanczos_callable_step(ws, Q, ldq, n, i, u, alphas, betas, r)
+ *          r = u - alpha_{i-1} Q[i-1] - beta_{i-2} Q[i-2] ; c = Q^T r ; r -= Q c ; beta_{i-1} = ||r|| ; Q[i] = r / beta_{i-1}
+ *          (and the bf16 shadow row if one is registered); alphas[i-1], betas[i-1] are stored.  Four launches: the two scalar
+ *          reductions (alpha, ||r||^2) are summed in the prologues of their consumers, as in dsea_lanczos_run's step.
+ * The last alpha has no consumer: pass alpha_out = alphas + (k-1) to the last dsea_lanczos_callable_alpha to have it summed.
+ * Full re-orthogonalisation, one pass (the partial / CGS2 options keep the phase calls: DSEA_ERR_UNSUPPORTED).          */
+int dsea_lanczos_callable_alpha(dsea_ws_t ws, const double *q, const double *u, int64_t n, double *alpha_out, void *stream);
+int dsea_lanczos_callable_step(dsea_ws_t ws, double *Q, int64_t ldq, int64_t n, int i, const double *u, double *alphas,
+                               double *betas, double *r, void *stream);
+
 /* out = sum_{j<k} s[j] Q[j]   (the one needed column of Qk @ eigvecs, Lanczos.py:99-105)      */
 int dsea_ritz_combine(dsea_ws_t ws, const double *Q, int64_t ldq, int64_t n, int k,
                       const double *s, double *out, void *stream);

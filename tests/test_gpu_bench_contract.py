@@ -17,7 +17,10 @@ REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 def _run(extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--L-local", "14", "--k", "48", "--steps", "2",
            "--warmup", "1", "--cpu-k", "8", "--cpu-cg-cap", "5"] + extra
+    # (the N = 1 supervisor of bench.py -- a child measures, the parent relays its line -- has its own test below; the other
+    #  cases run the measuring process directly: one interpreter start less per case)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561")
+    env.setdefault("DSEA_BENCH_NO_WATCHDOG", "1")
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.strip().splitlines() if ln.strip()]
@@ -40,6 +43,28 @@ def test_bench_line_single_gpu():
     assert d["config"]["traffic_model_bytes_per_step"] <= d["config"]["algorithmic_bytes_per_step"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+
+
+def test_bench_one_gpu_supervisor_relays_the_line_and_survives_a_dead_measuring_process():
+    """N = 1: bench.py measures in a child and relays its ONE line; a child that dies without a line (what the GPU hang of
+    round 6 did: SIGABRT, empty stdout) is replaced by a fresh one that measures without the live PMC passes and the extras, and
+    the line says so."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--L-local", "14", "--k", "48", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-anchors"]
+    env = {k: v for k, v in os.environ.items() if k != "DSEA_BENCH_NO_WATCHDOG"}
+    ok = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    lines = [ln for ln in ok.stdout.strip().splitlines() if ln.strip()]
+    assert len(lines) == 1 and "supervisor" not in json.loads(lines[0])["config"] and "config3" in json.loads(lines[0])["config"]
+    bad = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(env, DSEA_BENCH_INJECT_ABORT="1"), cwd=ROOT)
+    assert bad.returncode == 0, bad.stderr[-2000:]
+    lines = [ln for ln in bad.stdout.strip().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    sup = d["config"]["supervisor"]
+    assert sup["attempt"] == 2 and "attempt 1: exit -6" in sup["earlier_attempts"][0] and "config3" not in d["config"]
+    assert d["ms_per_step"] > 0 and abs(d["config"]["E0_per_site"] - d["config"]["E0_per_site_closed_form"]) < 1e-9
+    assert "attempt 1" in bad.stderr
 
 
 def test_bench_line_cpu_baseline_forms():

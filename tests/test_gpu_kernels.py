@@ -214,3 +214,29 @@ def test_cg_step_around_a_callable_equals_the_phase_calls_and_the_native_streami
         ws.set_persist(-1)
     assert engine.last_cg.iters == outs[True][1]
     assert float((xn - outs[True][0]).abs().max()) <= 1e-13 * scale
+
+
+@pytest.mark.parametrize("n,k,shadow", [(1, 1, False), (3, 3, False), (1000, 40, False), (4097, 64, True), (100000, 50, True),
+                                        (1 << 20, 24, True)])
+def test_lanczos_step_around_a_callable_equals_the_phase_calls(monkeypatch, n, k, shadow):
+    """dsea_lanczos_callable_step / _alpha (two calls per step around the CALLER'S mat-vec: reference Lanczos.py:60-75 with Amap a
+    Python function) against the five phase calls they replace: T to rounding, the basis to 1e-12, with and without the bf16
+    shadow of the basis (split and wave-owned geometries, the lp pass from 2^20 rows)."""
+    import scipy.sparse as sp
+    from dominantsparseeigenad_amd.operators import CSROperator
+    rng = np.random.RandomState(n + k)
+    diags = [rng.rand(n) + 1.0] + ([rng.randn(n - 1) * 0.4] * 2 if n > 1 else [])
+    M = sp.diags(diags, [0, 1, -1][:len(diags)], format="csr")
+    op = CSROperator.from_scipy(M, dev(), layout="csr")
+    q0 = vec(n, 9200)
+    monkeypatch.setattr(engine, "USE_SHADOW", shadow)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(engine, "CALLABLE_LANCZOS_FUSED_STEP", fused)
+        Q, ldq, alphas, betas = engine.lanczos(None, k, n, dev(), q0, callable_A=lambda v: op(v))
+        res[fused] = (Q[:, :n].clone(), alphas.clone(), betas.clone())
+    scale = float(res[False][1].abs().max())
+    assert float((res[True][1] - res[False][1]).abs().max()) <= 1e-13 * scale
+    if k > 1:
+        assert float((res[True][2] - res[False][2]).abs().max()) <= 1e-13 * scale
+    assert float((res[True][0] - res[False][0]).abs().max()) <= 1e-12

@@ -10,6 +10,7 @@
 #   bench               default bench.py line                            benchq         bench without baseline / anchors / pmc
 #   stats               rocprofv3 --kernel-trace --stats of 3 headline steps -> kernel_stats.csv
 #   pmc                 FETCH_SIZE / WRITE_SIZE passes (separate) -> pmc_traffic.json via tools/pmc_traffic.py
+#   callable            kernel traces of tools/bench_generic.py (native / lambda / gather-table operand) through tools/trace_gaps.py
 #   pmcsell             the same with --operator sell -> pmc_traffic_sell.json          statsop:OP   kernel stats with --operator OP
 #   libdriver:LL        bench --force-partitioned --L-local LL (library driver, one rank over RCCL) + its kernel stats
 #   ldprof[:LL]         native loop vs library driver at 2^LL rows (default 20), per-kernel averages per Lanczos step
@@ -76,6 +77,14 @@ for spec in "$@"; do
       F=$(find "$O/_pmcs_FETCH_SIZE" -name "*counter_collection.csv" | head -1); W=$(find "$O/_pmcs_WRITE_SIZE" -name "*counter_collection.csv" | head -1)
       DSEA_COMMIT=$(cat .commit 2>/dev/null) python tools/pmc_traffic.py "$F" "$W" 2 "$O/pmc_traffic_sell.json" > "$O/pmc_traffic_sell.log" 2>&1; tail -24 "$O/pmc_traffic_sell.log"
       rm -rf "$O"/_pmcs_* ;;
+    callable)  # the reference's calling convention (A an opaque callable): kernel trace per mode -> durations and idle gaps
+      for m in native callable tables; do
+        rocprofv3 --kernel-trace --output-format csv -d "$O/_tr_$m" -o t -- python3 tools/bench_generic.py --mode $m --reps 4 > "$O/callable_$m.log" 2>&1
+        T=$(find "$O/_tr_$m" -name "*kernel_trace.csv" | head -1)
+        echo "== $m: $(grep 'fwd+bwd' "$O/callable_$m.log" | cut -c1-200)"
+        python3 tools/trace_gaps.py "$T" 0 | head -9
+        rm -rf "$O/_tr_$m"
+      done ;;
     statsop)   # statsop:<operator>: rocprofv3 kernel stats of 3 headline steps with --operator <operator>
       stats_of kernel_stats_$a1 --operator $a1 --steps 3 --warmup 1 $Q ;;
     libdriver)
