@@ -764,7 +764,8 @@ int dsea_lanczos_callable_step(dsea_ws_t ws, double* Q, int64_t ldq, int64_t n, 
   REQUIRE(aligned16(Q) && aligned16(u) && aligned16(r) && (ldq % 2 == 0), DSEA_ERR_ALIGN);
   Workspace& w = ws->w;
   REQUIRE(w.callable_na > 0, DSEA_ERR_ARG);                                  // dsea_lanczos_callable_alpha first
-  if (w.partial_reorth || w.reorth_passes != 1) return DSEA_ERR_UNSUPPORTED; // (those options keep the phase calls)
+  // (always ONE full re-orthogonalisation pass, whatever dsea_ws_set_reorth_passes / _partial_reorth say: those are options of
+  //  dsea_lanczos_run; a caller that wants them around its own mat-vec composes them from the phase calls)
   hipStream_t st = static_cast<hipStream_t>(stream);
   const TileGeom g = w.geom(n);
   double* aP = w.aux;

@@ -316,7 +316,8 @@ int dsea_lanczos_store(dsea_ws_t ws, const double *r, const double *nrm2, double
  *          (and the bf16 shadow row if one is registered); alphas[i-1], betas[i-1] are stored.  Four launches: the two scalar
  *          reductions (alpha, ||r||^2) are summed in the prologues of their consumers, as in dsea_lanczos_run's step.
  * The last alpha has no consumer: pass alpha_out = alphas + (k-1) to the last dsea_lanczos_callable_alpha to have it summed.
- * Full re-orthogonalisation, one pass (the partial / CGS2 options keep the phase calls: DSEA_ERR_UNSUPPORTED).          */
+ * Always full re-orthogonalisation in one pass (the workspace's partial / CGS2 options apply to dsea_lanczos_run; around a
+ * caller's mat-vec they are composed from the phase calls).                                                              */
 int dsea_lanczos_callable_alpha(dsea_ws_t ws, const double *q, const double *u, int64_t n, double *alpha_out, void *stream);
 int dsea_lanczos_callable_step(dsea_ws_t ws, double *Q, int64_t ldq, int64_t n, int i, const double *u, double *alphas,
                                double *betas, double *r, void *stream);

@@ -123,7 +123,31 @@ class _ResultChannel:
         self.queue.put((rank, value))
 
 
-def spawn_collect(fn, args, nprocs):
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_collect(fn, args, nprocs, port_index=None):
+    """``_spawn_collect_once`` with ONE thing retried: the rendezvous port.  A port found free can be taken by another process
+    of the host before rank 0 listens on it (seen once in eight full runs of round 6: ``EADDRINUSE`` -- the GPU boxes share a
+    network namespace with other jobs); with ``port_index`` given, such a start is repeated on a fresh port (twice at most)."""
+    args = tuple(args)
+    for attempt in range(3):
+        try:
+            return _spawn_collect_once(fn, args, nprocs)
+        except Exception as exc:  # noqa: BLE001
+            busy = "EADDRINUSE" in str(exc) or "address already in use" in str(exc).lower()
+            if port_index is None or not busy or attempt == 2:
+                raise
+            args = args[:port_index] + (_free_port(),) + args[port_index + 1:]
+
+
+def _spawn_collect_once(fn, args, nprocs):
     """``torch.multiprocessing.spawn(fn, args + (ret,), nprocs)`` where every worker does ``ret[rank] = value``; returns
     {rank: value}.  The parent reads while the workers run (a result larger than the pipe buffer would otherwise block its
     writer) and a crashed worker raises here instead of leaving the parent waiting."""

@@ -130,7 +130,7 @@ def _spawn_config5(Lg, k):
     import torch.multiprocessing as mp
     from test_gpu_partitioned import _free_port
     from helpers import spawn_collect
-    return spawn_collect(_worker_config5, (_free_port(), Lg, k), 1)[0]
+    return spawn_collect(_worker_config5, (_free_port(), Lg, k), 1, port_index=0)[0]
 
 
 @pytest.mark.slow

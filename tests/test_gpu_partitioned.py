@@ -267,7 +267,7 @@ def _run(world, backend, case, *args):
         pytest.skip("eight workers beside a parent that holds a GPU context exceed the eight compute processes the GPU "
                     "serves at a time (time-sliced: minutes per test); the 8-rank cases run first, in test_gpu_0_world8.py")
     from helpers import spawn_collect
-    ret = spawn_collect(_worker, (world, _free_port(), backend, case, args), world)
+    ret = spawn_collect(_worker, (world, _free_port(), backend, case, args), world, port_index=1)
     assert len(ret) == world
     return [ret[r] for r in range(world)]
 

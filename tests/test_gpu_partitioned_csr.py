@@ -114,7 +114,7 @@ def _worker(rank, world, port, backend, args, ret):
 def _run(world, kind, mode, python_driver=False, force=True):
     from helpers import spawn_collect
     backend = "nccl" if mode == "nccl" else "gloo"
-    ret = spawn_collect(_worker, (world, _free_port(), backend, (kind, mode, python_driver, force)), world)
+    ret = spawn_collect(_worker, (world, _free_port(), backend, (kind, mode, python_driver, force)), world, port_index=1)
     assert len(ret) == world
     return [ret[r] for r in range(world)]
 

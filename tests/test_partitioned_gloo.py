@@ -209,7 +209,7 @@ def _worker(rank, world, port, case, args, ret):
 
 def _run(world, case, *args):
     from helpers import spawn_collect
-    ret = spawn_collect(_worker, (world, _free_port(), case, args), world)
+    ret = spawn_collect(_worker, (world, _free_port(), case, args), world, port_index=1)
     assert len(ret) == world
     return [ret[r] for r in range(world)]
 
