@@ -300,7 +300,30 @@ def sell_operand_figures(ctx, args, steps=3):
         n, k = pa.n, pa.k
         operand = 12.0 * 21 * n * (k + m + 1)
         moved = traffic_model_bytes(n, k, m, (k - 1) if pa.use_shadow else 0) + operand
+        # the fused Lanczos tail on this operand, per launch, from HIP events attached to the dispatches (as the headline's roofline)
+        tail = None
+        try:
+            from dominantsparseeigenad_amd import _lib, engine
+            lib = _lib.load()
+            launches, total_ms = (c_int64 * 3)(), (c_double * 3)()
+            ws = engine.Workspace.get(n, k, ctx.dev)
+            _lib.check(lib.dsea_profile_begin(ws.handle, 3 * k * 2 + 8), "dsea_profile_begin")
+            pa.step()
+            pa.barrier()
+            _lib.check(lib.dsea_profile_end(ws.handle, launches, total_ms), "dsea_profile_end")
+            if launches[2] > 0:
+                us = total_ms[2] / launches[2] * 1e3
+                alg = 12.0 * 21 * n + 8.0 * (n // 64 + 1) + 16.0 * n        # 12 B per non-zero + two vectors
+                tail = {"kernel": "k_spmv_sell<fused Lanczos tail>", "avg_launch_us": round(us, 2), "launches": int(launches[2]),
+                        "algorithmic_bytes_per_launch": alg, "algorithmic_GBs": round(alg / us / 1e3, 1),
+                        "frac_of_hbm_peak_on_algorithmic_bytes": round(alg / us / 1e3 / HBM_PEAK_GBS, 4),
+                        "columns": "16-bit deltas" if getattr(pa.A_operand, "col16", False) else "int32",
+                        "note": "in situ (Infinity Cache swept by the basis passes; also writes q and its bf16 shadow); the kernel "
+                                "alone: profiles/r06_kbench_csr.txt"}
+        except Exception as exc:  # noqa: BLE001
+            tail = "failed: %s: %s" % (type(exc).__name__, exc)
         return {"workload": pa.describe(), "ms_per_step": round(ms, 3), "steps": steps, "cg_iterations": int(m),
+                "fused_tail": tail,
                 "bytes_per_step": moved, "GBs": round(moved / (ms * 1e-3) / 1e9, 1),
                 "frac_of_hbm_peak": round(moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "E0_per_site_minus_closed_form": E0.item() / 20 - analytic_E0_per_site(20, 1.0),

@@ -1767,7 +1767,9 @@ __global__ __launch_bounds__(256) void k_spmv_sell(SellParams p, const double* _
   int64_t sl = lin0 < ntrip ? sell_slice_of(p, lin0) : p.nslices;
   double v0 = 0.0;
   if (sl < p.nslices) v0 = sell_row_sum<MODE, UN, C16, NT>(p, x, p.slice_ptr[sl], p.slice_ptr[sl + 1], lane);
-  // (measured and dropped, round 6: every WAVE summing the partials itself -- no block barrier in the middle -- 52 -> 59 us)
+  // (measured and dropped, round 6 -- every variant same box, alternated: every WAVE summing the partials itself, after the row
+  //  sums 52 -> 59 us, with its loads in front of the matrix stream 52 -> 57-58 us; the block version with its loads in front of
+  //  the stream: no change.  With beta a constant the tail takes 49 us, without its q / shadow stores 50 / 51: profiles/r06_kbench_csr.txt)
   if (FUSED && !fused_beta(fa, sm5, beta)) return;
   if (sl < p.nslices) finish(sl, v0);
   for (int64_t lin = lin0 + (int64_t)gridDim.x * 4; lin < ntrip; lin += (int64_t)gridDim.x * 4) {
