@@ -144,8 +144,6 @@ _SIGNATURES = {
                                            c_void_p, c_void_p, c_void_p]),
     "dsea_arnoldi_extend": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int,
                                     c_void_p]),
-    "dsea_arnoldi_extend_pair": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p,
-                                         c_void_p, c_int, c_void_p]),
     "dsea_arnoldi_second_passes": (c_int, [c_void_p, POINTER(c_int64), c_void_p]),
     "dsea_ws_set_arnoldi_optimistic": (c_int, [c_void_p, c_int]),
     "dsea_arnoldi_status": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), c_void_p]),

@@ -1219,51 +1219,6 @@ int dsea_arnoldi_extend(dsea_op_t op, dsea_ws_t ws, const double* shift, double*
   return check_launch();
 }
 
-int dsea_arnoldi_extend_pair(dsea_op_t opA, dsea_op_t opB, dsea_ws_t wsA, dsea_ws_t wsB, double* VA, double* VB, int64_t ldv,
-                             int j0, int j1, double* HA, double* HB, int ldh, void* stream) {
-  REQUIRE(opA && opB && wsA && wsB && wsA != wsB && VA && VB && HA && HB && j0 >= 0 && j1 > j0 && ldh >= j1 + 1, DSEA_ERR_ARG);
-  const int64_t n = opA->d.n;
-  REQUIRE(opB->d.n == n && ldv >= n && wsA->w.n >= n && wsB->w.n >= n, DSEA_ERR_ARG);
-  REQUIRE(j1 + 1 <= wsA->w.kmax && j1 + 1 <= wsB->w.kmax, DSEA_ERR_WORKSPACE);
-  REQUIRE(aligned16(VA) && aligned16(VB) && (ldv % 2 == 0), DSEA_ERR_ALIGN);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  Workspace* W[2] = {&wsA->w, &wsB->w};
-  const OpDesc* O[2] = {&opA->d, &opB->d};
-  double* V[2] = {VA, VB};
-  double* H[2] = {HA, HB};
-  const TileGeom g = W[0]->geom(n);
-  if (g.split_w) return DSEA_ERR_UNSUPPORTED;          // (small n: the single-side call per factorisation)
-  double* brk[2];
-  for (int s = 0; s < 2; ++s) {
-    brk[s] = W[s]->scal + DSEA_SCAL_BREAK;
-    if (j0 == 0 && (hipMemsetAsync(W[s]->scal + 31, 0, sizeof(double), st) != hipSuccess ||
-                    hipMemsetAsync(W[s]->scal + DSEA_SCAL_LZ_FAIL, 0, sizeof(double), st) != hipSuccess ||
-                    hipMemsetAsync(brk[s], 0, 2 * sizeof(double), st) != hipSuccess)) {
-      g_last_hip = (int)hipGetLastError();
-      return DSEA_ERR_HIP;
-    }
-  }
-  for (int j = j0; j < j1; ++j) {
-    const double* u[2];
-    const double* shift[2];
-    double* w1[2];
-    double* P[2];
-    double* c1[2];
-    double* hcol[2];
-    for (int s = 0; s < 2; ++s) {
-      if (launch_spmv(*O[s], V[s] + (int64_t)j * ldv, W[s]->vec[0], nullptr, brk[s], nullptr, st) < 0) return DSEA_ERR_UNSUPPORTED;
-      u[s] = W[s]->vec[0];
-      shift[s] = W[s]->zero;
-      w1[s] = W[s]->vec[1];
-      P[s] = W[s]->partials;
-      c1[s] = W[s]->coef;
-      hcol[s] = H[s] + (int64_t)j * ldh;
-    }
-    if (launch_arnoldi_orth_pair(g, n, ldv, j, u, shift, V, w1, P, c1, brk, hcol, st) != 0) return DSEA_ERR_UNSUPPORTED;
-  }
-  return check_launch();
-}
-
 int dsea_ws_set_arnoldi_optimistic(dsea_ws_t ws, int on) {
   if (!ws || (on != 0 && on != 1)) return DSEA_ERR_ARG;
   ws->w.arnoldi_optimistic = on;

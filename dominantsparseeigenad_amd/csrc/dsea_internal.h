@@ -190,9 +190,6 @@ void launch_cg_direction_fused(const double* r, double* d, double* state, int pa
 void launch_axpy_norm(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* c,
                       double* r, double* P, double* nrm2_out, hipStream_t st, EventPair* ev = nullptr,
                       const double* brk = nullptr, const double* sel = nullptr);
-int launch_arnoldi_orth_pair(const TileGeom& g, int64_t n, int64_t ldv, int j, const double* const* u, const double* const* shift,
-                             double* const* V, double* const* w1, double* const* P, double* const* c1, double* const* brk,
-                             double* const* hcol, hipStream_t st);
 void launch_ritz(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int k, const double* s,
                  double* out, hipStream_t st);
 void launch_dot(const double* x, const double* y, int64_t n, double* P, double* out, hipStream_t st);

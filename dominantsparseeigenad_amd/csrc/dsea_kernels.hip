@@ -347,139 +347,6 @@ __global__ __launch_bounds__(256) void k_axpy_norm(const double* __restrict__ Q,
 }
 
 // ------------------------------------------------------------------------------------------
-// TWO independent Arnoldi factorisations orthogonalised in the SAME launches (the right and left eigenvector solves of
-// reference eig.py:29-30,116-117 on A and A^T: same n, same step index): blockIdx.y selects the side.  The tile functions
-// are the single-side ones (same rounding sequence per side: bit-identical to dsea_arnoldi_extend in its optimistic mode).
-// ------------------------------------------------------------------------------------------
-struct ArnoldiPair {
-  const double* V[2];
-  const double* u[2];
-  const double* shift[2];
-  double* w1[2];
-  double* P[2];
-  double* c1[2];
-  double* brk[2];
-  double* hcol[2];
-  double* vout[2];
-};
-
-template <int RPL>
-__global__ __launch_bounds__(256) void k_rdots_pair(ArnoldiPair a, int64_t ldq, int i, int64_t n, int64_t pstride, int nw,
-                                                    int64_t ntiles) {
-  const int s = blockIdx.y;
-  const double* __restrict__ Q = a.V[s];
-  double* __restrict__ P = a.P[s];
-  const int lane = threadIdx.x & 63;
-  const int wpb = blockDim.x >> 6;
-  const int64_t widx = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6);
-  constexpr int64_t TILE = 64 * RPL;
-  extern __shared__ double rdots_lds[];
-  double* __restrict__ sP = rdots_lds + (threadIdx.x >> 6) * (i + 1);
-  const int cnt = i + 1;
-  RdotsPre<RPL / 2> pre;
-  if (broken(a.brk[s])) return;
-  if (widx < nw) {
-    const double sh = a.shift[s][0];
-    bool first = true;
-    for (int64_t tile = widx; tile < ntiles; tile += nw) {
-      const int64_t base = tile * TILE;
-      if (base + TILE <= n)
-        rdots_tile<RPL, false, false>(Q, ldq, i, i, n, base, lane, a.u[s], sh, 0.0, a.w1[s], sP, !first, true, pre);
-      else
-        rdots_tile<RPL, true, false>(Q, ldq, i, i, n, base, lane, a.u[s], sh, 0.0, a.w1[s], sP, !first, true, pre);
-      first = false;
-    }
-  } else {
-    for (int idx = lane; idx < cnt; idx += 64) sP[idx] = 0.0;
-  }
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < cnt; idx += blockDim.x) {
-    double t = rdots_lds[idx];
-    for (int w = 1; w < wpb; ++w) t += rdots_lds[w * (i + 1) + idx];
-    P[(int64_t)idx * pstride + blockIdx.x] = t;
-  }
-}
-
-__global__ __launch_bounds__(256) void k_finalize_multi_pair(ArnoldiPair a, int64_t pstride, int nw) {
-  __shared__ double sm4[4];
-  const int s = blockIdx.y;
-  if (broken(a.brk[s])) return;
-  const int j = blockIdx.x;
-  const double* __restrict__ row = a.P[s] + (int64_t)j * pstride;
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  int w = threadIdx.x;
-  for (; w + 768 < nw; w += 1024) {
-    a0 += row[w];
-    a1 += row[w + 256];
-    a2 += row[w + 512];
-    a3 += row[w + 768];
-  }
-  for (; w < nw; w += 256) a0 += row[w];
-  double t = block_sum((a0 + a1) + (a2 + a3), sm4);
-  if (threadIdx.x == 0) a.c1[s][j] = t;
-}
-
-template <int RPL>
-__global__ __launch_bounds__(256) void k_axpy_norm_pair(ArnoldiPair a, int64_t ldq, int i, int64_t n, int nw, int64_t ntiles) {
-  const int s = blockIdx.y;
-  const int lane = threadIdx.x & 63;
-  const int64_t widx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (widx >= nw) return;
-  if (broken(a.brk[s])) return;
-  constexpr int64_t TILE = 64 * RPL;
-  double acc = 0.0;
-  for (int64_t tile = widx; tile < ntiles; tile += nw) {
-    const int64_t base = tile * TILE;
-    if (base + TILE <= n)
-      acc += axpy_tile<RPL, false, 0>(a.V[s], ldq, i, n, base, lane, a.c1[s], a.w1[s]);
-    else
-      acc += axpy_tile<RPL, true, 0>(a.V[s], ldq, i, n, base, lane, a.c1[s], a.w1[s]);
-  }
-  acc = wave_sum(acc);
-  if (lane == 0) a.P[s][widx] = acc;
-}
-
-__global__ __launch_bounds__(256) void k_arnoldi_finish_opt_pair(ArnoldiPair a, int count, int j, int64_t n) {
-  __shared__ double sm4[4];
-  __shared__ double s_nrm1;
-  const int s = blockIdx.y;
-  double* __restrict__ brk = a.brk[s];
-  if (broken(brk)) return;
-  const double* __restrict__ P = a.P[s];
-  const double* __restrict__ c1 = a.c1[s];
-  double acc = 0.0;
-  for (int b = threadIdx.x; b < count; b += 256) acc += P[b];
-  const double t0 = block_sum(acc, sm4);
-  if (threadIdx.x == 0) s_nrm1 = t0;
-  __syncthreads();
-  const double nrm1 = s_nrm1;
-  const double ww = c1[j + 1];
-  if (!(nrm1 >= 0.5 * ww)) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) brk[0] = -(double)(j + 1);
-    return;
-  }
-  const double beta = sqrt(nrm1);
-  const bool dead = !(beta > DSEA_BREAK_TOL * sqrt(ww));
-  if (blockIdx.x == 0) {
-    for (int t = threadIdx.x; t <= j; t += 256) a.hcol[s][t] = c1[t];
-    if (threadIdx.x == 0) {
-      a.hcol[s][j + 1] = beta;
-      if (dead) brk[0] = (double)(j + 1);
-    }
-  }
-  if (dead) return;
-  const double* __restrict__ w1 = a.w1[s];
-  double* __restrict__ v_out = a.vout[s];
-  const int64_t stride = (int64_t)gridDim.x * 512;
-  for (int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; row < n; row += stride) {
-    double2 v = ld2<true>(w1, row, n);
-    v.x = v.x / beta;
-    v.y = v.y / beta;
-    st2<true>(v_out, row, n, v);
-  }
-}
-
-// ------------------------------------------------------------------------------------------
 // Small-n form of the two passes ("split"): with fewer than ~1000 row tiles a wave that walks all i basis
 // vectors alone is bound by the latency of its serial trips, not by bandwidth.  Here a block of W waves shares
 // ONE row tile of 128 rows (2 per lane) and splits the basis vectors between its waves in chunks of four
@@ -2938,47 +2805,6 @@ int rdots_partial_count(const TileGeom& g, int i) {
   if (g.split_w) return (int)((g.ntiles + g.dots_nt - 1) / g.dots_nt);
   const int wpb = (i + 1) <= 2048 ? 4 : ((i + 1) <= 4096 ? 2 : 1);
   return (g.nw + wpb - 1) / wpb;
-}
-
-// orthogonalisation of step j of TWO Arnoldi factorisations in four launches (wave-owned geometry only; returns -1 otherwise)
-int launch_arnoldi_orth_pair(const TileGeom& g, int64_t n, int64_t ldv, int j, const double* const* u, const double* const* shift,
-                             double* const* V, double* const* w1, double* const* P, double* const* c1, double* const* brk,
-                             double* const* hcol, hipStream_t st) {
-  if (g.split_w) return -1;
-  const int i = j + 1;
-  ArnoldiPair a;
-  for (int s = 0; s < 2; ++s) {
-    a.V[s] = V[s];
-    a.u[s] = u[s];
-    a.shift[s] = shift[s];
-    a.w1[s] = w1[s];
-    a.P[s] = P[s];
-    a.c1[s] = c1[s];
-    a.brk[s] = brk[s];
-    a.hcol[s] = hcol[s];
-    a.vout[s] = V[s] + (int64_t)(j + 1) * ldv;
-  }
-  const int wpb = (i + 1) <= 2048 ? 4 : ((i + 1) <= 4096 ? 2 : 1);
-  const int grid = (g.nw + wpb - 1) / wpb;
-  const size_t lds = (size_t)wpb * (i + 1) * sizeof(double);
-  const dim3 gr2(grid, 2), gax((g.nw + 3) / 4, 2);
-  switch (g.rpl) {
-    case 2: hipLaunchKernelGGL((k_rdots_pair<2>), gr2, dim3(64 * wpb), lds, st, a, ldv, i, n, (int64_t)g.pstride, g.nw, g.ntiles); break;
-    case 4: hipLaunchKernelGGL((k_rdots_pair<4>), gr2, dim3(64 * wpb), lds, st, a, ldv, i, n, (int64_t)g.pstride, g.nw, g.ntiles); break;
-    case 8: hipLaunchKernelGGL((k_rdots_pair<8>), gr2, dim3(64 * wpb), lds, st, a, ldv, i, n, (int64_t)g.pstride, g.nw, g.ntiles); break;
-    default: hipLaunchKernelGGL((k_rdots_pair<16>), gr2, dim3(64 * wpb), lds, st, a, ldv, i, n, (int64_t)g.pstride, g.nw, g.ntiles);
-  }
-  hipLaunchKernelGGL(k_finalize_multi_pair, dim3(i + 1, 2), dim3(256), 0, st, a, (int64_t)g.pstride, grid);
-  switch (g.rpl) {
-    case 2: hipLaunchKernelGGL((k_axpy_norm_pair<2>), gax, dim3(256), 0, st, a, ldv, i, n, g.nw, g.ntiles); break;
-    case 4: hipLaunchKernelGGL((k_axpy_norm_pair<4>), gax, dim3(256), 0, st, a, ldv, i, n, g.nw, g.ntiles); break;
-    case 8: hipLaunchKernelGGL((k_axpy_norm_pair<8>), gax, dim3(256), 0, st, a, ldv, i, n, g.nw, g.ntiles); break;
-    default: hipLaunchKernelGGL((k_axpy_norm_pair<16>), gax, dim3(256), 0, st, a, ldv, i, n, g.nw, g.ntiles);
-  }
-  int64_t nbk = (n + 2047) / 2048;
-  if (nbk > DSEA_MAX_EW_BLOCKS) nbk = DSEA_MAX_EW_BLOCKS;
-  hipLaunchKernelGGL(k_arnoldi_finish_opt_pair, dim3((unsigned)nbk, 2), dim3(256), 0, st, a, g.nw, j, n);
-  return 0;
 }
 
 void launch_axpy_norm(const TileGeom& g, const double* Q, int64_t ldq, int64_t n, int i, const double* c,

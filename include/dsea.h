@@ -555,14 +555,6 @@ int dsea_lanczos_status(dsea_ws_t ws, int *break_step, void *stream);
 int dsea_arnoldi_extend(dsea_op_t op, dsea_ws_t ws, const double *shift, double *V, int64_t ldv, int j0, int j1,
                         double *H, int ldh, void *stream);
 
-/* TWO factorisations of the same dimension extended in lock step, their orthogonalisation in the SAME launches (the right and
- * left eigenvector solves of eig.py:29-30,116-117 on A and A^T): per step two mat-vecs + four launches for both sides instead of
- * 2 x (mat-vec + four).  OPTIMISTIC mode semantics on both sides (a step that needs its second Gram-Schmidt pass records itself in
- * ITS workspace: dsea_arnoldi_status per workspace), no shift, wave-owned geometry (DSEA_ERR_UNSUPPORTED for small n: call
- * dsea_arnoldi_extend per side).  Columns of H and vectors of V are bit-identical to dsea_arnoldi_extend's.               */
-int dsea_arnoldi_extend_pair(dsea_op_t opA, dsea_op_t opB, dsea_ws_t wsA, dsea_ws_t wsB, double *VA, double *VB, int64_t ldv,
-                             int j0, int j1, double *HA, double *HB, int ldh, void *stream);
-
 /* diagnostics (synchronises): how many steps since the last j0 == 0 call needed the second Gram-Schmidt pass */
 int dsea_arnoldi_second_passes(dsea_ws_t ws, int64_t *count, void *stream);
 
