@@ -485,7 +485,9 @@ int dsea_pop_create_stencil3(int64_t n_local, double coef, const double *V_dev, 
 /*   csr      : explicit sparse matrix in contiguous row slabs of the SAME n_local rows on every rank (the host layer pads
  *              the last slab with empty rows): `local_op` is this rank's SELL operator with its slab description
  *              (dsea_op_set_slab) -- neighbour halo of hb elements per side, or the all-gather fallback.  The pop borrows
- *              local_op's arrays and exchange buffers; the caller keeps them alive.  Halo-type operator: the exchange
+ *              local_op's arrays and exchange buffers (the caller keeps them alive) and SNAPSHOTS its descriptor: values
+ *              refreshed through dsea_op_update_vals(local_op, ...) are seen (same arrays), a later dsea_op_set_tuning /
+ *              dsea_op_set_slab on local_op is not.  Halo-type operator: the exchange
  *              precedes the slab mat-vec (as for stencil3).                                                          */
 int dsea_pop_create_csr(dsea_op_t local_op, dsea_comm_t comm, dsea_pop_t *out);
 /* the adjoint hook of a row-partitioned explicit matrix (dsea_op_sddmm on slabs): out[e] (+)= alpha v1[row e] v2[col e] for this
