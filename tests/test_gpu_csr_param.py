@@ -249,3 +249,54 @@ def test_sell_kernel_beyond_one_trip_and_beyond_64_slice_columns():
         rows = torch.from_numpy(_rows_of(D))
         v1 = torch.from_numpy(normal_vector(n2, 7802))
         assert torch.equal(op2.sddmm(v1.to(dev()), x2).cpu(), v1[rows] * x2.cpu()[torch.from_numpy(D.indices.astype("int64"))])
+
+
+def test_example_sparse_matrix_parameters_lbfgs_follows_the_dense_eigh_loop(monkeypatch):
+    """examples/sparse_matrix_parameters.py (the inverse problem of reference examples/schrodinger1D.py:101-127 with the
+    Hamiltonian's stored non-zeros as the parameters): first loss and gradient against torch.linalg.eigh autograd on the
+    symmetrised dense matrix; three LBFGS steps -- in-place updates of the leaf, followed through its version counter --
+    against the same optimiser driven by dense eigh from the same start"""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "examples", "sparse_matrix_parameters.py")
+    spec = importlib.util.spec_from_file_location("sparse_matrix_parameters", path)
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    monkeypatch.setattr(CG, "EPS_DEFAULT", 1e-12)
+    N, k = 200, 200
+    xm = np.linspace(-1.0, 1.0, num=N, endpoint=False)
+    xmesh = torch.from_numpy(xm).to(dev())
+    target = torch.from_numpy(ex.target_wavefunction(xm)).to(dev())
+    model = ex.SparseHamiltonian(-1.0, 1.0, N, xmesh)
+    start = model.vals.detach().clone()
+
+    def dense_loss(vals):
+        lam, U = torch.linalg.eigh(model.dense(vals).cpu())
+        return 1.0 - (U[:, 0].abs() * target.cpu()).sum()
+
+    loss = model.forward_sparseAD(target, k)
+    (g,) = torch.autograd.grad(loss, model.vals)
+    ref_vals = start.clone().requires_grad_(True)
+    ref_loss = dense_loss(ref_vals)
+    (g_ref,) = torch.autograd.grad(ref_loss, ref_vals)
+    assert abs(loss.item() - ref_loss.item()) < 1e-11
+    assert float((g.cpu() - g_ref.cpu()).abs().max()) < TOL * float(g_ref.abs().max())
+
+    def run(params, loss_of):
+        opt = torch.optim.LBFGS([params], max_iter=10, tolerance_change=1e-7, tolerance_grad=1e-7, line_search_fn="strong_wolfe")
+
+        def closure():
+            opt.zero_grad()
+            value = loss_of()
+            value.backward()
+            return value
+        return [opt.step(closure).item() for _ in range(3)]
+
+    ours = run(model.vals, lambda: model.forward_sparseAD(target, k))
+    ref_vals = start.clone().requires_grad_(True)
+    theirs = run(ref_vals, lambda: dense_loss(ref_vals))
+    print("losses:", ours, "dense eigh:", theirs)
+    assert ours[-1] < ours[0]
+    for a, b in zip(ours, theirs):
+        assert abs(a - b) < 1e-7 * max(1.0, abs(b)), (ours, theirs)
+    assert float((model.vals.detach().cpu() - ref_vals.detach().cpu()).abs().max()) < 1e-5 * float(start.abs().max())
