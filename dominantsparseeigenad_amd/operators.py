@@ -262,8 +262,8 @@ def sell_layout(rowptr, colidx, n, col16="auto"):
     span_ok = total > 0 and int((blocks.max(dim=1).values - cmin[:, 0]).max().item()) < 65536
     if col16 is True and not span_ok and total > 0:
         raise ValueError("col16=True: a slice column of this pattern spans 65536 columns or more")
-    if total == 0:        # no stored entry at all: keep the arrays addressable (the C ABI refuses null pointers)
-        return slice_ptr, (torch.zeros(64, dtype=torch.int32, device=dev)[:0],), 0
+    if total == 0:        # no stored entry at all: keep the arrays addressable (the C ABI refuses null pointers, and torch
+        return slice_ptr, (torch.zeros(64, dtype=torch.int32, device=dev),), 0      # reports one for every EMPTY tensor)
     if col16 in ("auto", True) and span_ok:
         delta = blocks - cmin                                        # 0 .. 65535
         delta = torch.where(delta >= 32768, delta - 65536, delta).to(torch.int16)   # the same 16 bits, as torch can hold them
@@ -331,11 +331,14 @@ class CSROperator:
             self.col16 = len(cols) == 2
             keep = self._sell
         elif layout == "csr":
+            # (a matrix without a stored entry -- e.g. a slab that is all padding: one addressable dummy element per array)
+            c_arr = self.colidx if self.nnz else torch.zeros(1, dtype=torch.int32, device=self.device)
+            v_arr = data if self.nnz else torch.zeros(1, dtype=F64, device=self.device)
             check(lib.dsea_op_create_csr(self.n, self.nnz, c_void_p(self.rowptr.data_ptr()),
-                                         c_void_p(self.colidx.data_ptr()), c_void_p(data.data_ptr()),
+                                         c_void_p(c_arr.data_ptr()), c_void_p(v_arr.data_ptr()),
                                          byref(raw)), "dsea_op_create_csr")
             self.col16 = False
-            keep = (self.rowptr, self.colidx, data)
+            keep = (self.rowptr, c_arr, v_arr)
         else:
             raise ValueError("layout must be 'sell' or 'csr'")
         self._H = _NativeView(_Handle(raw, self.n, keep))
@@ -393,6 +396,9 @@ class CSROperator:
         in place through rowptr, the layout is not rebuilt).  Called automatically when ``vals`` has been modified in
         place since the last look (optimiser step); call it yourself after writing through a view torch cannot see."""
         data = self.vals.detach()
+        if self.nnz == 0:                   # nothing stored: nothing to rewrite
+            self._seen_version = self.vals._version
+            return
         if data.data_ptr() != self._vals_data.data_ptr():
             self._vals_data = data          # (vals re-bound to another tensor of the same shape)
         check(_lib.load().dsea_op_update_vals(self._H.handle, c_void_p(self.rowptr.data_ptr()),
@@ -450,6 +456,8 @@ class CSROperator:
         v1, v2 = engine.as_vector(v1.detach(), self.n), engine.as_vector(v2.detach(), self.n)
         if out is None:
             out = torch.empty(self.nnz, dtype=F64, device=self.device)
+        if self.nnz == 0:
+            return out
         flags = (_lib.SDDMM_ACCUMULATE if accumulate else 0) | (_lib.SDDMM_SYMMETRIC if symmetric else 0)
         check(_lib.load().dsea_op_sddmm(self._H.handle, c_void_p(self.rowptr.data_ptr()), c_void_p(v1.data_ptr()),
                                         c_void_p(v2.data_ptr()), float(alpha), flags, c_void_p(out.data_ptr()),

@@ -1533,18 +1533,19 @@ class PartitionedCSROperator(PartitionedOperator):
 
     def _sddmm(self, v1, v2, sym):
         be = self.be
-        out = be.zeros(int(self.vals.numel()))
+        nnz = int(self.vals.numel())
+        out = be.zeros(max(nnz, 1))      # (a slab without a stored entry still takes part in the exchanges: one dummy element)
         if self._pop:
             from . import _lib
             _lib.check(be.lib.dsea_pop_sddmm(self._pop, be._p(self._local.rowptr), be._p(v1), be._p(v2), 1.0,
                                              _lib.SDDMM_SYMMETRIC if sym else 0, be._p(out), be._st()), "dsea_pop_sddmm")
-            return out
+            return out[:nnz]
         self._exchange(v2)
         be.csr_sddmm_local(v1, v2, 0.5 if sym else 1.0, False, out)
         if sym:
             self._exchange(v1)
             be.csr_sddmm_local(v2, v1, 0.5, True, out)
-        return out
+        return out[:nnz]
 
     def Aadjoint_to_valsadjoint(self, v1, v2):
         """vals-bar[e] = v1[row e] v2[col e] for this rank's non-zeros (CSR order)"""

@@ -100,10 +100,11 @@ class CpuBackend:
     def csr_sddmm_local(self, v1, v2, alpha, accumulate, out):
         src, o = self._csr_source(v2)
         g = alpha * (v1[self.csr_rows] * src[self.csr_cols + o])
+        o_ = out[:g.numel()]              # (a slab without a stored entry hands over one dummy element)
         if accumulate:
-            out.add_(g)
+            o_.add_(g)
         else:
-            out.copy_(g)
+            o_.copy_(g)
 
     def form_r(self, Q, ldq, n, i, u, alpha, beta, r, r_copy):
         r.copy_(u - alpha[0] * Q[i - 1, :n] - (beta[0] * Q[i - 2, :n] if (beta is not None and i >= 2) else 0.0))

@@ -299,4 +299,19 @@ def test_example_sparse_matrix_parameters_lbfgs_follows_the_dense_eigh_loop(monk
     assert ours[-1] < ours[0]
     for a, b in zip(ours, theirs):
         assert abs(a - b) < 1e-7 * max(1.0, abs(b)), (ours, theirs)
-    assert float((model.vals.detach().cpu() - ref_vals.detach().cpu()).abs().max()) < 1e-5 * float(start.abs().max())
+    # (the parameters themselves are NOT compared: psi is invariant under H -> c H and nearly so along other directions, and
+    #  LBFGS wanders along them with the rounding -- measured 1e-3 relative between the two loops at equal losses)
+
+
+@pytest.mark.parametrize("layout", ["sell", "csr"])
+def test_operator_without_a_stored_entry(layout):
+    """the zero matrix as an operand (a row slab that is all padding is one): mat-vec = 0, the sampled outer product and the
+    value refresh are no-ops on empty arrays (torch reports a null pointer for an empty tensor; the C ABI refuses those)"""
+    n = 130
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev())
+    vals = torch.zeros(0, dtype=F64, device=dev(), requires_grad=True)
+    op = CSROperator(rowptr, torch.zeros(0, dtype=torch.int32, device=dev()), vals, n, layout=layout)
+    x = torch.from_numpy(normal_vector(n, 1)).to(dev())
+    assert float(op(x).abs().max()) == 0.0
+    assert op.sddmm(x, x).numel() == 0 and op.Aadjoint_to_valsadjoint_symmetric(x, x).numel() == 0
+    op.refresh()

@@ -193,3 +193,66 @@ def test_partitioned_csr_rccl_branch_equals_callback_path(world, kind):
     py = _run(world, kind, "callbacks", True)
     assert all(r["driver"] == "python" for r in py)
     _check(py, kind, world)
+
+
+def _tiny_matrix():
+    from helpers import banded_spd
+    return banded_spd(5, 1, 7)
+
+
+def _tiny_case(rank, world, dev):
+    from dominantsparseeigenad_amd.partitioned import PartitionedCSROperator, RankOrderedHostStagedComm, csr_partition
+    M = _tiny_matrix()
+    n = M.shape[0]
+    nloc, off, real = csr_partition(n, world, rank)
+    sub = M[off:off + real] if real else M[0:0]
+    vals = torch.from_numpy(sub.data.copy()).to(dev).requires_grad_(True)
+    op = PartitionedCSROperator(torch.from_numpy(sub.indptr.astype("int64")).to(dev), torch.from_numpy(sub.indices.astype("int64")).to(dev),
+                                vals, n, dev, comm=RankOrderedHostStagedComm())
+    op.force_driver = True
+    pad = nloc * world - n
+    x = op.slab(torch.cat([torch.from_numpy(normal_vector(n, 8300)), torch.zeros(pad, dtype=torch.float64)])).to(dev)
+    v1 = op.slab(torch.cat([torch.from_numpy(normal_vector(n, 8301)), torch.zeros(pad, dtype=torch.float64)])).to(dev)
+    y = op.H(x.clone())
+    g = op.Aadjoint_to_valsadjoint(v1, x)
+    gs = op.Aadjoint_to_valsadjoint_symmetric(v1, x)
+    with torch.no_grad():
+        vals.mul_(1.5)
+    y_upd = op.H(x.clone())
+    torch.cuda.synchronize()
+    return dict(real=real, nnz=int(vals.numel()), y=y.cpu().numpy()[:real].copy(), ypad=float(y[real:].abs().sum()),
+                y_upd=y_upd.cpu().numpy()[:real].copy(), g=g.cpu().numpy().copy(), gs=gs.cpu().numpy().copy())
+
+
+def _tiny_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        ret[rank] = _tiny_case(rank, world, dev)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_partitioned_csr_slab_that_is_all_padding():
+    """5 rows on 4 ranks: slabs of 2 rows, the third holds one real row, the FOURTH NONE -- no stored entry, yet it takes
+    part in every exchange (found by tools/fuzz_partitioned_csr.py: torch reports a null pointer for every empty tensor and
+    the C ABI refuses null pointers; the host side keeps one addressable dummy element instead)"""
+    from helpers import spawn_collect
+    from dominantsparseeigenad_amd.operators import CSROperator
+    world = 4
+    ret = spawn_collect(_tiny_worker, (world, _free_port()), world, port_index=1)
+    assert [ret[r]["real"] for r in range(world)] == [2, 2, 1, 0] and ret[3]["nnz"] == 0
+    M = _tiny_matrix()
+    dev = torch.device("cuda:0")
+    op = CSROperator.from_scipy(M, dev)
+    x = torch.from_numpy(normal_vector(5, 8300)).to(dev)
+    v1 = torch.from_numpy(normal_vector(5, 8301)).to(dev)
+    assert np.array_equal(np.concatenate([ret[r]["y"] for r in range(world)]), op(x).cpu().numpy())
+    assert np.array_equal(np.concatenate([ret[r]["y_upd"] for r in range(world)]), CSROperator.from_scipy(M * 1.5, dev)(x).cpu().numpy())
+    assert np.array_equal(np.concatenate([ret[r]["g"] for r in range(world)]), op.sddmm(v1, x).cpu().numpy())
+    gs1 = op.sddmm(v1, x, symmetric=True).cpu().numpy()
+    assert np.max(np.abs(np.concatenate([ret[r]["gs"] for r in range(world)]) - gs1)) <= 4e-16 * np.max(np.abs(gs1))
+    assert all(ret[r]["ypad"] == 0.0 for r in range(world))
