@@ -7,7 +7,7 @@ to look for edge cases (tests/test_gpu_partitioned_csr.py holds the fixed cases)
 What is drawn: world size (2, 3, 4, 5, 8); n from "smaller than the world" to a few thousand, never chosen to divide evenly
 (padded last slab, slabs that are ALL padding, slabs shorter than a SELL slice); pattern: diagonal only, banded with a reach
 below / at / above the slab length (halo <-> all-gather decision), scattered far couplings, symmetric empty rows; library
-driver or Python step driver.
+driver (callback communicator, or its RCCL branch over the stand-in tests/fake_rccl: "rccl*") or Python step driver.
 
 What is checked per case:
   * slab mat-vec, one-sided sampled outer product, and the mat-vec after an in-place update of the non-zeros: BIT FOR BIT
@@ -35,6 +35,7 @@ import torch  # noqa: E402
 WORLDS = (2, 3, 4, 5, 8)
 KINDS = ("diagonal", "banded", "banded-wide", "scattered", "holes")
 CASE_TIMEOUT = 90
+FAKE_RCCL = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
 
 
 def draw(rng):
@@ -47,7 +48,9 @@ def draw(rng):
         n = int(rng.randint(4 * world, 64 * world + 70))       # slabs around one SELL slice
     else:
         n = int(rng.randint(400, 2600))
-    return dict(world=world, kind=kind, n=n, mseed=int(rng.randint(1, 1 << 30)), python_driver=bool(rng.rand() < 0.25))
+    case = dict(world=world, kind=kind, n=n, mseed=int(rng.randint(1, 1 << 30)), python_driver=bool(rng.rand() < 0.25))
+    case["rccl"] = bool(rng.rand() < 0.35) and not case["python_driver"]
+    return case
 
 
 def matrix(case):
@@ -112,8 +115,12 @@ def run_case(rank, world, dev, case, cpu):
         from cpu_backend import CpuBackend
         op = PartitionedCSROperator(rowptr, cols, vals, n, "cpu", backend=CpuBackend(nloc))
     else:
-        from dominantsparseeigenad_amd.partitioned import RankOrderedHostStagedComm
-        op = PartitionedCSROperator(rowptr, cols, vals, n, dev, comm=RankOrderedHostStagedComm())
+        from dominantsparseeigenad_amd.partitioned import NativeComm, RankOrderedHostStagedComm
+        comm = RankOrderedHostStagedComm()
+        if case.get("rccl"):              # the library's RCCL branch (group Send/Recv halos, all-gather, all-reduce) over the stand-in
+            os.environ["DSEA_RCCL_LIB"] = FAKE_RCCL
+            comm.native_comm = NativeComm.own(None, dev)
+        op = PartitionedCSROperator(rowptr, cols, vals, n, dev, comm=comm)
     op.force_driver = True
     pad = nloc * world - n
 
@@ -262,7 +269,7 @@ def main():
         eig += "vs eigh" in line
         print("%-4s #%d world=%d n=%4d (slab %4d) %-11s nnz=%6d %s | %s%s" % (
             "FAIL" if bad else "ok", i, case["world"], case["n"], -(-case["n"] // case["world"]), case["kind"], M.nnz,
-            "python" if case["python_driver"] else "library", line, ("  <-- " + "; ".join(bad)) if bad else ""), flush=True)
+            "python" if case["python_driver"] else ("rccl*" if case.get("rccl") and not args.cpu else "library"), line, ("  <-- " + "; ".join(bad)) if bad else ""), flush=True)
     print("cases %d  failures %d  (%d with the eigen-solve + adjoint against dense eigh)" % (len(cases), failures, eig))
     return 1 if failures else 0
 
