@@ -388,7 +388,10 @@ namespace {
 // wins (2^20: 37.0 vs 55.3 us, 2^21: 75.0 vs 99.9 us).
 inline int lp_rows_per_step(int64_t n, bool dots_are_split) {
   if (dots_are_split || n < ((int64_t)1 << 20)) return 0;
-  return 2;
+#ifndef DSEA_LP_RPS
+#define DSEA_LP_RPS 2
+#endif
+  return DSEA_LP_RPS;
 }
 }  // namespace
 
