@@ -447,6 +447,25 @@ int dsea_op_create_sell(int64_t n, int64_t nslices, const int64_t* slice_ptr, co
   return DSEA_OK;
 }
 
+int dsea_op_create_sell16v8(int64_t n, int64_t nslices, const int64_t* slice_ptr, const int32_t* colbase,
+                            const uint16_t* coldelta, const uint8_t* code, const double* table256, dsea_op_t* out) {
+  if (!out || n < 1 || nslices != (n + 63) / 64 || !slice_ptr || !colbase || !coldelta || !code || !table256) return DSEA_ERR_ARG;
+  dsea_op_s* op = new (std::nothrow) dsea_op_s;
+  if (!op) return DSEA_ERR_ARG;
+  memset(&op->d, 0, sizeof(op->d));
+  op->d.tune_tile_log2 = DSEA_TFIM_TILE_LOG2;
+  op->d.kind = OP_SELL;
+  op->d.n = n;
+  op->d.sell = SellParams{n, nslices, slice_ptr, nullptr, nullptr};
+  op->d.sell.colbase = colbase;
+  op->d.sell.col16 = coldelta;
+  op->d.sell.code8 = code;
+  op->d.sell.vtab = table256;
+  op->d.sell.xcd = 1;
+  *out = op;
+  return DSEA_OK;
+}
+
 int dsea_op_create_sell16(int64_t n, int64_t nslices, const int64_t* slice_ptr, const int32_t* colbase,
                           const uint16_t* coldelta, const double* vals, dsea_op_t* out) {
   if (!out || n < 1 || nslices != (n + 63) / 64 || !slice_ptr || !colbase || !coldelta || !vals) return DSEA_ERR_ARG;
@@ -552,6 +571,7 @@ int dsea_op_update_vals(dsea_op_t op, const int64_t* rowptr, const double* vals_
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (op->d.kind == OP_SELL) {
     if (!rowptr) return DSEA_ERR_ARG;
+    if (op->d.sell.code8) return DSEA_ERR_UNSUPPORTED;      // value-coded operand: read-only (dsea_op_create_sell16v8)
     launch_sell_update_vals(op->d, rowptr, vals_csr, st);
     return check_launch();
   }
@@ -581,7 +601,7 @@ int dsea_op_sddmm(dsea_op_t op, const int64_t* rowptr, const double* v1, const d
 }
 
 int dsea_op_set_slab(dsea_op_t op, int64_t halo_width, double* halo_lo, double* halo_hi, double* x_gathered) {
-  if (!op || op->d.kind != OP_SELL) return op ? DSEA_ERR_UNSUPPORTED : DSEA_ERR_ARG;
+  if (!op || op->d.kind != OP_SELL || op->d.sell.code8) return op ? DSEA_ERR_UNSUPPORTED : DSEA_ERR_ARG;
   SellParams& p = op->d.sell;
   if (halo_width == -1) {
     if (!x_gathered) return DSEA_ERR_ARG;

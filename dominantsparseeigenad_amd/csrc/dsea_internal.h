@@ -56,6 +56,9 @@ struct SellParams {
   const uint16_t* col16;
   int xcd;   // 1: XCD-contiguous slice map (dsea_op_set_tuning DSEA_TUNE_SELL_XCD_MAP)
   int nt;    // 1: non-temporal matrix loads (DSEA_TUNE_SELL_NT; 16-bit-column operands)
+  // value-coded operand (dsea_op_create_sell16v8): value of element e = vtab[code8[e]] (256 doubles); vals unused (null)
+  const uint8_t* code8;
+  const double* vtab;
 };
 struct Stencil3Params {
   int64_t n;

@@ -1734,13 +1734,69 @@ __device__ __forceinline__ double sell_row_sum(const SellParams& p, const double
   return s0 + s1;
 }
 
-template <bool FUSED, int MODE, int UN, bool C16, bool NT = false>
+// VALUE-CODED operand (dsea_op_create_sell16v8): the value of an element is vt[code], a table of 256 doubles in LDS, and
+// the per-element metadata is PACKED four slice columns to a lane: element (column 4 G + j, lane l) of a slice sits at
+// 256 G + 4 l + j of its arrays, so one uint32 holds a lane's four codes and one 8-byte word its four column deltas --
+// 2 + 4 memory instructions per four non-zeros of a row instead of 12.  Why that matters: with 3 instead of 10 bytes per
+// non-zero the kernel no longer sits on the fabric but on the rate at which the CU's address unit takes per-lane loads
+// (measured with one byte / short / gather load per element: 84 MB moved in 34 us against 238 MB in 44 us).
+// Same products in the same order as sell_row_sum<0, 8, true>: bit-identical to the fp64-value operand.
+__device__ __forceinline__ double sell_row_sum_vc(const SellParams& p, const double* __restrict__ x, int64_t b0, int64_t b1,
+                                                  int lane, const double* vt) {
+  double s0 = 0.0, s1 = 0.0;
+  const int width = (int)((b1 - b0) >> 6);     // a multiple of 4
+  const uint32_t* __restrict__ code4 = reinterpret_cast<const uint32_t*>(p.code8 + b0) + lane;
+  const uint2* __restrict__ delta4 = reinterpret_cast<const uint2*>(p.col16 + b0) + lane;
+  int cbl = 0, kb = -64;
+  for (int k0 = 0; k0 < width; k0 += 8) {
+    if ((k0 & ~63) != kb) {
+      kb = k0 & ~63;
+      const int64_t cbi = (b0 >> 6) + kb + lane;
+      cbl = cbi < (b1 >> 6) ? p.colbase[cbi] : 0;
+    }
+    const bool two = k0 + 4 < width;
+    const uint32_t cw0 = code4[(k0 >> 2) * 64];
+    const uint2 dw0 = delta4[(k0 >> 2) * 64];
+    uint32_t cw1 = 0;
+    uint2 dw1 = make_uint2(0u, 0u);
+    if (two) {
+      cw1 = code4[((k0 >> 2) + 1) * 64];
+      dw1 = delta4[((k0 >> 2) + 1) * 64];
+    }
+    int c[8];
+    double g[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const uint2 dw = u < 4 ? dw0 : dw1;
+      const uint32_t half = (u & 2) ? dw.y : dw.x;
+      c[u] = __builtin_amdgcn_readlane(cbl, (k0 + u) & 63) + (int)((half >> (16 * (u & 1))) & 0xffffu);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) g[u] = (u < 4 || two) ? x[c[u]] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (u < 4 || two) {
+        const double v = vt[((u < 4 ? cw0 : cw1) >> (8 * (u & 3))) & 255u];
+        if (u & 1) s1 = fma(v, g[u], s1);
+        else s0 = fma(v, g[u], s0);
+      }
+    }
+  }
+  return s0 + s1;
+}
+
+template <bool FUSED, int MODE, int UN, bool C16, bool NT = false, bool VC = false>
 __global__ __launch_bounds__(256) void k_spmv_sell(SellParams p, const double* __restrict__ x,
                                                    double* __restrict__ y, const double* __restrict__ shift,
                                                    const double* __restrict__ skip, double* __restrict__ P,
                                                    TfimFusedArgs fa) {
   __shared__ double sm5[5];
+  __shared__ double vt[VC ? 256 : 1];
   if (!FUSED && skip && skip[0] != 0.0) return;
+  if (VC) {
+    vt[threadIdx.x] = p.vtab[threadIdx.x];
+    __syncthreads();
+  }
   const double s = shift ? shift[0] : 0.0;
   const int lane = threadIdx.x & 63;
   double acc = 0.0, beta = 1.0;
@@ -1766,7 +1822,9 @@ __global__ __launch_bounds__(256) void k_spmv_sell(SellParams p, const double* _
   // stream of the wave's first slice instead of in front of it; nothing has been written when a breakdown returns.
   int64_t sl = lin0 < ntrip ? sell_slice_of(p, lin0) : p.nslices;
   double v0 = 0.0;
-  if (sl < p.nslices) v0 = sell_row_sum<MODE, UN, C16, NT>(p, x, p.slice_ptr[sl], p.slice_ptr[sl + 1], lane);
+  if (sl < p.nslices)
+    v0 = VC ? sell_row_sum_vc(p, x, p.slice_ptr[sl], p.slice_ptr[sl + 1], lane, vt)
+            : sell_row_sum<MODE, UN, C16, NT>(p, x, p.slice_ptr[sl], p.slice_ptr[sl + 1], lane);
   // (measured and dropped, round 6 -- every variant same box, alternated: every WAVE summing the partials itself, after the row
   //  sums 52 -> 59 us, with its loads in front of the matrix stream 52 -> 57-58 us; the block version with its loads in front of
   //  the stream: no change.  With beta a constant the tail takes 49 us, without its q / shadow stores 50 / 51: profiles/r06_kbench_csr.txt)
@@ -1775,7 +1833,8 @@ __global__ __launch_bounds__(256) void k_spmv_sell(SellParams p, const double* _
   for (int64_t lin = lin0 + (int64_t)gridDim.x * 4; lin < ntrip; lin += (int64_t)gridDim.x * 4) {
     sl = sell_slice_of(p, lin);
     if (sl >= p.nslices) continue;
-    finish(sl, sell_row_sum<MODE, UN, C16, NT>(p, x, p.slice_ptr[sl], p.slice_ptr[sl + 1], lane));
+    finish(sl, VC ? sell_row_sum_vc(p, x, p.slice_ptr[sl], p.slice_ptr[sl + 1], lane, vt)
+                  : sell_row_sum<MODE, UN, C16, NT>(p, x, p.slice_ptr[sl], p.slice_ptr[sl + 1], lane));
   }
   if (P) {
     __syncthreads();
@@ -1846,7 +1905,9 @@ __global__ __launch_bounds__(256) void k_sell_sddmm(SellParams p, const int64_t*
     int64_t k = 0;
     for (int64_t e = b0 + lane; e < b1; e += 64, ++k) {
       if (k < len) {
-        const int c = p.col16 ? p.colbase[e >> 6] + (int)p.col16[e] : p.colidx[e];
+        // (value-coded operand: its 16-bit deltas are packed four slice columns to a lane, see sell_row_sum_vc)
+        const int64_t e16 = p.code8 ? ((e & ~(int64_t)255) | ((e & 63) << 2) | ((e >> 6) & 3)) : e;
+        const int c = p.col16 ? p.colbase[e >> 6] + (int)p.col16[e16] : p.colidx[e];
         double g = __dmul_rn(a1, sell_gather<MODE>(p, v2, c));
         if (SYM) g = __dmul_rn(0.5, __dadd_rn(g, __dmul_rn(sell_gather<MODE>(p, v1, c), a2)));
         g = __dmul_rn(alpha, g);
@@ -3083,7 +3144,8 @@ int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shif
       } else if (p.mode == 2) {
         if (c16) SELL_GO(false, 2, 8, true); else SELL_GO(false, 2, 4, false);
       } else if (c16) {
-        if (p.nt) KLAUNCH(ev, (k_spmv_sell<false, 0, 8, true, true>), (unsigned)nb, 256, st, p, x, y, shift, skip, P, fa0);
+        if (p.code8) KLAUNCH(ev, (k_spmv_sell<false, 0, 8, true, false, true>), (unsigned)nb, 256, st, p, x, y, shift, skip, P, fa0);
+        else if (p.nt) KLAUNCH(ev, (k_spmv_sell<false, 0, 8, true, true>), (unsigned)nb, 256, st, p, x, y, shift, skip, P, fa0);
         else SELL_GO(false, 0, 8, true);
       } else {
         switch (op.tune_sell_unroll) {
@@ -3142,7 +3204,8 @@ int launch_tfim_fused(const OpDesc& op, const double* r, const double* nP, int n
     if (p.mode != 0) return -1;                         // slab of a row-partitioned matrix: the unfused sequence
 #define SELL_GO(U, C) KLAUNCH(ev, (k_spmv_sell<true, 0, U, C>), (unsigned)nb, 256, st, p, r, y, nullc, nullc, P, fa)
     if (p.col16) {
-      if (p.nt) KLAUNCH(ev, (k_spmv_sell<true, 0, 8, true, true>), (unsigned)nb, 256, st, p, r, y, nullc, nullc, P, fa);
+      if (p.code8) KLAUNCH(ev, (k_spmv_sell<true, 0, 8, true, false, true>), (unsigned)nb, 256, st, p, r, y, nullc, nullc, P, fa);
+      else if (p.nt) KLAUNCH(ev, (k_spmv_sell<true, 0, 8, true, true>), (unsigned)nb, 256, st, p, r, y, nullc, nullc, P, fa);
       else SELL_GO(8, true);
     } else {
       switch (op.tune_sell_unroll) {

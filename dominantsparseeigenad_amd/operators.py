@@ -116,7 +116,7 @@ class TFIMOperator:
             raise RuntimeError("set the parameter g before using the operator")
         return self._H.handle
 
-    def to_csr(self, layout="sell", col16="auto"):
+    def to_csr(self, layout="sell", col16="auto", values="auto"):
         """The same operator as an explicit device CSR matrix (L + 1 entries per row, int32 columns): the
         "generic sparse operand" form of BASELINE config 2.  Built on the device with index arithmetic."""
         n, L = self.n, self.L_local
@@ -138,7 +138,7 @@ class TFIMOperator:
         cols = torch.gather(cols, 1, order)
         vals = torch.gather(vals, 1, order)
         rowptr = torch.arange(n + 1, dtype=torch.int64, device=self.device) * (L + 1)
-        return CSROperator(rowptr, cols.reshape(-1), vals.reshape(-1), n, layout=layout, col16=col16)
+        return CSROperator(rowptr, cols.reshape(-1), vals.reshape(-1), n, layout=layout, col16=col16, values=values)
 
     def pHpg(self, v):
         """dH/dg v = -sum_j v[i xor (1<<j)]   (TFIM.py:58-65)"""
@@ -234,7 +234,7 @@ class _Stencil3Apply(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------ CSR
-def sell_layout(rowptr, colidx, n, col16="auto"):
+def sell_layout(rowptr, colidx, n, col16="auto", pad_cols=1):
     """SELL-64 structure of a CSR pattern (device tensors, torch index ops -- built once per operator):
     returns (slice_ptr int64 [nslices+1], columns, total) with ``columns`` = (int32 [total],) or, when every
     64-element slice column spans fewer than 65536 columns (``col16`` "auto" / True), (colbase int32 [total/64],
@@ -247,6 +247,8 @@ def sell_layout(rowptr, colidx, n, col16="auto"):
     padded = torch.zeros(nsl * 64, dtype=torch.int64, device=dev)
     padded[:n] = lens
     width = padded.view(nsl, 64).max(dim=1).values
+    if pad_cols > 1:      # (the value-coded layout packs four slice columns to a lane: widths in multiples of pad_cols)
+        width = (width + (pad_cols - 1)) // pad_cols * pad_cols
     slice_ptr = torch.zeros(nsl + 1, dtype=torch.int64, device=dev)
     slice_ptr[1:] = torch.cumsum(width * 64, 0)
     total = int(slice_ptr[-1].item())
@@ -258,6 +260,7 @@ def sell_layout(rowptr, colidx, n, col16="auto"):
     s_cols[dest] = colidx.to(torch.int32)
     blocks = s_cols.view(-1, 64)
     cmin = blocks.min(dim=1, keepdim=True).values
+    cmin = torch.where(cmin == big, torch.zeros_like(cmin), cmin)     # (a slice column that is ALL padding: column 0)
     blocks.copy_(torch.where(blocks == big, cmin.expand_as(blocks), blocks))
     span_ok = total > 0 and int((blocks.max(dim=1).values - cmin[:, 0]).max().item()) < 65536
     if col16 is True and not span_ok and total > 0:
@@ -269,6 +272,39 @@ def sell_layout(rowptr, colidx, n, col16="auto"):
         delta = torch.where(delta >= 32768, delta - 65536, delta).to(torch.int16)   # the same 16 bits, as torch can hold them
         return slice_ptr, (cmin[:, 0].contiguous(), delta.reshape(-1).contiguous()), total
     return slice_ptr, (s_cols.contiguous(),), total
+
+
+def sell_positions(rowptr, n, slice_ptr, packed=False):
+    """position of every CSR element in the SELL arrays of ``sell_layout`` (int64 [nnz]); ``packed``: in the per-element
+    arrays of the value-coded layout (four slice columns to a lane: 256 G + 4 l + j, include/dsea.h dsea_op_create_sell16v8)"""
+    lens = rowptr[1:] - rowptr[:-1]
+    rows = torch.repeat_interleave(torch.arange(n, dtype=torch.int64, device=rowptr.device), lens)
+    k = torch.arange(rows.numel(), dtype=torch.int64, device=rowptr.device) - rowptr[rows]
+    if packed:
+        return slice_ptr[rows // 64] + (k // 4) * 256 + (rows % 64) * 4 + (k % 4)
+    return slice_ptr[rows // 64] + k * 64 + (rows % 64)
+
+
+def pack4(a):
+    """a per-element SELL array in slice-column-major order -> four slice columns to a lane (slices hold multiples of 256)"""
+    return a.view(-1, 4, 64).permute(0, 2, 1).contiguous().view(-1)
+
+
+def value_codes(data, limit=255):
+    """(table float64 [256], codes uint8 [nnz]) with data == table[codes] BIT FOR BIT and table[0] = 0.0 (the padding's
+    code), or None when ``data`` takes more than ``limit`` distinct bit patterns.  A strided sample is looked at first, so
+    that a matrix of arbitrary values costs one small sort."""
+    bits = data.detach().contiguous().view(torch.int64)
+    if bits.numel() > (1 << 16):
+        step = bits.numel() >> 16
+        if torch.unique(bits[::step]).numel() > limit:
+            return None
+    uniq, inv = torch.unique(bits, return_inverse=True)
+    if uniq.numel() > limit:
+        return None
+    table = torch.zeros(256, dtype=torch.int64, device=data.device)
+    table[1:1 + uniq.numel()] = uniq
+    return table.view(F64), (inv + 1).to(torch.uint8)
 
 
 class CSROperator:
@@ -296,7 +332,7 @@ class CSROperator:
 
     _native_methods = ("__call__",)
 
-    def __init__(self, rowptr, colidx, vals, n, layout="sell", col16="auto"):
+    def __init__(self, rowptr, colidx, vals, n, layout="sell", col16="auto", values="auto"):
         self.n = int(n)
         self.rowptr = rowptr.to(torch.int64).contiguous()
         self.colidx = colidx.to(torch.int32).contiguous()
@@ -317,19 +353,43 @@ class CSROperator:
         raw = c_void_p()
         lib = _lib.load()
         if layout == "sell":
-            slice_ptr, cols, total = sell_layout(self.rowptr, self.colidx, self.n, col16)
-            s_vals = torch.zeros(max(total, 1), dtype=F64, device=self.device)
             nsl = (self.n + 63) // 64
-            if len(cols) == 2:
-                check(lib.dsea_op_create_sell16(self.n, nsl, c_void_p(slice_ptr.data_ptr()), c_void_p(cols[0].data_ptr()),
-                                                c_void_p(cols[1].data_ptr()), c_void_p(s_vals.data_ptr()), byref(raw)),
-                      "dsea_op_create_sell16")
+            import os as _os
+            if values == "auto":
+                values = _os.environ.get("DSEA_SELL_VALUES", "auto")      # A/B switch: "plain" | "auto" | "coded"
+            if values not in ("auto", "plain", "coded"):
+                raise ValueError("values must be 'auto', 'plain' or 'coded'")
+            # VALUE CODES (include/dsea.h dsea_op_create_sell16v8): few distinct stored values -> a uint8 per element into a
+            # table of 256 doubles, 3 instead of 10 bytes per non-zero, bit-identical products.  Not for a parameter (its
+            # values spread with the first optimiser step) unless asked for.
+            coded = None
+            if values != "plain" and col16 is not False and self.nnz > 0 and (values == "coded" or not vals.requires_grad):
+                coded = value_codes(data)
+            if coded is not None:
+                slice_ptr, cols, total = sell_layout(self.rowptr, self.colidx, self.n, col16, pad_cols=4)
+                if len(cols) != 2:
+                    coded = None          # (a slice column spans 65536 columns or more: 32-bit columns, fp64 values)
+            if values == "coded" and coded is None:
+                raise ValueError("values='coded' needs 16-bit columns and at most 255 distinct stored values")
+            self._coded = coded is not None
+            if self._coded:
+                self._vtab = coded[0]
+                self._codes = torch.zeros(total, dtype=torch.uint8, device=self.device)
+                self._codes[sell_positions(self.rowptr, self.n, slice_ptr, packed=True)] = coded[1]
+                cols = (cols[0], pack4(cols[1]))
+                check(lib.dsea_op_create_sell16v8(self.n, nsl, c_void_p(slice_ptr.data_ptr()), c_void_p(cols[0].data_ptr()),
+                                                  c_void_p(cols[1].data_ptr()), c_void_p(self._codes.data_ptr()),
+                                                  c_void_p(self._vtab.data_ptr()), byref(raw)), "dsea_op_create_sell16v8")
+                self._sell = (slice_ptr,) + tuple(cols) + (None,)
+                keep = self._sell + (self._codes, self._vtab)
             else:
-                check(lib.dsea_op_create_sell(self.n, nsl, c_void_p(slice_ptr.data_ptr()), c_void_p(cols[0].data_ptr()),
-                                              c_void_p(s_vals.data_ptr()), byref(raw)), "dsea_op_create_sell")
-            self._sell = (slice_ptr,) + tuple(cols) + (s_vals,)
+                slice_ptr, cols, total = sell_layout(self.rowptr, self.colidx, self.n, col16)
+                s_vals = torch.zeros(max(total, 1), dtype=F64, device=self.device)
+                raw = self._create_plain(slice_ptr, cols, s_vals)
+                self._sell = (slice_ptr,) + tuple(cols) + (s_vals,)
+                keep = self._sell
+            self._sell_total = total
             self.col16 = len(cols) == 2
-            keep = self._sell
         elif layout == "csr":
             # (a matrix without a stored entry -- e.g. a slab that is all padding: one addressable dummy element per array)
             c_arr = self.colidx if self.nnz else torch.zeros(1, dtype=torch.int32, device=self.device)
@@ -346,7 +406,22 @@ class CSROperator:
         if layout == "sell" and _os.environ.get("DSEA_SELL_NT", "") in ("0", "1"):     # A/B switch (tools/gpu_evidence.sh abenv)
             check(lib.dsea_op_set_tuning(raw, _lib.TUNE_SELL_NT, int(_os.environ["DSEA_SELL_NT"])), "dsea_op_set_tuning")
         self._seen_version = None
-        self.refresh()
+        if getattr(self, "_coded", False):
+            self._seen_version = self.vals._version        # (the codes were just taken from these values)
+        else:
+            self.refresh()
+
+    def _create_plain(self, slice_ptr, cols, s_vals):
+        """SELL operand with fp64 values on this pattern (16- or 32-bit columns as ``cols`` has them)"""
+        raw, lib, nsl = c_void_p(), _lib.load(), (self.n + 63) // 64
+        if len(cols) == 2:
+            check(lib.dsea_op_create_sell16(self.n, nsl, c_void_p(slice_ptr.data_ptr()), c_void_p(cols[0].data_ptr()),
+                                            c_void_p(cols[1].data_ptr()), c_void_p(s_vals.data_ptr()), byref(raw)),
+                  "dsea_op_create_sell16")
+        else:
+            check(lib.dsea_op_create_sell(self.n, nsl, c_void_p(slice_ptr.data_ptr()), c_void_p(cols[0].data_ptr()),
+                                          c_void_p(s_vals.data_ptr()), byref(raw)), "dsea_op_create_sell")
+        return raw
 
     # -- the parameter tensor (reference: ``model.g`` / ``model.potential``): in-place updates are followed through its version
     #    counter; binding ANOTHER tensor of the same shape (``op.vals = new``) marks the device copy stale as well
@@ -364,23 +439,21 @@ class CSROperator:
     # -- structure shared, values replaced (the mat-vec M(G) x of the hooks' backward)
     def with_vals(self, vals):
         """an operator on the SAME pattern with other values (shares the SELL structure; one value array is allocated)"""
+        if getattr(self, "_coded", False):      # (the value-coded layout pads and packs differently: a fresh fp64-value operator)
+            return CSROperator(self.rowptr, self.colidx, vals.detach().to(F64).contiguous(), self.n, layout=self.layout, values="plain")
         twin = object.__new__(CSROperator)
-        twin.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("_H", "_sell", "_vals", "_vals_data", "_T")})
+        twin.__dict__.update({k: v for k, v in self.__dict__.items()
+                              if k not in ("_H", "_sell", "_vals", "_vals_data", "_T", "_codes", "_vtab", "_coded")})
         data = vals.detach().to(F64).contiguous()
         twin._vals, twin._vals_data, twin._T = data, data, None
         raw = c_void_p()
         lib = _lib.load()
         if self.layout == "sell":
-            s_vals = torch.zeros_like(self._sell[-1])
+            s_vals = torch.zeros(max(self._sell_total, 1), dtype=F64, device=self.device)
             st = self._sell
-            if self.col16:
-                check(lib.dsea_op_create_sell16(self.n, (self.n + 63) // 64, c_void_p(st[0].data_ptr()), c_void_p(st[1].data_ptr()),
-                                                c_void_p(st[2].data_ptr()), c_void_p(s_vals.data_ptr()), byref(raw)),
-                      "dsea_op_create_sell16")
-            else:
-                check(lib.dsea_op_create_sell(self.n, (self.n + 63) // 64, c_void_p(st[0].data_ptr()), c_void_p(st[1].data_ptr()),
-                                              c_void_p(s_vals.data_ptr()), byref(raw)), "dsea_op_create_sell")
+            raw = self._create_plain(st[0], st[1:-1], s_vals)
             twin._sell = st[:-1] + (s_vals,)
+            twin._coded = False
             keep = twin._sell
         else:
             check(lib.dsea_op_create_csr(self.n, self.nnz, c_void_p(self.rowptr.data_ptr()), c_void_p(self.colidx.data_ptr()),
@@ -401,10 +474,33 @@ class CSROperator:
             return
         if data.data_ptr() != self._vals_data.data_ptr():
             self._vals_data = data          # (vals re-bound to another tensor of the same shape)
+        if getattr(self, "_coded", False):
+            self._recode()
+            if self._coded:
+                self._seen_version = self.vals._version
+                return
         check(_lib.load().dsea_op_update_vals(self._H.handle, c_void_p(self.rowptr.data_ptr()),
                                               c_void_p(self._vals_data.data_ptr()), engine._stream(self.device)),
               "dsea_op_update_vals")
         self._seen_version = self.vals._version
+
+    def _recode(self):
+        """value-coded operand whose values have changed: new table and codes IN PLACE (the handle stays), or -- once they no
+        longer fit 255 codes -- the fp64 layout on the same pattern, built once (the handle changes: ``handle`` is read
+        per call; a row-partitioned slab is never value-coded)"""
+        coded = value_codes(self._vals_data)
+        if coded is not None:
+            self._vtab.copy_(coded[0])
+            self._codes[sell_positions(self.rowptr, self.n, self._sell[0], packed=True)] = coded[1]
+            return
+        slice_ptr, cols, total = sell_layout(self.rowptr, self.colidx, self.n, True)
+        s_vals = torch.zeros(max(total, 1), dtype=F64, device=self.device)
+        raw = self._create_plain(slice_ptr, cols, s_vals)
+        self._sell = (slice_ptr,) + tuple(cols) + (s_vals,)
+        self._sell_total = total
+        self._coded = False
+        del self._codes, self._vtab
+        self._H = _NativeView(_Handle(raw, self.n, self._sell))
 
     def _current(self):
         # (plain CSR layout: the kernel reads the registered tensor itself, so only a re-bound ``vals`` needs the copy)
@@ -413,12 +509,12 @@ class CSROperator:
         return self._H
 
     @classmethod
-    def from_scipy(cls, M, device="cuda", layout="sell", col16="auto"):
+    def from_scipy(cls, M, device="cuda", layout="sell", col16="auto", values="auto"):
         M = M.tocsr()
         M.sort_indices()
         return cls(torch.from_numpy(M.indptr.astype("int64")).to(device),
                    torch.from_numpy(M.indices.astype("int32")).to(device),
-                   torch.from_numpy(M.data.astype("float64")).to(device), M.shape[0], layout=layout, col16=col16)
+                   torch.from_numpy(M.data.astype("float64")).to(device), M.shape[0], layout=layout, col16=col16, values=values)
 
     @classmethod
     def from_npz(cls, path, device="cuda", layout="sell"):

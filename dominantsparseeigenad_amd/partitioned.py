@@ -106,7 +106,7 @@ class HipBackend(_engine_mod.Phases):
         two neighbour halos in ``halo`` (2 hb doubles: [from rank-1 | from rank+1]), or GLOBAL with the all-gathered
         vector ``xg`` (hb = -1)                                                   include/dsea.h: dsea_op_set_slab"""
         from .operators import CSROperator
-        self.op = CSROperator(rowptr, cols, vals, int(n_local))
+        self.op = CSROperator(rowptr, cols, vals, int(n_local), values="plain")   # (a slab is never value-coded: dsea_op_set_slab)
         lo = c_void_p(halo.data_ptr()) if hb > 0 else c_void_p(None)
         hi = c_void_p(halo.data_ptr() + 8 * hb) if hb > 0 else c_void_p(None)
         self._ck(self.lib.dsea_op_set_slab(self.op._H.handle, int(hb), lo, hi, self._p(xg) if hb < 0 else c_void_p(None)),

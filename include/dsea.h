@@ -161,6 +161,22 @@ int dsea_op_create_sell(int64_t n, int64_t nslices, const int64_t *slice_ptr, co
 int dsea_op_create_sell16(int64_t n, int64_t nslices, const int64_t *slice_ptr, const int32_t *colbase,
                           const uint16_t *coldelta, const double *vals, dsea_op_t *out);
 
+/* VALUE-CODED SELL-64 for operands whose stored entries take few distinct values (lattice Hamiltonians held as explicit
+ * matrices: couplings, fields and a handful of diagonal levels -- the 21-nnz/row TFIM matrix at L = 20 has 11): the value of an
+ * element is table256[code], a uint8 per element into 256 doubles (unused entries: anything finite; padding elements code a
+ * 0.0), columns as in dsea_op_create_sell16 -- 3.06 instead of 10.06 bytes per non-zero.  The products are formed with the
+ * SAME doubles in the same order: the result is bit-identical to dsea_op_create_sell16 on the decoded values.
+ * Layout: every slice is padded to a MULTIPLE OF FOUR slice columns (slice_ptr counts the padded elements, multiples of
+ * 256), colbase has one entry per slice column as before (a column that is all padding: any valid column), and the two
+ * per-element arrays are packed four slice columns to a lane: element (slice column 4 G + j, lane l) of the slice starting
+ * at slice_ptr[s] sits at slice_ptr[s] + 256 G + 4 l + j of code[] and coldelta[] -- a lane reads its four codes as one
+ * uint32 and its four deltas as one 8-byte word (with 3 bytes per non-zero the kernel sits on the CU's per-lane load rate,
+ * not on the fabric: docs/design/12-round6.md).  The table is copied into LDS by every workgroup.
+ * Such an operand is READ-ONLY: dsea_op_update_vals and dsea_op_set_slab answer DSEA_ERR_UNSUPPORTED (the host layer
+ * re-codes in place, or rebuilds the fp64 layout once the values stop fitting 256 codes); dsea_op_sddmm works.        */
+int dsea_op_create_sell16v8(int64_t n, int64_t nslices, const int64_t *slice_ptr, const int32_t *colbase,
+                            const uint16_t *coldelta, const uint8_t *code, const double *table256, dsea_op_t *out);
+
 /* 3-point stencil + diagonal (reference examples/schrodinger1D.py:18-27):
  *     y[i] = coef * ((-2 x[i] + x[i+1]) + x[i-1]) + V[i] * x[i],  x[-1] = *halo_lo, x[n] = *halo_hi
  * (null halo pointer = 0, the Dirichlet padding of the reference).                            */

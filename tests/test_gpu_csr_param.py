@@ -315,3 +315,83 @@ def test_operator_without_a_stored_entry(layout):
     assert float(op(x).abs().max()) == 0.0
     assert op.sddmm(x, x).numel() == 0 and op.Aadjoint_to_valsadjoint_symmetric(x, x).numel() == 0
     op.refresh()
+
+
+def _few_valued(n=1037, seed=5, levels=7):
+    """ragged symmetric pattern (an empty row, n not a multiple of 64) whose entries take a handful of values, +0.0 and -0.0
+    among them"""
+    M = _ragged(n, seed)
+    rng = np.random.RandomState(seed)
+    table = np.concatenate([rng.randn(levels), [0.0, -0.0]])
+    M.data = table[rng.randint(0, len(table), size=M.nnz)]
+    return M
+
+
+def test_value_coded_operand_is_bit_identical_to_the_fp64_value_operand(monkeypatch):
+    """dsea_op_create_sell16v8 (8-bit value codes into a table of 256 doubles, metadata packed four slice columns to a lane)
+    against dsea_op_create_sell16 on the same matrix: mat-vec (+ shift, + x.y), sampled outer product, and a whole
+    DominantSparseSymeig forward + backward (fused Lanczos tail, CG) -- equal bit for bit"""
+    from dominantsparseeigenad_amd.engine import Workspace
+    M = _few_valued()
+    n = M.shape[0]
+    coded = CSROperator.from_scipy(M, dev(), values="coded")
+    plain = CSROperator.from_scipy(M, dev(), values="plain")
+    auto = CSROperator.from_scipy(M, dev())
+    assert coded._coded and auto._coded and not plain._coded and coded.col16
+    x = torch.from_numpy(normal_vector(n, 7900)).to(dev())
+    y = coded(x)
+    assert torch.equal(y, plain(x)) and torch.equal(y, auto(x))
+    assert rel(y.cpu(), torch.from_numpy(M @ x.cpu().numpy())) < 1e-13
+    # signed zeros survive the coding (the codes are taken from the bit patterns)
+    assert torch.equal(coded._vtab[coded._codes.long()].view(torch.int64).sort().values.unique(),
+                       torch.cat([torch.from_numpy(M.data), torch.zeros(1, dtype=F64)]).view(torch.int64).unique().to(dev()))
+    v1 = torch.from_numpy(normal_vector(n, 7901)).to(dev())
+    for sym in (False, True):
+        assert torch.equal(coded.sddmm(v1, x, symmetric=sym), plain.sddmm(v1, x, symmetric=sym))
+    # the TFIM matrix (21 per row at L = 12: the slice width 13 is padded to 16) through the whole primitive
+    monkeypatch.setattr(CG, "EPS_DEFAULT", 1e-12)
+    L, k = 12, 120
+    tf = TFIMOperator(L, dev(), g=torch.tensor([1.0], dtype=F64, device=dev()))
+    res = []
+    for values in ("coded", "plain"):
+        op = tf.to_csr(values=values)
+        assert op._coded == (values == "coded")
+        vals = op.vals.requires_grad_(True)            # (after the layout was chosen: 'auto' would keep a parameter uncoded)
+        symeig.setDominantSparseSymeig(op, op.Aadjoint_to_valsadjoint_symmetric)
+        t = unit(1 << L, 7902).to(dev())
+        with PatchRandn(7903):
+            E0, psi = symeig.DominantSparseSymeig.apply(vals, k, 1 << L, dev())
+            (gv,) = torch.autograd.grad(E0 + psi @ t, vals)
+        res.append((E0.detach().clone(), psi.detach().clone(), gv.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
+def test_value_coded_operand_selection_recoding_and_fallback():
+    """'auto' codes a matrix of few distinct values unless it is a parameter; an in-place change that keeps the values few is
+    re-coded in place (same handle), one that does not rebuilds the fp64 layout once -- each equal to a fresh operator"""
+    M = _few_valued(n=500, seed=9)
+    n = M.shape[0]
+    x = torch.from_numpy(normal_vector(n, 7910)).to(dev())
+    rp, ci = torch.from_numpy(M.indptr.astype("int64")).to(dev()), torch.from_numpy(M.indices.astype("int32")).to(dev())
+    leaf = torch.from_numpy(M.data.copy()).to(dev()).requires_grad_(True)
+    assert not CSROperator(rp, ci, leaf, n)._coded                               # a parameter: fp64 values
+    assert CSROperator(rp, ci, leaf, n, values="coded")._coded                   # ... unless asked for
+    many = torch.from_numpy(normal_vector(M.nnz, 7911)).to(dev())
+    assert not CSROperator(rp, ci, many, n)._coded
+    with pytest.raises(ValueError):
+        CSROperator(rp, ci, many, n, values="coded")
+    vals = torch.from_numpy(M.data.copy()).to(dev())
+    op = CSROperator(rp, ci, vals, n)
+    handle = op.handle.value
+    with torch.no_grad():
+        vals.mul_(-2.5)                                                          # still few values
+    assert torch.equal(op(x), CSROperator(rp, ci, vals.clone(), n, values="plain")(x))
+    assert op._coded and op.handle.value == handle
+    with torch.no_grad():
+        vals.copy_(many)                                                         # no longer codable
+    assert torch.equal(op(x), CSROperator(rp, ci, many.clone(), n, values="plain")(x))
+    assert not op._coded
+    with torch.no_grad():
+        vals.mul_(0.5)                                                           # from here on the ordinary refresh
+    assert torch.equal(op(x), CSROperator(rp, ci, (many * 0.5), n, values="plain")(x))

@@ -15,6 +15,7 @@ n = 1 << L
 g = torch.tensor([1.0], dtype=torch.float64, device=dev)
 op = TFIMOperator(L, dev, g=g)
 csr = op.to_csr(layout="csr")
+CODED_ONLY = "--coded" in sys.argv
 x = torch.randn(n, dtype=torch.float64, device=dev); y1 = torch.empty_like(x); y2 = torch.empty_like(x); y3 = torch.empty_like(x)
 out = torch.zeros(1, dtype=torch.float64, device=dev); ws = Workspace.get(n, 8, dev); st = _stream(dev)
 def timeit(fn, reps=200):
@@ -46,11 +47,25 @@ if "--csr" in sys.argv:
         lib.dsea_op_set_tuning(csr.handle, 2, G)
         tt = timeit(lambda: lib.dsea_spmv(csr.handle, ws.handle, _ptr(x), _ptr(y2), None, _ptr(out), None, st))
         print("CSR G=%d: %.1f us" % (G, tt))
-sell = op.to_csr(layout="sell", col16=False)
-sell16 = op.to_csr(layout="sell", col16=True)
+sell = op.to_csr(layout="sell", col16=False, values="plain")
+sell16 = op.to_csr(layout="sell", col16=True, values="plain")
 lib.dsea_op_set_tuning(sell.handle, 3, 1)
 lib.dsea_spmv(sell.handle, ws.handle, _ptr(x), _ptr(y3), None, _ptr(out), None, st)
 bytes16 = nnz * 10 + nnz // 64 * 4 + (n // 64 + 1) * 8 + 16 * n
+# value-coded operand (dsea_op_create_sell16v8): 16-bit column deltas + 8-bit value codes
+sellv = op.to_csr(layout="sell", col16=True, values="coded")
+bytesv = nnz * 3 + nnz // 64 * 4 + (n // 64 + 1) * 8 + 16 * n + 2048
+lib.dsea_spmv(sell16.handle, ws.handle, _ptr(x), _ptr(y3), None, _ptr(out), None, st)
+for rnd in range(2):
+    for label, o, moved in (("16-bit columns, fp64 values ", sell16, bytes16), ("16-bit columns, 8-bit codes ", sellv, bytesv)):
+        _lib.check(lib.dsea_op_set_tuning(o.handle, 4, 1), "tune")
+        tt = timeit(lambda: lib.dsea_spmv(o.handle, ws.handle, _ptr(x), _ptr(y2), None, None, None, st))
+        tc = timeit_cold(lambda: lib.dsea_spmv(o.handle, ws.handle, _ptr(x), _ptr(y2), None, None, None, st))
+        print("SELL-64 %s (%d distinct values): back to back %6.1f us | cold %6.1f us  (moves %d MB: %.0f GB/s cold)  bit-identical to the fp64-value operand: %s"
+              % (label, int((sellv._vtab != 0).sum()) if o is sellv else -1, tt, tc, moved / 1e6, moved / tc / 1e3, bool(torch.equal(y2, y3))))
+if CODED_ONLY:
+    sys.exit(0)
+lib.dsea_spmv(sell.handle, ws.handle, _ptr(x), _ptr(y3), None, _ptr(out), None, st)
 for rnd in range(int(os.environ.get('SELL_ROUNDS', '2'))):
     for label, o, U, xcd in (("round-5 kernel        ", sell, 1, 0), ("2 columns in flight   ", sell, 2, 0), ("4 columns in flight   ", sell, 4, 0),
                              ("8 columns in flight   ", sell, 8, 0), ("8 columns, XCD map    ", sell, 8, 1),
