@@ -289,9 +289,25 @@ def sweep_figures(dev, N=20, k=200, idxs=(25, 50, 75), warm=80):
     return out
 
 
+def _fused_tail_us(pa, ctx):
+    """(average us, launches) of the fused Lanczos tail of one step of ``pa``, from HIP events attached to the dispatches (as the
+    headline's roofline)"""
+    from dominantsparseeigenad_amd import _lib, engine
+    lib = _lib.load()
+    launches, total_ms = (c_int64 * 3)(), (c_double * 3)()
+    ws = engine.Workspace.get(pa.n, pa.k, ctx.dev)
+    _lib.check(lib.dsea_profile_begin(ws.handle, 3 * pa.k * 2 + 8), "dsea_profile_begin")
+    pa.step()
+    pa.barrier()
+    _lib.check(lib.dsea_profile_end(ws.handle, launches, total_ms), "dsea_profile_end")
+    return (total_ms[2] / launches[2] * 1e3, int(launches[2])) if launches[2] > 0 else (None, 0)
+
+
 def sell_operand_figures(ctx, args, steps=3):
     """SURVEY 8d C2 (ii) as a driver-observed figure: the headline workload with the operator given as an EXPLICIT matrix
-    (21 non-zeros per row, SELL-64 layout, fp64 values + int32 columns) instead of the matrix-free kernel"""
+    (21 non-zeros per row, SELL-64 layout, fp64 values + 16-bit column deltas) instead of the matrix-free kernel; beside it
+    the same matrix VALUE-CODED (dsea_op_create_sell16v8: what the host layer picks for a non-parameter operand of few
+    distinct values -- this one has 11)"""
     pa = Problem(ctx, 20, 200, False, operator="sell")
     try:
         dt, E0, _ = pa.measure(steps, 1)
@@ -300,21 +316,12 @@ def sell_operand_figures(ctx, args, steps=3):
         n, k = pa.n, pa.k
         operand = 12.0 * 21 * n * (k + m + 1)
         moved = traffic_model_bytes(n, k, m, (k - 1) if pa.use_shadow else 0) + operand
-        # the fused Lanczos tail on this operand, per launch, from HIP events attached to the dispatches (as the headline's roofline)
         tail = None
         try:
-            from dominantsparseeigenad_amd import _lib, engine
-            lib = _lib.load()
-            launches, total_ms = (c_int64 * 3)(), (c_double * 3)()
-            ws = engine.Workspace.get(n, k, ctx.dev)
-            _lib.check(lib.dsea_profile_begin(ws.handle, 3 * k * 2 + 8), "dsea_profile_begin")
-            pa.step()
-            pa.barrier()
-            _lib.check(lib.dsea_profile_end(ws.handle, launches, total_ms), "dsea_profile_end")
-            if launches[2] > 0:
-                us = total_ms[2] / launches[2] * 1e3
+            us, cnt = _fused_tail_us(pa, ctx)
+            if us is not None:
                 alg = 12.0 * 21 * n + 8.0 * (n // 64 + 1) + 16.0 * n        # 12 B per non-zero + two vectors
-                tail = {"kernel": "k_spmv_sell<fused Lanczos tail>", "avg_launch_us": round(us, 2), "launches": int(launches[2]),
+                tail = {"kernel": "k_spmv_sell<fused Lanczos tail>", "avg_launch_us": round(us, 2), "launches": cnt,
                         "algorithmic_bytes_per_launch": alg, "algorithmic_GBs": round(alg / us / 1e3, 1),
                         "frac_of_hbm_peak_on_algorithmic_bytes": round(alg / us / 1e3 / HBM_PEAK_GBS, 4),
                         "columns": "16-bit deltas" if getattr(pa.A_operand, "col16", False) else "int32",
@@ -322,15 +329,34 @@ def sell_operand_figures(ctx, args, steps=3):
                                 "alone: profiles/r06_kbench_csr.txt"}
         except Exception as exc:  # noqa: BLE001
             tail = "failed: %s: %s" % (type(exc).__name__, exc)
-        return {"workload": pa.describe(), "ms_per_step": round(ms, 3), "steps": steps, "cg_iterations": int(m),
-                "fused_tail": tail,
-                "bytes_per_step": moved, "GBs": round(moved / (ms * 1e-3) / 1e9, 1),
-                "frac_of_hbm_peak": round(moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "E0_per_site_minus_closed_form": E0.item() / 20 - analytic_E0_per_site(20, 1.0),
-                "bytes_note": "the matrix-free step's traffic model + the matrix stream: 12 B per non-zero, 21 per row, in each "
-                              "of the %d mat-vecs" % (k + m + 1)}
+        out = {"workload": pa.describe(), "ms_per_step": round(ms, 3), "steps": steps, "cg_iterations": int(m),
+               "fused_tail": tail,
+               "bytes_per_step": moved, "GBs": round(moved / (ms * 1e-3) / 1e9, 1),
+               "frac_of_hbm_peak": round(moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "E0_per_site_minus_closed_form": E0.item() / 20 - analytic_E0_per_site(20, 1.0),
+               "bytes_note": "the matrix-free step's traffic model + the matrix stream: 12 B per non-zero, 21 per row, in each "
+                             "of the %d mat-vecs" % (k + m + 1)}
     finally:
         pa.release()
+    try:
+        pc = Problem(ctx, 20, 200, False, operator="sell-coded")
+        try:
+            dt, E0c, _ = pc.measure(steps, 1)
+            us, cnt = _fused_tail_us(pc, ctx)
+            opv = pc.A_operand
+            out["value_coded"] = {
+                "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "cg_iterations": int(pc.cg_iterations()),
+                "fused_tail_avg_launch_us": None if us is None else round(us, 2),
+                "distinct_values": int((opv._vtab != 0).sum().item()), "bytes_per_stored_element": 3.0625,
+                "E0_equal_to_the_fp64_value_operand": bool(E0c.item() == E0.item()),
+                "note": "same matrix, values as 8-bit codes into a 256-entry fp64 table, slices padded 21 -> 24 columns; products "
+                        "formed with the same doubles in the same order (bit-identical results); NOT a roofline figure on the "
+                        "12 B / non-zero the general layout is priced on -- it moves 3.06"}
+        finally:
+            pc.release()
+    except Exception as exc:  # noqa: BLE001
+        out["value_coded"] = "failed: %s: %s" % (type(exc).__name__, exc)
+    return out
 
 
 class _ReferenceStyleTFIM:
@@ -765,8 +791,10 @@ class Problem:
             self.op = TFIMOperator(L, dev)
             self.op.g = self.g
             self.A_operand = self.op.H
-            if operator in ("sell", "csr"):
-                self.A_operand = self.op.to_csr(layout=operator)      # explicit matrix (values fixed at the current g)
+            if operator in ("sell", "csr", "sell-coded"):
+                # explicit matrix (values fixed at the current g); "sell" = the general layout, fp64 values
+                self.A_operand = self.op.to_csr(layout="csr" if operator == "csr" else "sell",
+                                                values="coded" if operator == "sell-coded" else "plain")
             elif operator == "callable-native":
                 # the reference's calling convention (examples/TFIM/E0.py:59-62): an OPAQUE Python callable -- here a lambda
                 # around the native mat-vec, so the loops cannot see the operator and every other vector operation is a phase call
@@ -1042,7 +1070,7 @@ def parse_args():
                          "passes (~20 s each) before the timed run; the newest committed profiles/r<NN>_pmc_traffic.json is "
                          "quoted instead")
     ap.add_argument("--rpl", type=int, default=0)
-    ap.add_argument("--operator", choices=["matrix-free", "sell", "csr"], default="matrix-free",
+    ap.add_argument("--operator", choices=["matrix-free", "sell", "sell-coded", "csr"], default="matrix-free",
                     help="operand form of the TFIM operator at N=1: native matrix-free kernel (headline) or the "
                          "explicit 21-nnz/row matrix in SELL-64 / CSR layout")
     ap.add_argument("--reorth", choices=["full", "none", "partial"], default="full",
