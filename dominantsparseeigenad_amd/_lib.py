@@ -67,6 +67,7 @@ _SIGNATURES = {
     "dsea_op_create_csr": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
     "dsea_op_create_sell": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
     "dsea_op_create_sell16": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
+    "dsea_op_create_sell16p2": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
     "dsea_op_create_sell16v8": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
     "dsea_op_create_stencil3": (c_int, [c_int64, c_double, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
     "dsea_op_create_dense": (c_int, [c_int64, c_void_p, c_int64, c_int, POINTER(c_void_p)]),

@@ -447,6 +447,13 @@ int dsea_op_create_sell(int64_t n, int64_t nslices, const int64_t* slice_ptr, co
   return DSEA_OK;
 }
 
+int dsea_op_create_sell16p2(int64_t n, int64_t nslices, const int64_t* slice_ptr, const int32_t* colbase,
+                            const uint16_t* coldelta, const double* vals, dsea_op_t* out) {
+  const int rc = dsea_op_create_sell16(n, nslices, slice_ptr, colbase, coldelta, vals, out);
+  if (rc == DSEA_OK) (*out)->d.sell.pack2 = 1;
+  return rc;
+}
+
 int dsea_op_create_sell16v8(int64_t n, int64_t nslices, const int64_t* slice_ptr, const int32_t* colbase,
                             const uint16_t* coldelta, const uint8_t* code, const double* table256, dsea_op_t* out) {
   if (!out || n < 1 || nslices != (n + 63) / 64 || !slice_ptr || !colbase || !coldelta || !code || !table256) return DSEA_ERR_ARG;

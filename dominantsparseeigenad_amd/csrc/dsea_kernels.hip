@@ -1785,7 +1785,54 @@ __device__ __forceinline__ double sell_row_sum_vc(const SellParams& p, const dou
   return s0 + s1;
 }
 
-template <bool FUSED, int MODE, int UN, bool C16, bool NT = false, bool VC = false>
+// fp64 values with the per-element arrays packed TWO slice columns to a lane (dsea_op_create_sell16p2): element (column
+// 2 G + j, lane l) of a slice sits at 128 G + 2 l + j -- a lane reads its two values as one 16-byte load and its two column
+// deltas as one uint32: 4 instead of 6 memory instructions per two non-zeros of a row (section 12.9: beside the matrix stream
+// the kernel sits on the rate at which a CU takes per-lane loads).  Same products in the same order as sell_row_sum<.., 8, true>.
+template <int MODE>
+__device__ __forceinline__ double sell_row_sum_p2(const SellParams& p, const double* __restrict__ x, int64_t b0, int64_t b1,
+                                                  int lane) {
+  double s0 = 0.0, s1 = 0.0;
+  const int width = (int)((b1 - b0) >> 6);     // even
+  const double2* __restrict__ val2 = reinterpret_cast<const double2*>(p.vals + b0) + lane;
+  const uint32_t* __restrict__ del2 = reinterpret_cast<const uint32_t*>(p.col16 + b0) + lane;
+  int cbl = 0, kb = -64;
+  for (int k0 = 0; k0 < width; k0 += 8) {
+    if ((k0 & ~63) != kb) {
+      kb = k0 & ~63;
+      const int64_t cbi = (b0 >> 6) + kb + lane;
+      cbl = cbi < (b1 >> 6) ? p.colbase[cbi] : 0;
+    }
+    double2 v[4];
+    uint32_t d[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      v[g] = make_double2(0.0, 0.0);
+      d[g] = 0u;
+      if (k0 + 2 * g < width) {
+        v[g] = val2[((k0 >> 1) + g) * 64];
+        d[g] = del2[((k0 >> 1) + g) * 64];
+      }
+    }
+    double gx[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = __builtin_amdgcn_readlane(cbl, (k0 + u) & 63) + (int)((d[u >> 1] >> (16 * (u & 1))) & 0xffffu);
+      gx[u] = (k0 + (u & ~1) < width) ? sell_gather<MODE>(p, x, c) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (k0 + (u & ~1) < width) {
+        const double vv = (u & 1) ? v[u >> 1].y : v[u >> 1].x;
+        if (u & 1) s1 = fma(vv, gx[u], s1);
+        else s0 = fma(vv, gx[u], s0);
+      }
+    }
+  }
+  return s0 + s1;
+}
+
+template <bool FUSED, int MODE, int UN, bool C16, bool NT = false, bool VC = false, bool P2 = false>
 __global__ __launch_bounds__(256) void k_spmv_sell(SellParams p, const double* __restrict__ x,
                                                    double* __restrict__ y, const double* __restrict__ shift,
                                                    const double* __restrict__ skip, double* __restrict__ P,
@@ -1822,9 +1869,11 @@ __global__ __launch_bounds__(256) void k_spmv_sell(SellParams p, const double* _
   // stream of the wave's first slice instead of in front of it; nothing has been written when a breakdown returns.
   int64_t sl = lin0 < ntrip ? sell_slice_of(p, lin0) : p.nslices;
   double v0 = 0.0;
+  constexpr bool p2 = P2;
   if (sl < p.nslices)
-    v0 = VC ? sell_row_sum_vc(p, x, p.slice_ptr[sl], p.slice_ptr[sl + 1], lane, vt)
-            : sell_row_sum<MODE, UN, C16, NT>(p, x, p.slice_ptr[sl], p.slice_ptr[sl + 1], lane);
+    v0 = VC   ? sell_row_sum_vc(p, x, p.slice_ptr[sl], p.slice_ptr[sl + 1], lane, vt)
+         : p2 ? sell_row_sum_p2<MODE>(p, x, p.slice_ptr[sl], p.slice_ptr[sl + 1], lane)
+              : sell_row_sum<MODE, UN, C16, NT>(p, x, p.slice_ptr[sl], p.slice_ptr[sl + 1], lane);
   // (measured and dropped, round 6 -- every variant same box, alternated: every WAVE summing the partials itself, after the row
   //  sums 52 -> 59 us, with its loads in front of the matrix stream 52 -> 57-58 us; the block version with its loads in front of
   //  the stream: no change.  With beta a constant the tail takes 49 us, without its q / shadow stores 50 / 51: profiles/r06_kbench_csr.txt)
@@ -1833,8 +1882,9 @@ __global__ __launch_bounds__(256) void k_spmv_sell(SellParams p, const double* _
   for (int64_t lin = lin0 + (int64_t)gridDim.x * 4; lin < ntrip; lin += (int64_t)gridDim.x * 4) {
     sl = sell_slice_of(p, lin);
     if (sl >= p.nslices) continue;
-    finish(sl, VC ? sell_row_sum_vc(p, x, p.slice_ptr[sl], p.slice_ptr[sl + 1], lane, vt)
-                  : sell_row_sum<MODE, UN, C16, NT>(p, x, p.slice_ptr[sl], p.slice_ptr[sl + 1], lane));
+    finish(sl, VC   ? sell_row_sum_vc(p, x, p.slice_ptr[sl], p.slice_ptr[sl + 1], lane, vt)
+               : p2 ? sell_row_sum_p2<MODE>(p, x, p.slice_ptr[sl], p.slice_ptr[sl + 1], lane)
+                    : sell_row_sum<MODE, UN, C16, NT>(p, x, p.slice_ptr[sl], p.slice_ptr[sl + 1], lane));
   }
   if (P) {
     __syncthreads();
@@ -1876,7 +1926,7 @@ __global__ __launch_bounds__(256) void k_sell_update_vals(SellParams p, const in
     __builtin_amdgcn_wave_barrier();
     int64_t k = 0;
     for (int64_t e = b0 + lane; e < b1; e += 64, ++k)
-      vals_sell[e] = k < len ? (staged ? seg[w][lo - lo0 + k] : vals_csr[lo + k]) : 0.0;
+      vals_sell[p.pack2 ? b0 + 128 * (k >> 1) + 2 * lane + (k & 1) : e] = k < len ? (staged ? seg[w][lo - lo0 + k] : vals_csr[lo + k]) : 0.0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
@@ -1906,7 +1956,9 @@ __global__ __launch_bounds__(256) void k_sell_sddmm(SellParams p, const int64_t*
     for (int64_t e = b0 + lane; e < b1; e += 64, ++k) {
       if (k < len) {
         // (value-coded operand: its 16-bit deltas are packed four slice columns to a lane, see sell_row_sum_vc)
-        const int64_t e16 = p.code8 ? ((e & ~(int64_t)255) | ((e & 63) << 2) | ((e >> 6) & 3)) : e;
+        const int64_t e16 = p.code8   ? ((e & ~(int64_t)255) | ((e & 63) << 2) | ((e >> 6) & 3))
+                            : p.pack2 ? ((e & ~(int64_t)127) | ((e & 63) << 1) | ((e >> 6) & 1))
+                                      : e;
         const int c = p.col16 ? p.colbase[e >> 6] + (int)p.col16[e16] : p.colidx[e];
         double g = __dmul_rn(a1, sell_gather<MODE>(p, v2, c));
         if (SYM) g = __dmul_rn(0.5, __dadd_rn(g, __dmul_rn(sell_gather<MODE>(p, v1, c), a2)));
@@ -3139,7 +3191,10 @@ int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shif
       TfimFusedArgs fa0 = {nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
 #define SELL_GO(F, M, U, C) KLAUNCH(ev, (k_spmv_sell<F, M, U, C>), (unsigned)nb, 256, st, p, x, y, shift, skip, P, fa0)
       const bool c16 = p.col16 != nullptr;
-      if (p.mode == 1) {
+#define SELL_P2(M) KLAUNCH(ev, (k_spmv_sell<false, M, 8, true, false, false, true>), (unsigned)nb, 256, st, p, x, y, shift, skip, P, fa0)
+      if (p.pack2) {
+        if (p.mode == 1) SELL_P2(1); else if (p.mode == 2) SELL_P2(2); else SELL_P2(0);
+      } else if (p.mode == 1) {
         if (c16) SELL_GO(false, 1, 8, true); else SELL_GO(false, 1, 4, false);
       } else if (p.mode == 2) {
         if (c16) SELL_GO(false, 2, 8, true); else SELL_GO(false, 2, 4, false);
@@ -3156,6 +3211,7 @@ int launch_spmv(const OpDesc& op, const double* x, double* y, const double* shif
         }
       }
 #undef SELL_GO
+#undef SELL_P2
       return (int)nb;
     }
     case OP_SYMDENSE: {
@@ -3203,7 +3259,9 @@ int launch_tfim_fused(const OpDesc& op, const double* r, const double* nP, int n
     if (nb > DSEA_MAX_TFIM_BLOCKS) nb = DSEA_MAX_TFIM_BLOCKS;
     if (p.mode != 0) return -1;                         // slab of a row-partitioned matrix: the unfused sequence
 #define SELL_GO(U, C) KLAUNCH(ev, (k_spmv_sell<true, 0, U, C>), (unsigned)nb, 256, st, p, r, y, nullc, nullc, P, fa)
-    if (p.col16) {
+    if (p.pack2) {
+      KLAUNCH(ev, (k_spmv_sell<true, 0, 8, true, false, false, true>), (unsigned)nb, 256, st, p, r, y, nullc, nullc, P, fa);
+    } else if (p.col16) {
       if (p.code8) KLAUNCH(ev, (k_spmv_sell<true, 0, 8, true, false, true>), (unsigned)nb, 256, st, p, r, y, nullc, nullc, P, fa);
       else if (p.nt) KLAUNCH(ev, (k_spmv_sell<true, 0, 8, true, true>), (unsigned)nb, 256, st, p, r, y, nullc, nullc, P, fa);
       else SELL_GO(8, true);

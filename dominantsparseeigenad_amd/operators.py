@@ -285,6 +285,11 @@ def sell_positions(rowptr, n, slice_ptr, packed=False):
     return slice_ptr[rows // 64] + k * 64 + (rows % 64)
 
 
+def pack2(a):
+    """... -> two slice columns to a lane (dsea_op_create_sell16p2; slices hold multiples of 128)"""
+    return a.view(-1, 2, 64).permute(0, 2, 1).contiguous().view(-1)
+
+
 def pack4(a):
     """a per-element SELL array in slice-column-major order -> four slice columns to a lane (slices hold multiples of 256)"""
     return a.view(-1, 4, 64).permute(0, 2, 1).contiguous().view(-1)
@@ -383,7 +388,7 @@ class CSROperator:
                 self._sell = (slice_ptr,) + tuple(cols) + (None,)
                 keep = self._sell + (self._codes, self._vtab)
             else:
-                slice_ptr, cols, total = sell_layout(self.rowptr, self.colidx, self.n, col16)
+                slice_ptr, cols, total = self._plain_layout(col16)
                 s_vals = torch.zeros(max(total, 1), dtype=F64, device=self.device)
                 raw = self._create_plain(slice_ptr, cols, s_vals)
                 self._sell = (slice_ptr,) + tuple(cols) + (s_vals,)
@@ -411,13 +416,26 @@ class CSROperator:
         else:
             self.refresh()
 
+    def _plain_layout(self, col16):
+        """(slice_ptr, columns, total) of the fp64-value SELL layout: with 16-bit deltas the per-element arrays are packed two
+        slice columns to a lane (include/dsea.h dsea_op_create_sell16p2; DSEA_SELL_PACK2=0: the unpacked layout, for A/B)"""
+        import os as _os
+        self._pack2 = False
+        if col16 is not False and _os.environ.get("DSEA_SELL_PACK2", "1") != "0":
+            slice_ptr, cols, total = sell_layout(self.rowptr, self.colidx, self.n, col16, pad_cols=2)
+            if len(cols) == 2:
+                self._pack2 = True
+                return slice_ptr, (cols[0], pack2(cols[1])), total
+        return sell_layout(self.rowptr, self.colidx, self.n, col16)
+
     def _create_plain(self, slice_ptr, cols, s_vals):
         """SELL operand with fp64 values on this pattern (16- or 32-bit columns as ``cols`` has them)"""
         raw, lib, nsl = c_void_p(), _lib.load(), (self.n + 63) // 64
         if len(cols) == 2:
-            check(lib.dsea_op_create_sell16(self.n, nsl, c_void_p(slice_ptr.data_ptr()), c_void_p(cols[0].data_ptr()),
-                                            c_void_p(cols[1].data_ptr()), c_void_p(s_vals.data_ptr()), byref(raw)),
-                  "dsea_op_create_sell16")
+            create = lib.dsea_op_create_sell16p2 if getattr(self, "_pack2", False) else lib.dsea_op_create_sell16
+            check(create(self.n, nsl, c_void_p(slice_ptr.data_ptr()), c_void_p(cols[0].data_ptr()),
+                         c_void_p(cols[1].data_ptr()), c_void_p(s_vals.data_ptr()), byref(raw)),
+                  "dsea_op_create_sell16(p2)")
         else:
             check(lib.dsea_op_create_sell(self.n, nsl, c_void_p(slice_ptr.data_ptr()), c_void_p(cols[0].data_ptr()),
                                           c_void_p(s_vals.data_ptr()), byref(raw)), "dsea_op_create_sell")
@@ -493,7 +511,7 @@ class CSROperator:
             self._vtab.copy_(coded[0])
             self._codes[sell_positions(self.rowptr, self.n, self._sell[0], packed=True)] = coded[1]
             return
-        slice_ptr, cols, total = sell_layout(self.rowptr, self.colidx, self.n, True)
+        slice_ptr, cols, total = self._plain_layout(True)
         s_vals = torch.zeros(max(total, 1), dtype=F64, device=self.device)
         raw = self._create_plain(slice_ptr, cols, s_vals)
         self._sell = (slice_ptr,) + tuple(cols) + (s_vals,)

@@ -161,6 +161,16 @@ int dsea_op_create_sell(int64_t n, int64_t nslices, const int64_t *slice_ptr, co
 int dsea_op_create_sell16(int64_t n, int64_t nslices, const int64_t *slice_ptr, const int32_t *colbase,
                           const uint16_t *coldelta, const double *vals, dsea_op_t *out);
 
+/* dsea_op_create_sell16 with the per-element arrays PACKED TWO slice columns to a lane: every slice is padded to an EVEN
+ * number of slice columns (slice_ptr counts the padded elements, multiples of 128) and element (slice column 2 G + j, lane l)
+ * of the slice starting at slice_ptr[s] sits at slice_ptr[s] + 128 G + 2 l + j of vals[] and coldelta[]; colbase as before.
+ * A lane then reads its two values as one 16-byte load and its two deltas as one uint32 -- 4 instead of 6 memory
+ * instructions per two non-zeros of a row (beside the matrix stream the kernel sits on the CU's per-lane load rate,
+ * docs/design/12-round6.md section 12.9).  Same products in the same order; everything dsea_op_create_sell16 supports
+ * (dsea_op_update_vals, dsea_op_sddmm, dsea_op_set_slab) works on it.                                                        */
+int dsea_op_create_sell16p2(int64_t n, int64_t nslices, const int64_t *slice_ptr, const int32_t *colbase,
+                            const uint16_t *coldelta, const double *vals, dsea_op_t *out);
+
 /* VALUE-CODED SELL-64 for operands whose stored entries take few distinct values (lattice Hamiltonians held as explicit
  * matrices: couplings, fields and a handful of diagonal levels -- the 21-nnz/row TFIM matrix at L = 20 has 11): the value of an
  * element is table256[code], a uint8 per element into 256 doubles (unused entries: anything finite; padding elements code a

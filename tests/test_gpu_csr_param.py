@@ -395,3 +395,31 @@ def test_value_coded_operand_selection_recoding_and_fallback():
     with torch.no_grad():
         vals.mul_(0.5)                                                           # from here on the ordinary refresh
     assert torch.equal(op(x), CSROperator(rp, ci, (many * 0.5), n, values="plain")(x))
+
+
+def test_packed_and_unpacked_fp64_value_layouts_are_bit_identical(monkeypatch):
+    """dsea_op_create_sell16p2 (the default with 16-bit deltas: values and deltas packed two slice columns to a lane, slices
+    padded to even widths) against dsea_op_create_sell16 (DSEA_SELL_PACK2=0): mat-vec, in-place refresh, sampled outer
+    product -- odd and even slice widths, an empty row, n not a multiple of 64"""
+    M = _ragged()
+    n = M.shape[0]
+    monkeypatch.setenv("DSEA_SELL_PACK2", "0")
+    flat = CSROperator.from_scipy(M, dev())
+    monkeypatch.setenv("DSEA_SELL_PACK2", "1")
+    packed = CSROperator.from_scipy(M, dev())
+    assert packed._pack2 and not flat._pack2 and packed.col16 and flat.col16
+    assert packed._sell_total >= flat._sell_total and packed._sell_total % 128 == 0
+    x = torch.from_numpy(normal_vector(n, 7920)).to(dev())
+    v1 = torch.from_numpy(normal_vector(n, 7921)).to(dev())
+    assert torch.equal(packed(x), flat(x))
+    for sym in (False, True):
+        assert torch.equal(packed.sddmm(v1, x, symmetric=sym), flat.sddmm(v1, x, symmetric=sym))
+    newv = torch.from_numpy(normal_vector(M.nnz, 7922)).to(dev())
+    packed.vals.copy_(newv)
+    flat.vals.copy_(newv)
+    assert torch.equal(packed(x), flat(x))
+    M2 = M.copy()
+    M2.data = newv.cpu().numpy()
+    assert rel(packed(x).cpu(), torch.from_numpy(M2 @ x.cpu().numpy())) < 1e-13
+    twin = packed.with_vals(newv * 2.0)               # (the hooks' backward builds operators on the same structure)
+    assert torch.equal(twin(x), CSROperator(packed.rowptr, packed.colidx, newv * 2.0, n)(x))

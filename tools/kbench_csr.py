@@ -47,8 +47,12 @@ if "--csr" in sys.argv:
         lib.dsea_op_set_tuning(csr.handle, 2, G)
         tt = timeit(lambda: lib.dsea_spmv(csr.handle, ws.handle, _ptr(x), _ptr(y2), None, _ptr(out), None, st))
         print("CSR G=%d: %.1f us" % (G, tt))
+os.environ["DSEA_SELL_PACK2"] = "0"
 sell = op.to_csr(layout="sell", col16=False, values="plain")
 sell16 = op.to_csr(layout="sell", col16=True, values="plain")
+os.environ["DSEA_SELL_PACK2"] = "1"
+sell16p = op.to_csr(layout="sell", col16=True, values="plain")      # per-element arrays packed two slice columns to a lane
+assert sell16p._pack2 and not sell16._pack2
 lib.dsea_op_set_tuning(sell.handle, 3, 1)
 lib.dsea_spmv(sell.handle, ws.handle, _ptr(x), _ptr(y3), None, _ptr(out), None, st)
 bytes16 = nnz * 10 + nnz // 64 * 4 + (n // 64 + 1) * 8 + 16 * n
@@ -57,7 +61,8 @@ sellv = op.to_csr(layout="sell", col16=True, values="coded")
 bytesv = nnz * 3 + nnz // 64 * 4 + (n // 64 + 1) * 8 + 16 * n + 2048
 lib.dsea_spmv(sell16.handle, ws.handle, _ptr(x), _ptr(y3), None, _ptr(out), None, st)
 for rnd in range(2):
-    for label, o, moved in (("16-bit columns, fp64 values ", sell16, bytes16), ("16-bit columns, 8-bit codes ", sellv, bytesv)):
+    for label, o, moved in (("16-bit columns, fp64 values ", sell16, bytes16), ("the same, packed by two     ", sell16p, bytes16 * 22 // 21),
+                            ("16-bit columns, 8-bit codes ", sellv, bytesv)):
         _lib.check(lib.dsea_op_set_tuning(o.handle, 4, 1), "tune")
         tt = timeit(lambda: lib.dsea_spmv(o.handle, ws.handle, _ptr(x), _ptr(y2), None, None, None, st))
         tc = timeit_cold(lambda: lib.dsea_spmv(o.handle, ws.handle, _ptr(x), _ptr(y2), None, None, None, st))
