@@ -305,7 +305,8 @@ def _fused_tail_us(pa, ctx):
 
 def sell_operand_figures(ctx, args, steps=3):
     """SURVEY 8d C2 (ii) as a driver-observed figure: the headline workload with the operator given as an EXPLICIT matrix
-    (21 non-zeros per row, SELL-64 layout, fp64 values + 16-bit column deltas) instead of the matrix-free kernel; beside it
+    (21 non-zeros per row, SELL-64 layout, fp64 values + 16-bit column deltas, dsea_op_create_sell16p2) instead of the matrix-free
+    kernel; beside it
     the same matrix VALUE-CODED (dsea_op_create_sell16v8: what the host layer picks for a non-parameter operand of few
     distinct values -- this one has 11)"""
     pa = Problem(ctx, 20, 200, False, operator="sell")
@@ -324,7 +325,9 @@ def sell_operand_figures(ctx, args, steps=3):
                 tail = {"kernel": "k_spmv_sell<fused Lanczos tail>", "avg_launch_us": round(us, 2), "launches": cnt,
                         "algorithmic_bytes_per_launch": alg, "algorithmic_GBs": round(alg / us / 1e3, 1),
                         "frac_of_hbm_peak_on_algorithmic_bytes": round(alg / us / 1e3 / HBM_PEAK_GBS, 4),
-                        "columns": "16-bit deltas" if getattr(pa.A_operand, "col16", False) else "int32",
+                        "columns": ("16-bit deltas" + (", values and deltas packed two slice columns to a lane"
+                                                       if getattr(pa.A_operand, "_pack2", False) else ""))
+                        if getattr(pa.A_operand, "col16", False) else "int32",
                         "note": "in situ (Infinity Cache swept by the basis passes; also writes q and its bf16 shadow); the kernel "
                                 "alone: profiles/r06_kbench_csr.txt"}
         except Exception as exc:  # noqa: BLE001
