@@ -43,6 +43,10 @@ def make_case():
         if rng.rand() < 0.3 and n > 3:      # some completely empty rows / columns
             M = M.tolil(); idx = rng.randint(0, n, size=max(1, n // 10)); M[idx, :] = 0; M[:, idx] = 0; M = M.tocsr()
         M = M.tocsr(); M.eliminate_zeros()
+        if kind == "csr" and rng.rand() < 0.35 and M.nnz:      # few distinct values: the host layer value-codes such an operand
+            levels = rng.rand(int(rng.randint(2, 40))) + 0.25
+            M.data = levels[rng.randint(0, len(levels), size=M.nnz)]
+            M = ((M + M.T) * 0.5).tocsr()                      # (still few: at most len(levels)^2 averages)
         Md = torch.from_numpy(M.toarray())
         return kind, n, CSROperator.from_scipy(M, dev, layout="sell" if kind == "csr" else "csr"), (lambda v, Md=Md: Md @ v), float(Md.abs().sum(1).max())
     if kind == "tfim":
