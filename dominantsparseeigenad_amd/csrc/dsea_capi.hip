@@ -167,6 +167,8 @@ int dsea_op_set_tuning(dsea_op_t op, int key, int value) {
       return DSEA_OK;
     case DSEA_TUNE_SELL_NT:
       if (op->d.kind != OP_SELL || (value != 0 && value != 1)) return DSEA_ERR_ARG;
+      // (an A/B switch of the unpacked 16-bit layout: the packed and the value-coded kernels have no such variant)
+      if (value && (op->d.sell.pack2 || op->d.sell.code8)) return DSEA_ERR_UNSUPPORTED;
       op->d.sell.nt = value;
       return DSEA_OK;
     default: return DSEA_ERR_ARG;

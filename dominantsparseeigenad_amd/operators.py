@@ -408,6 +408,8 @@ class CSROperator:
             raise ValueError("layout must be 'sell' or 'csr'")
         self._H = _NativeView(_Handle(raw, self.n, keep))
         import os as _os
+        if layout == "sell" and _os.environ.get("DSEA_SELL_NT", "") == "1" and (getattr(self, "_pack2", False) or self._coded):
+            raise ValueError("DSEA_SELL_NT=1 is an A/B switch of the unpacked layout: set DSEA_SELL_PACK2=0 and DSEA_SELL_VALUES=plain")
         if layout == "sell" and _os.environ.get("DSEA_SELL_NT", "") in ("0", "1"):     # A/B switch (tools/gpu_evidence.sh abenv)
             check(lib.dsea_op_set_tuning(raw, _lib.TUNE_SELL_NT, int(_os.environ["DSEA_SELL_NT"])), "dsea_op_set_tuning")
         self._seen_version = None

@@ -203,7 +203,8 @@ int dsea_op_create_stencil3(int64_t n, double coef, const double *V_dev, const d
 #define DSEA_TUNE_SELL_UNROLL 3
 /* SELL mat-vec: 1 = XCD-contiguous slice map (workgroup b works on eighth b % 8 of the slices), 0 = round-robin (default) */
 #define DSEA_TUNE_SELL_XCD_MAP 4
-/* SELL mat-vec with 16-bit columns: 1 = non-temporal loads of the matrix stream (values, column deltas), 0 = default policy */
+/* SELL mat-vec with 16-bit columns (dsea_op_create_sell16 only; DSEA_ERR_UNSUPPORTED on the packed / value-coded layouts):
+ * 1 = non-temporal loads of the matrix stream (values, column deltas), 0 = default policy */
 #define DSEA_TUNE_SELL_NT 5
 int dsea_op_set_tuning(dsea_op_t op, int key, int value);
 
