@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """TFIM as an explicit device matrix (21 nnz/row, fp64 values + int32 columns): mat-vec time of the CSR kernels and of the
 SELL-64 kernel at every unroll setting (1 = the round-5 kernel) vs the matrix-free kernel, plus the two kernels that make
-the matrix a parameter (dsea_op_sddmm, dsea_op_update_vals).  Evidence file: profiles/r06_kbench_csr.txt"""
+the matrix a parameter (dsea_op_sddmm, dsea_op_update_vals); first of all the three 16-bit-column layouts side by side --
+unpacked (dsea_op_create_sell16), packed two slice columns to a lane (dsea_op_create_sell16p2, the default), value-coded
+(dsea_op_create_sell16v8) -- back to back and from a cold Infinity Cache (``--coded``: only that).
+Evidence file: profiles/r06_kbench_csr.txt"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
