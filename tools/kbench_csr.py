@@ -71,6 +71,14 @@ for rnd in range(2):
         tc = timeit_cold(lambda: lib.dsea_spmv(o.handle, ws.handle, _ptr(x), _ptr(y2), None, None, None, st))
         print("SELL-64 %s (%d distinct values): back to back %6.1f us | cold %6.1f us  (moves %d MB: %.0f GB/s cold)  bit-identical to the fp64-value operand: %s"
               % (label, int((sellv._vtab != 0).sum()) if o is sellv else -1, tt, tc, moved / 1e6, moved / tc / 1e3, bool(torch.equal(y2, y3))))
+# the parameter kernels on the DEFAULT layout (packed by two): sampled outer product and in-place refresh
+_v1 = torch.randn(n, dtype=torch.float64, device=dev); _gb = torch.empty(nnz, dtype=torch.float64, device=dev)
+_rp = c_void_p(sell16p.rowptr.data_ptr())
+for flags, name in ((0, "plain"), (2, "symmetric")):
+    tt = timeit(lambda: lib.dsea_op_sddmm(sell16p.handle, _rp, _ptr(_v1), _ptr(x), 1.0, flags, _ptr(_gb), st), reps=50)
+    print("dsea_op_sddmm (%s, packed SELL): %.1f us" % (name, tt))
+tt = timeit(lambda: lib.dsea_op_update_vals(sell16p.handle, _rp, _ptr(sell16p.vals), st), reps=50)
+print("dsea_op_update_vals (packed SELL): %.1f us  (%.0f GB/s of 16 B per non-zero)" % (tt, nnz * 16 / tt / 1e3))
 if CODED_ONLY:
     sys.exit(0)
 lib.dsea_spmv(sell.handle, ws.handle, _ptr(x), _ptr(y3), None, _ptr(out), None, st)
