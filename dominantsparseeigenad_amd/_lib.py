@@ -27,6 +27,7 @@ ERR_SECOND_PASS = -11
 ERR_UNSUPPORTED = -6
 COMM_ID_BYTES = 128
 TUNE_TFIM_TILE_LOG2, TUNE_CSR_GROUP, TUNE_SELL_UNROLL, TUNE_SELL_XCD_MAP, TUNE_SELL_NT = 1, 2, 3, 4, 5
+TUNE_SELL_MAX_WIDTH = 6
 SDDMM_ACCUMULATE, SDDMM_SYMMETRIC = 1, 2
 POP_OVERLAP, POP_PAIRWISE, POP_NO_EXCHANGE, POP_CG_REFERENCE, POP_CG_ONE_REDUCTION = 1, 2, 4, 8, 16
 # caller-supplied collectives of dsea_comm_create_callbacks (device pointers + the stream the data was produced on)

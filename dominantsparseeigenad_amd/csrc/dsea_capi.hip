@@ -171,6 +171,10 @@ int dsea_op_set_tuning(dsea_op_t op, int key, int value) {
       if (value && (op->d.sell.pack2 || op->d.sell.code8)) return DSEA_ERR_UNSUPPORTED;
       op->d.sell.nt = value;
       return DSEA_OK;
+    case DSEA_TUNE_SELL_MAX_WIDTH:
+      if (op->d.kind != OP_SELL || value < 0) return DSEA_ERR_ARG;
+      op->d.sell.max_width = value;
+      return DSEA_OK;
     default: return DSEA_ERR_ARG;
   }
 }

@@ -56,6 +56,7 @@ struct SellParams {
   const uint16_t* col16;
   int xcd;   // 1: XCD-contiguous slice map (dsea_op_set_tuning DSEA_TUNE_SELL_XCD_MAP)
   int nt;    // 1: non-temporal matrix loads (DSEA_TUNE_SELL_NT; 16-bit-column operands)
+  int max_width;  // hint: no slice is wider than this many slice columns (0 = unknown; DSEA_TUNE_SELL_MAX_WIDTH)
   int pack2;  // 1: fp64 values and 16-bit deltas packed TWO slice columns to a lane (dsea_op_create_sell16p2)
   // value-coded operand (dsea_op_create_sell16v8): value of element e = vtab[code8[e]] (256 doubles); vals unused (null)
   const uint8_t* code8;

@@ -1899,15 +1899,28 @@ __global__ __launch_bounds__(256) void k_spmv_sell(SellParams p, const double* _
 // element rowptr[i] + k.
 //   k_sell_update_vals : vals_sell[slice, k, lane] = vals_csr[rowptr[row] + k]        (in-place refresh, padding stays 0)
 //   k_sell_sddmm       : out[rowptr[row] + k] (+)= alpha * v1[row] * v2[col]   (SYM: alpha/2 (v1[row] v2[col] + v1[col] v2[row]))
-#define SELL_SEG_CAP 2048   /* doubles of LDS per wave: CSR segments of 64 rows up to 32 non-zeros per row on average */
+#define SELL_SEG_CAP 2048   /* doubles of LDS per wave at most: CSR segments of 64 rows up to 32 non-zeros per row on average */
+// LDS per wave of a launch: the widest slice of the operand if the host said so (dsea_op_set_tuning DSEA_TUNE_SELL_MAX_WIDTH --
+// 64 KB per workgroup are two workgroups per CU, and both kernels are latency-bound), else the cap; a segment beyond it takes
+// the direct form either way
+static inline int sell_seg_cap(const SellParams& p) {
+  if (p.max_width <= 0) return SELL_SEG_CAP;
+  const int64_t need = ((int64_t)p.max_width * 64 + 63) / 64 * 64;
+  return (int)(need < 256 ? 256 : (need > SELL_SEG_CAP ? SELL_SEG_CAP : need));
+}
 // Both kernels move a slice's values between the SELL order (lane = row, coalesced) and the caller's CSR order, where
 // the 64 rows of a slice are ONE contiguous segment [rowptr[r0], rowptr[r0 + 64)): the segment is staged in LDS so that
 // both sides are coalesced (measured at L = 20 without the staging: 514 us sddmm / 216 us update -- the per-lane CSR
 // accesses are 168 bytes apart).  Segments beyond SELL_SEG_CAP use the direct form.
+// Every loop of the two kernels works on EIGHT elements per lane and trip with the loads of a trip issued together: written
+// one element per iteration they ran one dependent memory round trip per element (sddmm: two -- column, then gather) at two
+// waves per SIMD, 18 us per slice and wave.
 __global__ __launch_bounds__(256) void k_sell_update_vals(SellParams p, const int64_t* __restrict__ rowptr,
-                                                          const double* __restrict__ vals_csr, double* __restrict__ vals_sell) {
-  __shared__ double seg[4][SELL_SEG_CAP];
+                                                          const double* __restrict__ vals_csr, double* __restrict__ vals_sell,
+                                                          int cap) {
+  extern __shared__ double seg_all[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double* __restrict__ segw = seg_all + (int64_t)w * cap;
   for (int64_t sl = (int64_t)blockIdx.x * 4 + w; sl < p.nslices; sl += (int64_t)gridDim.x * 4) {
     const int64_t b0 = p.slice_ptr[sl], b1 = p.slice_ptr[sl + 1];
     const int64_t r0 = sl * 64, r1 = r0 + 64 < p.n ? r0 + 64 : p.n;
@@ -1918,15 +1931,37 @@ __global__ __launch_bounds__(256) void k_sell_update_vals(SellParams p, const in
       lo = rowptr[row];
       len = rowptr[row + 1] - lo;
     }
-    const bool staged = hi0 - lo0 <= SELL_SEG_CAP;
-    if (staged)
-      for (int64_t i = lane; i < hi0 - lo0; i += 64) seg[w][i] = vals_csr[lo0 + i];
+    const int64_t seglen = hi0 - lo0;
+    const bool staged = seglen <= cap;
+    if (staged) {
+      const double* __restrict__ src = vals_csr + lo0;
+      for (int64_t i0 = lane; i0 < seglen; i0 += 512) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = i0 + 64 * u < seglen ? src[i0 + 64 * u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (i0 + 64 * u < seglen) segw[i0 + 64 * u] = t[u];
+      }
+    }
     // one wave owns seg[w]: the LDS operations of a wave are executed in order; the fence keeps the compiler from moving them
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    int64_t k = 0;
-    for (int64_t e = b0 + lane; e < b1; e += 64, ++k)
-      vals_sell[p.pack2 ? b0 + 128 * (k >> 1) + 2 * lane + (k & 1) : e] = k < len ? (staged ? seg[w][lo - lo0 + k] : vals_csr[lo + k]) : 0.0;
+    const int64_t width = (b1 - b0) >> 6;
+    const int64_t off = lo - lo0;
+    for (int64_t k0 = 0; k0 < width; k0 += 8) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t k = k0 + u;
+        t[u] = k < len ? (staged ? segw[off + k] : vals_csr[lo + k]) : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t k = k0 + u;
+        if (k < width) vals_sell[p.pack2 ? b0 + 128 * (k >> 1) + 2 * lane + (k & 1) : b0 + 64 * k + lane] = t[u];
+      }
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
@@ -1935,9 +1970,10 @@ __global__ __launch_bounds__(256) void k_sell_update_vals(SellParams p, const in
 template <int MODE, bool SYM>
 __global__ __launch_bounds__(256) void k_sell_sddmm(SellParams p, const int64_t* __restrict__ rowptr,
                                                     const double* __restrict__ v1, const double* __restrict__ v2,
-                                                    double alpha, int accumulate, double* __restrict__ out) {
-  __shared__ double seg[4][SELL_SEG_CAP];
+                                                    double alpha, int accumulate, double* __restrict__ out, int cap) {
+  extern __shared__ double seg_all[];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double* __restrict__ segw = seg_all + (int64_t)w * cap;
   for (int64_t sl = (int64_t)blockIdx.x * 4 + w; sl < p.nslices; sl += (int64_t)gridDim.x * 4) {
     const int64_t b0 = p.slice_ptr[sl], b1 = p.slice_ptr[sl + 1];
     const int64_t r0 = sl * 64, r1 = r0 + 64 < p.n ? r0 + 64 : p.n;
@@ -1951,26 +1987,74 @@ __global__ __launch_bounds__(256) void k_sell_sddmm(SellParams p, const int64_t*
       a1 = v1[row];
       if (SYM) a2 = v2[row];
     }
-    const bool staged = hi0 - lo0 <= SELL_SEG_CAP;
-    int64_t k = 0;
-    for (int64_t e = b0 + lane; e < b1; e += 64, ++k) {
-      if (k < len) {
-        // (value-coded operand: its 16-bit deltas are packed four slice columns to a lane, see sell_row_sum_vc)
-        const int64_t e16 = p.code8   ? ((e & ~(int64_t)255) | ((e & 63) << 2) | ((e >> 6) & 3))
-                            : p.pack2 ? ((e & ~(int64_t)127) | ((e & 63) << 1) | ((e >> 6) & 1))
-                                      : e;
-        const int c = p.col16 ? p.colbase[e >> 6] + (int)p.col16[e16] : p.colidx[e];
-        double g = __dmul_rn(a1, sell_gather<MODE>(p, v2, c));
-        if (SYM) g = __dmul_rn(0.5, __dadd_rn(g, __dmul_rn(sell_gather<MODE>(p, v1, c), a2)));
-        g = __dmul_rn(alpha, g);
-        if (staged) seg[w][lo - lo0 + k] = g;
-        else out[lo + k] = accumulate ? __dadd_rn(out[lo + k], g) : g;
+    const int64_t seglen = hi0 - lo0;
+    const bool staged = seglen <= cap;
+    const int64_t width = (b1 - b0) >> 6;
+    const int64_t off = lo - lo0;
+    // the columns of trip t + 1 are requested before the gathers of trip t are consumed (one dependent round trip per trip
+    // instead of two)
+    auto load_cols = [&](int64_t k0, int* c) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t k = k0 + u;
+        c[u] = 0;
+        if (k < len) {
+          const int64_t e = b0 + 64 * k + lane;
+          // (packed layouts: the 16-bit deltas sit two / four slice columns to a lane, see sell_row_sum_p2 / _vc)
+          const int64_t e16 = p.code8   ? ((e & ~(int64_t)255) | ((e & 63) << 2) | ((e >> 6) & 3))
+                              : p.pack2 ? ((e & ~(int64_t)127) | ((e & 63) << 1) | ((e >> 6) & 1))
+                                        : e;
+          c[u] = p.col16 ? p.colbase[e >> 6] + (int)p.col16[e16] : p.colidx[e];
+        }
       }
+    };
+    int c[8], cn[8];
+    load_cols(0, c);
+    for (int64_t k0 = 0; k0 < width; k0 += 8) {
+      double g2[8], g1[8];
+      if (k0 + 8 < width) load_cols(k0 + 8, cn);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        g2[u] = g1[u] = 0.0;
+        if (k0 + u < len) {
+          g2[u] = sell_gather<MODE>(p, v2, c[u]);
+          if (SYM) g1[u] = sell_gather<MODE>(p, v1, c[u]);
+        }
+      }
+      double old[8];
+      if (!staged && accumulate) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) old[u] = k0 + u < len ? out[lo + k0 + u] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t k = k0 + u;
+        if (k < len) {
+          double g = __dmul_rn(a1, g2[u]);
+          if (SYM) g = __dmul_rn(0.5, __dadd_rn(g, __dmul_rn(g1[u], a2)));
+          g = __dmul_rn(alpha, g);
+          if (staged) segw[off + k] = g;
+          else out[lo + k] = accumulate ? __dadd_rn(old[u], g) : g;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c[u] = cn[u];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (staged)
-      for (int64_t i = lane; i < hi0 - lo0; i += 64) out[lo0 + i] = accumulate ? __dadd_rn(out[lo0 + i], seg[w][i]) : seg[w][i];
+    if (staged) {
+      double* __restrict__ dst = out + lo0;
+      for (int64_t i0 = lane; i0 < seglen; i0 += 512) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = (accumulate && i0 + 64 * u < seglen) ? dst[i0 + 64 * u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int64_t i = i0 + 64 * u;
+          if (i < seglen) dst[i] = accumulate ? __dadd_rn(t[u], segw[i]) : segw[i];
+        }
+      }
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
@@ -3304,7 +3388,9 @@ int launch_sell_update_vals(const OpDesc& op, const int64_t* rowptr, const doubl
   const SellParams& p = op.sell;
   int64_t nb = (p.nslices + 3) / 4;
   if (nb > DSEA_MAX_TFIM_BLOCKS) nb = DSEA_MAX_TFIM_BLOCKS;
-  hipLaunchKernelGGL(k_sell_update_vals, dim3((unsigned)nb), dim3(256), 0, st, p, rowptr, vals_csr, const_cast<double*>(p.vals));
+  const int cap = sell_seg_cap(p);
+  hipLaunchKernelGGL(k_sell_update_vals, dim3((unsigned)nb), dim3(256), (size_t)cap * 4 * sizeof(double), st, p, rowptr, vals_csr,
+                     const_cast<double*>(p.vals), cap);
   return 0;
 }
 
@@ -3314,7 +3400,10 @@ int launch_sddmm(const OpDesc& op, const int64_t* rowptr, const double* v1, cons
     const SellParams& p = op.sell;
     int64_t nb = (p.nslices + 3) / 4;
     if (nb > DSEA_MAX_TFIM_BLOCKS) nb = DSEA_MAX_TFIM_BLOCKS;
-#define SDDMM_CASE(M, S) hipLaunchKernelGGL((k_sell_sddmm<M, S>), dim3((unsigned)nb), dim3(256), 0, st, p, rowptr, v1, v2, alpha, accumulate, out)
+    const int cap = sell_seg_cap(p);
+#define SDDMM_CASE(M, S)                                                                                                  \
+  hipLaunchKernelGGL((k_sell_sddmm<M, S>), dim3((unsigned)nb), dim3(256), (size_t)cap * 4 * sizeof(double), st, p, rowptr, v1, v2, \
+                     alpha, accumulate, out, cap)
     if (p.mode == 0) {
       if (sym) SDDMM_CASE(0, true); else SDDMM_CASE(0, false);
     } else if (sym) {

@@ -408,6 +408,8 @@ class CSROperator:
             raise ValueError("layout must be 'sell' or 'csr'")
         self._H = _NativeView(_Handle(raw, self.n, keep))
         import os as _os
+        if layout == "sell":
+            self._hint_width(raw)
         if layout == "sell" and _os.environ.get("DSEA_SELL_NT", "") == "1" and (getattr(self, "_pack2", False) or self._coded):
             raise ValueError("DSEA_SELL_NT=1 is an A/B switch of the unpacked layout: set DSEA_SELL_PACK2=0 and DSEA_SELL_VALUES=plain")
         if layout == "sell" and _os.environ.get("DSEA_SELL_NT", "") in ("0", "1"):     # A/B switch (tools/gpu_evidence.sh abenv)
@@ -417,6 +419,12 @@ class CSROperator:
             self._seen_version = self.vals._version        # (the codes were just taken from these values)
         else:
             self.refresh()
+
+    def _hint_width(self, raw):
+        """tell the library the widest slice (LDS reservation of the parameter kernels: dsea_op_set_tuning DSEA_TUNE_SELL_MAX_WIDTH)"""
+        sp = self._sell[0]
+        width = int(((sp[1:] - sp[:-1]).max().item()) // 64) if sp.numel() > 1 else 0
+        check(_lib.load().dsea_op_set_tuning(raw, _lib.TUNE_SELL_MAX_WIDTH, width), "dsea_op_set_tuning")
 
     def _plain_layout(self, col16):
         """(slice_ptr, columns, total) of the fp64-value SELL layout: with 16-bit deltas the per-element arrays are packed two
@@ -472,6 +480,7 @@ class CSROperator:
             s_vals = torch.zeros(max(self._sell_total, 1), dtype=F64, device=self.device)
             st = self._sell
             raw = self._create_plain(st[0], st[1:-1], s_vals)
+            self._hint_width(raw)
             twin._sell = st[:-1] + (s_vals,)
             twin._coded = False
             keep = twin._sell
@@ -517,6 +526,7 @@ class CSROperator:
         s_vals = torch.zeros(max(total, 1), dtype=F64, device=self.device)
         raw = self._create_plain(slice_ptr, cols, s_vals)
         self._sell = (slice_ptr,) + tuple(cols) + (s_vals,)
+        self._hint_width(raw)
         self._sell_total = total
         self._coded = False
         del self._codes, self._vtab

@@ -206,6 +206,10 @@ int dsea_op_create_stencil3(int64_t n, double coef, const double *V_dev, const d
 /* SELL mat-vec with 16-bit columns (dsea_op_create_sell16 only; DSEA_ERR_UNSUPPORTED on the packed / value-coded layouts):
  * 1 = non-temporal loads of the matrix stream (values, column deltas), 0 = default policy */
 #define DSEA_TUNE_SELL_NT 5
+/* SELL operand: a HINT that no slice is wider than `value` slice columns (0 = unknown).  dsea_op_sddmm and dsea_op_update_vals
+ * stage a slice's CSR segment in LDS; knowing the widest one they reserve that much instead of 16 KB per wave and more
+ * workgroups fit a CU (both are latency-bound).  A wrong hint costs speed, not correctness. */
+#define DSEA_TUNE_SELL_MAX_WIDTH 6
 int dsea_op_set_tuning(dsea_op_t op, int key, int value);
 
 /* The explicit-matrix operand as a PARAMETER of the primitives.  The reference's contract is that the adjoint of the
