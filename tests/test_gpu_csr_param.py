@@ -423,3 +423,36 @@ def test_packed_and_unpacked_fp64_value_layouts_are_bit_identical(monkeypatch):
     assert rel(packed(x).cpu(), torch.from_numpy(M2 @ x.cpu().numpy())) < 1e-13
     twin = packed.with_vals(newv * 2.0)               # (the hooks' backward builds operators on the same structure)
     assert torch.equal(twin(x), CSROperator(packed.rowptr, packed.colidx, newv * 2.0, n)(x))
+
+
+def test_parameter_kernels_on_slices_beyond_the_lds_cap():
+    """a slice whose 64 rows hold more than 2048 non-zeros does not fit the LDS staging of dsea_op_sddmm / dsea_op_update_vals:
+    they take their direct form (here 48 per row = 3072 per slice), plain, symmetric and accumulating"""
+    import scipy.sparse as sp
+    rng = np.random.RandomState(23)
+    n = 200
+    D = sp.lil_matrix((n, n))
+    for r in range(n):
+        cols = rng.choice(n, size=48 if r < 130 else 5, replace=False)
+        D[r, cols] = rng.randn(len(cols))
+    D = sp.csr_matrix(D)
+    D.sort_indices()
+    rows, cols = torch.from_numpy(_rows_of(D)), torch.from_numpy(D.indices.astype("int64"))
+    v1, v2 = torch.from_numpy(normal_vector(n, 7930)), torch.from_numpy(normal_vector(n, 7931))
+    plain = v1[rows] * v2[cols]
+    sym = 0.5 * (v1[rows] * v2[cols] + v1[cols] * v2[rows])
+    for col16 in ("auto", False):
+        op = CSROperator.from_scipy(D, dev(), col16=col16)
+        assert torch.equal(op.sddmm(v1.to(dev()), v2.to(dev())).cpu(), plain)
+        assert torch.equal(op.sddmm(v1.to(dev()), v2.to(dev()), symmetric=True).cpu(), sym)
+        base = torch.from_numpy(normal_vector(D.nnz, 7932))
+        out = base.clone().to(dev())
+        op.sddmm(v1.to(dev()), v2.to(dev()), out=out, alpha=1.25, accumulate=True)
+        assert torch.equal(out.cpu(), base + 1.25 * plain)
+        x = torch.from_numpy(normal_vector(n, 7933)).to(dev())
+        newv = torch.from_numpy(normal_vector(D.nnz, 7934)).to(dev())
+        op.vals.copy_(newv)
+        D2 = D.copy()
+        D2.data = newv.cpu().numpy()
+        assert rel(op(x).cpu(), torch.from_numpy(D2 @ x.cpu().numpy())) < 1e-13
+        assert torch.equal(op(x), CSROperator(op.rowptr, op.colidx, newv.clone(), n, col16=col16)(x))
