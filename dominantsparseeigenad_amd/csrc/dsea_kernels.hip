@@ -1956,10 +1956,17 @@ __global__ __launch_bounds__(256) void k_sell_update_vals(SellParams p, const in
         const int64_t k = k0 + u;
         t[u] = k < len ? (staged ? segw[off + k] : vals_csr[lo + k]) : 0.0;
       }
+      if (p.pack2) {      // a lane's two values of a column pair are neighbours: one 16-byte store (widths are even)
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int64_t k = k0 + u;
-        if (k < width) vals_sell[p.pack2 ? b0 + 128 * (k >> 1) + 2 * lane + (k & 1) : b0 + 64 * k + lane] = t[u];
+        for (int g = 0; g < 4; ++g)
+          if (k0 + 2 * g < width)
+            *reinterpret_cast<double2*>(vals_sell + b0 + 128 * ((k0 >> 1) + g) + 2 * lane) = make_double2(t[2 * g], t[2 * g + 1]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int64_t k = k0 + u;
+          if (k < width) vals_sell[b0 + 64 * k + lane] = t[u];
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1993,7 +2000,26 @@ __global__ __launch_bounds__(256) void k_sell_sddmm(SellParams p, const int64_t*
     const int64_t off = lo - lo0;
     // the columns of trip t + 1 are requested before the gathers of trip t are consumed (one dependent round trip per trip
     // instead of two)
+    // default layout (packed by two): one uint32 of deltas per two columns and the slice-column bases held by the lanes
+    // (v_readlane with a wave-uniform index), as in sell_row_sum_p2 -- 4 loads per trip instead of 16
+    int cbl = 0, kb = -64;
+    const uint32_t* __restrict__ del2 = p.pack2 ? reinterpret_cast<const uint32_t*>(p.col16 + b0) + lane : nullptr;
     auto load_cols = [&](int64_t k0, int* c) {
+      if (p.pack2) {
+        const int k0i = (int)k0;
+        if ((k0i & ~63) != kb) {
+          kb = k0i & ~63;
+          const int64_t cbi = (b0 >> 6) + kb + lane;
+          cbl = cbi < (b1 >> 6) ? p.colbase[cbi] : 0;
+        }
+        uint32_t d[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) d[g] = k0i + 2 * g < (int)width ? del2[((k0i >> 1) + g) * 64] : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          c[u] = __builtin_amdgcn_readlane(cbl, (k0i + u) & 63) + (int)((d[u >> 1] >> (16 * (u & 1))) & 0xffffu);
+        return;
+      }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int64_t k = k0 + u;
